@@ -1,0 +1,734 @@
+#!/usr/bin/env python3
+"""CPU oracle for the pyapes FDM stencil + Krylov hot path.
+
+THIS FILE IS TEST INFRASTRUCTURE, NOT PRODUCT CODE.  Only ``tests/``,
+``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may import
+it.  Nothing under ``pyapes_amd/`` imports it, and the product path has no CPU
+fallback: it raises when the HIP library is missing.
+
+What it is: a from-scratch torch-CPU restatement of the *literal* algorithm of
+the reference (kyoungseoun-chung/pyapes v0.2.13), op for op -- dense coefficient
+tables, ``torch.roll`` stencils, boolean-mask boundary fill in list order, the
+``|x_new - x_old|`` stop test -- written from SURVEY.md Appendix A.  Because it
+keeps the reference's operation sequence (including its temporaries) it also
+serves as the ``cpu_baseline`` (kind "port") timed by ``bench.py``.
+
+Parity pin: ``tests/golden/make_golden.py`` (run in the build container only,
+where /root/reference is importable) drives the reference and this file on the
+same seeded inputs and stores the reference's outputs as ``tests/golden/*.npz``.
+``tests/test_oracle_golden.py`` checks this file against those vectors
+(bit-exact for operator / BC-fill outputs, <=1e-13 rel for solver iterates).
+
+Reference citations (relative to the reference repo root):
+  mesh / masks      pyapes/mesh/_mesh.py:30-117, 321-399
+  BC objects        pyapes/variables/bcs.py:70-95 (shifted masks), 200-280 (apply)
+  interior slicer   pyapes/mesh/tools.py:7-20
+  stencil tables    pyapes/solver/tools.py:29-108, pyapes/solver/fdc.py:376-423,
+                    480-492, 543-609, 623-664, 708-772
+  stencil apply     pyapes/solver/fdc.py:67-118, 171-200
+  rhs adjustment    pyapes/solver/fdc.py:426-458, 505-540, 667-694
+  edge treatment    pyapes/solver/fdc.py:203-366
+  operator sum      pyapes/solver/ops.py:122-154, pyapes/solver/fdm.py:159-169
+  CG / BiCGSTAB     pyapes/solver/linalg.py:74-159, 162-279, 282-338
+Functions marked [NEW] have no reference counterpart.
+"""
+from __future__ import annotations
+
+import math
+import warnings
+from dataclasses import dataclass, field
+from typing import Any, Callable, Sequence
+
+import torch
+from torch import Tensor
+
+FACES = ["xl", "xu", "yl", "yu", "zl", "zu"]
+_AXIS = {"x": 0, "y": 1, "z": 2}
+
+
+def _tdtype(dtype: str | int) -> torch.dtype:
+    if dtype in ("double", "d", 64):
+        return torch.float64
+    if dtype in ("single", "s", 32):
+        return torch.float32
+    raise ValueError(f"oracle: unknown dtype {dtype!r}")
+
+
+# --------------------------------------------------------------------------
+# mesh (pyapes/mesh/_mesh.py:30-117)
+# --------------------------------------------------------------------------
+class OMesh:
+    """Node-based equidistant box mesh; ``spacing`` = node counts (ints) or dx (floats)."""
+
+    def __init__(self, lower: Sequence[float], upper: Sequence[float],
+                 spacing: Sequence[int | float], dtype: str | int = "double"):
+        self.dtype = _tdtype(dtype)
+        self.lower = [float(v) for v in lower]
+        self.upper = [float(v) for v in upper]
+        self.dim = len(self.lower)
+        lo = torch.tensor(self.lower, dtype=self.dtype)
+        up = torch.tensor(self.upper, dtype=self.dtype)
+        lx = up - lo
+        if any(isinstance(s, int) for s in spacing):
+            self.nx = [int(s) for s in spacing]
+            self.dx_list = [float(l / (n - 1.0)) for l, n in zip(lx, self.nx)]
+        else:
+            self.dx_list = [float(s) for s in spacing]
+            self.nx = [int(l / d + 1.0) for l, d in zip(lx, self.dx_list)]
+        self.x = [
+            torch.linspace(lo[i].item(), up[i].item(), self.nx[i], dtype=self.dtype)
+            for i in range(self.dim)
+        ]
+        self.grid = torch.meshgrid(self.x, indexing="ij")
+
+    @property
+    def dx(self) -> Tensor:
+        return torch.tensor(self.dx_list, dtype=self.dtype)
+
+    def face_mask(self, face: str) -> Tensor:
+        """Whole boundary plane incl. edges/corners (_mesh.py:321-399)."""
+        a = _AXIS[face[0]]
+        m = torch.zeros(*self.nx, dtype=torch.bool)
+        idx: list[Any] = [slice(None)] * self.dim
+        idx[a] = 0 if face[1] == "l" else self.nx[a] - 1
+        m[tuple(idx)] = True
+        return m
+
+
+# --------------------------------------------------------------------------
+# boundary conditions (pyapes/variables/bcs.py)
+# --------------------------------------------------------------------------
+@dataclass
+class OBC:
+    face: str
+    type: str            # dirichlet | neumann | symmetry | periodic
+    val: Any             # number | list | Tensor | callable(grid, mask, var, opt) | None
+    mesh: OMesh
+    opt: Any = None
+    axis: int = field(init=False)
+    n_dir: int = field(init=False)
+
+    def __post_init__(self):
+        self.type = self.type.lower()
+        self.axis = _AXIS[self.face[0]]
+        self.n_dir = -1 if self.face[1] == "l" else 1
+        self.mask = self.mesh.face_mask(self.face)
+        # bcs.py:84-93: rolled copies of the face mask along the face normal
+        self.prev = torch.roll(self.mask, -self.n_dir, self.axis)
+        self.prev2 = torch.roll(self.mask, -2 * self.n_dir, self.axis)
+        self.fwd = torch.roll(self.mask, self.n_dir, self.axis)
+        self.fwd2 = torch.roll(self.mask, 2 * self.n_dir, self.axis)
+        self.n_vec = torch.zeros(3, dtype=self.mesh.dtype)
+        self.n_vec[self.axis] = self.n_dir
+
+    # bcs.py:200-280
+    def apply(self, var: Tensor, d: int) -> None:
+        grid = self.mesh.grid
+        if self.type == "dirichlet":
+            v = self.val
+            if callable(v):
+                var[d, self.mask] = v(grid, self.mask, var, self.opt)
+            elif isinstance(v, list):
+                var[d, self.mask] = v[d]
+            elif isinstance(v, (int, float)):
+                var[d, self.mask] = float(v)
+            elif isinstance(v, Tensor):
+                var[d, self.mask] = v
+            else:
+                raise TypeError("oracle: bad dirichlet value")
+        elif self.type == "neumann":
+            dx = grid[self.axis][self.mask] - grid[self.axis][self.prev]
+            vp = var[d][self.prev]
+            vpp = var[d][self.prev2]
+            v = self.val
+            if callable(v):
+                c = v(grid, self.mask, var, self.opt)
+            elif isinstance(v, list):
+                c = v[d]
+            elif isinstance(v, (int, float)):
+                c = float(v)
+            elif isinstance(v, Tensor):
+                c = v
+            else:
+                raise TypeError("oracle: bad neumann value")
+            var[d][self.mask] = 4 / 3 * vp - 1 / 3 * vpp + 2 / 3 * c * dx * self.n_dir
+        elif self.type == "symmetry":
+            var[d, self.mask] = var[d, self.prev]
+        elif self.type == "periodic":
+            if self.n_dir < 0:
+                vp = var[d, self.prev]
+                vf = var[d, self.fwd]
+                vff = var[d, self.fwd2]
+                var[d, self.mask] = vp - vf + vff
+            else:
+                var[d, self.mask] = var[d, self.fwd]
+        else:
+            raise ValueError(f"oracle: unknown bc type {self.type}")
+
+
+def make_bcs(mesh: OMesh, cfg: Sequence[dict]) -> list[OBC]:
+    """cfg: list of {bc_face, bc_type, bc_val[, bc_val_opt]} in application order."""
+    return [OBC(c["bc_face"], c["bc_type"], c["bc_val"], mesh, c.get("bc_val_opt"))
+            for c in cfg]
+
+
+def homogeneous_cfg(dim: int, val: Any, typ: str) -> list[dict]:
+    return [{"bc_face": FACES[i], "bc_type": typ,
+             "bc_val": val[i] if isinstance(val, list) else val} for i in range(2 * dim)]
+
+
+def mixed_cfg(vals: Sequence[Any], types: Sequence[str]) -> list[dict]:
+    return [{"bc_face": FACES[i], "bc_type": t, "bc_val": v}
+            for i, (v, t) in enumerate(zip(vals, types))]
+
+
+def bc_fill(var: Tensor, bcs: Sequence[OBC]) -> Tensor:
+    """linalg.py:282-299: for every component, every face in list order."""
+    for d in range(var.shape[0]):
+        for bc in bcs:
+            bc.apply(var, d)
+    return var
+
+
+def interior_slicer(ndim: int, bcs: Sequence[OBC]) -> tuple[slice, ...]:
+    """mesh/tools.py:7-20."""
+    lim: list[list[int | None]] = [[1, -1] for _ in range(ndim)]
+    for bc in bcs:
+        if bc.type == "periodic":
+            lim[bc.axis][0 if bc.face[1] == "l" else 1] = None
+    return tuple(slice(*l) for l in lim)
+
+
+def _bc_value(bc: OBC, var: Tensor, d: int) -> Any:
+    """fdc.py:803-817."""
+    v = bc.val
+    if callable(v):
+        return v(bc.mesh.grid, bc.mask, var, bc.n_vec)
+    if isinstance(v, list):
+        return v[d]
+    if isinstance(v, (int, float)):
+        return v
+    if v is None:
+        return 0.0
+    raise ValueError("oracle: unknown bc value")
+
+
+# --------------------------------------------------------------------------
+# coefficient tables [App, Ap, Ac, Am, Amm], each a list over mesh axes of
+# tensors shaped like var (dim, *nx)         (solver/tools.py:29-108)
+# --------------------------------------------------------------------------
+def _base_tables(var: Tensor, ndim: int, p: float, c: float, m: float):
+    z = lambda: [torch.zeros_like(var) for _ in range(ndim)]  # noqa: E731
+    return [z(),
+            [p * torch.ones_like(var) for _ in range(ndim)],
+            [c * torch.ones_like(var) if c != 0.0 else torch.zeros_like(var) for _ in range(ndim)],
+            [m * torch.ones_like(var) for _ in range(ndim)],
+            z()]
+
+
+def laplacian_tables(var: Tensor, mesh: OMesh, bcs: Sequence[OBC] | None):
+    """fdc.py:376-423 (xyz only)."""
+    App, Ap, Ac, Am, Amm = _base_tables(var, mesh.dim, 1.0, -2.0, 1.0)
+    dx = mesh.dx
+    for i in range(var.shape[0]):
+        for j in range(mesh.dim):
+            if bcs is None:
+                continue
+            for bc in bcs:
+                if bc.n_vec[j] == 0:
+                    continue
+                if bc.type in ("neumann", "symmetry"):
+                    alpha = torch.zeros_like(mesh.grid[j][bc.prev])
+                    if bc.n_dir < 0:
+                        Ap[j][i][bc.prev] = 2 / 3 + alpha
+                        Ac[j][i][bc.prev] = -(2 / 3 + alpha)
+                        Am[j][i][bc.prev] = 0.0
+                    else:
+                        Ap[j][i][bc.prev] = 0.0
+                        Ac[j][i][bc.prev] = -(2 / 3 + alpha)
+                        Am[j][i][bc.prev] = 2 / 3 + alpha
+            Ap[j][i] /= dx[j] ** 2
+            Ac[j][i] /= dx[j] ** 2
+            Am[j][i] /= dx[j] ** 2
+    return [App, Ap, Ac, Am, Amm]
+
+
+def laplacian_rhs_adjust(var: Tensor, mesh: OMesh, bcs: Sequence[OBC] | None) -> Tensor:
+    """fdc.py:426-458 (literal, incl. the upper-face sign)."""
+    adj = torch.zeros_like(var)
+    dx = mesh.dx
+    for i in range(var.shape[0]):
+        if bcs is None:
+            continue
+        for j in range(mesh.dim):
+            for bc in bcs:
+                if bc.type == "neumann":
+                    alpha = torch.zeros_like(mesh.grid[j][bc.prev])
+                    at_bc = _bc_value(bc, var, i)
+                    adj[i][bc.prev] += (2 / 3 - alpha) * (at_bc * bc.n_vec[j]) / dx[j]
+    return adj
+
+
+def _grad_adjust(var: Tensor, mesh: OMesh, bcs: Sequence[OBC], tabs, comp: int,
+                 gamma: tuple[Tensor, ...] | None = None) -> None:
+    """fdc.py:543-609."""
+    if gamma is None:
+        gmin = torch.ones_like(var)
+        gmax = torch.ones_like(var)
+    else:
+        gmin = gamma[0]
+        gmax = gamma[0] if len(gamma) == 1 else gamma[1]
+    Ap, Ac, Am = tabs
+    dx = mesh.dx
+    for j in range(mesh.dim):
+        for bc in bcs:
+            if bc.n_vec[j] == 0:
+                continue
+            if bc.type in ("neumann", "symmetry"):
+                gx = gmax[comp][bc.prev]
+                gn = gmin[comp][bc.prev]
+                if bc.n_dir < 0:
+                    Ap[j][comp][bc.prev] += 1 / 3 * gx
+                    Ac[j][comp][bc.prev] -= 1 / 3 * gn
+                    Am[j][comp][bc.prev] = 0.0
+                else:
+                    Ap[j][comp][bc.prev] = 0.0
+                    Ac[j][comp][bc.prev] += 1 / 3 * gn
+                    Am[j][comp][bc.prev] -= 1 / 3 * gx
+            elif bc.type == "periodic":
+                if bc.n_dir < 0:
+                    Am[j][comp][bc.prev] = 0.0
+                else:
+                    Ap[j][comp][bc.prev] = 0.0
+        Ap[j][comp] /= 2.0 * dx[j]
+        Ac[j][comp] /= 2.0 * dx[j]
+        Am[j][comp] /= 2.0 * dx[j]
+
+
+def grad_tables(var: Tensor, mesh: OMesh, bcs: Sequence[OBC] | None):
+    """fdc.py:480-492."""
+    App, Ap, Ac, Am, Amm = _base_tables(var, mesh.dim, 1.0, 0.0, -1.0)
+    if bcs is not None:
+        for i in range(var.shape[0]):
+            _grad_adjust(var, mesh, bcs, [Ap, Ac, Am], i)
+    return [App, Ap, Ac, Am, Amm]
+
+
+def _grad_rhs(var: Tensor, mesh: OMesh, bcs: Sequence[OBC], adj: Tensor, comp: int,
+              gamma: tuple[Tensor, ...] | None = None) -> None:
+    """fdc.py:505-540."""
+    if gamma is None:
+        gmin = torch.ones_like(var)
+        gmax = torch.ones_like(var)
+    else:
+        gmin = 2.0 * gamma[0]
+        gmax = 2.0 * (gamma[0] if len(gamma) == 1 else gamma[1])
+    for j in range(mesh.dim):
+        for bc in bcs:
+            if bc.type == "neumann":
+                at_bc = _bc_value(bc, var, comp)
+                g = gmax if bc.n_dir < 0 else gmin
+                adj[comp][bc.prev] -= (1 / 3) * (at_bc * bc.n_vec[j]) * g[comp][bc.prev]
+
+
+def grad_rhs_adjust(var: Tensor, mesh: OMesh, bcs: Sequence[OBC] | None) -> Tensor:
+    adj = torch.zeros_like(var)
+    if bcs is not None:
+        for i in range(var.shape[0]):
+            _grad_rhs(var, mesh, bcs, adj, i)
+    return adj
+
+
+def adv_tensor(u: float | Tensor, var: Tensor) -> Tensor:
+    """fdc.py:775-792 (float | Tensor only)."""
+    if isinstance(u, float):
+        return torch.ones_like(var) * u
+    assert u.shape == var.shape, "oracle: adv shape must match var shape"
+    return u
+
+
+def div_tables(u: float | Tensor, var: Tensor, mesh: OMesh, bcs: Sequence[OBC] | None,
+               limiter: str = "none"):
+    """fdc.py:623-664, 708-772 (literal; 'upwind' is the reference's defective form, Q3)."""
+    adv = adv_tensor(u, var)
+    App, Ap, Ac, Am, Amm = _base_tables(var, mesh.dim, 1.0, 0.0, -1.0)
+    limiter = limiter.lower()
+    if limiter == "none":
+        advection = torch.zeros_like(var[0])
+        for i in range(var.shape[0]):
+            for j in range(mesh.dim):
+                advection = adv[i]
+                Ap[j][i] *= torch.roll(advection, -1, dims=j)
+                Ac[j][i] *= advection
+                Am[j][i] *= torch.roll(advection, 1, dims=j)
+            _grad_adjust(var, mesh, bcs or [], [Ap, Ac, Am], i, (advection,))
+    elif limiter == "upwind":
+        zeros = torch.zeros_like(var[0])
+        for i in range(var.shape[0]):
+            for j in range(mesh.dim):
+                advection = adv[i]
+                Ap[j][i] = 2.0 * torch.min(advection, zeros)
+                Ac[j][i] *= 2.0 * advection
+                Am[j][i] = 2.0 * torch.max(advection, zeros)
+    else:
+        raise RuntimeError(f"oracle: unknown limiter {limiter}")
+    return [App, Ap, Ac, Am, Amm]
+
+
+def div_rhs_adjust(u: float | Tensor, var: Tensor, mesh: OMesh, bcs: Sequence[OBC] | None,
+                   limiter: str = "none") -> Tensor:
+    """fdc.py:667-694."""
+    adj = torch.zeros_like(var)
+    if bcs is not None:
+        adv = adv_tensor(u, var)
+        if limiter.lower() == "none":
+            for i in range(var.shape[0]):
+                _grad_rhs(var, mesh, bcs, adj, i, (adv,))
+        else:
+            z = torch.zeros_like(var)
+            for i in range(var.shape[0]):
+                _grad_rhs(var, mesh, bcs, adj, i, (torch.min(adv, z), torch.max(adv, z)))
+    return adj
+
+
+# --------------------------------------------------------------------------
+# stencil application (fdc.py:67-118, 171-200)
+# --------------------------------------------------------------------------
+def _axis_sum(tabs, var: Tensor, comp: int, axis: int) -> Tensor:
+    out = torch.zeros_like(var[0])
+    for k, c in enumerate(tabs):
+        if var.shape[0] == 1:
+            coeff, vi = c[axis][0], 0
+        else:
+            coeff, vi = c[axis][comp], comp
+        out += coeff * torch.roll(var[vi], -2 + k, axis)
+    return out
+
+
+def apply_laplacian(tabs, var: Tensor, ndim: int) -> Tensor:
+    out = torch.zeros_like(var)
+    for i in range(var.shape[0]):
+        for a in range(ndim):
+            out[i] += _axis_sum(tabs, var, i, a)
+    return out
+
+
+def apply_grad(tabs, var: Tensor, ndim: int) -> Tensor:
+    comps = []
+    for i in range(var.shape[0]):
+        comps.append(torch.stack([_axis_sum(tabs, var, i, a) for a in range(ndim)]))
+    return torch.stack(comps)
+
+
+def apply_div(tabs, var: Tensor, ndim: int) -> Tensor:
+    out = torch.zeros_like(var[0]).unsqueeze(0)
+    for a in range(ndim):
+        out[0] += _axis_sum(tabs, var, a, a)
+    return out
+
+
+# fdc.py:203-366 (explicit one-sided boundary formulas, edge=True)
+def edge_laplacian(out: Tensor, var: Tensor, mesh: OMesh) -> None:
+    nd = mesh.dim
+    for comp in range(var.shape[0]):
+        for a in range(nd):
+            for side in (0, 1):
+                s = [[slice(None)] * nd for _ in range(4)]
+                for q in range(4):
+                    s[q][a] = q if side == 0 else -1 - q
+                v0, v1, v2, v3 = (var[comp][tuple(s[q])] for q in range(4))
+                out[comp][tuple(s[0])] = (2.0 * v0 - 5.0 * v1 + 4.0 * v2 - v3) / (mesh.dx[a] ** 2)
+
+
+def edge_grad(out: Tensor, var: Tensor, mesh: OMesh) -> None:
+    nd = mesh.dim
+    for comp in range(out.shape[0]):
+        for a in range(nd):
+            for side in (0, 1):
+                s = [[slice(None)] * nd for _ in range(3)]
+                for q in range(3):
+                    s[q][a] = q if side == 0 else -1 - q
+                v0, v1, v2 = (var[comp][tuple(s[q])] for q in range(3))
+                e = (3 / 2 * v0 - 2.0 * v1 + 1 / 2 * v2) / (mesh.dx[a])
+                out[comp][a][tuple(s[0])] = -e if side == 0 else e
+
+
+# --------------------------------------------------------------------------
+# operator sum (ops.py:122-154)
+# --------------------------------------------------------------------------
+@dataclass
+class OTerm:
+    kind: str                    # "laplacian" | "grad" | "div"
+    tabs: Any
+    param: Any = None            # laplacian/grad multiplier (float | Tensor | None)
+    sign: float = 1.0
+
+
+def Aop(var: Tensor, terms: Sequence[OTerm], ndim: int) -> Tensor:
+    res = torch.zeros_like(var)
+    for t in terms:
+        if t.kind == "laplacian":
+            ax = apply_laplacian(t.tabs, var, ndim)
+            if t.param is not None:
+                ax = ax * t.param
+        elif t.kind == "grad":
+            ax = apply_grad(t.tabs, var, ndim)
+            if t.param is not None:
+                ax = ax * t.param
+        elif t.kind == "div":
+            ax = apply_div(t.tabs, var, ndim)
+        else:
+            raise ValueError(t.kind)
+        ax = ax * t.sign
+        if t.kind == "grad":
+            ax = ax.view(var.size())
+        res += ax
+    return res
+
+
+def _nan_to_num(t: Tensor) -> Tensor:
+    return torch.nan_to_num(t, nan=0.0, posinf=0.0, neginf=0.0)
+
+
+def _tolerance(a: Tensor, b: Tensor) -> float:
+    """linalg.py:321-338."""
+    tol = torch.zeros(a.shape[0], dtype=a.dtype)
+    for d in range(a.shape[0]):
+        tol[d] = torch.linalg.norm(a[d] - b[d])
+    if torch.isnan(tol) or torch.isinf(tol):
+        raise RuntimeError(f"Invalid tolerance detected! tol: {tol}")
+    return torch.max(tol).item()
+
+
+# --------------------------------------------------------------------------
+# Krylov loops (linalg.py:74-279)
+# --------------------------------------------------------------------------
+def cg(x: Tensor, rhs: Tensor, terms: Sequence[OTerm], mesh: OMesh, bcs: Sequence[OBC],
+       tol: float, max_it: int, history: list | None = None, snapshots: dict | None = None):
+    """Returns (x, report).  x is a new tensor per iteration like the reference
+    (set_var_tensor rebinding), the final one is returned."""
+    nd = mesh.dim
+    axes = list(range(1, nd + 1))
+    S = interior_slicer(nd, bcs)
+    cur_tol, itr = 1.0, 0
+    bc_fill(x, bcs)
+    Ad = torch.zeros_like(rhs)
+    r = torch.zeros_like(x)
+    for i in range(x.shape[0]):
+        r[i][S] = rhs[i][S] - Aop(x, terms, nd)[i][S]
+    d = r.clone()
+    while cur_tol > tol:
+        x_old = x.clone()
+        for i in range(x.shape[0]):
+            Ad[i][S] = Aop(d, terms, nd)[i][S]
+        alpha = _nan_to_num(torch.sum(r * r, dim=axes) / torch.sum(d * Ad, dim=axes))
+        x = x + alpha * d
+        bc_fill(x, bcs)
+        beta_denom = torch.sum(r * r, dim=axes)
+        r -= alpha * Ad
+        cur_tol = _tolerance(x, x_old)
+        beta = torch.sum(r * r, dim=axes) / beta_denom
+        d = r + beta * d
+        itr += 1
+        if history is not None:
+            history.append(cur_tol)
+        if snapshots is not None and itr in snapshots:
+            snapshots[itr] = {"x": x.clone(), "r": r.clone(), "d": d.clone()}
+        if itr > max_it:
+            warnings.warn(f"Maximum iteration reached! max_it: {max_it}", RuntimeWarning)
+            break
+    return x, {"itr": itr, "tol": cur_tol, "converge": itr < max_it}
+
+
+def bicgstab(x: Tensor, rhs: Tensor, terms: Sequence[OTerm], mesh: OMesh, bcs: Sequence[OBC],
+             tol: float, max_it: int):
+    nd = mesh.dim
+    axes = list(range(1, nd + 1))
+    S = interior_slicer(nd, bcs)
+    itr = 0
+    bc_fill(x, bcs)
+    r0 = torch.zeros_like(x)
+    for i in range(x.shape[0]):
+        r0[i][S] = rhs[i][S] - Aop(x, terms, nd)[i][S]
+    r = r0.clone()
+    t = torch.zeros_like(x)
+    v = torch.zeros_like(x)
+    p = torch.zeros_like(x)
+    s = torch.zeros_like(x)
+    rho: Any = 1.0
+    alpha: Any = 1.0
+    omega: Any = 1.0
+    rho_next = torch.sum(r0 * r0, dim=axes)
+    cur_tol = torch.sqrt(rho_next.max()).item()
+    finished = False
+    while not finished:
+        beta = rho_next / rho * alpha / omega
+        rho = rho_next
+        p = r + beta * (p - omega * v)
+        for i in range(x.shape[0]):
+            v[i][S] = Aop(p, terms, nd)[i][S]
+        itr += 1
+        alpha = _nan_to_num(rho / torch.sum(r0 * v, dim=axes))
+        s = r - alpha * v
+        cur_tol = _tolerance(r, alpha * v)
+        if cur_tol <= tol:
+            x = x + alpha * p
+            bc_fill(x, bcs)
+            finished = True
+            continue
+        for i in range(x.shape[0]):
+            t[i][S] = Aop(s, terms, nd)[i][S]
+        omega = _nan_to_num(torch.sum(t * s, dim=axes) / torch.sum(t * t, dim=axes))
+        rho_next = -omega * torch.sum(r0 * t, dim=axes)
+        x = x + alpha * p + s * omega
+        bc_fill(x, bcs)
+        r = s - omega * t
+        cur_tol = _tolerance(s, omega * t)
+        if cur_tol <= tol:
+            finished = True
+        if itr >= max_it:
+            warnings.warn(f"Maximum iteration reached! max_it: {max_it}", RuntimeWarning)
+            break
+    return x, {"itr": itr, "tol": cur_tol, "converge": itr < max_it}
+
+
+# --------------------------------------------------------------------------
+# [NEW] pieces required by north_star that the reference lacks
+# --------------------------------------------------------------------------
+def laplacian_diag(var: Tensor, tabs, ndim: int) -> Tensor:
+    """[NEW] diagonal of the Laplacian table: sum over axes of Ac."""
+    dg = torch.zeros_like(var)
+    for i in range(var.shape[0]):
+        for a in range(ndim):
+            dg[i] += tabs[2][a][i]
+    return dg
+
+
+def jacobi(x: Tensor, rhs: Tensor, terms: Sequence[OTerm], mesh: OMesh, bcs: Sequence[OBC],
+           tol: float, max_it: int, omega: float = 1.0):
+    """[NEW] weighted Jacobi  x <- x + omega (b - A x)/diag(A)  on the interior set,
+    with the SAME BC fill, interior slicer, stop test (|x_new - x_old|_2 over all
+    nodes), K+1 iteration rule and report as the reference CG (linalg.py:74-159).
+    diag(A) = sum_k sign_k * param_k * sum_axes Ac  (laplacian terms only)."""
+    nd = mesh.dim
+    S = interior_slicer(nd, bcs)
+    diag = torch.zeros_like(x)
+    for t in terms:
+        assert t.kind == "laplacian", "oracle jacobi: laplacian terms only"
+        dg = laplacian_diag(x, t.tabs, nd)
+        if t.param is not None:
+            dg = dg * t.param
+        diag += dg * t.sign
+    cur_tol, itr = 1.0, 0
+    bc_fill(x, bcs)
+    while cur_tol > tol:
+        x_old = x.clone()
+        res = torch.zeros_like(x)
+        for i in range(x.shape[0]):
+            res[i][S] = (rhs[i][S] - Aop(x, terms, nd)[i][S]) / diag[i][S]
+        x = x + omega * res
+        bc_fill(x, bcs)
+        cur_tol = _tolerance(x, x_old)
+        itr += 1
+        if itr > max_it:
+            warnings.warn(f"Maximum iteration reached! max_it: {max_it}", RuntimeWarning)
+            break
+    return x, {"itr": itr, "tol": cur_tol, "converge": itr < max_it}
+
+
+def div_upwind_intended(u: float | Tensor, var: Tensor, mesh: OMesh) -> Tensor:
+    """[NEW] first-order upwind advection as the reference's own test states it
+    (tests/test_fdm.py:239):  sum_a [ u+ (phi_i - phi_{i-1}) + u- (phi_{i+1} - phi_i) ] / dx_a,
+    u+ = max(u,0), u- = min(u,0); scalar phi uses adv[0] on every axis.
+    Wrap-around neighbours like every other roll stencil; boundary rows are
+    meaningless and overwritten by the BC fill of the time-march."""
+    adv = adv_tensor(u, var)
+    out = torch.zeros_like(var[0]).unsqueeze(0)
+    zeros = torch.zeros_like(var[0])
+    dx = mesh.dx
+    for a in range(mesh.dim):
+        ai = a if var.shape[0] > 1 else 0
+        up = torch.max(adv[ai], zeros)
+        um = torch.min(adv[ai], zeros)
+        phi = var[ai]
+        bwd = (phi - torch.roll(phi, 1, a)) / dx[a]
+        fwd = (torch.roll(phi, -1, a) - phi) / dx[a]
+        out[0] += up * bwd + um * fwd
+    return out
+
+
+def euler_step(phi: Tensor, u: float | Tensor, nu: float, dt: float, mesh: OMesh,
+               bcs: Sequence[OBC], limiter: str = "upwind") -> Tensor:
+    """[NEW] explicit Euler step of  d(phi)/dt + div(u phi) = nu lap(phi):
+    phi <- B( phi + dt * ( nu * lap(phi) - adv(phi) ) ) on the interior set,
+    lap/adv from the explicit operators (edge=False) evaluated on the BC-filled phi."""
+    nd = mesh.dim
+    S = interior_slicer(nd, bcs)
+    lap = apply_laplacian(laplacian_tables(phi, mesh, bcs), phi, nd)
+    if limiter == "upwind":
+        adv = div_upwind_intended(u, phi, mesh)
+    elif limiter == "none":
+        adv = apply_div(div_tables(u, phi, mesh, bcs, "none"), phi, nd)
+    else:
+        raise ValueError(limiter)
+    new = phi.clone()
+    for i in range(phi.shape[0]):
+        new[i][S] = phi[i][S] + dt * (nu * lap[i][S] - adv[i][S])
+    bc_fill(new, bcs)
+    return new
+
+
+# --------------------------------------------------------------------------
+# analytic Poisson inputs (formulas of pyapes/testing/poisson.py:20-87)
+# --------------------------------------------------------------------------
+def poisson_rhs(mesh: OMesh) -> Tensor:
+    g = mesh.grid
+    rhs = torch.zeros(1, *mesh.nx, dtype=mesh.dtype)
+    if mesh.dim == 1:
+        rhs[0] = 1.0 - 2.0 * g[0] ** 2
+    elif mesh.dim == 2:
+        rhs[0] = 6.0 * g[0] * g[1] * (1.0 - g[1]) - 2.0 * (g[0] ** 3)
+    else:
+        rhs[0] = torch.sin(math.pi * g[0]) * torch.sin(math.pi * g[1]) * torch.sin(math.pi * g[2])
+    return rhs
+
+
+def poisson_exact(mesh: OMesh) -> Tensor:
+    g = mesh.grid
+    if mesh.dim == 1:
+        return 7.0 / 9.0 - 2.0 / 9.0 * g[0] + g[0] ** 2 / 2.0 - g[0] ** 4 / 6.0
+    if mesh.dim == 2:
+        return g[1] * (1.0 - g[1]) * (g[0] ** 3)
+    return (-1.0 / (3 * math.pi ** 2) * torch.sin(math.pi * g[0]) * torch.sin(math.pi * g[1])
+            * torch.sin(math.pi * g[2]))
+
+
+def _p1(grid, mask, *_):
+    return 7.0 / 9.0 - 2.0 / 9.0 * grid[0][mask] + grid[0][mask] ** 2 / 2.0 - grid[0][mask] ** 4 / 6.0
+
+
+def _p2(grid, mask, *_):
+    return grid[1][mask] * (1.0 - grid[1][mask]) * (grid[0][mask] ** 3)
+
+
+def poisson_cfg(dim: int) -> list[dict]:
+    val: Any = _p1 if dim == 1 else (_p2 if dim == 2 else 0.0)
+    return [{"bc_face": FACES[i], "bc_type": "dirichlet", "bc_val": val} for i in range(2 * dim)]
+
+
+# --------------------------------------------------------------------------
+# convenience: the equation  sign*laplacian(coeff, x) == rhs  end to end
+# (fdm.py:124-169 + ops.py:47-81 + linalg.py:33-71)
+# --------------------------------------------------------------------------
+def solve_poisson(mesh: OMesh, bc_cfg: Sequence[dict], rhs: Tensor, x0: Tensor | None = None,
+                  method: str = "cg", tol: float = 1e-6, max_it: int = 1000,
+                  coeff: float | None = 1.0, sign: float = 1.0, **kw):
+    """NOTE: like the reference (ops.py:61-77) the caller's ``rhs`` is modified in
+    place by the rhs adjustment."""
+    bcs = make_bcs(mesh, bc_cfg)
+    x = torch.zeros(1, *mesh.nx, dtype=mesh.dtype) if x0 is None else x0
+    tabs = laplacian_tables(x, mesh, bcs)
+    rhs += laplacian_rhs_adjust(x, mesh, bcs)
+    terms = [OTerm("laplacian", tabs, coeff, sign)]
+    fn = {"cg": cg, "bicgstab": bicgstab, "jacobi": jacobi}[method.lower()]
+    return fn(x, rhs, terms, mesh, bcs, tol, max_it, **kw)

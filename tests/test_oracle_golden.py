@@ -1,0 +1,121 @@
+"""The oracle (CPU restatement) against the golden vectors produced by the reference.
+
+These pin the oracle: operator / BC-fill / rhs outputs bit-exact, solver results
+<= 1e-13 rel (fp64) with identical iteration counts.  CPU only.
+"""
+import warnings
+
+import numpy as np
+import pytest
+import torch
+
+import pyapes_oracle as O
+from conftest import golden_cases, golden_load
+
+warnings.filterwarnings("ignore")
+
+
+def _cfg(case):
+    nd = len(case["lower"])
+    if case["bcs"] == "poisson":
+        return O.poisson_cfg(nd)
+    return [{"bc_face": O.FACES[i], "bc_type": t, "bc_val": v} for i, (t, v) in enumerate(case["bcs"])]
+
+
+def _mesh(case):
+    return O.OMesh(case["lower"], case["upper"], case["spacing"], case["dtype"])
+
+
+def _eq(a, b, what):
+    assert torch.equal(torch.as_tensor(a), torch.as_tensor(b)), f"{what}: not bit-exact"
+
+
+@pytest.mark.parametrize("case", golden_cases("ops"), ids=lambda c: c["name"])
+def test_oracle_ops_bit_exact(case):
+    g = golden_load(case["name"])
+    mesh = _mesh(case)
+    nd = mesh.dim
+    bcs = O.make_bcs(mesh, _cfg(case))
+    x = torch.from_numpy(g["x0"]).clone()
+    O.bc_fill(x, bcs)
+    _eq(x, g["bc_fill"], "bc_fill")
+    tabs = O.laplacian_tables(x, mesh, bcs)
+    rhs = torch.from_numpy(g["rhs0"]).clone() + O.laplacian_rhs_adjust(x, mesh, bcs)
+    _eq(rhs, g["rhs_set_eq"], "rhs_set_eq")
+    coeff, sign = case.get("coeff", 1.0), case.get("sign", 1.0)
+    _eq(O.Aop(x, [O.OTerm("laplacian", tabs, coeff, sign)], nd), g["aop"], "aop")
+    lap = O.apply_laplacian(tabs, x, nd)
+    _eq(lap, g["lap"], "lap")
+    O.edge_laplacian(lap, x, mesh)
+    _eq(lap, g["lap_edge"], "lap_edge")
+    gr = O.apply_grad(O.grad_tables(x, mesh, bcs), x, nd)
+    _eq(gr, g["grad"], "grad")
+    O.edge_grad(gr, x, mesh)
+    _eq(gr, g["grad_edge"], "grad_edge")
+    _eq(O.grad_rhs_adjust(x, mesh, bcs), g["grad_rhs_adj"], "grad_rhs_adj")
+    ut = torch.from_numpy(g["u_tensor"])
+    u = case.get("u", 1.5)
+    if "div_none_f" in g:
+        _eq(O.apply_div(O.div_tables(u, x, mesh, bcs, "none"), x, nd), g["div_none_f"], "div_none_f")
+        _eq(O.apply_div(O.div_tables(ut, x, mesh, bcs, "none"), x, nd), g["div_none_t"], "div_none_t")
+    _eq(O.apply_div(O.div_tables(u, x, mesh, bcs, "upwind"), x, nd), g["div_upwind_f"], "div_upwind_f")
+    _eq(O.apply_div(O.div_tables(ut, x, mesh, bcs, "upwind"), x, nd), g["div_upwind_t"], "div_upwind_t")
+
+
+@pytest.mark.parametrize("case", golden_cases("solve"), ids=lambda c: c["name"])
+def test_oracle_solve(case):
+    g = golden_load(case["name"])
+    mesh = _mesh(case)
+    rtol = 1e-13 if case["dtype"] == "double" else 1e-6
+    for K in case["max_its"]:
+        rep_ref = g["_reports"][str(K)]
+        x, rep = O.solve_poisson(mesh, _cfg(case), torch.from_numpy(g["rhs0"]).clone(),
+                                 method=case["method"], tol=case["tol"], max_it=K,
+                                 coeff=case.get("coeff", 1.0), sign=case.get("sign", 1.0))
+        assert rep["itr"] == rep_ref["itr"]
+        assert rep["converge"] == rep_ref["converge"]
+        ref = torch.from_numpy(g[f"x_K{K}"]).double()
+        err = float(torch.linalg.norm(x.double() - ref)) / max(float(torch.linalg.norm(ref)), 1e-300)
+        assert err <= rtol, (case["name"], K, err)
+
+
+def test_known_answers():
+    """Iteration counts recorded by the reference's demo notebook / survey probes
+    (demos/poisson_equations/pure_dirichlet.ipynb:107-108)."""
+    g = golden_load("cg2d_poisson_n100_f64")["_reports"]["1000"]
+    assert g["itr"] == 210 and abs(g["tol"] - 9.661285603057063e-07) < 1e-15
+    assert golden_load("cg2d_poisson128_f64")["_reports"]["1000"]["itr"] == 271
+    assert golden_load("cg3d_mix33_f64")["_reports"]["1000"]["itr"] == 402
+    r = golden_load("cg3d_poisson_dx01_f64")["_reports"]["1000"]
+    assert r["itr"] == 2 and abs(r["tol"] - 2.5114204125896697e-17) < 1e-25
+
+
+def test_reference_csv_fixture():
+    """tests/test_solver.py:91-151 of the reference: BiCGSTAB heat conduction vs its CSV."""
+    case = [c for c in golden_cases("solve") if c["name"] == "bicg2d_heat_f64"][0]
+    g = golden_load(case["name"])
+    ref = golden_load("ref_heat_10x10")["sol"]
+    mesh = _mesh(case)
+    x, rep = O.solve_poisson(mesh, _cfg(case), torch.from_numpy(g["rhs0"]).clone(), method="bicgstab",
+                             tol=case["tol"], max_it=1000, coeff=None)
+    np.testing.assert_allclose(x[0][:-1, :-1].numpy(), ref, atol=0.01, rtol=0.01)
+
+
+def test_jacobi_reaches_cg_solution():
+    """[NEW] Jacobi has no reference: converged Jacobi == reference CG solution to solver tol."""
+    mesh = O.OMesh([0.0, 0.0], [1.0, 1.0], [17, 17], "double")
+    rhs = O.poisson_rhs(mesh)
+    xj, rj = O.solve_poisson(mesh, O.poisson_cfg(2), rhs.clone(), method="jacobi", tol=1e-10, max_it=20000)
+    xc, rc = O.solve_poisson(mesh, O.poisson_cfg(2), rhs.clone(), method="cg", tol=1e-12, max_it=1000)
+    assert rj["converge"] and rc["converge"]
+    assert float((xj - xc).abs().max()) < 1e-7
+
+
+def test_upwind_intended_closed_form():
+    """[NEW] intended upwind: u (phi_i - phi_{i-1}) / dx for u>0 (reference tests/test_fdm.py:239)."""
+    mesh = O.OMesh([0.0], [1.0], [11], "double")
+    phi = torch.zeros(1, 11, dtype=torch.float64)
+    phi[0] = mesh.grid[0] ** 2
+    out = O.div_upwind_intended(2.0, phi, mesh)
+    expect = 2.0 * (phi[0][1:-1] - phi[0][:-2]) / mesh.dx[0]
+    assert torch.allclose(out[0][1:-1], expect, rtol=0, atol=1e-14)
