@@ -1,0 +1,179 @@
+/*
+ * pyapes_hip.h -- C ABI of libpyapes_hip.so, the MI355X (gfx950) FDM stencil +
+ * iterative-solve core that drops in under pyapes/solver and pyapes/backend.
+ *
+ * The reference (kyoungseoun-chung/pyapes v0.2.13) is pure Python/torch and has
+ * no FFI; the seams this library replaces are the Python call sites listed per
+ * entry point below (paths relative to the reference repo).  The host side that
+ * binds this ABI with ctypes is pyapes_amd/hip/lib.py; INTEGRATION.md shows the
+ * stub a pyapes maintainer would add.
+ *
+ * Conventions
+ *   - Every pointer named x/y/rhs/phi/... is a DEVICE pointer to a C-contiguous
+ *     scalar field (n0[,n1[,n2]]) of the ctx dtype (float or double).  The caller
+ *     (PyTorch-ROCm tensors, tensor.data_ptr()) owns all of them; the library
+ *     never allocates user-visible memory, only its own scratch.
+ *   - Faces are numbered 0..5 = xl,xu,yl,yu,zl,zu (pyapes/geometry/basis.py:16).
+ *   - One ctx <-> one HIP stream <-> one host thread.  Distinct ctxs are
+ *     independent (the reference's class-level singletons are not).
+ *   - Return value 0 = ok, <0 = error (PA_E_*); pa_last_error() gives the text.
+ *     Non-convergence is not an error (report.converge = 0), as in the reference.
+ *   - All work is enqueued on the ctx stream; only the solver entry points and
+ *     pa_report_read synchronise the stream.
+ */
+#ifndef PYAPES_HIP_H
+#define PYAPES_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct pa_ctx pa_ctx;
+
+enum { PA_F32 = 0, PA_F64 = 1 };
+
+/* boundary types: pyapes/variables/bcs.py:197-280, BC_FACTORY :460 */
+enum { PA_BC_NONE = 0, PA_BC_DIRICHLET = 1, PA_BC_NEUMANN = 2, PA_BC_SYMMETRY = 3, PA_BC_PERIODIC = 4 };
+
+/* operator kinds: pyapes/solver/fdc.py Laplacian :369, Grad :461, Div :612 */
+enum {
+  PA_OP_LAPLACIAN = 0,
+  PA_OP_GRAD = 1,          /* solver use is 1-D only (ops.py:145-147) */
+  PA_OP_DIV_CENTRAL = 2,   /* limiter "none"  (fdc.py:708-743) */
+  PA_OP_DIV_UPWIND_COMPAT = 3, /* limiter "upwind", literal reference output (fdc.py:746-772) */
+  PA_OP_DIV_UPWIND = 4     /* first-order upwind as the reference's test states it (tests/test_fdm.py:239) */
+};
+
+enum {
+  PA_OK = 0,
+  PA_E_ARG = -1,       /* bad argument / unsupported configuration */
+  PA_E_HIP = -2,       /* HIP runtime error */
+  PA_E_STATE = -3,     /* call order (grid / equation not set) */
+  PA_E_NONFINITE = -4  /* stop-test value became NaN/Inf: RuntimeError in linalg.py:334-336 */
+};
+
+/* pyapes/solver/linalg.py:22-30 ReportType, plus timing/diagnostics (non-breaking) */
+typedef struct {
+  int64_t itr;       /* iterations executed */
+  double tol;        /* last stop-test value */
+  int32_t converge;  /* itr < max_it */
+  int32_t status;    /* PA_OK or PA_E_NONFINITE */
+  double rr;         /* last sum r.r (diagnostic) */
+  double gpu_ms;     /* stream time of the solve loop (HIP events) */
+} pa_report;
+
+/* one term of  sum_k sign_k * param_k * Op_k(x)   (pyapes/solver/ops.py:122-154, fdm.py OPStype) */
+typedef struct {
+  int32_t kind;          /* PA_OP_* */
+  int32_t has_coeff;     /* laplacian/grad: param is not None (fdm.py:166-169) */
+  double sign;           /* +1 / -1 (fdm.py:95-105) */
+  double coeff;          /* scalar param */
+  const void* coeff_field; /* tensor param (device, field-shaped) or NULL */
+  double u;              /* div: scalar advection speed (fdc.py:778-779) */
+  const void* u_field;   /* div: advection tensor (device, field-shaped) or NULL */
+} pa_term;
+
+/* ---- context ---------------------------------------------------------- */
+/* replaces: device/dtype gate Mesh(..., device, dtype) pyapes/mesh/_mesh.py:30-44, backend.py:7-94 */
+int pa_ctx_create(int device, void* hip_stream, pa_ctx** out);
+int pa_ctx_destroy(pa_ctx* ctx);
+const char* pa_last_error(const pa_ctx* ctx); /* ctx may be NULL: error of the failed create */
+const char* pa_version(void);
+
+/* ---- grid -------------------------------------------------------------
+ * replaces: Mesh node counts / spacing (pyapes/mesh/_mesh.py:67-93, 258-298).
+ * n[]: LOCAL node counts; dx[]: spacing exactly as stored in the mesh dtype.
+ * Slab decomposition (new): this rank owns global planes
+ * [i_off, i_off + n[0]) of n0_global along axis 0.  Single GPU: i_off = 0,
+ * n0_global = n[0]. */
+int pa_grid_set(pa_ctx* ctx, int ndim, const int64_t* n, const double* dx, int dtype,
+                int64_t i_off, int64_t n0_global);
+
+/* ---- boundary conditions ---------------------------------------------
+ * replaces: BC objects + BC.apply (pyapes/variables/bcs.py:70-95, 200-280) and the
+ * list order of Field.bcs (fields.py:378-416).  order_pos = position in the
+ * application list.  value/face_vals: Dirichlet value g, or Neumann gradient V,
+ * scalar or per-node array in boolean-mask gather order (= C order of the face
+ * plane); face_vals is a device pointer the caller keeps alive, or NULL.
+ * dxf = grid[face] - grid[prev] (the literal coordinate difference used by
+ * Neumann.apply, bcs.py:228-231); ignored for the other types. */
+int pa_bc_set(pa_ctx* ctx, int face, int order_pos, int type, double value,
+              const void* face_vals, double dxf);
+int pa_bc_clear(pa_ctx* ctx);
+/* linalg._apply_bc_otf (linalg.py:282-299): all faces, in order, in place */
+int pa_apply_bc(pa_ctx* ctx, void* x);
+
+/* ---- equation ---------------------------------------------------------
+ * replaces: the ops dict built by fdm.laplacian/grad/div(...) and +,-,neg
+ * (pyapes/solver/fdm.py:75-105, 124-312) consumed by ops._Aop (ops.py:122-154) */
+int pa_eq_set(pa_ctx* ctx, int nterms, const pa_term* terms);
+/* y = sum_k sign_k param_k Op_k(x).  interior_only=0: every node, wrap-around
+ * neighbours like torch.roll (fdc.py:171-200); 1: interior set S only
+ * (mesh/tools.py:7-20), y = 0 elsewhere. */
+int pa_aop(pa_ctx* ctx, const void* x, void* y, int interior_only);
+/* rhs += sum_k rhs_adj_k  (Solver.set_eq, ops.py:63-77; fdc.py:426-458, 505-540, 667-694) */
+int pa_rhs_adjust(pa_ctx* ctx, void* rhs);
+
+/* ---- explicit operators (Discretizer.__call__/apply, fdc.py:67-168) ---- */
+int pa_laplacian(pa_ctx* ctx, const void* x, void* y, int edge);
+/* y is (ndim, n...) */
+int pa_grad(pa_ctx* ctx, const void* x, void* y, int edge);
+/* kind = PA_OP_DIV_*; u_field NULL -> scalar u */
+int pa_div(pa_ctx* ctx, int kind, double u, const void* u_field, const void* x, void* y);
+
+/* ---- solvers (linalg.solve -> cg | bicgstab, linalg.py:33-279) --------- */
+int pa_cg(pa_ctx* ctx, void* x, const void* rhs, double tol, int64_t max_it, pa_report* out);
+int pa_bicgstab(pa_ctx* ctx, void* x, const void* rhs, double tol, int64_t max_it, pa_report* out);
+/* new: weighted Jacobi with the CG's BC fill / interior set / stop test */
+int pa_jacobi(pa_ctx* ctx, void* x, const void* rhs, double tol, int64_t max_it, double omega,
+              pa_report* out);
+/* new: phi_out = B(phi + dt (nu lap(phi) - div(u phi))) on the interior set */
+int pa_euler_step(pa_ctx* ctx, const void* phi_in, void* phi_out, int div_kind, double u,
+                  const void* u_field, double nu, double dt);
+
+/* ---- stepwise CG (slab-decomposed multi-GPU driver and bench.py) -------
+ * pa_cg above is the single-GPU loop.  The stepwise form lets a host driver put
+ * the halo exchange and the scalar all-reduces (RCCL through torch.distributed)
+ * between the phases of one iteration:
+ *   begin -> [exchange r planes] -> [all-reduce sums] -> per iteration:
+ *     phase_a   d' = r + beta d, local sum d'.(A d')        -> [all-reduce sums]
+ *     phase_b   alpha; x += alpha d'; r -= alpha A d'; BC fill; local sums
+ *               -> [exchange r planes] -> [all-reduce sums]
+ *     finish_iter   beta, stop test, iteration count (device side)
+ * With no slab set (P = 1) the reductions and scalar logic run inside the phases
+ * and finish_iter is a no-op.  Nothing here synchronises the stream. */
+#define PA_NSUM 8
+enum { PA_SUM_DAD = 0, PA_SUM_RR = 1, PA_SUM_DX2 = 2 };
+
+/* Exchange buffers of a slab rank; all device pointers owned by the caller
+ * (torch tensors), n1*n2 elements per plane.  NULL recv pointer = physical
+ * (non-periodic) end of the domain on that side. */
+typedef struct {
+  void* sums;              /* PA_NSUM doubles: local partial sums out, all-reduced sums in */
+  void* r_send_lo;         /* out: first owned plane of r (after begin / phase_b) */
+  void* r_send_hi;         /* out: last owned plane of r */
+  const void* r_recv_lo;   /* in: ghost plane of r below the slab */
+  const void* r_recv_hi;   /* in: ghost plane of r above the slab */
+  const void* x_ghost_lo;  /* in: ghost planes of x for the initial residual / pa_aop */
+  const void* x_ghost_hi;
+  const void* bc_far_lo0;  /* periodic axis-0 BC fill on the lower end rank: x[N-1], x[N-2] */
+  const void* bc_far_lo1;
+  const void* bc_far_hi0;  /* ... on the upper end rank: the new x[0] */
+} pa_slab;
+int pa_slab_set(pa_ctx* ctx, const pa_slab* slab); /* NULL: back to single GPU */
+
+int pa_cg_begin(pa_ctx* ctx, void* x, const void* rhs, double tol, int64_t max_it);
+int pa_cg_phase_a(pa_ctx* ctx);
+int pa_cg_phase_b(pa_ctx* ctx);
+int pa_cg_finish_iter(pa_ctx* ctx);
+/* P = 1 only: enqueue n whole iterations back to back */
+int pa_cg_iterate(pa_ctx* ctx, int64_t n);
+int pa_cg_end(pa_ctx* ctx, pa_report* out);       /* synchronises */
+int pa_report_read(pa_ctx* ctx, pa_report* out);  /* synchronises */
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PYAPES_HIP_H */

@@ -1,0 +1,1729 @@
+// pa_core.hip -- libpyapes_hip: generic (any dimension / extent / BC mix) kernels and
+// the host side of the C ABI declared in include/pyapes_hip.h.  gfx950 only.
+//
+// Reference seams (paths relative to the reference repo) are cited per function.
+// The 3-D fast-path kernels for the CG phases live in pa_cg3d.hip.
+#include "pa_host.h"
+
+#include <math.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <algorithm>
+#include <new>
+
+// ============================================================================
+//  kernels
+// ============================================================================
+
+__device__ __forceinline__ void pa_decode(const DevGeom& G, int64_t idx, int64_t& i, int64_t& j, int64_t& k) {
+  i = idx / G.s0;
+  int64_t rem = idx - i * G.s0;
+  j = rem / G.s1;
+  k = rem - j * G.s1;
+}
+
+// ---- BC fill of one face (pyapes/variables/bcs.py:200-280) --------------------------
+template <typename T>
+struct BCArgs {
+  int axis, side, type;
+  T sval;            // dirichlet value, or neumann additive constant for scalar V
+  const T* vals;     // per-node values (dirichlet g / neumann V) or null
+  T c23, dxf, ndir;  // neumann with per-node V: ((2/3)*V)*dxf*ndir
+  T c43, c13;
+  const T* far0;     // periodic axis-0 on a slab: planes that live on the other end rank
+  const T* far1;
+  const int* done;   // when set and *done != 0 the fill is skipped (iterate already final)
+};
+
+template <typename T>
+__global__ void __launch_bounds__(PA_BLOCK) k_bc_face(DevGeom G, T* __restrict__ x, BCArgs<T> B) {
+  if (B.done && *B.done) return;
+  const int a = B.axis;
+  const int64_t nu = (a == 0) ? G.n1 : G.n0;
+  const int64_t nv = (a == 2) ? G.n1 : G.n2;
+  const int64_t N = (a == 0) ? G.g0 : (a == 1 ? G.n1 : G.n2);
+  const int64_t off = (a == 0) ? G.off0 : 0;
+  const int64_t st = (a == 0) ? G.s0 : (a == 1 ? G.s1 : 1);
+  for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < nu * nv;
+       q += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t u = q / nv, v = q - u * nv;
+    int64_t base;  // offset of the node with axis index 0
+    if (a == 0) base = u * G.s1 + v;
+    else if (a == 1) base = u * G.s0 + v;
+    else base = u * G.s0 + v * G.s1;
+    const int64_t f = (B.side == 0) ? 0 : N - 1;
+    const int64_t p1 = (B.side == 0) ? pa_wrap(1, N) : pa_wrap(N - 2, N);
+    const int64_t p2 = (B.side == 0) ? pa_wrap(2 % N, N) : pa_wrap(N - 3 < 0 ? N - 3 + N : N - 3, N);
+    T* xf = x + base + (f - off) * st;
+    if (B.type == 1) {
+      *xf = B.vals ? B.vals[q] : B.sval;
+    } else if (B.type == 2) {
+      T vp = x[base + (p1 - off) * st];
+      T vpp = x[base + (p2 - off) * st];
+      T ct;
+      if (B.vals) {
+        ct = B.c23 * B.vals[q];
+        ct = ct * B.dxf;
+        ct = ct * B.ndir;
+      } else {
+        ct = B.sval;
+      }
+      T t1 = B.c43 * vp;
+      T t2 = B.c13 * vpp;
+      t1 = t1 - t2;
+      *xf = t1 + ct;
+    } else if (B.type == 3) {
+      *xf = x[base + (p1 - off) * st];
+    } else if (B.type == 4) {
+      if (B.side == 0) {
+        // x[0] = x[1] - x[N-1] + x[N-2]
+        T vp = x[base + (p1 - off) * st];
+        T vf, vff;
+        if (B.far0) {
+          vf = B.far0[q];
+          vff = B.far1[q];
+        } else {
+          vf = x[base + (N - 1 - off) * st];
+          vff = x[base + (pa_wrap(N - 2, N) - off) * st];
+        }
+        T t1 = vp - vf;
+        *xf = t1 + vff;
+      } else {
+        *xf = B.far0 ? B.far0[q] : x[base + (0 - off) * st];
+      }
+    }
+  }
+}
+
+// ---- y = A(x) (pyapes/solver/ops.py:122-154) -----------------------------------------
+template <typename T>
+__global__ void __launch_bounds__(PA_BLOCK) k_aop(DevGeom G, DevEq<T> E, Vec<T> xv, T* __restrict__ y,
+                                                   int interior_only) {
+  FieldAcc<T> acc{xv};
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < G.ncell;
+       idx += (int64_t)gridDim.x * blockDim.x) {
+    int64_t i, j, k;
+    pa_decode(G, idx, i, j, k);
+    T out = (T)0;
+    if (!interior_only || pa_in_S(G, i, j, k)) {
+      T xc = xv.p[idx];
+      out = pa_apply_terms<T>(G, E, acc, i, j, k, xc);
+    }
+    y[idx] = out;
+  }
+}
+
+// ---- explicit gradient: y[(a), n...] (fdc.py:80-87) -----------------------------------
+template <typename T>
+__global__ void __launch_bounds__(PA_BLOCK) k_grad(DevGeom G, DevEq<T> E, Vec<T> xv, T* __restrict__ y,
+                                                    int nd) {
+  FieldAcc<T> acc{xv};
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < G.ncell;
+       idx += (int64_t)gridDim.x * blockDim.x) {
+    int64_t i, j, k;
+    pa_decode(G, idx, i, j, k);
+    int64_t g[3], N[3];
+    pa_gidx(G, i, j, k, g, N);
+    T xc = xv.p[idx];
+    for (int a = 3 - nd; a < 3; ++a) {
+      T cP = E.grd.g[a], cC = (T)0, cM = E.grd.mg[a];
+      int rc = pa_row_case(G, a, g[a], N[a], G.treat);
+      if (rc == 1) { cP = E.grd.lo_p[a]; cC = E.grd.lo_c[a]; cM = (T)0; }
+      if (rc == 2) { cP = (T)0; cC = E.grd.hi_c[a]; cM = E.grd.hi_m[a]; }
+      if (G.bct[2 * a] == 4 && g[a] == 1) cM = (T)0;
+      if (G.bct[2 * a + 1] == 4 && g[a] == N[a] - 2) cP = (T)0;
+      T xp, xm;
+      pa_nbrs<T>(G, acc, a, i, j, k, xp, xm);
+      T s = cP * xp;
+      T m = cC * xc;
+      s = s + m;
+      m = cM * xm;
+      s = s + m;
+      y[(int64_t)(a - (3 - nd)) * G.ncell + idx] = s;
+    }
+  }
+}
+
+// ---- edge=True one-sided boundary formulas (fdc.py:203-288) ---------------------------
+// mode 0: laplacian (y is one field; the LAST mesh axis whose index is on the boundary wins,
+// because the reference overwrites faces axis by axis); mode 1: grad (y[a] on faces normal to a).
+template <typename T>
+__global__ void __launch_bounds__(PA_BLOCK) k_edge(DevGeom G, DevEq<T> E, const T* __restrict__ x,
+                                                    T* __restrict__ y, int nd, int mode) {
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < G.ncell;
+       idx += (int64_t)gridDim.x * blockDim.x) {
+    int64_t i, j, k;
+    pa_decode(G, idx, i, j, k);
+    int64_t c[3] = {i, j, k};
+    int64_t n[3] = {G.n0, G.n1, G.n2};
+    int64_t st[3] = {G.s0, G.s1, 1};
+    if (mode == 0) {
+      int sel = -1;
+      for (int a = 3 - nd; a < 3; ++a)
+        if (c[a] == 0 || c[a] == n[a] - 1) sel = a;
+      if (sel < 0) continue;
+      int64_t dir = (c[sel] == 0) ? 1 : -1;
+      T v0 = x[idx], v1 = x[idx + dir * st[sel]], v2 = x[idx + 2 * dir * st[sel]],
+        v3 = x[idx + 3 * dir * st[sel]];
+      T s = (T)2 * v0;
+      T m = (T)5 * v1;
+      s = s - m;
+      m = (T)4 * v2;
+      s = s + m;
+      s = s - v3;
+      T h2 = E.grd.h[sel] * E.grd.h[sel];
+      y[idx] = s / h2;
+    } else {
+      for (int a = 3 - nd; a < 3; ++a) {
+        if (!(c[a] == 0 || c[a] == n[a] - 1)) continue;
+        int64_t dir = (c[a] == 0) ? 1 : -1;
+        T v0 = x[idx], v1 = x[idx + dir * st[a]], v2 = x[idx + 2 * dir * st[a]];
+        T s = (T)1.5 * v0;
+        T m = (T)2 * v1;
+        s = s - m;
+        m = (T)0.5 * v2;
+        s = s + m;
+        if (c[a] == 0) s = -s;
+        y[(int64_t)(a - (3 - nd)) * G.ncell + idx] = s / E.grd.h[a];
+      }
+    }
+  }
+}
+
+// ---- rhs adjustment of Solver.set_eq (ops.py:63-77; fdc.py:426-458, 505-540, 667-694) --
+template <typename T>
+struct RhsFace {
+  int type;       // PA_BC_*
+  T sval;         // scalar V
+  const T* vals;  // per-node V or null
+};
+template <typename T>
+struct RhsArgs {
+  RhsFace<T> f[6];
+  int order[6];   // internal face ids in list order
+  int nfaces;
+  T c23, c13;     // (T)(2/3), (T)(1/3)
+  T h[3];
+};
+
+template <typename T>
+__device__ __forceinline__ T pa_face_val(const DevGeom& G, const RhsFace<T>& F, int a, int64_t i, int64_t j,
+                                         int64_t k) {
+  if (!F.vals) return F.sval;
+  if (a == 0) return F.vals[j * G.n2 + k];
+  if (a == 1) return F.vals[i * G.n2 + k];
+  return F.vals[i * G.n1 + j];
+}
+
+template <typename T>
+__global__ void __launch_bounds__(PA_BLOCK) k_rhs_adjust(DevGeom G, DevEq<T> E, RhsArgs<T> R,
+                                                          T* __restrict__ rhs) {
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < G.ncell;
+       idx += (int64_t)gridDim.x * blockDim.x) {
+    int64_t i, j, k;
+    pa_decode(G, idx, i, j, k);
+    int64_t g[3], N[3];
+    pa_gidx(G, i, j, k, g, N);
+    T val = rhs[idx];
+    bool touched = false;
+    for (int q = 0; q < E.nterms; ++q) {
+      const DevTerm<T>& t = E.t[q];
+      T adj = (T)0;
+      bool any = false;
+      // reference loop nest: for axis j: for bc in list order (only faces normal to j contribute)
+      for (int a = 0; a < 3; ++a) {
+        if (!G.act[a]) continue;
+        for (int w = 0; w < R.nfaces; ++w) {
+          int fc = R.order[w];
+          if ((fc >> 1) != a) continue;
+          if (R.f[fc].type != 2) continue;
+          int side = fc & 1;
+          int64_t prev = side == 0 ? pa_wrap(1, N[a]) : pa_wrap(N[a] - 2, N[a]);
+          if (g[a] != prev) continue;
+          T V = pa_face_val<T>(G, R.f[fc], a, i, j, k);
+          T nv = side == 0 ? (T)-1 : (T)1;
+          T vn = V * nv;
+          if (t.kind == 0) {            // laplacian: += (2/3)(V n)/h   (fdc.py:450-453)
+            T s = R.c23 * vn;
+            s = s / R.h[a];
+            adj = adj + s;
+          } else if (t.kind == 1) {     // grad: -= (1/3)(V n) * 1      (fdc.py:526-537)
+            T s = R.c13 * vn;
+            adj = adj - s;
+          } else {                      // div: -= (1/3)(V n) * gamma   (fdc.py:680-686)
+            T ucen = t.u_f ? t.u_f[idx] : t.u;
+            T gm;
+            if (t.kind == 2) gm = (T)2 * ucen;
+            else {
+              // upwind: lower face uses 2*max(u,0), upper face 2*min(u,0)
+              T mx = ucen > (T)0 ? ucen : (T)0, mn = ucen < (T)0 ? ucen : (T)0;
+              gm = side == 0 ? (T)2 * mx : (T)2 * mn;
+            }
+            T s = R.c13 * vn;
+            s = s * gm;
+            adj = adj - s;
+          }
+          any = true;
+        }
+      }
+      if (any) { val = val + adj; touched = true; }
+    }
+    if (touched) rhs[idx] = val;
+  }
+}
+
+// ---- device-resident solver scalars ---------------------------------------------------
+struct SolverScalars {
+  double rr, rr_old, dAd, alpha, beta, tol, tolerance;
+  double rho, omega, rho_next, r0v, ts, tt, r0t;  // bicgstab
+  long long itr, max_it;
+  int done, err, finished_early;
+};
+
+// ---- CG: r = (b - A x) on S, d = r, partial sum r.r (linalg.py:98-107) ---------------
+template <typename T>
+__global__ void __launch_bounds__(PA_BLOCK) k_cg_init(DevGeom G, DevEq<T> E, Vec<T> xv,
+                                                       const T* __restrict__ rhs, T* __restrict__ r,
+                                                       T* __restrict__ d, double* __restrict__ partials) {
+  FieldAcc<T> acc{xv};
+  double s[1] = {0.0};
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < G.ncell;
+       idx += (int64_t)gridDim.x * blockDim.x) {
+    int64_t i, j, k;
+    pa_decode(G, idx, i, j, k);
+    T rv = (T)0;
+    if (pa_in_S(G, i, j, k)) {
+      T ax = pa_apply_terms<T>(G, E, acc, i, j, k, xv.p[idx]);
+      rv = rhs[idx] - ax;
+      T p = rv * rv;
+      s[0] += (double)p;
+    }
+    r[idx] = rv;
+    if (d) d[idx] = rv;
+  }
+  pa_block_reduce_store<1>(s, partials);
+}
+
+// ---- CG phase A: d' = r + beta d ; partial sum d'.(A d')  (linalg.py:115-120, 141) ----
+template <typename T>
+__global__ void __launch_bounds__(PA_BLOCK) k_cg_a(DevGeom G, DevEq<T> E, const SolverScalars* __restrict__ sc,
+                                                    Vec<T> rv, Vec<T> dv, T* __restrict__ dnew,
+                                                    double* __restrict__ partials) {
+  if (sc->done) return;
+  DirAcc<T> acc{rv, dv, (T)sc->beta};
+  double s[1] = {0.0};
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < G.ncell;
+       idx += (int64_t)gridDim.x * blockDim.x) {
+    int64_t i, j, k;
+    pa_decode(G, idx, i, j, k);
+    T e = (T)0;
+    if (pa_in_S(G, i, j, k)) {
+      e = acc.at(G, i, j, k);
+      T Ad = pa_apply_terms<T>(G, E, acc, i, j, k, e);
+      T p = e * Ad;
+      s[0] += (double)p;
+    }
+    dnew[idx] = e;
+  }
+  pa_block_reduce_store<1>(s, partials);
+}
+
+// ---- CG phase B: x += alpha d ; r -= alpha A d ; partial sums r.r and |dx|^2 off-shell
+//      (linalg.py:122-134)
+template <typename T>
+__global__ void __launch_bounds__(PA_BLOCK) k_cg_b(DevGeom G, DevEq<T> E, const SolverScalars* __restrict__ sc,
+                                                    Vec<T> dv, T* __restrict__ x, T* __restrict__ r,
+                                                    T* __restrict__ send_lo, T* __restrict__ send_hi,
+                                                    double* __restrict__ partials) {
+  if (sc->done) return;
+  FieldAcc<T> acc{dv};
+  const T alpha = (T)sc->alpha;
+  double s[2] = {0.0, 0.0};
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < G.ncell;
+       idx += (int64_t)gridDim.x * blockDim.x) {
+    int64_t i, j, k;
+    pa_decode(G, idx, i, j, k);
+    T rn = (T)0;
+    if (pa_in_S(G, i, j, k)) {
+      T dc = dv.p[idx];
+      T Ad = pa_apply_terms<T>(G, E, acc, i, j, k, dc);
+      T xo = x[idx];
+      T ad = alpha * dc;
+      T xn = xo + ad;
+      x[idx] = xn;
+      T aAd = alpha * Ad;
+      rn = r[idx] - aAd;
+      r[idx] = rn;
+      T p = rn * rn;
+      s[0] += (double)p;
+      if (!pa_on_shell(G, i, j, k)) {
+        T df = xn - xo;
+        T p2 = df * df;
+        s[1] += (double)p2;
+      }
+    }
+    if (send_lo && i == 0) send_lo[j * G.s1 + k] = rn;
+    if (send_hi && i == G.n0 - 1) send_hi[j * G.s1 + k] = rn;
+  }
+  pa_block_reduce_store<2>(s, partials);
+}
+
+// ---- boundary shell: sum (x_new - x_old)^2 over shell nodes after the BC fill, and keep
+//      x_old for the next iteration (stop test of linalg.py:134 includes boundary nodes) ---
+template <typename T>
+__global__ void __launch_bounds__(PA_BLOCK) k_shell(DevGeom G, const SolverScalars* __restrict__ sc,
+                                                     const T* __restrict__ x, T* __restrict__ shell_old,
+                                                     double* __restrict__ partials, int mode) {
+  if (mode == 1 && sc->done) return;
+  const int64_t sz[3] = {G.n1 * G.n2, G.n0 * G.n2, G.n0 * G.n1};
+  int64_t total = 0;
+  int64_t start[6];
+  for (int f = 0; f < 6; ++f) {
+    start[f] = total;
+    total += G.act[f >> 1] ? sz[f >> 1] : 0;
+  }
+  double s[1] = {0.0};
+  for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < total;
+       q += (int64_t)gridDim.x * blockDim.x) {
+    int f = 0;
+    for (int w = 1; w < 6; ++w)
+      if (G.act[w >> 1] && q >= start[w]) f = w;
+    const int a = f >> 1, side = f & 1;
+    const int64_t local = q - start[f];
+    int64_t i, j, k;
+    if (a == 0) {
+      // owned by this rank only if it holds the global boundary plane
+      int64_t gi = side == 0 ? 0 : G.g0 - 1;
+      i = gi - G.off0;
+      if (i < 0 || i >= G.n0) continue;
+      j = local / G.n2; k = local - j * G.n2;
+    } else if (a == 1) {
+      i = local / G.n2; k = local - i * G.n2;
+      j = side == 0 ? 0 : G.n1 - 1;
+      int64_t gi = i + G.off0;
+      if (G.act[0] && (gi == 0 || gi == G.g0 - 1)) continue;  // owned by an axis-0 face
+    } else {
+      i = local / G.n1; j = local - i * G.n1;
+      k = side == 0 ? 0 : G.n2 - 1;
+      int64_t gi = i + G.off0;
+      if (G.act[0] && (gi == 0 || gi == G.g0 - 1)) continue;
+      if (G.act[1] && (j == 0 || j == G.n1 - 1)) continue;
+    }
+    // a node on both the lower and the upper face of one axis (extent 1) cannot occur: act => n > 1
+    const int64_t o = i * G.s0 + j * G.s1 + k;
+    T xn = x[o];
+    if (mode == 1) {
+      T df = xn - shell_old[q];
+      T p = df * df;
+      s[0] += (double)p;
+    }
+    shell_old[q] = xn;
+  }
+  if (mode == 1) pa_block_reduce_store<1>(s, partials);
+}
+
+// ---- reductions of per-block partials + scalar logic ------------------------------------
+// sums[slot[s]] (+)= sum over blocks of partials[b*ns + s]
+__device__ __forceinline__ double pa_reduce_partials(const double* __restrict__ partials, int nblk, int ns,
+                                                     int s, double* sm) {
+  double v = 0.0;
+  for (int b = threadIdx.x; b < nblk; b += blockDim.x) v += partials[(int64_t)b * ns + s];
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+  if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = v;
+  __syncthreads();
+  double t = 0.0;
+  if (threadIdx.x == 0)
+    for (int w = 0; w < (int)(blockDim.x >> 6); ++w) t += sm[w];
+  __syncthreads();
+  return t;  // valid on thread 0
+}
+
+template <typename T>
+__device__ __forceinline__ double pa_nan_to_num(T v) {
+  return (isnan(v) || isinf(v)) ? 0.0 : (double)v;  // linalg.py:302-305
+}
+
+// stage 0: reduce only (multi-GPU, before the all-reduce); 1: logic only; 2: both
+template <typename T>
+__global__ void __launch_bounds__(PA_BLOCK) k_cg_post_a(SolverScalars* sc, const double* partials, int nblk,
+                                                         double* sums, int stage) {
+  __shared__ double sm[PA_BLOCK / 64];
+  if (sc->done) return;
+  if (stage != 1) {
+    double v = pa_reduce_partials(partials, nblk, 1, 0, sm);
+    if (threadIdx.x == 0) sums[0] = v;
+  }
+  if (stage != 0 && threadIdx.x == 0) {
+    T dAd = (T)sums[0];
+    T rr = (T)sc->rr;
+    sc->dAd = (double)dAd;
+    sc->alpha = pa_nan_to_num<T>(rr / dAd);
+  }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(PA_BLOCK) k_cg_post_b(SolverScalars* sc, const double* partials, int nblk,
+                                                         const double* partials_shell, int nblk_shell,
+                                                         double* sums, int stage) {
+  __shared__ double sm[PA_BLOCK / 64];
+  if (sc->done) return;
+  if (stage != 1) {
+    double rr = pa_reduce_partials(partials, nblk, 2, 0, sm);
+    double dx2 = pa_reduce_partials(partials, nblk, 2, 1, sm);
+    double sh = nblk_shell > 0 ? pa_reduce_partials(partials_shell, nblk_shell, 1, 0, sm) : 0.0;
+    if (threadIdx.x == 0) {
+      sums[1] = rr;
+      sums[2] = dx2 + sh;
+    }
+  }
+  if (stage != 0 && threadIdx.x == 0) {
+    T rr_new = (T)sums[1];
+    T tol = (T)sqrt(sums[2]);
+    sc->tol = (double)tol;
+    if (isnan(tol) || isinf(tol)) {  // linalg.py:334-336 raises before beta / itr
+      sc->err = 1;
+      sc->done = 1;
+      return;
+    }
+    T rr_old = (T)sc->rr;
+    sc->rr_old = (double)rr_old;
+    sc->beta = (double)(rr_new / rr_old);
+    sc->rr = (double)rr_new;
+    sc->itr += 1;
+    if (sc->itr > sc->max_it || !(sc->tol > sc->tolerance)) sc->done = 1;
+  }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(PA_BLOCK) k_cg_post_init(SolverScalars* sc, const double* partials, int nblk,
+                                                            double* sums, int stage) {
+  __shared__ double sm[PA_BLOCK / 64];
+  if (stage != 1) {
+    double v = pa_reduce_partials(partials, nblk, 1, 0, sm);
+    if (threadIdx.x == 0) sums[1] = v;
+  }
+  if (stage != 0 && threadIdx.x == 0) sc->rr = (double)(T)sums[1];
+}
+
+// ---- Jacobi sweep [new, SURVEY a15] -----------------------------------------------------
+template <typename T>
+__global__ void __launch_bounds__(PA_BLOCK) k_jacobi(DevGeom G, DevEq<T> E, const SolverScalars* __restrict__ sc,
+                                                      Vec<T> xv, const T* __restrict__ rhs,
+                                                      T* __restrict__ xnew, T omega,
+                                                      double* __restrict__ partials) {
+  if (sc->done) return;
+  FieldAcc<T> acc{xv};
+  double s[2] = {0.0, 0.0};
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < G.ncell;
+       idx += (int64_t)gridDim.x * blockDim.x) {
+    int64_t i, j, k;
+    pa_decode(G, idx, i, j, k);
+    T xo = xv.p[idx];
+    T xn = xo;
+    if (pa_in_S(G, i, j, k)) {
+      int64_t g[3], N[3];
+      pa_gidx(G, i, j, k, g, N);
+      T diag = (T)0;
+      for (int q = 0; q < E.nterms; ++q) {
+        const DevTerm<T>& t = E.t[q];
+        T dg = (T)0;
+        for (int a = 0; a < 3; ++a) {
+          if (!G.act[a]) continue;
+          int rc = pa_row_case(G, a, g[a], N[a], G.treat);
+          T cC = rc == 0 ? E.lap.m2inv[a] : -E.lap.c23[a];
+          dg = dg + cC;
+        }
+        if (t.has_coeff) dg = dg * (t.coeff_f ? t.coeff_f[idx] : t.coeff);
+        dg = dg * t.sign;
+        diag = diag + dg;
+      }
+      T ax = pa_apply_terms<T>(G, E, acc, i, j, k, xo);
+      T res = rhs[idx] - ax;
+      res = res / diag;
+      T w = omega * res;
+      xn = xo + w;
+      if (!pa_on_shell(G, i, j, k)) {
+        T df = xn - xo;
+        T p2 = df * df;
+        s[1] += (double)p2;
+      }
+    }
+    xnew[idx] = xn;
+  }
+  pa_block_reduce_store<2>(s, partials);
+}
+
+template <typename T>
+__global__ void __launch_bounds__(PA_BLOCK) k_jacobi_post(SolverScalars* sc, const double* partials, int nblk,
+                                                           const double* partials_shell, int nblk_shell,
+                                                           double* sums) {
+  __shared__ double sm[PA_BLOCK / 64];
+  if (sc->done) return;
+  double dx2 = pa_reduce_partials(partials, nblk, 2, 1, sm);
+  double sh = nblk_shell > 0 ? pa_reduce_partials(partials_shell, nblk_shell, 1, 0, sm) : 0.0;
+  if (threadIdx.x == 0) {
+    sums[2] = dx2 + sh;
+    T tol = (T)sqrt(sums[2]);
+    sc->tol = (double)tol;
+    if (isnan(tol) || isinf(tol)) { sc->err = 1; sc->done = 1; return; }
+    sc->itr += 1;
+    if (sc->itr > sc->max_it || !(sc->tol > sc->tolerance)) sc->done = 1;
+  }
+}
+
+// ---- explicit Euler step [new, SURVEY a15] ----------------------------------------------
+template <typename T>
+__global__ void __launch_bounds__(PA_BLOCK) k_euler(DevGeom G, DevEq<T> Elap, DevEq<T> Eadv, Vec<T> pv,
+                                                     T* __restrict__ out, T nu, T dt) {
+  FieldAcc<T> acc{pv};
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < G.ncell;
+       idx += (int64_t)gridDim.x * blockDim.x) {
+    int64_t i, j, k;
+    pa_decode(G, idx, i, j, k);
+    T pc = pv.p[idx];
+    T v = pc;
+    if (pa_in_S(G, i, j, k)) {
+      T lap = pa_apply_terms<T>(G, Elap, acc, i, j, k, pc);
+      T adv = pa_apply_terms<T>(G, Eadv, acc, i, j, k, pc);
+      T a = nu * lap;
+      a = a - adv;
+      a = dt * a;
+      v = pc + a;
+    }
+    out[idx] = v;
+  }
+}
+
+template <typename T>
+__global__ void k_copy(const T* __restrict__ a, T* __restrict__ b, int64_t n) {
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < n;
+       idx += (int64_t)gridDim.x * blockDim.x)
+    b[idx] = a[idx];
+}
+
+// ---- BiCGSTAB kernels (linalg.py:162-279) ------------------------------------------------
+// p' = r + beta (p - omega v) (with neighbours, so A p' needs no second pass); v' = A p' on S;
+// partial sum r0.v'
+template <typename T>
+struct BicgPAcc {
+  Vec<T> r, p, v;
+  T beta, omega;
+  __device__ __forceinline__ T at(const DevGeom& G, int64_t i, int64_t j, int64_t k) const {
+    T rv, pv, vv;
+    if (i < 0) { int64_t o = j * G.s1 + k; rv = r.glo[o]; pv = p.glo[o]; vv = v.glo[o]; }
+    else if (i >= G.n0) { int64_t o = j * G.s1 + k; rv = r.ghi[o]; pv = p.ghi[o]; vv = v.ghi[o]; }
+    else { int64_t o = i * G.s0 + j * G.s1 + k; rv = r.p[o]; pv = p.p[o]; vv = v.p[o]; }
+    T t = omega * vv;
+    t = pv - t;
+    t = beta * t;
+    return rv + t;
+  }
+};
+
+template <typename T>
+__global__ void __launch_bounds__(PA_BLOCK) k_bicg_pv(DevGeom G, DevEq<T> E, const SolverScalars* __restrict__ sc,
+                                                       Vec<T> rv, Vec<T> pv, Vec<T> vv, const T* __restrict__ r0,
+                                                       T* __restrict__ pnew, T* __restrict__ vnew,
+                                                       double* __restrict__ partials) {
+  if (sc->done) return;
+  BicgPAcc<T> acc{rv, pv, vv, (T)sc->beta, (T)sc->omega};
+  double s[1] = {0.0};
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < G.ncell;
+       idx += (int64_t)gridDim.x * blockDim.x) {
+    int64_t i, j, k;
+    pa_decode(G, idx, i, j, k);
+    T pc = acc.at(G, i, j, k);
+    T vn = (T)0;
+    if (pa_in_S(G, i, j, k)) {
+      vn = pa_apply_terms<T>(G, E, acc, i, j, k, pc);
+      T p = r0[idx] * vn;
+      s[0] += (double)p;
+    }
+    pnew[idx] = pc;
+    vnew[idx] = vn;
+  }
+  pa_block_reduce_store<1>(s, partials);
+}
+
+// s = r - alpha v ; partial sum |s|^2 (tol = |r - alpha v|, linalg.py:230-233)
+template <typename T>
+__global__ void __launch_bounds__(PA_BLOCK) k_bicg_s(DevGeom G, const SolverScalars* __restrict__ sc,
+                                                      const T* __restrict__ r, const T* __restrict__ v,
+                                                      T* __restrict__ s_out, double* __restrict__ partials) {
+  if (sc->done) return;
+  const T alpha = (T)sc->alpha;
+  double s[1] = {0.0};
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < G.ncell;
+       idx += (int64_t)gridDim.x * blockDim.x) {
+    T av = alpha * v[idx];
+    T sv = r[idx] - av;
+    s_out[idx] = sv;
+    T p = sv * sv;
+    s[0] += (double)p;
+  }
+  pa_block_reduce_store<1>(s, partials);
+}
+
+// t = A s on S ; partial sums t.s, t.t, r0.t
+template <typename T>
+__global__ void __launch_bounds__(PA_BLOCK) k_bicg_t(DevGeom G, DevEq<T> E, const SolverScalars* __restrict__ sc,
+                                                      Vec<T> sv, const T* __restrict__ r0, T* __restrict__ t_out,
+                                                      double* __restrict__ partials) {
+  if (sc->done || sc->finished_early) return;
+  FieldAcc<T> acc{sv};
+  double s[3] = {0.0, 0.0, 0.0};
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < G.ncell;
+       idx += (int64_t)gridDim.x * blockDim.x) {
+    int64_t i, j, k;
+    pa_decode(G, idx, i, j, k);
+    T tv = (T)0;
+    if (pa_in_S(G, i, j, k)) {
+      T sc_ = sv.p[idx];
+      tv = pa_apply_terms<T>(G, E, acc, i, j, k, sc_);
+      T a = tv * sc_;
+      T b = tv * tv;
+      T c = r0[idx] * tv;
+      s[0] += (double)a;
+      s[1] += (double)b;
+      s[2] += (double)c;
+    }
+    t_out[idx] = tv;
+  }
+  pa_block_reduce_store<3>(s, partials);
+}
+
+// early exit: x += alpha p ; otherwise x = x + alpha p + s omega ; r = s - omega t ; |r|^2
+template <typename T>
+__global__ void __launch_bounds__(PA_BLOCK) k_bicg_x(DevGeom G, const SolverScalars* __restrict__ sc,
+                                                      T* __restrict__ x, const T* __restrict__ p,
+                                                      const T* __restrict__ s_in, const T* __restrict__ t_in,
+                                                      T* __restrict__ r, double* __restrict__ partials) {
+  if (sc->done) return;
+  const T alpha = (T)sc->alpha, omega = (T)sc->omega;
+  const int early = sc->finished_early;
+  double s[1] = {0.0};
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < G.ncell;
+       idx += (int64_t)gridDim.x * blockDim.x) {
+    T ap = alpha * p[idx];
+    T xn = x[idx] + ap;
+    if (!early) {
+      T so = s_in[idx] * omega;
+      xn = xn + so;
+      T ot = omega * t_in[idx];
+      T rn = s_in[idx] - ot;
+      r[idx] = rn;
+      T q = rn * rn;
+      s[0] += (double)q;
+    }
+    x[idx] = xn;
+  }
+  pa_block_reduce_store<1>(s, partials);
+}
+
+// stage: 0 after pv (alpha), 1 after s (tol check 1), 2 after t (omega, rho_next), 3 after x (tol check 2)
+template <typename T>
+__global__ void __launch_bounds__(PA_BLOCK) k_bicg_post(SolverScalars* sc, const double* partials, int nblk,
+                                                         int stage) {
+  __shared__ double sm[PA_BLOCK / 64];
+  if (sc->done) return;
+  if (stage == 0) {
+    double v = pa_reduce_partials(partials, nblk, 1, 0, sm);
+    if (threadIdx.x == 0) {
+      sc->itr += 1;
+      T r0v = (T)v;
+      T rho = (T)sc->rho;
+      sc->alpha = pa_nan_to_num<T>(rho / r0v);
+    }
+  } else if (stage == 1) {
+    double v = pa_reduce_partials(partials, nblk, 1, 0, sm);
+    if (threadIdx.x == 0) {
+      T tol = (T)sqrt(v);
+      sc->tol = (double)tol;
+      if (isnan(tol) || isinf(tol)) { sc->err = 1; sc->done = 1; return; }
+      sc->finished_early = (sc->tol <= sc->tolerance) ? 1 : 0;
+    }
+  } else if (stage == 2) {
+    if (sc->finished_early) return;
+    double ts = pa_reduce_partials(partials, nblk, 3, 0, sm);
+    double tt = pa_reduce_partials(partials, nblk, 3, 1, sm);
+    double r0t = pa_reduce_partials(partials, nblk, 3, 2, sm);
+    if (threadIdx.x == 0) {
+      T om = (T)pa_nan_to_num<T>((T)ts / (T)tt);
+      sc->omega = (double)om;
+      T rn = -om;
+      rn = rn * (T)r0t;
+      sc->rho_next = (double)rn;
+    }
+  } else {
+    double v = pa_reduce_partials(partials, nblk, 1, 0, sm);
+    if (threadIdx.x == 0) {
+      if (sc->finished_early) { sc->done = 1; return; }
+      T tol = (T)sqrt(v);
+      sc->tol = (double)tol;
+      if (isnan(tol) || isinf(tol)) { sc->err = 1; sc->done = 1; return; }
+      if (sc->tol <= sc->tolerance) sc->done = 1;
+      if (sc->itr >= sc->max_it) sc->done = 1;
+      // next iteration's beta = rho_next / rho * alpha / omega ; rho = rho_next (linalg.py:212-214)
+      T b = (T)sc->rho_next / (T)sc->rho;
+      b = b * (T)sc->alpha;
+      b = b / (T)sc->omega;
+      sc->beta = (double)b;
+      sc->rho = sc->rho_next;
+    }
+  }
+}
+
+// ============================================================================
+//  host side
+// ============================================================================
+
+static thread_local char g_create_err[512] = "";
+
+static inline const int* pa_done_flag(const pa_ctx* c) { return &c->sc->done; }
+
+void pa_set_err(pa_ctx* c, const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  if (c) vsnprintf(c->err, sizeof(c->err), fmt, ap);
+  else vsnprintf(g_create_err, sizeof(g_create_err), fmt, ap);
+  va_end(ap);
+}
+
+int pa_hip_fail(pa_ctx* c, hipError_t e, const char* what) {
+  pa_set_err(c, "HIP error in %s: %s", what, hipGetErrorString(e));
+  return PA_E_HIP;
+}
+
+int pa_grid_blocks(int64_t work) {
+  int64_t b = (work + PA_BLOCK - 1) / PA_BLOCK;
+  if (b < 1) b = 1;
+  if (b > PA_MAX_GRID) b = PA_MAX_GRID;
+  return (int)b;
+}
+
+int pa_scratch(pa_ctx* c, void** slot, size_t* cap, size_t bytes) {
+  if (*cap >= bytes && *slot) return PA_OK;
+  if (*slot) { (void)hipFree(*slot); *slot = nullptr; *cap = 0; }
+  if (bytes == 0) return PA_OK;
+  PA_HIP(c, hipMalloc(slot, bytes));
+  *cap = bytes;
+  return PA_OK;
+}
+
+template <typename T>
+static void fill_coefs(const pa_ctx* c, DevEq<T>& E) {
+  for (int a = 0; a < 3; ++a) {
+    T h = (T)c->dx[a];
+    T h2 = h * h;
+    E.lap.inv[a] = (T)1 / h2;
+    E.lap.m2inv[a] = (T)-2 / h2;
+    E.lap.c23[a] = (T)(2.0 / 3.0) / h2;
+    T th = (T)2 * h;
+    T third = (T)(1.0 / 3.0);
+    E.grd.h[a] = h;
+    E.grd.h2[a] = th;
+    E.grd.g[a] = (T)1 / th;
+    E.grd.mg[a] = (T)-1 / th;
+    T v = (T)1 + third;
+    E.grd.lo_p[a] = v / th;
+    v = (T)0 - third;
+    E.grd.lo_c[a] = v / th;
+    v = (T)0 + third;
+    E.grd.hi_c[a] = v / th;
+    v = (T)-1 - third;
+    E.grd.hi_m[a] = v / th;
+  }
+}
+
+template <typename T>
+void pa_build_eq(const pa_ctx* c, int nterms, const pa_term* terms, DevEq<T>& E) {
+  memset(&E, 0, sizeof(E));
+  E.nterms = nterms;
+  for (int q = 0; q < nterms; ++q) {
+    E.t[q].kind = terms[q].kind;
+    E.t[q].has_coeff = terms[q].has_coeff;
+    E.t[q].sign = (T)terms[q].sign;
+    E.t[q].coeff = (T)terms[q].coeff;
+    E.t[q].coeff_f = (const T*)terms[q].coeff_field;
+    E.t[q].u = (T)terms[q].u;
+    E.t[q].u_f = (const T*)terms[q].u_field;
+  }
+  fill_coefs<T>(c, E);
+}
+template void pa_build_eq<float>(const pa_ctx*, int, const pa_term*, DevEq<float>&);
+template void pa_build_eq<double>(const pa_ctx*, int, const pa_term*, DevEq<double>&);
+
+// interior set, BC flags (mesh/tools.py:7-20, bcs.py:158-163)
+void pa_refresh_geom(pa_ctx* c) {
+  DevGeom& G = c->G;
+  for (int a = 0; a < 3; ++a) {
+    int64_t N = a == 0 ? G.g0 : (a == 1 ? G.n1 : G.n2);
+    if (!G.act[a]) { G.slo[a] = 0; G.shi[a] = 0; continue; }
+    G.slo[a] = 1;
+    G.shi[a] = N - 2;
+    int lo_pos = -1, hi_pos = -1;
+    for (int w = 0; w < c->nbc; ++w) {
+      if (c->bc_order[w] == 2 * a) lo_pos = w;
+      if (c->bc_order[w] == 2 * a + 1) hi_pos = w;
+    }
+    G.hi_last[a] = hi_pos > lo_pos;
+  }
+  for (int f = 0; f < 6; ++f) {
+    int t = c->bc[f].type;
+    G.bct[f] = t;
+    G.treat[f] = (t == PA_BC_NEUMANN || t == PA_BC_SYMMETRY);
+    if (t == PA_BC_PERIODIC) {
+      int a = f >> 1;
+      int64_t N = a == 0 ? G.g0 : (a == 1 ? G.n1 : G.n2);
+      if ((f & 1) == 0) G.slo[a] = 0; else G.shi[a] = N - 1;
+    }
+  }
+}
+
+template <typename T>
+Vec<T> pa_vec_self(const pa_ctx* c, const T* p) {
+  // P = 1 (or no exchange needed): ghost planes are the field's own wrap-around planes
+  Vec<T> v;
+  v.p = p;
+  v.glo = p + (c->G.n0 - 1) * c->G.s0;
+  v.ghi = p;
+  return v;
+}
+template Vec<float> pa_vec_self<float>(const pa_ctx*, const float*);
+template Vec<double> pa_vec_self<double>(const pa_ctx*, const double*);
+
+template <typename T>
+static int bc_apply_t(pa_ctx* c, T* x, bool guarded = false) {
+  const DevGeom& G = c->G;
+  for (int w = 0; w < c->nbc; ++w) {
+    int f = c->bc_order[w];
+    const HostBC& b = c->bc[f];
+    if (b.type == PA_BC_NONE) continue;
+    int a = f >> 1, side = f & 1;
+    if (!G.act[a]) continue;
+    if (a == 0) {  // slab: only the rank holding the global boundary plane
+      if (side == 0 && G.off0 != 0) continue;
+      if (side == 1 && G.off0 + G.n0 != G.g0) continue;
+    }
+    BCArgs<T> B;
+    memset(&B, 0, sizeof(B));
+    B.axis = a; B.side = side; B.type = b.type;
+    B.vals = (const T*)b.vals;
+    B.c43 = (T)(4.0 / 3.0);
+    B.c13 = (T)(1.0 / 3.0);
+    B.c23 = (T)(2.0 / 3.0);
+    B.dxf = (T)b.dxf;
+    B.ndir = side == 0 ? (T)-1 : (T)1;
+    B.done = guarded ? pa_done_flag(c) : nullptr;
+    if (b.type == PA_BC_DIRICHLET) B.sval = (T)b.value;
+    if (b.type == PA_BC_NEUMANN) {
+      // scalar V: python computes 2/3*V in double, casts to the tensor dtype when it meets dx
+      T pre = (T)((2.0 / 3.0) * b.value);
+      pre = pre * B.dxf;
+      pre = pre * B.ndir;
+      B.sval = pre;
+    }
+    if (b.type == PA_BC_PERIODIC && a == 0 && G.n0 != G.g0) {
+      B.far0 = (const T*)(side == 0 ? c->bc_far_lo0 : c->bc_far_hi0);
+      B.far1 = (const T*)c->bc_far_lo1;
+      if (!B.far0) { pa_set_err(c, "periodic axis-0 BC on a slab needs pa_bc_halo_ptrs planes"); return PA_E_STATE; }
+    }
+    int64_t nu = (a == 0) ? G.n1 : G.n0;
+    int64_t nv = (a == 2) ? G.n1 : G.n2;
+    hipLaunchKernelGGL(k_bc_face<T>, dim3(pa_grid_blocks(nu * nv)), dim3(PA_BLOCK), 0, c->stream, G, x, B);
+  }
+  PA_HIP(c, hipGetLastError());
+  return PA_OK;
+}
+
+int pa_bc_apply_any(pa_ctx* c, void* x) {
+  return c->dtype == PA_F64 ? bc_apply_t<double>(c, (double*)x) : bc_apply_t<float>(c, (float*)x);
+}
+
+// ---------------------------------------------------------------------------------------
+extern "C" {
+
+const char* pa_version(void) { return "pyapes_hip 0.1 (gfx950)"; }
+
+const char* pa_last_error(const pa_ctx* c) { return c ? c->err : g_create_err; }
+
+int pa_ctx_create(int device, void* hip_stream, pa_ctx** out) {
+  if (!out) { pa_set_err(nullptr, "pa_ctx_create: out is NULL"); return PA_E_ARG; }
+  *out = nullptr;
+  int ndev = 0;
+  hipError_t e = hipGetDeviceCount(&ndev);
+  if (e != hipSuccess || ndev == 0) {
+    pa_set_err(nullptr, "pa_ctx_create: no HIP device visible (%s)", hipGetErrorString(e));
+    return PA_E_HIP;
+  }
+  if (device < 0 || device >= ndev) { pa_set_err(nullptr, "pa_ctx_create: bad device %d", device); return PA_E_ARG; }
+  e = hipSetDevice(device);
+  if (e != hipSuccess) { pa_set_err(nullptr, "hipSetDevice: %s", hipGetErrorString(e)); return PA_E_HIP; }
+  pa_ctx* c = new (std::nothrow) pa_ctx();
+  if (!c) { pa_set_err(nullptr, "out of host memory"); return PA_E_ARG; }
+  c->device = device;
+  c->stream = (hipStream_t)hip_stream;
+  c->err[0] = 0;
+  if (hipMalloc((void**)&c->sc, sizeof(SolverScalars)) != hipSuccess ||
+      hipMalloc((void**)&c->sums, PA_NSUM * sizeof(double)) != hipSuccess ||
+      hipHostMalloc((void**)&c->h_sc, sizeof(SolverScalars)) != hipSuccess ||
+      hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess) {
+    pa_set_err(nullptr, "pa_ctx_create: allocation failed");
+    delete c;
+    return PA_E_HIP;
+  }
+  (void)hipMemsetAsync(c->sc, 0, sizeof(SolverScalars), c->stream);
+  (void)hipMemsetAsync(c->sums, 0, PA_NSUM * sizeof(double), c->stream);
+  *out = c;
+  return PA_OK;
+}
+
+int pa_ctx_destroy(pa_ctx* c) {
+  if (!c) return PA_OK;
+  (void)hipSetDevice(c->device);
+  (void)hipStreamSynchronize(c->stream);
+  for (int q = 0; q < PA_NSCRATCH; ++q)
+    if (c->scr[q]) (void)hipFree(c->scr[q]);
+  if (c->sc) (void)hipFree(c->sc);
+  if (c->sums) (void)hipFree(c->sums);
+  if (c->h_sc) (void)hipHostFree(c->h_sc);
+  if (c->ev0) (void)hipEventDestroy(c->ev0);
+  if (c->ev1) (void)hipEventDestroy(c->ev1);
+  delete c;
+  return PA_OK;
+}
+
+int pa_grid_set(pa_ctx* c, int ndim, const int64_t* n, const double* dx, int dtype, int64_t i_off,
+                int64_t n0_global) {
+  if (!c) return PA_E_ARG;
+  if (ndim < 1 || ndim > 3) { pa_set_err(c, "pa_grid_set: ndim must be 1..3"); return PA_E_ARG; }
+  if (dtype != PA_F32 && dtype != PA_F64) { pa_set_err(c, "pa_grid_set: bad dtype"); return PA_E_ARG; }
+  for (int a = 0; a < ndim; ++a)
+    if (n[a] < 3 && !(a == 0 && n0_global >= 3 && n[a] >= 1)) {
+      pa_set_err(c, "pa_grid_set: every axis needs >= 3 nodes (linalg.py:43-45)");
+      return PA_E_ARG;
+    }
+  if (ndim < 3 && (i_off != 0 || n0_global != n[0])) {
+    pa_set_err(c, "pa_grid_set: slab decomposition is for 3-D meshes only (1-D/2-D: replicas)");
+    return PA_E_ARG;
+  }
+  if (i_off < 0 || i_off + n[0] > n0_global) { pa_set_err(c, "pa_grid_set: slab outside the global grid"); return PA_E_ARG; }
+  DevGeom& G = c->G;
+  memset(&G, 0, sizeof(G));
+  int64_t ext[3] = {1, 1, 1};
+  double h[3] = {1.0, 1.0, 1.0};
+  const int sh = 3 - ndim;
+  for (int a = 0; a < ndim; ++a) { ext[a + sh] = n[a]; h[a + sh] = dx[a]; G.act[a + sh] = 1; }
+  G.n0 = ext[0]; G.n1 = ext[1]; G.n2 = ext[2];
+  G.s1 = G.n2; G.s0 = G.n1 * G.n2;
+  G.ncell = G.n0 * G.n1 * G.n2;
+  G.off0 = ndim == 3 ? i_off : 0;
+  G.g0 = ndim == 3 ? n0_global : 1;
+  for (int a = 0; a < 3; ++a) c->dx[a] = h[a];
+  c->ndim = ndim;
+  c->dtype = dtype;
+  c->esize = dtype == PA_F64 ? 8 : 4;
+  c->grid_set = 1;
+  c->eq_set = 0;
+  c->solver_live = 0;
+  for (int f = 0; f < 6; ++f) c->bc[f] = HostBC();
+  c->nbc = 0;
+  pa_refresh_geom(c);
+  return PA_OK;
+}
+
+int pa_bc_clear(pa_ctx* c) {
+  if (!c || !c->grid_set) return PA_E_STATE;
+  for (int f = 0; f < 6; ++f) c->bc[f] = HostBC();
+  c->nbc = 0;
+  pa_refresh_geom(c);
+  return PA_OK;
+}
+
+int pa_bc_set(pa_ctx* c, int face, int order_pos, int type, double value, const void* face_vals, double dxf) {
+  if (!c || !c->grid_set) { if (c) pa_set_err(c, "pa_bc_set before pa_grid_set"); return PA_E_STATE; }
+  if (face < 0 || face >= 2 * c->ndim) { pa_set_err(c, "pa_bc_set: face %d outside a %d-D mesh", face, c->ndim); return PA_E_ARG; }
+  if (order_pos < 0 || order_pos >= 6) { pa_set_err(c, "pa_bc_set: bad order_pos"); return PA_E_ARG; }
+  if (type < PA_BC_NONE || type > PA_BC_PERIODIC) { pa_set_err(c, "pa_bc_set: bad type"); return PA_E_ARG; }
+  int fi = face + 2 * (3 - c->ndim);
+  HostBC& b = c->bc[fi];
+  b.type = type; b.value = value; b.vals = face_vals; b.dxf = dxf;
+  c->bc_order[order_pos] = fi;
+  if (order_pos + 1 > c->nbc) c->nbc = order_pos + 1;
+  pa_refresh_geom(c);
+  return PA_OK;
+}
+
+int pa_apply_bc(pa_ctx* c, void* x) {
+  if (!c || !c->grid_set) return PA_E_STATE;
+  PA_HIP(c, hipSetDevice(c->device));
+  return pa_bc_apply_any(c, x);
+}
+
+int pa_eq_set(pa_ctx* c, int nterms, const pa_term* terms) {
+  if (!c || !c->grid_set) { if (c) pa_set_err(c, "pa_eq_set before pa_grid_set"); return PA_E_STATE; }
+  if (nterms < 1 || nterms > PA_MAX_TERMS) { pa_set_err(c, "pa_eq_set: 1..%d terms", PA_MAX_TERMS); return PA_E_ARG; }
+  for (int q = 0; q < nterms; ++q) {
+    int k = terms[q].kind;
+    if (k < PA_OP_LAPLACIAN || k > PA_OP_DIV_UPWIND) { pa_set_err(c, "pa_eq_set: bad kind"); return PA_E_ARG; }
+    if (k == PA_OP_GRAD && c->ndim != 1) {
+      pa_set_err(c, "pa_eq_set: Grad in a solver equation is 1-D only (ops.py:145-147 view)");
+      return PA_E_ARG;
+    }
+    if (k == PA_OP_DIV_CENTRAL)
+      for (int f = 0; f < 6; ++f)
+        if (c->G.treat[f]) {
+          pa_set_err(c, "central Div with neumann/symmetry faces: the reference raises IndexError (fdc.py:583)");
+          return PA_E_ARG;
+        }
+    if (k == PA_OP_DIV_CENTRAL && terms[q].u_field && c->G.n0 != c->G.g0 && c->ndim == 3) {
+      pa_set_err(c, "tensor-u central Div is single-GPU only");
+      return PA_E_ARG;
+    }
+  }
+  c->nterms = nterms;
+  for (int q = 0; q < nterms; ++q) c->terms[q] = terms[q];
+  c->eq_set = 1;
+  return PA_OK;
+}
+
+}  // extern "C"
+
+// -------- typed implementations behind the remaining entry points ------------------------
+template <typename T>
+static int aop_t(pa_ctx* c, const T* x, T* y, int interior_only, int nterms, const pa_term* terms) {
+  DevEq<T> E;
+  pa_build_eq<T>(c, nterms, terms, E);
+  Vec<T> xv = pa_vec_self<T>(c, x);
+  if (c->G.n0 != c->G.g0 && c->ndim == 3) {
+    // slab: ghost planes of x must have been supplied
+    if (!c->x_glo || !c->x_ghi) { pa_set_err(c, "pa_aop on a slab needs ghost planes (pa_x_ghost_set)"); return PA_E_STATE; }
+    xv.glo = (const T*)c->x_glo;
+    xv.ghi = (const T*)c->x_ghi;
+  }
+  hipLaunchKernelGGL(k_aop<T>, dim3(pa_grid_blocks(c->G.ncell)), dim3(PA_BLOCK), 0, c->stream, c->G, E, xv, y,
+                     interior_only);
+  PA_HIP(c, hipGetLastError());
+  return PA_OK;
+}
+
+template <typename T>
+static int rhs_adjust_t(pa_ctx* c, T* rhs) {
+  DevEq<T> E;
+  pa_build_eq<T>(c, c->nterms, c->terms, E);
+  RhsArgs<T> R;
+  memset(&R, 0, sizeof(R));
+  bool any = false;
+  for (int f = 0; f < 6; ++f) {
+    R.f[f].type = c->bc[f].type;
+    R.f[f].sval = (T)c->bc[f].value;
+    R.f[f].vals = (const T*)c->bc[f].vals;
+    if (c->bc[f].type == PA_BC_NEUMANN) any = true;
+  }
+  R.nfaces = c->nbc;
+  for (int w = 0; w < c->nbc; ++w) R.order[w] = c->bc_order[w];
+  R.c23 = (T)(2.0 / 3.0);
+  R.c13 = (T)(1.0 / 3.0);
+  for (int a = 0; a < 3; ++a) R.h[a] = (T)c->dx[a];
+  if (!any) return PA_OK;
+  hipLaunchKernelGGL(k_rhs_adjust<T>, dim3(pa_grid_blocks(c->G.ncell)), dim3(PA_BLOCK), 0, c->stream, c->G, E, R,
+                     rhs);
+  PA_HIP(c, hipGetLastError());
+  return PA_OK;
+}
+
+template <typename T>
+static int lap_t(pa_ctx* c, const T* x, T* y, int edge) {
+  pa_term t;
+  memset(&t, 0, sizeof(t));
+  t.kind = PA_OP_LAPLACIAN; t.sign = 1.0; t.has_coeff = 0;
+  int rc = aop_t<T>(c, x, y, 0, 1, &t);
+  if (rc) return rc;
+  if (edge) {
+    for (int a = 0; a < c->ndim; ++a) {
+      int64_t n = a + (3 - c->ndim) == 0 ? c->G.n0 : (a + (3 - c->ndim) == 1 ? c->G.n1 : c->G.n2);
+      if (n < 4) { pa_set_err(c, "edge laplacian needs >= 4 nodes per axis"); return PA_E_ARG; }
+    }
+    if (c->G.n0 != c->G.g0 && c->ndim == 3) { pa_set_err(c, "edge operators are single-GPU only"); return PA_E_ARG; }
+    DevEq<T> E;
+    pa_build_eq<T>(c, 1, &t, E);
+    hipLaunchKernelGGL(k_edge<T>, dim3(pa_grid_blocks(c->G.ncell)), dim3(PA_BLOCK), 0, c->stream, c->G, E, x, y,
+                       c->ndim, 0);
+    PA_HIP(c, hipGetLastError());
+  }
+  return PA_OK;
+}
+
+template <typename T>
+static int grad_t(pa_ctx* c, const T* x, T* y, int edge) {
+  pa_term t;
+  memset(&t, 0, sizeof(t));
+  t.kind = PA_OP_GRAD; t.sign = 1.0;
+  DevEq<T> E;
+  pa_build_eq<T>(c, 1, &t, E);
+  Vec<T> xv = pa_vec_self<T>(c, x);
+  if (c->G.n0 != c->G.g0 && c->ndim == 3) {
+    if (!c->x_glo || !c->x_ghi) { pa_set_err(c, "pa_grad on a slab needs ghost planes"); return PA_E_STATE; }
+    xv.glo = (const T*)c->x_glo; xv.ghi = (const T*)c->x_ghi;
+  }
+  hipLaunchKernelGGL(k_grad<T>, dim3(pa_grid_blocks(c->G.ncell)), dim3(PA_BLOCK), 0, c->stream, c->G, E, xv, y,
+                     c->ndim);
+  if (edge) {
+    if (c->G.n0 != c->G.g0 && c->ndim == 3) { pa_set_err(c, "edge operators are single-GPU only"); return PA_E_ARG; }
+    hipLaunchKernelGGL(k_edge<T>, dim3(pa_grid_blocks(c->G.ncell)), dim3(PA_BLOCK), 0, c->stream, c->G, E, x, y,
+                       c->ndim, 1);
+  }
+  PA_HIP(c, hipGetLastError());
+  return PA_OK;
+}
+
+static int check_div_kind(pa_ctx* c, int kind) {
+  if (kind != PA_OP_DIV_CENTRAL && kind != PA_OP_DIV_UPWIND_COMPAT && kind != PA_OP_DIV_UPWIND) {
+    pa_set_err(c, "bad div kind %d", kind);
+    return PA_E_ARG;
+  }
+  if (kind == PA_OP_DIV_CENTRAL)
+    for (int f = 0; f < 6; ++f)
+      if (c->G.treat[f]) {
+        pa_set_err(c, "central Div with neumann/symmetry faces: the reference raises IndexError (fdc.py:583)");
+        return PA_E_ARG;
+      }
+  return PA_OK;
+}
+
+template <typename T>
+static int euler_t(pa_ctx* c, const T* in, T* out, int kind, double u, const void* u_field, double nu, double dt) {
+  pa_term tl, ta;
+  memset(&tl, 0, sizeof(tl));
+  memset(&ta, 0, sizeof(ta));
+  tl.kind = PA_OP_LAPLACIAN; tl.sign = 1.0;
+  ta.kind = kind; ta.sign = 1.0; ta.u = u; ta.u_field = u_field;
+  DevEq<T> El, Ea;
+  pa_build_eq<T>(c, 1, &tl, El);
+  pa_build_eq<T>(c, 1, &ta, Ea);
+  Vec<T> pv = pa_vec_self<T>(c, in);
+  if (c->G.n0 != c->G.g0 && c->ndim == 3) {
+    if (!c->x_glo || !c->x_ghi) { pa_set_err(c, "pa_euler_step on a slab needs ghost planes"); return PA_E_STATE; }
+    pv.glo = (const T*)c->x_glo; pv.ghi = (const T*)c->x_ghi;
+  }
+  hipLaunchKernelGGL(k_euler<T>, dim3(pa_grid_blocks(c->G.ncell)), dim3(PA_BLOCK), 0, c->stream, c->G, El, Ea, pv,
+                     out, (T)nu, (T)dt);
+  PA_HIP(c, hipGetLastError());
+  return bc_apply_t<T>(c, out);
+}
+
+extern "C" {
+
+int pa_slab_set(pa_ctx* c, const pa_slab* s) {
+  if (!c || !c->grid_set) { if (c) pa_set_err(c, "pa_slab_set before pa_grid_set"); return PA_E_STATE; }
+  if (c->solver_live) { pa_set_err(c, "pa_slab_set during a solve"); return PA_E_STATE; }
+  if (!s) {
+    c->slab = 0;
+    c->ext_sums = nullptr;
+    c->x_glo = c->x_ghi = nullptr;
+    c->r_send_lo = c->r_send_hi = nullptr;
+    c->r_recv_lo = c->r_recv_hi = nullptr;
+    c->bc_far_lo0 = c->bc_far_lo1 = c->bc_far_hi0 = nullptr;
+    return PA_OK;
+  }
+  if (c->ndim != 3) { pa_set_err(c, "pa_slab_set: slabs are for 3-D meshes"); return PA_E_ARG; }
+  if (!s->sums) { pa_set_err(c, "pa_slab_set: sums buffer is required"); return PA_E_ARG; }
+  c->slab = 1;
+  c->ext_sums = (double*)s->sums;
+  c->r_send_lo = s->r_send_lo; c->r_send_hi = s->r_send_hi;
+  c->r_recv_lo = s->r_recv_lo; c->r_recv_hi = s->r_recv_hi;
+  c->x_glo = s->x_ghost_lo; c->x_ghi = s->x_ghost_hi;
+  c->bc_far_lo0 = s->bc_far_lo0; c->bc_far_lo1 = s->bc_far_lo1; c->bc_far_hi0 = s->bc_far_hi0;
+  return PA_OK;
+}
+
+int pa_aop(pa_ctx* c, const void* x, void* y, int interior_only) {
+  if (!c || !c->grid_set || !c->eq_set) { if (c) pa_set_err(c, "pa_aop: grid/equation not set"); return PA_E_STATE; }
+  PA_HIP(c, hipSetDevice(c->device));
+  return c->dtype == PA_F64 ? aop_t<double>(c, (const double*)x, (double*)y, interior_only, c->nterms, c->terms)
+                            : aop_t<float>(c, (const float*)x, (float*)y, interior_only, c->nterms, c->terms);
+}
+
+int pa_rhs_adjust(pa_ctx* c, void* rhs) {
+  if (!c || !c->grid_set || !c->eq_set) { if (c) pa_set_err(c, "pa_rhs_adjust: grid/equation not set"); return PA_E_STATE; }
+  PA_HIP(c, hipSetDevice(c->device));
+  return c->dtype == PA_F64 ? rhs_adjust_t<double>(c, (double*)rhs) : rhs_adjust_t<float>(c, (float*)rhs);
+}
+
+int pa_laplacian(pa_ctx* c, const void* x, void* y, int edge) {
+  if (!c || !c->grid_set) return PA_E_STATE;
+  PA_HIP(c, hipSetDevice(c->device));
+  return c->dtype == PA_F64 ? lap_t<double>(c, (const double*)x, (double*)y, edge)
+                            : lap_t<float>(c, (const float*)x, (float*)y, edge);
+}
+
+int pa_grad(pa_ctx* c, const void* x, void* y, int edge) {
+  if (!c || !c->grid_set) return PA_E_STATE;
+  PA_HIP(c, hipSetDevice(c->device));
+  return c->dtype == PA_F64 ? grad_t<double>(c, (const double*)x, (double*)y, edge)
+                            : grad_t<float>(c, (const float*)x, (float*)y, edge);
+}
+
+int pa_div(pa_ctx* c, int kind, double u, const void* u_field, const void* x, void* y) {
+  if (!c || !c->grid_set) return PA_E_STATE;
+  int rc = check_div_kind(c, kind);
+  if (rc) return rc;
+  PA_HIP(c, hipSetDevice(c->device));
+  pa_term t;
+  memset(&t, 0, sizeof(t));
+  t.kind = kind; t.sign = 1.0; t.u = u; t.u_field = u_field;
+  return c->dtype == PA_F64 ? aop_t<double>(c, (const double*)x, (double*)y, 0, 1, &t)
+                            : aop_t<float>(c, (const float*)x, (float*)y, 0, 1, &t);
+}
+
+int pa_euler_step(pa_ctx* c, const void* in, void* out, int kind, double u, const void* u_field, double nu,
+                  double dt) {
+  if (!c || !c->grid_set) return PA_E_STATE;
+  int rc = check_div_kind(c, kind);
+  if (rc) return rc;
+  if (in == out) { pa_set_err(c, "pa_euler_step: in-place step is not allowed"); return PA_E_ARG; }
+  PA_HIP(c, hipSetDevice(c->device));
+  return c->dtype == PA_F64 ? euler_t<double>(c, (const double*)in, (double*)out, kind, u, u_field, nu, dt)
+                            : euler_t<float>(c, (const float*)in, (float*)out, kind, u, u_field, nu, dt);
+}
+
+}  // extern "C"
+
+// ============================================================================
+//  solvers
+// ============================================================================
+static int shell_blocks(const pa_ctx* c) {
+  const DevGeom& G = c->G;
+  int64_t tot = 0;
+  if (G.act[0]) tot += 2 * G.n1 * G.n2;
+  if (G.act[1]) tot += 2 * G.n0 * G.n2;
+  if (G.act[2]) tot += 2 * G.n0 * G.n1;
+  return pa_grid_blocks(tot);
+}
+static int64_t shell_elems(const pa_ctx* c) {
+  const DevGeom& G = c->G;
+  return 2 * (G.n1 * G.n2 + G.n0 * G.n2 + G.n0 * G.n1);
+}
+
+// B(x) is a no-op after the first fill when every face is dirichlet (values frozen per solve)
+static bool bc_is_static(const pa_ctx* c) {
+  for (int f = 0; f < 6; ++f) {
+    int t = c->bc[f].type;
+    if (t != PA_BC_NONE && t != PA_BC_DIRICHLET) return false;
+  }
+  return true;
+}
+
+static int init_scalars(pa_ctx* c, double tol, int64_t max_it) {
+  SolverScalars h;
+  memset(&h, 0, sizeof(h));
+  h.tolerance = tol;
+  h.max_it = max_it;
+  h.tol = 1.0;
+  h.rho = 1.0; h.alpha = 1.0; h.omega = 1.0;
+  h.done = !(1.0 > tol);  // `while tol > tolerance` with tol = 1.0 (linalg.py:90,109)
+  *c->h_sc = h;
+  PA_HIP(c, hipMemcpyAsync(c->sc, c->h_sc, sizeof(h), hipMemcpyHostToDevice, c->stream));
+  PA_HIP(c, hipStreamSynchronize(c->stream));
+  return PA_OK;
+}
+
+static int read_scalars(pa_ctx* c) {
+  PA_HIP(c, hipMemcpyAsync(c->h_sc, c->sc, sizeof(SolverScalars), hipMemcpyDeviceToHost, c->stream));
+  PA_HIP(c, hipStreamSynchronize(c->stream));
+  return PA_OK;
+}
+
+static int poll_interval(const pa_ctx* c) {
+  // keep >= ~300 us of queued GPU work between host polls of the done flag
+  double est_us = (double)c->G.ncell * 80.0 / 4.0e6 + 30.0;
+  int k = (int)ceil(300.0 / est_us);
+  return std::max(1, std::min(k, 64));
+}
+
+static void fill_report(pa_ctx* c, pa_report* out, float ms) {
+  const SolverScalars& h = *c->h_sc;
+  out->itr = h.itr;
+  out->tol = h.tol;
+  out->converge = h.itr < h.max_it;
+  out->status = h.err ? PA_E_NONFINITE : PA_OK;
+  out->rr = h.rr;
+  out->gpu_ms = ms;
+}
+
+template <typename T>
+static int cg_begin_t(pa_ctx* c, T* x, const T* rhs, double tol, int64_t max_it) {
+  const DevGeom& G = c->G;
+  const size_t fb = (size_t)G.ncell * sizeof(T);
+  const int nblk = pa_grid_blocks(G.ncell);
+  int rc;
+  if ((rc = pa_scratch(c, &c->scr[SCR_R], &c->cap[SCR_R], fb))) return rc;
+  if ((rc = pa_scratch(c, &c->scr[SCR_D0], &c->cap[SCR_D0], fb))) return rc;
+  if ((rc = pa_scratch(c, &c->scr[SCR_D1], &c->cap[SCR_D1], fb))) return rc;
+  if ((rc = pa_scratch(c, &c->scr[SCR_PART], &c->cap[SCR_PART], (size_t)PA_MAX_GRID * 4 * sizeof(double)))) return rc;
+  if ((rc = pa_scratch(c, &c->scr[SCR_PART2], &c->cap[SCR_PART2], (size_t)PA_MAX_GRID * sizeof(double)))) return rc;
+  if ((rc = pa_scratch(c, &c->scr[SCR_SHELL], &c->cap[SCR_SHELL], (size_t)shell_elems(c) * sizeof(T)))) return rc;
+  if ((rc = init_scalars(c, tol, max_it))) return rc;
+  c->cg_x = x;
+  c->cur = 0;
+  c->bc_static = bc_is_static(c);
+  c->solver_live = 1;
+  DevEq<T> E;
+  pa_build_eq<T>(c, c->nterms, c->terms, E);
+  if ((rc = bc_apply_t<T>(c, x))) return rc;  // linalg.py:97
+  T* r = (T*)c->scr[SCR_R];
+  T* d = (T*)c->scr[SCR_D0];
+  double* part = (double*)c->scr[SCR_PART];
+  Vec<T> xv = pa_vec_self<T>(c, x);
+  if (c->slab) { xv.glo = (const T*)c->x_glo; xv.ghi = (const T*)c->x_ghi; }
+  hipLaunchKernelGGL(k_cg_init<T>, dim3(nblk), dim3(PA_BLOCK), 0, c->stream, G, E, xv, rhs, r, d, part);
+  hipLaunchKernelGGL(k_cg_post_init<T>, dim3(1), dim3(PA_BLOCK), 0, c->stream, c->sc, part, nblk, pa_sums(c),
+                     c->slab ? 0 : 2);
+  hipLaunchKernelGGL(k_shell<T>, dim3(shell_blocks(c)), dim3(PA_BLOCK), 0, c->stream, G, c->sc, (const T*)x,
+                     (T*)c->scr[SCR_SHELL], (double*)c->scr[SCR_PART2], 0);
+  PA_HIP(c, hipGetLastError());
+  return PA_OK;
+}
+
+template <typename T>
+static Vec<T> cg_vec(pa_ctx* c, const T* p, int which /*0 r, 1 d cur*/) {
+  Vec<T> v = pa_vec_self<T>(c, p);
+  if (c->slab) {
+    if (which == 0) { v.glo = (const T*)c->r_recv_lo; v.ghi = (const T*)c->r_recv_hi; }
+    else { v.glo = (const T*)c->d_glo[c->cur]; v.ghi = (const T*)c->d_ghi[c->cur]; }
+  }
+  return v;
+}
+
+template <typename T>
+int pa_cg_phase_a_t(pa_ctx* c, int stage_post) {
+  const DevGeom& G = c->G;
+  const int nblk = pa_grid_blocks(G.ncell);
+  DevEq<T> E;
+  pa_build_eq<T>(c, c->nterms, c->terms, E);
+  T* r = (T*)c->scr[SCR_R];
+  T* dold = (T*)c->scr[c->cur ? SCR_D1 : SCR_D0];
+  T* dnew = (T*)c->scr[c->cur ? SCR_D0 : SCR_D1];
+  double* part = (double*)c->scr[SCR_PART];
+  Vec<T> rv = cg_vec<T>(c, r, 0), dv = cg_vec<T>(c, dold, 1);
+  int rc = pa_cg3d_phase_a<T>(c, E, rv, dv, dnew, part);
+  if (rc < 0) return rc;
+  int used_blocks = rc;
+  if (rc == 0) {
+    hipLaunchKernelGGL(k_cg_a<T>, dim3(nblk), dim3(PA_BLOCK), 0, c->stream, G, E, c->sc, rv, dv, dnew, part);
+    used_blocks = nblk;
+  }
+  c->cur ^= 1;
+  hipLaunchKernelGGL(k_cg_post_a<T>, dim3(1), dim3(PA_BLOCK), 0, c->stream, c->sc, part, used_blocks, pa_sums(c),
+                     stage_post);
+  PA_HIP(c, hipGetLastError());
+  return PA_OK;
+}
+
+template <typename T>
+int pa_cg_phase_b_t(pa_ctx* c, int stage_post) {
+  const DevGeom& G = c->G;
+  const int nblk = pa_grid_blocks(G.ncell);
+  DevEq<T> E;
+  pa_build_eq<T>(c, c->nterms, c->terms, E);
+  T* r = (T*)c->scr[SCR_R];
+  T* d = (T*)c->scr[c->cur ? SCR_D1 : SCR_D0];
+  T* x = (T*)c->cg_x;
+  double* part = (double*)c->scr[SCR_PART];
+  double* part2 = (double*)c->scr[SCR_PART2];
+  Vec<T> dv = cg_vec<T>(c, d, 1);
+  int rc = pa_cg3d_phase_b<T>(c, E, dv, x, r, part);
+  if (rc < 0) return rc;
+  int used_blocks = rc;
+  if (rc == 0) {
+    hipLaunchKernelGGL(k_cg_b<T>, dim3(nblk), dim3(PA_BLOCK), 0, c->stream, G, E, c->sc, dv, x, r,
+                       (T*)c->r_send_lo, (T*)c->r_send_hi, part);
+    used_blocks = nblk;
+  }
+  int nsh = 0;
+  if (!c->bc_static) {
+    if ((rc = bc_apply_t<T>(c, x, true))) return rc;
+    nsh = shell_blocks(c);
+    hipLaunchKernelGGL(k_shell<T>, dim3(nsh), dim3(PA_BLOCK), 0, c->stream, G, c->sc, (const T*)x,
+                       (T*)c->scr[SCR_SHELL], part2, 1);
+  }
+  hipLaunchKernelGGL(k_cg_post_b<T>, dim3(1), dim3(PA_BLOCK), 0, c->stream, c->sc, part, used_blocks, part2, nsh,
+                     pa_sums(c), stage_post);
+  PA_HIP(c, hipGetLastError());
+  return PA_OK;
+}
+
+template <typename T>
+static int cg_run_t(pa_ctx* c, T* x, const T* rhs, double tol, int64_t max_it, pa_report* out) {
+  int rc = cg_begin_t<T>(c, x, rhs, tol, max_it);
+  if (rc) return rc;
+  const int poll = poll_interval(c);
+  PA_HIP(c, hipEventRecord(c->ev0, c->stream));
+  int64_t enq = 0;
+  int next_poll = 1;
+  for (;;) {
+    if ((rc = pa_cg_phase_a_t<T>(c, 2))) return rc;
+    if ((rc = pa_cg_phase_b_t<T>(c, 2))) return rc;
+    ++enq;
+    if (enq >= next_poll || enq > max_it) {
+      if ((rc = read_scalars(c))) return rc;
+      if (c->h_sc->done) break;
+      next_poll = (int)std::min<int64_t>(enq + std::min<int64_t>(poll, std::max<int64_t>(1, enq)), max_it + 1);
+    }
+  }
+  PA_HIP(c, hipEventRecord(c->ev1, c->stream));
+  PA_HIP(c, hipEventSynchronize(c->ev1));
+  float ms = 0.f;
+  (void)hipEventElapsedTime(&ms, c->ev0, c->ev1);
+  fill_report(c, out, ms);
+  c->solver_live = 0;
+  return c->h_sc->err ? PA_E_NONFINITE : PA_OK;
+}
+
+template <typename T>
+static int jacobi_run_t(pa_ctx* c, T* x, const T* rhs, double tol, int64_t max_it, double omega, pa_report* out) {
+  const DevGeom& G = c->G;
+  for (int q = 0; q < c->nterms; ++q)
+    if (c->terms[q].kind != PA_OP_LAPLACIAN) { pa_set_err(c, "pa_jacobi: laplacian terms only"); return PA_E_ARG; }
+  if (c->slab) { pa_set_err(c, "pa_jacobi is single-GPU only"); return PA_E_ARG; }
+  const size_t fb = (size_t)G.ncell * sizeof(T);
+  const int nblk = pa_grid_blocks(G.ncell);
+  int rc;
+  if ((rc = pa_scratch(c, &c->scr[SCR_D0], &c->cap[SCR_D0], fb))) return rc;
+  if ((rc = pa_scratch(c, &c->scr[SCR_PART], &c->cap[SCR_PART], (size_t)PA_MAX_GRID * 4 * sizeof(double)))) return rc;
+  if ((rc = pa_scratch(c, &c->scr[SCR_PART2], &c->cap[SCR_PART2], (size_t)PA_MAX_GRID * sizeof(double)))) return rc;
+  if ((rc = pa_scratch(c, &c->scr[SCR_SHELL], &c->cap[SCR_SHELL], (size_t)shell_elems(c) * sizeof(T)))) return rc;
+  if ((rc = init_scalars(c, tol, max_it))) return rc;
+  DevEq<T> E;
+  pa_build_eq<T>(c, c->nterms, c->terms, E);
+  if ((rc = bc_apply_t<T>(c, x))) return rc;
+  const bool stat = bc_is_static(c);
+  double* part = (double*)c->scr[SCR_PART];
+  double* part2 = (double*)c->scr[SCR_PART2];
+  hipLaunchKernelGGL(k_shell<T>, dim3(shell_blocks(c)), dim3(PA_BLOCK), 0, c->stream, G, c->sc, (const T*)x,
+                     (T*)c->scr[SCR_SHELL], part2, 0);
+  T* buf[2] = {x, (T*)c->scr[SCR_D0]};
+  int cur = 0;
+  const int poll = poll_interval(c);
+  PA_HIP(c, hipEventRecord(c->ev0, c->stream));
+  int64_t enq = 0;
+  int next_poll = 1;
+  for (;;) {
+    // two sweeps per round so that the iterate is back in the caller's buffer at every poll
+    for (int half = 0; half < 2; ++half) {
+      Vec<T> xv = pa_vec_self<T>(c, buf[cur]);
+      hipLaunchKernelGGL(k_jacobi<T>, dim3(nblk), dim3(PA_BLOCK), 0, c->stream, G, E, c->sc, xv, rhs, buf[cur ^ 1],
+                         (T)omega, part);
+      int nsh = 0;
+      // NOTE: when done is set the sweep kernels return early, so buf[cur^1] is stale: the copy-back
+      // below is guarded by the iteration parity recorded on the device (itr).
+      if (!stat) {
+        if ((rc = bc_apply_t<T>(c, buf[cur ^ 1], true))) return rc;
+        nsh = shell_blocks(c);
+        hipLaunchKernelGGL(k_shell<T>, dim3(nsh), dim3(PA_BLOCK), 0, c->stream, G, c->sc, (const T*)buf[cur ^ 1],
+                           (T*)c->scr[SCR_SHELL], part2, 1);
+      }
+      hipLaunchKernelGGL(k_jacobi_post<T>, dim3(1), dim3(PA_BLOCK), 0, c->stream, c->sc, part, nblk, part2, nsh,
+                         pa_sums(c));
+      cur ^= 1;
+      ++enq;
+    }
+    if (enq >= next_poll || enq > max_it) {
+      if ((rc = read_scalars(c))) return rc;
+      if (c->h_sc->done) break;
+      next_poll = (int)std::min<int64_t>(enq + std::min<int64_t>(2 * poll, std::max<int64_t>(2, enq)), max_it + 2);
+    }
+  }
+  // the final iterate lives in buf[itr & 1]
+  if (c->h_sc->itr & 1) {
+    hipLaunchKernelGGL(k_copy<T>, dim3(nblk), dim3(PA_BLOCK), 0, c->stream, (const T*)buf[1], x, G.ncell);
+  }
+  PA_HIP(c, hipEventRecord(c->ev1, c->stream));
+  PA_HIP(c, hipEventSynchronize(c->ev1));
+  float ms = 0.f;
+  (void)hipEventElapsedTime(&ms, c->ev0, c->ev1);
+  fill_report(c, out, ms);
+  return c->h_sc->err ? PA_E_NONFINITE : PA_OK;
+}
+
+template <typename T>
+static int bicg_run_t(pa_ctx* c, T* x, const T* rhs, double tol, int64_t max_it, pa_report* out) {
+  const DevGeom& G = c->G;
+  if (c->slab) { pa_set_err(c, "pa_bicgstab is single-GPU only in this build"); return PA_E_ARG; }
+  const size_t fb = (size_t)G.ncell * sizeof(T);
+  const int nblk = pa_grid_blocks(G.ncell);
+  int rc;
+  const int ids[] = {SCR_R, SCR_D0, SCR_D1, SCR_R0, SCR_V0, SCR_V1, SCR_S, SCR_TT};
+  for (int id : ids)
+    if ((rc = pa_scratch(c, &c->scr[id], &c->cap[id], fb))) return rc;
+  if ((rc = pa_scratch(c, &c->scr[SCR_PART], &c->cap[SCR_PART], (size_t)PA_MAX_GRID * 4 * sizeof(double)))) return rc;
+  if ((rc = init_scalars(c, tol, max_it))) return rc;
+  DevEq<T> E;
+  pa_build_eq<T>(c, c->nterms, c->terms, E);
+  if ((rc = bc_apply_t<T>(c, x))) return rc;
+  T* r = (T*)c->scr[SCR_R];
+  T* r0 = (T*)c->scr[SCR_R0];
+  T* p[2] = {(T*)c->scr[SCR_D0], (T*)c->scr[SCR_D1]};
+  T* v[2] = {(T*)c->scr[SCR_V0], (T*)c->scr[SCR_V1]};
+  T* s = (T*)c->scr[SCR_S];
+  T* t = (T*)c->scr[SCR_TT];
+  double* part = (double*)c->scr[SCR_PART];
+  Vec<T> xv = pa_vec_self<T>(c, x);
+  hipLaunchKernelGGL(k_cg_init<T>, dim3(nblk), dim3(PA_BLOCK), 0, c->stream, G, E, xv, rhs, r0, r, part);
+  PA_HIP(c, hipMemsetAsync(p[0], 0, fb, c->stream));
+  PA_HIP(c, hipMemsetAsync(v[0], 0, fb, c->stream));
+  // rho_next = sum r0.r0 ; tol0 = sqrt(rho_next) ; first beta = rho_next / 1 * 1 / 1 (linalg.py:201-212)
+  hipLaunchKernelGGL(k_cg_post_init<T>, dim3(1), dim3(PA_BLOCK), 0, c->stream, c->sc, part, nblk, pa_sums(c), 2);
+  if ((rc = read_scalars(c))) return rc;
+  {
+    SolverScalars h = *c->h_sc;
+    h.rho_next = h.rr;
+    h.tol = (double)(T)sqrt((T)h.rr);
+    T b = (T)h.rho_next / (T)1.0;
+    b = b * (T)1.0;
+    b = b / (T)1.0;
+    h.beta = (double)b;
+    h.rho = h.rho_next;
+    h.done = 0;  // `while not finished`: at least one iteration
+    *c->h_sc = h;
+    PA_HIP(c, hipMemcpyAsync(c->sc, c->h_sc, sizeof(h), hipMemcpyHostToDevice, c->stream));
+    PA_HIP(c, hipStreamSynchronize(c->stream));
+  }
+  int cur = 0;
+  const int poll = poll_interval(c);
+  PA_HIP(c, hipEventRecord(c->ev0, c->stream));
+  int64_t enq = 0;
+  int next_poll = 1;
+  for (;;) {
+    Vec<T> rv = pa_vec_self<T>(c, r), pv = pa_vec_self<T>(c, p[cur]), vv = pa_vec_self<T>(c, v[cur]);
+    hipLaunchKernelGGL(k_bicg_pv<T>, dim3(nblk), dim3(PA_BLOCK), 0, c->stream, G, E, c->sc, rv, pv, vv, (const T*)r0,
+                       p[cur ^ 1], v[cur ^ 1], part);
+    hipLaunchKernelGGL(k_bicg_post<T>, dim3(1), dim3(PA_BLOCK), 0, c->stream, c->sc, part, nblk, 0);
+    hipLaunchKernelGGL(k_bicg_s<T>, dim3(nblk), dim3(PA_BLOCK), 0, c->stream, G, c->sc, (const T*)r,
+                       (const T*)v[cur ^ 1], s, part);
+    hipLaunchKernelGGL(k_bicg_post<T>, dim3(1), dim3(PA_BLOCK), 0, c->stream, c->sc, part, nblk, 1);
+    Vec<T> sv = pa_vec_self<T>(c, s);
+    hipLaunchKernelGGL(k_bicg_t<T>, dim3(nblk), dim3(PA_BLOCK), 0, c->stream, G, E, c->sc, sv, (const T*)r0, t, part);
+    hipLaunchKernelGGL(k_bicg_post<T>, dim3(1), dim3(PA_BLOCK), 0, c->stream, c->sc, part, nblk, 2);
+    hipLaunchKernelGGL(k_bicg_x<T>, dim3(nblk), dim3(PA_BLOCK), 0, c->stream, G, c->sc, x, (const T*)p[cur ^ 1],
+                       (const T*)s, (const T*)t, r, part);
+    if ((rc = bc_apply_t<T>(c, x, true))) return rc;
+    hipLaunchKernelGGL(k_bicg_post<T>, dim3(1), dim3(PA_BLOCK), 0, c->stream, c->sc, part, nblk, 3);
+    cur ^= 1;
+    ++enq;
+    if (enq >= next_poll || enq >= max_it) {
+      if ((rc = read_scalars(c))) return rc;
+      if (c->h_sc->done) break;
+      next_poll = (int)std::min<int64_t>(enq + std::min<int64_t>(poll, std::max<int64_t>(1, enq)), max_it);
+    }
+  }
+  PA_HIP(c, hipEventRecord(c->ev1, c->stream));
+  PA_HIP(c, hipEventSynchronize(c->ev1));
+  float ms = 0.f;
+  (void)hipEventElapsedTime(&ms, c->ev0, c->ev1);
+  fill_report(c, out, ms);
+  return c->h_sc->err ? PA_E_NONFINITE : PA_OK;
+}
+
+extern "C" {
+
+int pa_cg(pa_ctx* c, void* x, const void* rhs, double tol, int64_t max_it, pa_report* out) {
+  if (!c || !c->grid_set || !c->eq_set) { if (c) pa_set_err(c, "pa_cg: grid/equation not set"); return PA_E_STATE; }
+  if (!out) return PA_E_ARG;
+  if (c->slab) { pa_set_err(c, "pa_cg is the single-GPU loop; use the stepwise API on a slab"); return PA_E_STATE; }
+  PA_HIP(c, hipSetDevice(c->device));
+  return c->dtype == PA_F64 ? cg_run_t<double>(c, (double*)x, (const double*)rhs, tol, max_it, out)
+                            : cg_run_t<float>(c, (float*)x, (const float*)rhs, tol, max_it, out);
+}
+
+int pa_bicgstab(pa_ctx* c, void* x, const void* rhs, double tol, int64_t max_it, pa_report* out) {
+  if (!c || !c->grid_set || !c->eq_set) { if (c) pa_set_err(c, "pa_bicgstab: grid/equation not set"); return PA_E_STATE; }
+  if (!out) return PA_E_ARG;
+  PA_HIP(c, hipSetDevice(c->device));
+  return c->dtype == PA_F64 ? bicg_run_t<double>(c, (double*)x, (const double*)rhs, tol, max_it, out)
+                            : bicg_run_t<float>(c, (float*)x, (const float*)rhs, tol, max_it, out);
+}
+
+int pa_jacobi(pa_ctx* c, void* x, const void* rhs, double tol, int64_t max_it, double omega, pa_report* out) {
+  if (!c || !c->grid_set || !c->eq_set) { if (c) pa_set_err(c, "pa_jacobi: grid/equation not set"); return PA_E_STATE; }
+  if (!out) return PA_E_ARG;
+  PA_HIP(c, hipSetDevice(c->device));
+  return c->dtype == PA_F64 ? jacobi_run_t<double>(c, (double*)x, (const double*)rhs, tol, max_it, omega, out)
+                            : jacobi_run_t<float>(c, (float*)x, (const float*)rhs, tol, max_it, omega, out);
+}
+
+}  // extern "C"
+
+// ============================================================================
+//  stepwise CG (bench.py, slab-decomposed driver)
+// ============================================================================
+extern "C" {
+
+int pa_cg_begin(pa_ctx* c, void* x, const void* rhs, double tol, int64_t max_it) {
+  if (!c || !c->grid_set || !c->eq_set) { if (c) pa_set_err(c, "pa_cg_begin: grid/equation not set"); return PA_E_STATE; }
+  PA_HIP(c, hipSetDevice(c->device));
+  return c->dtype == PA_F64 ? cg_begin_t<double>(c, (double*)x, (const double*)rhs, tol, max_it)
+                            : cg_begin_t<float>(c, (float*)x, (const float*)rhs, tol, max_it);
+}
+
+int pa_cg_phase_a(pa_ctx* c) {
+  if (!c || !c->solver_live) { if (c) pa_set_err(c, "pa_cg_phase_a without pa_cg_begin"); return PA_E_STATE; }
+  const int st = c->slab ? 0 : 2;
+  return c->dtype == PA_F64 ? pa_cg_phase_a_t<double>(c, st) : pa_cg_phase_a_t<float>(c, st);
+}
+
+int pa_cg_phase_b(pa_ctx* c) {
+  if (!c || !c->solver_live) { if (c) pa_set_err(c, "pa_cg_phase_b without pa_cg_begin"); return PA_E_STATE; }
+  if (c->slab) {  // alpha from the all-reduced sum d.Ad
+    if (c->dtype == PA_F64)
+      hipLaunchKernelGGL(k_cg_post_a<double>, dim3(1), dim3(PA_BLOCK), 0, c->stream, c->sc, (const double*)nullptr, 0, pa_sums(c), 1);
+    else
+      hipLaunchKernelGGL(k_cg_post_a<float>, dim3(1), dim3(PA_BLOCK), 0, c->stream, c->sc, (const double*)nullptr, 0, pa_sums(c), 1);
+  }
+  const int st = c->slab ? 0 : 2;
+  return c->dtype == PA_F64 ? pa_cg_phase_b_t<double>(c, st) : pa_cg_phase_b_t<float>(c, st);
+}
+
+int pa_cg_finish_iter(pa_ctx* c) {
+  if (!c || !c->solver_live) { if (c) pa_set_err(c, "pa_cg_finish_iter without pa_cg_begin"); return PA_E_STATE; }
+  if (!c->slab) return PA_OK;  // logic already ran inside phase_b
+  if (c->dtype == PA_F64)
+    hipLaunchKernelGGL(k_cg_post_b<double>, dim3(1), dim3(PA_BLOCK), 0, c->stream, c->sc, (const double*)nullptr, 0,
+                       (const double*)nullptr, 0, pa_sums(c), 1);
+  else
+    hipLaunchKernelGGL(k_cg_post_b<float>, dim3(1), dim3(PA_BLOCK), 0, c->stream, c->sc, (const double*)nullptr, 0,
+                       (const double*)nullptr, 0, pa_sums(c), 1);
+  PA_HIP(c, hipGetLastError());
+  return PA_OK;
+}
+
+int pa_cg_iterate(pa_ctx* c, int64_t n) {
+  if (!c || !c->solver_live) { if (c) pa_set_err(c, "pa_cg_iterate without pa_cg_begin"); return PA_E_STATE; }
+  if (c->slab) { pa_set_err(c, "pa_cg_iterate is single-rank; drive the phases on a slab"); return PA_E_STATE; }
+  for (int64_t q = 0; q < n; ++q) {
+    int rc = c->dtype == PA_F64 ? pa_cg_phase_a_t<double>(c, 2) : pa_cg_phase_a_t<float>(c, 2);
+    if (rc) return rc;
+    rc = c->dtype == PA_F64 ? pa_cg_phase_b_t<double>(c, 2) : pa_cg_phase_b_t<float>(c, 2);
+    if (rc) return rc;
+  }
+  return PA_OK;
+}
+
+int pa_report_read(pa_ctx* c, pa_report* out) {
+  if (!c || !out) return PA_E_ARG;
+  int rc = read_scalars(c);
+  if (rc) return rc;
+  fill_report(c, out, 0.f);
+  return PA_OK;
+}
+
+int pa_cg_end(pa_ctx* c, pa_report* out) {
+  if (!c || !c->solver_live) { if (c) pa_set_err(c, "pa_cg_end without pa_cg_begin"); return PA_E_STATE; }
+  int rc = out ? pa_report_read(c, out) : PA_OK;
+  c->solver_live = 0;
+  if (rc) return rc;
+  return (out && out->status) ? PA_E_NONFINITE : PA_OK;
+}
+
+}  // extern "C"

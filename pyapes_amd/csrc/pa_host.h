@@ -1,0 +1,95 @@
+// pa_host.h -- host-side context of libpyapes_hip (shared by pa_core.hip / pa_cg3d.hip / pa_slab.hip)
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdarg.h>
+#include <stdint.h>
+
+#include "../../include/pyapes_hip.h"
+#include "pa_device.h"
+
+#define PA_MAX_GRID 2048  // 256 CUs x 8 resident workgroups of 256 threads
+
+struct SolverScalars;
+
+struct HostBC {
+  int type = PA_BC_NONE;
+  double value = 0.0;
+  const void* vals = nullptr;
+  double dxf = 0.0;
+};
+
+enum {
+  SCR_R = 0, SCR_D0, SCR_D1, SCR_PART, SCR_PART2, SCR_SHELL, SCR_R0, SCR_V0, SCR_V1, SCR_S, SCR_TT,
+  SCR_GHOST, PA_NSCRATCH
+};
+
+struct pa_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  char err[512];
+  // grid
+  int grid_set = 0, ndim = 0, dtype = PA_F64, esize = 8;
+  double dx[3] = {1, 1, 1};
+  DevGeom G;
+  // BCs (internal face numbering)
+  HostBC bc[6];
+  int bc_order[6] = {0, 0, 0, 0, 0, 0};
+  int nbc = 0;
+  // equation
+  int eq_set = 0, nterms = 0;
+  pa_term terms[PA_MAX_TERMS];
+  // scratch
+  void* scr[PA_NSCRATCH] = {nullptr};
+  size_t cap[PA_NSCRATCH] = {0};
+  SolverScalars* sc = nullptr;    // device
+  SolverScalars* h_sc = nullptr;  // pinned host mirror
+  double* sums = nullptr;         // device, PA_NSUM (internal)
+  double* ext_sums = nullptr;     // slab: caller-owned sums buffer (all-reduced by the host driver)
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  // CG state
+  int solver_live = 0, cur = 0, bc_static = 0;
+  void* cg_x = nullptr;
+  // slab decomposition (P > 1): externally owned exchange buffers
+  int slab = 0;
+  const void* x_glo = nullptr;   // ghost planes of the field handed to pa_aop / begin
+  const void* x_ghi = nullptr;
+  void* r_send_lo = nullptr;     // copies of r's first / last owned plane
+  void* r_send_hi = nullptr;
+  const void* r_recv_lo = nullptr;  // ghost planes of r
+  const void* r_recv_hi = nullptr;
+  void* d_glo[2] = {nullptr, nullptr};  // ghost planes of the two direction buffers (ctx scratch)
+  void* d_ghi[2] = {nullptr, nullptr};
+  const void* bc_far_lo0 = nullptr;  // periodic axis-0 fill: x[N-1] (for the lower end rank)
+  const void* bc_far_lo1 = nullptr;  //                       x[N-2]
+  const void* bc_far_hi0 = nullptr;  //                       x[0]   (for the upper end rank)
+  // 3-D fast path switch (PYAPES_HIP_FASTPATH=0 disables; tests compare both)
+  int fastpath = 1;
+};
+
+static inline double* pa_sums(const pa_ctx* c) { return (c->slab && c->ext_sums) ? c->ext_sums : c->sums; }
+
+void pa_set_err(pa_ctx* c, const char* fmt, ...);
+int pa_hip_fail(pa_ctx* c, hipError_t e, const char* what);
+int pa_grid_blocks(int64_t work);
+int pa_scratch(pa_ctx* c, void** slot, size_t* cap, size_t bytes);
+void pa_refresh_geom(pa_ctx* c);
+int pa_bc_apply_any(pa_ctx* c, void* x);
+
+#define PA_HIP(c, call)                                              \
+  do {                                                               \
+    hipError_t e__ = (call);                                         \
+    if (e__ != hipSuccess) return pa_hip_fail((c), e__, #call);      \
+  } while (0)
+
+template <typename T>
+void pa_build_eq(const pa_ctx* c, int nterms, const pa_term* terms, DevEq<T>& E);
+template <typename T>
+Vec<T> pa_vec_self(const pa_ctx* c, const T* p);
+
+// 3-D fast path (pa_cg3d.hip): return number of partial-sum rows written (> 0) when the
+// kernel ran, 0 when the configuration is not covered (caller falls back to the generic
+// kernel, which is still HIP), < 0 on error.
+template <typename T>
+int pa_cg3d_phase_a(pa_ctx* c, const DevEq<T>& E, Vec<T> r, Vec<T> d, T* dnew, double* partials);
+template <typename T>
+int pa_cg3d_phase_b(pa_ctx* c, const DevEq<T>& E, Vec<T> d, T* x, T* r, double* partials);

@@ -1,0 +1,243 @@
+"""``HipContext``: one ``pa_ctx`` per mesh, the only place Python talks to the C ABI.
+
+Tensors are handed over as ``data_ptr()``; the context keeps references to every
+tensor whose pointer the library still holds (face-value arrays, tensor
+coefficients) so that they outlive the call.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import warnings
+from typing import Any, Sequence
+
+import torch
+from torch import Tensor
+
+from ..backend import require_gpu
+from ..geometry.basis import FDIR
+from . import lib as L
+
+
+def _check(ctx: "HipContext | None", lib: C.CDLL, rc: int, handle: Any = None) -> None:
+    if rc == L.PA_OK:
+        return
+    msg = lib.pa_last_error(handle).decode() if lib is not None else "?"
+    raise L.PaError(rc, msg)
+
+
+class HipContext:
+    def __init__(self, mesh: Any):
+        if not mesh.is_cuda or not torch.cuda.is_available():
+            raise RuntimeError(
+                "pyapes_amd: a HIP context needs a mesh on device='cuda' and a visible MI355X; "
+                "this backend has no CPU compute path.")
+        self.lib = L.load_library()
+        self.mesh = mesh
+        self.device = mesh.device
+        dev_index = self.device.index if self.device.index is not None else torch.cuda.current_device()
+        self.stream = torch.cuda.current_stream(self.device)
+        h = C.c_void_p()
+        _check(None, self.lib, self.lib.pa_ctx_create(dev_index, C.c_void_p(self.stream.cuda_stream), C.byref(h)))
+        self.h = h
+        self.dtype = mesh.dtype.float
+        nd = mesh.dim
+        n = (C.c_int64 * nd)(*[int(v) for v in mesh.nx])
+        dx = (C.c_double * nd)(*mesh.dx_list)
+        n0g = int(mesh.global_nx[0])
+        self._rc(self.lib.pa_grid_set(self.h, nd, n, dx, L.PA_F64 if self.dtype == torch.float64 else L.PA_F32,
+                                      int(mesh.i_off), n0g))
+        self._keep: dict[str, Any] = {}
+        self._bc_sig: Any = None
+
+    def __del__(self):
+        try:
+            if getattr(self, "h", None) is not None and self.h.value:
+                self.lib.pa_ctx_destroy(self.h)
+                self.h = C.c_void_p()
+        except Exception:
+            pass
+
+    def _rc(self, rc: int) -> None:
+        _check(self, self.lib, rc, self.h)
+
+    def _ptr(self, t: Tensor | None) -> C.c_void_p:
+        return C.c_void_p(0 if t is None else t.data_ptr())
+
+    def _field(self, t: Tensor, what: str) -> Tensor:
+        """a contiguous scalar field view ``(*nx)`` of the mesh dtype on the GPU"""
+        require_gpu(t, what)
+        if t.dtype != self.dtype:
+            raise TypeError(f"pyapes_amd: {what}: tensor dtype {t.dtype} != mesh dtype {self.dtype}")
+        if not t.is_contiguous():
+            raise ValueError(f"pyapes_amd: {what}: tensor must be contiguous")
+        if t.numel() != self.mesh.N:
+            raise ValueError(f"pyapes_amd: {what}: expected {self.mesh.N} nodes, got {t.numel()}")
+        return t
+
+    # -- boundary conditions -----------------------------------------------------
+    def bind_bcs(self, var: Tensor, bcs: Sequence[Any], comp: int = 0, for_rhs: bool = False) -> None:
+        """(Re)load the ordered BC list for component ``comp`` of ``var`` ((dim,*nx) tensor)."""
+        self._rc(self.lib.pa_bc_clear(self.h))
+        keep = []
+        for pos, bc in enumerate(bcs):
+            scalar, arr = bc.resolve(var, comp, for_rhs=for_rhs)
+            if arr is not None:
+                keep.append(arr)
+            dxf = self.mesh.face_dxf(bc.bc_face) if bc.bc_type == "neumann" else 0.0
+            self._rc(self.lib.pa_bc_set(self.h, FDIR.index(bc.bc_face), pos, L.BC_CODE[bc.bc_type],
+                                        float(scalar), self._ptr(arr), float(dxf)))
+        self._keep["bc"] = keep
+
+    def apply_bcs(self, var: Tensor, bcs: Sequence[Any], comps: Sequence[int] | None = None) -> None:
+        """``linalg._apply_bc_otf``: every component, every face in list order, in place."""
+        require_gpu(var, "BC fill")
+        for d in (range(var.shape[0]) if comps is None else comps):
+            self.bind_bcs(var, bcs, d)
+            self._rc(self.lib.pa_apply_bc(self.h, self._ptr(self._field(var[d], "BC fill"))))
+
+    # -- equation -------------------------------------------------------------------
+    def set_terms(self, terms: Sequence[dict]) -> None:
+        """terms: dicts with kind, sign, coeff (None|float|Tensor), u (float|Tensor)."""
+        arr = (L.PaTerm * len(terms))()
+        keep = []
+        for q, t in enumerate(terms):
+            arr[q].kind = t["kind"]
+            arr[q].sign = float(t.get("sign", 1.0))
+            coeff = t.get("coeff")
+            arr[q].has_coeff = 0 if coeff is None else 1
+            arr[q].coeff = 0.0
+            arr[q].coeff_field = None
+            if isinstance(coeff, Tensor):
+                cf = torch.broadcast_to(coeff.to(self.device, self.dtype), (1, *self.mesh.nx)).contiguous()
+                keep.append(cf)
+                arr[q].coeff_field = cf.data_ptr()
+            elif coeff is not None:
+                arr[q].coeff = float(coeff)
+            u = t.get("u", 0.0)
+            arr[q].u = 0.0
+            arr[q].u_field = None
+            if isinstance(u, Tensor):
+                uf = self._field(u if u.dim() == self.mesh.dim else u[0], "advection tensor")
+                keep.append(uf)
+                arr[q].u_field = uf.data_ptr()
+            else:
+                arr[q].u = float(u)
+        self._keep["terms"] = (arr, keep)
+        self._rc(self.lib.pa_eq_set(self.h, len(terms), arr))
+
+    def aop(self, x: Tensor, interior_only: bool = False) -> Tensor:
+        x = self._field(x, "Aop")
+        y = torch.empty_like(x)
+        self._rc(self.lib.pa_aop(self.h, self._ptr(x), self._ptr(y), 1 if interior_only else 0))
+        return y
+
+    def rhs_adjust(self, rhs: Tensor) -> None:
+        self._rc(self.lib.pa_rhs_adjust(self.h, self._ptr(self._field(rhs, "rhs"))))
+
+    # -- explicit operators ------------------------------------------------------------
+    def laplacian(self, x: Tensor, edge: bool) -> Tensor:
+        x = self._field(x, "laplacian")
+        y = torch.empty_like(x)
+        self._rc(self.lib.pa_laplacian(self.h, self._ptr(x), self._ptr(y), int(edge)))
+        return y
+
+    def grad(self, x: Tensor, edge: bool) -> Tensor:
+        x = self._field(x, "grad")
+        y = torch.empty((self.mesh.dim, *self.mesh.nx), dtype=self.dtype, device=self.device)
+        self._rc(self.lib.pa_grad(self.h, self._ptr(x), self._ptr(y), int(edge)))
+        return y
+
+    def div(self, kind: int, u: float | Tensor, x: Tensor) -> Tensor:
+        x = self._field(x, "div")
+        y = torch.empty_like(x)
+        uf = None
+        us = 0.0
+        if isinstance(u, Tensor):
+            uf = self._field(u if u.dim() == self.mesh.dim else u[0], "advection tensor")
+        else:
+            us = float(u)
+        self._rc(self.lib.pa_div(self.h, kind, us, self._ptr(uf), self._ptr(x), self._ptr(y)))
+        return y
+
+    def euler_step(self, phi: Tensor, out: Tensor, kind: int, u: float | Tensor, nu: float, dt: float) -> None:
+        phi = self._field(phi, "euler_step")
+        out = self._field(out, "euler_step")
+        uf, us = None, 0.0
+        if isinstance(u, Tensor):
+            uf = self._field(u if u.dim() == self.mesh.dim else u[0], "advection tensor")
+        else:
+            us = float(u)
+        self._rc(self.lib.pa_euler_step(self.h, self._ptr(phi), self._ptr(out), kind, us, self._ptr(uf),
+                                        float(nu), float(dt)))
+
+    # -- solvers --------------------------------------------------------------------------
+    def solve(self, method: str, x: Tensor, rhs: Tensor, tol: float, max_it: int,
+              omega: float = 1.0) -> L.PaReport:
+        x = self._field(x, "solve")
+        rhs = self._field(rhs, "solve rhs")
+        rep = L.PaReport()
+        if method == "cg":
+            rc = self.lib.pa_cg(self.h, self._ptr(x), self._ptr(rhs), float(tol), int(max_it), C.byref(rep))
+        elif method == "bicgstab":
+            rc = self.lib.pa_bicgstab(self.h, self._ptr(x), self._ptr(rhs), float(tol), int(max_it), C.byref(rep))
+        elif method == "jacobi":
+            rc = self.lib.pa_jacobi(self.h, self._ptr(x), self._ptr(rhs), float(tol), int(max_it), float(omega),
+                                    C.byref(rep))
+        else:
+            raise RuntimeError(f"unknown method {method}")
+        if rc == L.PA_E_NONFINITE:
+            # linalg.py:334-336
+            raise RuntimeError(f"Invalid tolerance detected! tol: {rep.tol}")
+        self._rc(rc)
+        return rep
+
+    # stepwise CG (bench.py and the slab driver)
+    def cg_begin(self, x: Tensor, rhs: Tensor, tol: float, max_it: int) -> None:
+        self._keep["cg"] = (x, rhs)
+        self._rc(self.lib.pa_cg_begin(self.h, self._ptr(self._field(x, "cg")), self._ptr(self._field(rhs, "cg rhs")),
+                                      float(tol), int(max_it)))
+
+    def cg_iterate(self, n: int) -> None:
+        self._rc(self.lib.pa_cg_iterate(self.h, int(n)))
+
+    def cg_phase_a(self) -> None:
+        self._rc(self.lib.pa_cg_phase_a(self.h))
+
+    def cg_phase_b(self) -> None:
+        self._rc(self.lib.pa_cg_phase_b(self.h))
+
+    def cg_finish_iter(self) -> None:
+        self._rc(self.lib.pa_cg_finish_iter(self.h))
+
+    def cg_end(self) -> L.PaReport:
+        rep = L.PaReport()
+        rc = self.lib.pa_cg_end(self.h, C.byref(rep))
+        self._keep.pop("cg", None)
+        if rc == L.PA_E_NONFINITE:
+            raise RuntimeError(f"Invalid tolerance detected! tol: {rep.tol}")
+        self._rc(rc)
+        return rep
+
+    def report(self) -> L.PaReport:
+        rep = L.PaReport()
+        self._rc(self.lib.pa_report_read(self.h, C.byref(rep)))
+        return rep
+
+    def slab_set(self, bufs: dict[str, Tensor | None] | None) -> None:
+        if bufs is None:
+            self._rc(self.lib.pa_slab_set(self.h, None))
+            self._keep.pop("slab", None)
+            return
+        s = L.PaSlab()
+        for name, _ in L.PaSlab._fields_:
+            t = bufs.get(name)
+            setattr(s, name, None if t is None else t.data_ptr())
+        self._keep["slab"] = (s, bufs)
+        self._rc(self.lib.pa_slab_set(self.h, C.byref(s)))
+
+
+def context_for(mesh: Any) -> HipContext:
+    """The (lazily created) context of a mesh."""
+    if getattr(mesh, "_hip", None) is None:
+        mesh._hip = HipContext(mesh)
+    return mesh._hip

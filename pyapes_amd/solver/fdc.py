@@ -1,0 +1,225 @@
+"""Explicit finite-difference discretisers (mirrors ``pyapes/solver/fdc.py``).
+
+``FDC(config).laplacian(var)``, ``.grad(var)``, ``.div(var_j, var_i)`` evaluate the
+2nd-order stencils on the current field and return a tensor; ``build_A_coeffs`` /
+``adjust_rhs`` / ``apply`` keep their meaning.  All arithmetic is done by
+``k_aop`` / ``k_grad`` / ``k_edge`` / ``k_rhs_adjust`` in ``csrc/pa_core.hip``.
+Out of scope: DiffFlux, jacobian, hessian, rz terms.
+"""
+from __future__ import annotations
+
+import warnings
+from typing import Any
+
+import torch
+from torch import Tensor
+
+from ..backend import require_gpu
+from ..hip import lib as L
+from ..hip.context import context_for
+from ..variables import Field
+from .tools import StencilSpec
+from .types import DiscretizerConfigType
+
+
+def _limiter(cfg: dict | None) -> tuple[str, bool]:
+    """fdc.py:697-705"""
+    if cfg is not None and "limiter" in cfg:
+        return cfg["limiter"].lower(), bool(cfg.get("compat", False))
+    warnings.warn("FDM: no limiter is specified. Use `none` (central difference) as a default.")
+    return "none", False
+
+
+def div_kind(limiter: str, compat: bool) -> int:
+    if limiter == "none":
+        return L.OP_DIV_CENTRAL
+    if limiter == "upwind":
+        return L.OP_DIV_UPWIND_COMPAT if compat else L.OP_DIV_UPWIND
+    if limiter == "quick":
+        raise NotImplementedError("FDC Div: quick scheme is not implemented yet.")
+    raise RuntimeError(f"FDC Div: {limiter=} is an unknown limiter type.")
+
+
+def _adv_of(var_j: Any, var_i: Field) -> float | Tensor:
+    """fdc.py:775-792: float stays a scalar (the kernels broadcast it), Tensor / Field must be
+    field-shaped; a scalar target is advected by component 0 on every axis."""
+    if isinstance(var_j, Field):
+        var_j = var_j()
+    if isinstance(var_j, Tensor):
+        assert var_j.shape == var_i().shape, "FDC Div: adv shape must match var_i shape"
+        return var_j
+    if isinstance(var_j, (float, int)):
+        return float(var_j)
+    raise NotImplementedError("FDC Div: Jac / Hess advection is out of scope")
+
+
+class Discretizer:
+    """Base of the three operators (fdc.py:25-168)."""
+
+    _op_type = "Discretizer"
+
+    def __init__(self):
+        self.A_coeffs: StencilSpec | None = None
+        self._rhs_args: tuple | None = None
+        self._config: DiscretizerConfigType | None = None
+
+    @property
+    def op_type(self) -> str:
+        return self._op_type
+
+    @property
+    def config(self) -> DiscretizerConfigType | None:
+        return self._config
+
+    def set_config(self, config: DiscretizerConfigType) -> None:
+        self._config = config
+
+    def reset(self) -> None:
+        self.A_coeffs = None
+        self._rhs_args = None
+
+    @property
+    def rhs_adj(self) -> Tensor | None:
+        """RHS adjustment of the last call (evaluated on first access)."""
+        if self._rhs_args is None:
+            return None
+        return self.adjust_rhs(*self._rhs_args)
+
+    def _edge(self) -> bool:
+        if self._config is not None and self.op_type.lower() in self._config:
+            return bool(self._config[self.op_type.lower()].get("edge", False))  # type: ignore[literal-required]
+        warnings.warn("FDC: config is not defined! Using default config (edge=False).")
+        return False
+
+    def __call__(self, *args: Any) -> Tensor:
+        if len(args) == 1:
+            assert isinstance(args[0], Field), "FDC: only `Field` is allowed for var!"
+            self.A_coeffs = self.build_A_coeffs(args[0])
+            self._rhs_args = (args[0],)
+            return self.apply(self.A_coeffs, args[0])
+        assert isinstance(args[1], Field), "FDC: only `Field` is allowed for var_i!"
+        self.A_coeffs = self.build_A_coeffs(args[0], args[1], config=self._config)
+        self._rhs_args = (args[0], args[1], self._config)
+        self.var_addition = args[0]
+        return self.apply(self.A_coeffs, args[1])
+
+
+def _rhs_adjust(var: Field, term: dict, bcs: list) -> Tensor:
+    """rhs_adj tensor of one operator: the kernel adds into zeros."""
+    require_gpu(var(), "adjust_rhs")
+    ctx = context_for(var.mesh)
+    out = torch.zeros_like(var())
+    for d in range(var.dim):
+        ctx.bind_bcs(var(), bcs, d, for_rhs=True)
+        ctx.set_terms([term])
+        ctx.rhs_adjust(out[d])
+    return out
+
+
+class Laplacian(Discretizer):
+    _op_type = "Laplacian"
+
+    @staticmethod
+    def build_A_coeffs(var: Field) -> StencilSpec:
+        return StencilSpec("Laplacian", list(var.bcs) if var.bcs is not None else [])
+
+    @staticmethod
+    def adjust_rhs(var: Field) -> Tensor:
+        """``+(2/3) V n / dx`` on the first interior plane of every neumann face (fdc.py:426-458)."""
+        return _rhs_adjust(var, {"kind": L.OP_LAPLACIAN}, var.bcs or [])
+
+    def apply(self, A_coeffs: StencilSpec, var: Field) -> Tensor:
+        assert A_coeffs is not None, "FDC: A_A_coeffs is not defined!"
+        require_gpu(var(), "FDC.laplacian")
+        ctx = context_for(var.mesh)
+        edge = self._edge()
+        out = torch.empty_like(var())
+        for d in range(var.dim):
+            ctx.bind_bcs(var(), A_coeffs.bcs, d)
+            out[d] = ctx.laplacian(var()[d], edge)
+        return out
+
+
+class Grad(Discretizer):
+    """Returns ``(var.dim, mesh.dim, *nx)`` (fdc.py:461-502)."""
+
+    _op_type = "Grad"
+
+    @staticmethod
+    def build_A_coeffs(var: Field) -> StencilSpec:
+        return StencilSpec("Grad", list(var.bcs) if var.bcs is not None else [])
+
+    @staticmethod
+    def adjust_rhs(var: Field) -> Tensor:
+        return _rhs_adjust(var, {"kind": L.OP_GRAD}, var.bcs or [])
+
+    def apply(self, A_coeffs: StencilSpec, var: Field) -> Tensor:
+        assert A_coeffs is not None, "FDC: A_A_coeffs is not defined!"
+        require_gpu(var(), "FDC.grad")
+        ctx = context_for(var.mesh)
+        edge = self._edge()
+        comps = []
+        for d in range(var.dim):
+            ctx.bind_bcs(var(), A_coeffs.bcs, d)
+            comps.append(ctx.grad(var()[d], edge))
+        return torch.stack(comps)
+
+
+class Div(Discretizer):
+    """``div(var_j, var_i)``: central (limiter "none") or upwind (fdc.py:612-694).
+
+    limiter "upwind" evaluates the first-order upwind derivative the reference's own test
+    states (tests/test_fdm.py:239); ``{"div": {"limiter": "upwind", "compat": True}}``
+    reproduces the reference's literal (defective) output instead.
+    """
+
+    _op_type = "Div"
+
+    @staticmethod
+    def build_A_coeffs(var_j: Any, var_i: Field, config: DiscretizerConfigType | None = None) -> StencilSpec:
+        assert config is not None and "div" in config, "FDC Div: config should contain 'div' key."
+        limiter, compat = _limiter(config["div"])
+        div_kind(limiter, compat)
+        return StencilSpec("Div", list(var_i.bcs) if var_i.bcs is not None else [], limiter, compat, var_j)
+
+    @staticmethod
+    def adjust_rhs(var_j: Any, var_i: Field, config: DiscretizerConfigType | None = None) -> Tensor:
+        assert config is not None and "div" in config, "FDC Div: config should contain 'div' key."
+        limiter, compat = _limiter(config["div"])
+        return _rhs_adjust(var_i, {"kind": div_kind(limiter, compat), "u": _adv_of(var_j, var_i)},
+                           var_i.bcs or [])
+
+    def apply(self, A_coeffs: StencilSpec, var: Field) -> Tensor:
+        assert A_coeffs is not None, "FDC: A_A_coeffs is not defined!"
+        require_gpu(var(), "FDC.div")
+        if var.dim != 1:
+            raise NotImplementedError("pyapes_amd: Div of a vector field is not covered (scalar fields only)")
+        if self._edge():
+            raise NotImplementedError("pyapes_amd: edge=True Div is not covered yet")
+        ctx = context_for(var.mesh)
+        ctx.bind_bcs(var(), A_coeffs.bcs, 0)
+        u = _adv_of(A_coeffs.var_j, var)
+        out = ctx.div(div_kind(A_coeffs.limiter, A_coeffs.compat), u, var()[0])
+        return out.unsqueeze(0)
+
+
+class FDC:
+    """Collection of the explicit operators; every instance has its own operator objects
+    (the reference shares class-level singletons)."""
+
+    def __init__(self, config: DiscretizerConfigType | None = None):
+        self.div = Div()
+        self.laplacian = Laplacian()
+        self.grad = Grad()
+        self.config = config
+        if config is not None:
+            for c in config:
+                getattr(self, c).set_config(config)
+
+    def update_config(self, scheme: str, target: str, val: Any) -> None:
+        if self.config is not None:
+            self.config.setdefault(scheme, {})[target] = val  # type: ignore[index]
+        else:
+            self.config = {scheme: {target: val}}  # type: ignore[assignment,misc]
+        for c in self.config:  # type: ignore[union-attr]
+            getattr(self, c).set_config(self.config)
