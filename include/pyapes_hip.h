@@ -173,6 +173,14 @@ int pa_cg_iterate(pa_ctx* ctx, int64_t n);
 int pa_cg_end(pa_ctx* ctx, pa_report* out);       /* synchronises */
 int pa_report_read(pa_ctx* ctx, pa_report* out);  /* synchronises */
 
+/* ---- measurement (bench.py roofline leg) ---------------------------------
+ * on: bracket each launch of the two dominant CG kernels (phase A stencil+dot,
+ * phase B update+stencil+dots) with HIP events on the ctx stream and accumulate
+ * their durations (the host waits per launch: measurement loops only). */
+int pa_profile_set(pa_ctx* ctx, int on);
+int pa_profile_read(pa_ctx* ctx, double* ms_phase_a, int64_t* n_phase_a, double* ms_phase_b,
+                    int64_t* n_phase_b);
+
 #ifdef __cplusplus
 }
 #endif

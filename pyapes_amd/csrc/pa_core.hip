@@ -990,6 +990,8 @@ int pa_ctx_destroy(pa_ctx* c) {
   if (c->h_sc) (void)hipHostFree(c->h_sc);
   if (c->ev0) (void)hipEventDestroy(c->ev0);
   if (c->ev1) (void)hipEventDestroy(c->ev1);
+  for (int q = 0; q < 4; ++q)
+    if (c->pev[q]) (void)hipEventDestroy(c->pev[q]);
   delete c;
   return PA_OK;
 }
@@ -1067,10 +1069,6 @@ int pa_eq_set(pa_ctx* c, int nterms, const pa_term* terms) {
   for (int q = 0; q < nterms; ++q) {
     int k = terms[q].kind;
     if (k < PA_OP_LAPLACIAN || k > PA_OP_DIV_UPWIND) { pa_set_err(c, "pa_eq_set: bad kind"); return PA_E_ARG; }
-    if (k == PA_OP_GRAD && c->ndim != 1) {
-      pa_set_err(c, "pa_eq_set: Grad in a solver equation is 1-D only (ops.py:145-147 view)");
-      return PA_E_ARG;
-    }
     if (k == PA_OP_DIV_CENTRAL)
       for (int f = 0; f < 6; ++f)
         if (c->G.treat[f]) {
@@ -1089,6 +1087,17 @@ int pa_eq_set(pa_ctx* c, int nterms, const pa_term* terms) {
 }
 
 }  // extern "C"
+
+// Grad inside an operator sum only makes sense in 1-D (the reference reshapes the
+// (1, mesh.dim, n...) result onto the target, ops.py:145-147)
+static int check_eq_applicable(pa_ctx* c) {
+  for (int q = 0; q < c->nterms; ++q)
+    if (c->terms[q].kind == PA_OP_GRAD && c->ndim != 1) {
+      pa_set_err(c, "Grad in a solver equation is 1-D only (ops.py:145-147 view)");
+      return PA_E_ARG;
+    }
+  return PA_OK;
+}
 
 // -------- typed implementations behind the remaining entry points ------------------------
 template <typename T>
@@ -1240,6 +1249,7 @@ int pa_slab_set(pa_ctx* c, const pa_slab* s) {
 
 int pa_aop(pa_ctx* c, const void* x, void* y, int interior_only) {
   if (!c || !c->grid_set || !c->eq_set) { if (c) pa_set_err(c, "pa_aop: grid/equation not set"); return PA_E_STATE; }
+  if (int rc0 = check_eq_applicable(c)) return rc0;
   PA_HIP(c, hipSetDevice(c->device));
   return c->dtype == PA_F64 ? aop_t<double>(c, (const double*)x, (double*)y, interior_only, c->nterms, c->terms)
                             : aop_t<float>(c, (const float*)x, (float*)y, interior_only, c->nterms, c->terms);
@@ -1386,6 +1396,19 @@ static int cg_begin_t(pa_ctx* c, T* x, const T* rhs, double tol, int64_t max_it)
   return PA_OK;
 }
 
+// profiling build of the launch path: HIP events on the ctx stream bracket exactly one
+// dominant kernel; the host waits for each, so use it in a dedicated measurement loop only
+static void pa_profile_stop(pa_ctx* c, int which) {
+  hipEvent_t e0 = c->pev[2 * which], e1 = c->pev[2 * which + 1];
+  (void)hipEventRecord(e1, c->stream);
+  (void)hipEventSynchronize(e1);
+  float ms = 0.f;
+  if (hipEventElapsedTime(&ms, e0, e1) == hipSuccess) {
+    c->prof_ms[which] += ms;
+    c->prof_n[which] += 1;
+  }
+}
+
 template <typename T>
 static Vec<T> cg_vec(pa_ctx* c, const T* p, int which /*0 r, 1 d cur*/) {
   Vec<T> v = pa_vec_self<T>(c, p);
@@ -1407,6 +1430,7 @@ int pa_cg_phase_a_t(pa_ctx* c, int stage_post) {
   T* dnew = (T*)c->scr[c->cur ? SCR_D0 : SCR_D1];
   double* part = (double*)c->scr[SCR_PART];
   Vec<T> rv = cg_vec<T>(c, r, 0), dv = cg_vec<T>(c, dold, 1);
+  if (c->profile) (void)hipEventRecord(c->pev[0], c->stream);
   int rc = pa_cg3d_phase_a<T>(c, E, rv, dv, dnew, part);
   if (rc < 0) return rc;
   int used_blocks = rc;
@@ -1414,6 +1438,7 @@ int pa_cg_phase_a_t(pa_ctx* c, int stage_post) {
     hipLaunchKernelGGL(k_cg_a<T>, dim3(nblk), dim3(PA_BLOCK), 0, c->stream, G, E, c->sc, rv, dv, dnew, part);
     used_blocks = nblk;
   }
+  if (c->profile) pa_profile_stop(c, 0);
   c->cur ^= 1;
   hipLaunchKernelGGL(k_cg_post_a<T>, dim3(1), dim3(PA_BLOCK), 0, c->stream, c->sc, part, used_blocks, pa_sums(c),
                      stage_post);
@@ -1433,6 +1458,7 @@ int pa_cg_phase_b_t(pa_ctx* c, int stage_post) {
   double* part = (double*)c->scr[SCR_PART];
   double* part2 = (double*)c->scr[SCR_PART2];
   Vec<T> dv = cg_vec<T>(c, d, 1);
+  if (c->profile) (void)hipEventRecord(c->pev[2], c->stream);
   int rc = pa_cg3d_phase_b<T>(c, E, dv, x, r, part);
   if (rc < 0) return rc;
   int used_blocks = rc;
@@ -1441,6 +1467,7 @@ int pa_cg_phase_b_t(pa_ctx* c, int stage_post) {
                        (T*)c->r_send_lo, (T*)c->r_send_hi, part);
     used_blocks = nblk;
   }
+  if (c->profile) pa_profile_stop(c, 1);
   int nsh = 0;
   if (!c->bc_static) {
     if ((rc = bc_apply_t<T>(c, x, true))) return rc;
@@ -1630,6 +1657,7 @@ extern "C" {
 
 int pa_cg(pa_ctx* c, void* x, const void* rhs, double tol, int64_t max_it, pa_report* out) {
   if (!c || !c->grid_set || !c->eq_set) { if (c) pa_set_err(c, "pa_cg: grid/equation not set"); return PA_E_STATE; }
+  if (int rc0 = check_eq_applicable(c)) return rc0;
   if (!out) return PA_E_ARG;
   if (c->slab) { pa_set_err(c, "pa_cg is the single-GPU loop; use the stepwise API on a slab"); return PA_E_STATE; }
   PA_HIP(c, hipSetDevice(c->device));
@@ -1639,6 +1667,7 @@ int pa_cg(pa_ctx* c, void* x, const void* rhs, double tol, int64_t max_it, pa_re
 
 int pa_bicgstab(pa_ctx* c, void* x, const void* rhs, double tol, int64_t max_it, pa_report* out) {
   if (!c || !c->grid_set || !c->eq_set) { if (c) pa_set_err(c, "pa_bicgstab: grid/equation not set"); return PA_E_STATE; }
+  if (int rc0 = check_eq_applicable(c)) return rc0;
   if (!out) return PA_E_ARG;
   PA_HIP(c, hipSetDevice(c->device));
   return c->dtype == PA_F64 ? bicg_run_t<double>(c, (double*)x, (const double*)rhs, tol, max_it, out)
@@ -1647,6 +1676,7 @@ int pa_bicgstab(pa_ctx* c, void* x, const void* rhs, double tol, int64_t max_it,
 
 int pa_jacobi(pa_ctx* c, void* x, const void* rhs, double tol, int64_t max_it, double omega, pa_report* out) {
   if (!c || !c->grid_set || !c->eq_set) { if (c) pa_set_err(c, "pa_jacobi: grid/equation not set"); return PA_E_STATE; }
+  if (int rc0 = check_eq_applicable(c)) return rc0;
   if (!out) return PA_E_ARG;
   PA_HIP(c, hipSetDevice(c->device));
   return c->dtype == PA_F64 ? jacobi_run_t<double>(c, (double*)x, (const double*)rhs, tol, max_it, omega, out)
@@ -1662,6 +1692,7 @@ extern "C" {
 
 int pa_cg_begin(pa_ctx* c, void* x, const void* rhs, double tol, int64_t max_it) {
   if (!c || !c->grid_set || !c->eq_set) { if (c) pa_set_err(c, "pa_cg_begin: grid/equation not set"); return PA_E_STATE; }
+  if (int rc0 = check_eq_applicable(c)) return rc0;
   PA_HIP(c, hipSetDevice(c->device));
   return c->dtype == PA_F64 ? cg_begin_t<double>(c, (double*)x, (const double*)rhs, tol, max_it)
                             : cg_begin_t<float>(c, (float*)x, (const float*)rhs, tol, max_it);
@@ -1707,6 +1738,25 @@ int pa_cg_iterate(pa_ctx* c, int64_t n) {
     rc = c->dtype == PA_F64 ? pa_cg_phase_b_t<double>(c, 2) : pa_cg_phase_b_t<float>(c, 2);
     if (rc) return rc;
   }
+  return PA_OK;
+}
+
+int pa_profile_set(pa_ctx* c, int on) {
+  if (!c) return PA_E_ARG;
+  if (on && !c->pev[0])
+    for (int q = 0; q < 4; ++q) PA_HIP(c, hipEventCreate(&c->pev[q]));
+  c->profile = on ? 1 : 0;
+  c->prof_ms[0] = c->prof_ms[1] = 0.0;
+  c->prof_n[0] = c->prof_n[1] = 0;
+  return PA_OK;
+}
+
+int pa_profile_read(pa_ctx* c, double* ms_a, int64_t* n_a, double* ms_b, int64_t* n_b) {
+  if (!c) return PA_E_ARG;
+  if (ms_a) *ms_a = c->prof_ms[0];
+  if (n_a) *n_a = c->prof_n[0];
+  if (ms_b) *ms_b = c->prof_ms[1];
+  if (n_b) *n_b = c->prof_n[1];
   return PA_OK;
 }
 

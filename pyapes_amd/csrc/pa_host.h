@@ -62,6 +62,11 @@ struct pa_ctx {
   const void* bc_far_lo0 = nullptr;  // periodic axis-0 fill: x[N-1] (for the lower end rank)
   const void* bc_far_lo1 = nullptr;  //                       x[N-2]
   const void* bc_far_hi0 = nullptr;  //                       x[0]   (for the upper end rank)
+  // per-kernel timing of the two dominant CG kernels (pa_profile_set): HIP events on the ctx stream
+  int profile = 0;
+  hipEvent_t pev[4] = {nullptr, nullptr, nullptr, nullptr};
+  double prof_ms[2] = {0.0, 0.0};
+  int64_t prof_n[2] = {0, 0};
   // 3-D fast path switch (PYAPES_HIP_FASTPATH=0 disables; tests compare both)
   int fastpath = 1;
 };

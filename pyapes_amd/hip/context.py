@@ -223,6 +223,16 @@ class HipContext:
         self._rc(self.lib.pa_report_read(self.h, C.byref(rep)))
         return rep
 
+    def profile(self, on: bool) -> None:
+        self._rc(self.lib.pa_profile_set(self.h, int(on)))
+
+    def profile_read(self) -> dict[str, float]:
+        ma, mb = C.c_double(), C.c_double()
+        na, nb = C.c_int64(), C.c_int64()
+        self._rc(self.lib.pa_profile_read(self.h, C.byref(ma), C.byref(na), C.byref(mb), C.byref(nb)))
+        return {"phase_a_ms": ma.value / max(na.value, 1), "phase_a_n": na.value,
+                "phase_b_ms": mb.value / max(nb.value, 1), "phase_b_n": nb.value}
+
     def slab_set(self, bufs: dict[str, Tensor | None] | None) -> None:
         if bufs is None:
             self._rc(self.lib.pa_slab_set(self.h, None))

@@ -78,6 +78,8 @@ SIGNATURES: dict[str, tuple[Any, list[Any]]] = {
     "pa_cg_end": (C.c_int, [_VP, C.POINTER(PaReport)]),
     "pa_slab_set": (C.c_int, [_VP, C.POINTER(PaSlab)]),
     "pa_report_read": (C.c_int, [_VP, C.POINTER(PaReport)]),
+    "pa_profile_set": (C.c_int, [_VP, C.c_int]),
+    "pa_profile_read": (C.c_int, [_VP, _F64P, _I64P, _F64P, _I64P]),
 }
 
 _lib: C.CDLL | None = None

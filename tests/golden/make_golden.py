@@ -302,21 +302,21 @@ CASES += [
     mk("cg3d_per_randn12_f64", "solve", 3, [12, 12, 12], "double", [PE] * 6, rhs="randn",
        method="cg", tol=1e-30, max_its=[5]),
     mk("cg2d_xper101_f64", "solve", 2, [41, 41], "double", [PE, PE, D(0), D(0)], rhs="test_periodic_2d",
-       method="cg", tol=1e-8, max_its=[30], sign=-1.0),
+       method="cg", tol=1e-8, max_its=[2, 6, 30], sign=-1.0, sensitive=True),
     mk("cg2d_neumann_f64", "solve", 2, [33, 33], "double", [D(0), N(0), D(0), N(0)], rhs="randn",
        method="cg", tol=1e-8, max_its=[5, 1000], box=([0.0, 0.0], [0.5, 0.5])),
     mk("cg3d_sym_f64", "solve", 3, [12, 13, 14], "double", [D(1.0), SY, SY, D(0.0), N(0.2), D(0.5)],
        rhs="randn", method="cg", tol=1e-9, max_its=[6, 1000]),
     # BiCGSTAB
     mk("bicg1d_neumann_f64", "solve", 1, [101], "double", [N(-0.25), D(-0.5)], rhs="randn",
-       method="bicgstab", tol=1e-6, max_its=[1000], box=([-pi / 2], [pi / 4])),
+       method="bicgstab", tol=1e-6, max_its=[2, 6, 1000], box=([-pi / 2], [pi / 4]), sensitive=True),
     mk("bicg2d_heat_f64", "solve", 2, [11, 11], "double", [N(0.0), D(0.0), N(0.0), D(1.0)], rhs="zero",
-       method="bicgstab", tol=1e-8, max_its=[1000]),               # reference test + golden CSV
+       method="bicgstab", tol=1e-8, max_its=[2, 6, 1000], sensitive=True),  # reference test + golden CSV
     mk("bicg2d_xper_f64", "solve", 2, [41, 41], "double", [PE, PE, D(0), D(0)], rhs="test_periodic_2d",
-       method="bicgstab", tol=1e-8, max_its=[1000], sign=-1.0),
+       method="bicgstab", tol=1e-8, max_its=[2, 6, 1000], sign=-1.0, sensitive=True),
     mk("bicg3d_mix17_f64", "solve", 3, [17, 17, 17], "double",
        [D(0.0), N(0.5), D(0.0), N(0.0), D(1.0), N(-0.25)], rhs="sincosz", method="bicgstab", tol=1e-10,
-       max_its=[3, 1000]),
+       max_its=[3, 8, 1000], sensitive=True),
     mk("bicg3d_dir17_f32", "solve", 3, [17, 17, 17], "single", [D(0.0)] * 6, rhs="randn",
        method="bicgstab", tol=1e-4, max_its=[5]),
 ]

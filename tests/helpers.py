@@ -72,3 +72,37 @@ def rel_err(a, b):
 
 def bit_equal(a, b):
     return torch.equal(torch.as_tensor(a).cpu(), torch.as_tensor(b).cpu())
+
+
+def oracle_solve(case, rhs0, K, flip_sums=False):
+    """The oracle on a golden case; flip_sums=True evaluates every torch.sum over the reversed
+    tensor -- same algorithm, same inputs, a different (equally valid) summation order."""
+    import warnings
+    mesh = oracle_mesh(case)
+    orig = torch.sum
+
+    def fsum(t, dim=None, **kw):
+        if dim is None:
+            return orig(t.flip(tuple(range(t.dim()))).contiguous())
+        return orig(t.flip(tuple(dim)).contiguous(), dim=dim)
+
+    if flip_sums:
+        torch.sum = fsum
+    try:
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            return O.solve_poisson(mesh, oracle_cfg(case), torch.as_tensor(rhs0).clone(), method=case["method"],
+                                   tol=case["tol"], max_it=K, coeff=case.get("coeff", 1.0),
+                                   sign=case.get("sign", 1.0))
+    finally:
+        torch.sum = orig
+
+
+def summation_sensitivity(case, rhs0, K):
+    """(rel. change of the result, change of the iteration count) of the REFERENCE ALGORITHM when only
+    the order of its dot-product summations changes.  BiCGSTAB and CG on the reference's
+    non-symmetric periodic operator amplify 1e-16 perturbations; no implementation
+    with a different reduction tree can be closer to the reference than this."""
+    x0, r0 = oracle_solve(case, rhs0, K, False)
+    x1, r1 = oracle_solve(case, rhs0, K, True)
+    return rel_err(x1, x0), abs(r1["itr"] - r0["itr"])

@@ -119,3 +119,17 @@ def test_upwind_intended_closed_form():
     out = O.div_upwind_intended(2.0, phi, mesh)
     expect = 2.0 * (phi[0][1:-1] - phi[0][:-2]) / mesh.dx[0]
     assert torch.allclose(out[0][1:-1], expect, rtol=0, atol=1e-14)
+
+
+def test_reference_algorithm_is_summation_order_sensitive():
+    """Documents WHY long BiCGSTAB / periodic-CG runs cannot be pinned to 1e-10: the reference
+    algorithm itself moves by far more than that when only the order of its dot-product
+    summations changes (same inputs, same arithmetic otherwise).  SPD CG is stable."""
+    from helpers import summation_sensitivity
+    from conftest import golden_cases, golden_load
+    cases = {c["name"]: c for c in golden_cases("solve")}
+    s_bicg, _ = summation_sensitivity(cases["bicg2d_xper_f64"], golden_load("bicg2d_xper_f64")["rhs0"], 1000)
+    s_pcg, _ = summation_sensitivity(cases["cg2d_xper101_f64"], golden_load("cg2d_xper101_f64")["rhs0"], 30)
+    s_cg, d_cg = summation_sensitivity(cases["cg3d_mix33_f64"], golden_load("cg3d_mix33_f64")["rhs0"], 1000)
+    assert s_bicg > 1e-8 and s_pcg > 1e-8
+    assert s_cg < 1e-13 and d_cg == 0
