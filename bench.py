@@ -71,16 +71,37 @@ def synth_rhs(mesh, kind):
     return (base + noise).to(f).unsqueeze(0).contiguous()
 
 
+def host_cores() -> int:
+    """CPUs this process may actually use: min(os.cpu_count(), affinity, cgroup cpu.max quota)."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except Exception:
+        pass
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = min(n, max(1, int(int(q) / int(p))))
+    except Exception:
+        pass
+    return n
+
+
+def log(msg):
+    print(f"[bench] {msg}", file=sys.stderr, flush=True)
+
+
 def cpu_baseline(kind, dtype, target_s=12.0):
     """The oracle (literal torch-CPU restatement of the reference algorithm) timed on this box's
     host cores on a bounded sample of the same workload family.  Checker code used ONLY as the
     reported baseline, never on the measured path."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import pyapes_oracle as O
-    cores = os.cpu_count() or 1
+    cores = host_cores()
     torch.set_num_threads(cores)
-    n = 128
-    its = 40
+    log(f"cpu_baseline: oracle CG on {cores} host threads ...")
+    n = 256
+    its = 24
     mesh = O.OMesh([0, 0, 0], [1, 1, 1], [n, n, n], dtype)
     if kind == "periodic":
         cfg = O.homogeneous_cfg(3, None, "periodic")
@@ -149,6 +170,7 @@ def main():
                 slab=(rank, world) if world > 1 else None)
     var = Field("p", 1, mesh, {"domain": make_bcs(kind), "obstacle": None})
     rhs = synth_rhs(mesh, kind)
+    log(f"rank {rank}/{world}: workload {args.workload} global {gn} local {tuple(mesh.nx)} {dtype} {kind}")
     cells_global = gn[0] * gn[1] * gn[2]
     W, K = args.warmup, args.steps
     terms = [{"kind": L.OP_LAPLACIAN, "sign": 1.0, "coeff": 1.0}]
@@ -171,6 +193,7 @@ def main():
         torch.cuda.synchronize()
         wall = time.perf_counter() - t0
         ev_ms = e0.elapsed_time(e1)
+        log(f"timed {K} iterations: {wall*1e3/K:.4f} ms/iter")
         rep = ctx.report()
         assert rep.itr == W + K and rep.status == 0, f"work was skipped: itr={rep.itr} status={rep.status}"
         secs = wall

@@ -1,10 +1,448 @@
-// pa_cg3d.hip -- 3-D fast path of the two CG phases (placeholder: not covered yet)
+// pa_cg3d.hip -- 3-D fast path of the two CG phases for gfx950 (MI355X).
+//
+// Equation covered: one Laplacian term (scalar or no coefficient), any BC mix, fp64 / fp32,
+// single GPU or slab (ghost planes through Vec<T>).  Anything else returns 0 and the caller
+// launches the generic kernels of pa_core.hip.
+//
+// Data movement (both phases are HBM-bound; no MFMA):
+//   phase A  reads r, d      writes d' = r + beta d          + sum d'.(A d')      3 array passes
+//   phase B  reads x, r, d'  writes x += alpha d', r -= alpha A d'  + sums        5 array passes
+// A d' is never stored: phase B recomputes it from d' (13 flops) instead of moving 16 B/cell
+// through HBM twice, so an iteration moves 8 passes where the algorithmic count is 10.
+//
+// Tiling.  A workgroup (256 threads = 4 wave64) owns an in-plane tile of TJ = 4*RJ rows by
+// TK = 64*VEC contiguous k cells (VEC = 16 B / sizeof(T): every global access is a 16-byte
+// lane access, a wave covers 1 KiB of one row) and MARCHES along the slow axis i over a chunk
+// of planes.  Per thread the planes i-1, i, i+1 of its own RJ x VEC cells stay in registers;
+// the current plane, plus a halo ring (one row above / below, one cell left / right, loaded
+// with wrap-around indices = torch.roll semantics), is staged in LDS (double buffered, one
+// barrier per plane) for the j+-1 / k+-1 neighbours.  Each value is therefore read from
+// HBM/L2 once per chunk; the halo ring and the two extra planes per chunk are the only
+// re-reads and are mostly L2 hits because the tiles of one chunk run on one XCD at the same
+// time (blockIdx -> (chunk, tile) is XCD-aware: blocks b and b+8 share an XCD's L2).
+// Phase B marches the chunk in the opposite direction, so the planes phase A touched last
+// (still in the 256 MiB Infinity Cache) are the ones phase B reads first, and vice versa.
+//
+// The grid is exactly one resident wave of workgroups: chunks = capacity / tiles, so every
+// CU carries the same number of identical work items and nothing queues behind a tail.
 #include "pa_host.h"
 
+#include <stdlib.h>
+#include <string.h>
+
+template <typename T> struct VecOf;
+template <> struct VecOf<double> { static constexpr int N = 2; typedef double type __attribute__((ext_vector_type(2))); };
+template <> struct VecOf<float>  { static constexpr int N = 4; typedef float type __attribute__((ext_vector_type(4))); };
+
 template <typename T>
-int pa_cg3d_phase_a(pa_ctx*, const DevEq<T>&, Vec<T>, Vec<T>, T*, double*) { return 0; }
+struct Cg3dArgs {
+  DevGeom G;
+  LapCoef<T> lap;
+  T coeff, sign;
+  int has_coeff;
+  const SolverScalars* sc;
+  Vec<T> r, d;          // phase A: r and the old direction; phase B: d = new direction
+  T* dnew;              // phase A output
+  T* x;                 // phase B in/out
+  T* rw;                // phase B in/out (residual)
+  T* send_lo;           // phase B: copies of r's first / last owned plane (slab) or null
+  T* send_hi;
+  double* partials;
+  int tiles_j, tiles_k, chunks, reverse;
+};
+
+__device__ __forceinline__ int pa_xcd_remap(int b, int nb) {
+  // blocks b, b+8, b+16 ... share an XCD: give each XCD a contiguous range of work items
+  const int q = nb >> 3, r = nb & 7, xcd = b & 7, w = b >> 3;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + w;
+}
+
+__device__ __forceinline__ int64_t pa_wrapmod(int64_t v, int64_t n) {
+  v %= n;
+  return v < 0 ? v + n : v;
+}
+
+template <typename T, int RJ, int PHASE>
+__global__ void __launch_bounds__(256) k_cg3d(Cg3dArgs<T> A) {
+  typedef typename VecOf<T>::type V;
+  constexpr int VEC = VecOf<T>::N;
+  constexpr int TJ = 4 * RJ, TK = 64 * VEC, TKP = TK + 2 * VEC;
+  __shared__ __attribute__((aligned(16))) T tile[2][TJ + 2][TKP];
+
+  if (A.sc->done) return;
+  const DevGeom& G = A.G;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int vb = pa_xcd_remap(blockIdx.x, gridDim.x);
+  const int tiles = A.tiles_j * A.tiles_k;
+  const int chunk = vb / tiles, tl = vb - chunk * tiles;
+  const int tjb = tl / A.tiles_k, tkb = tl - tjb * A.tiles_k;
+  const int64_t i0 = (int64_t)chunk * G.n0 / A.chunks, i1 = (int64_t)(chunk + 1) * G.n0 / A.chunks;
+  const int CI = (int)(i1 - i0);
+  const int64_t j0 = (int64_t)tjb * TJ, k0 = (int64_t)tkb * TK;
+  const int rev = A.reverse;
+
+  // ---- per-thread geometry: RJ rows x VEC columns --------------------------------
+  const int64_t kg = k0 + (int64_t)lane * VEC;            // global k of element 0 (may be >= n2)
+  const int64_t kc = pa_wrapmod(kg, G.n2);                // wrapped column used for loads
+  const bool kvalid = kg < G.n2;
+  int64_t jrow[RJ];
+  unsigned rowS = 0, rowShell = 0, rowValid = 0, rowLo = 0, rowHi = 0;
+#pragma unroll
+  for (int jj = 0; jj < RJ; ++jj) {
+    const int64_t jg = j0 + wv * RJ + jj;
+    jrow[jj] = pa_wrapmod(jg, G.n1);
+    const bool valid = jg < G.n1;
+    if (valid) rowValid |= 1u << jj;
+    if (valid && jg >= G.slo[1] && jg <= G.shi[1]) rowS |= 1u << jj;
+    if (jg == 0 || jg == G.n1 - 1) rowShell |= 1u << jj;
+    const int rc = pa_row_case(G, 1, jg, G.n1, G.treat);
+    if (rc == 1) rowLo |= 1u << jj;
+    if (rc == 2) rowHi |= 1u << jj;
+  }
+  unsigned colS = 0, colShell = 0, colLo = 0, colHi = 0;
+#pragma unroll
+  for (int v = 0; v < VEC; ++v) {
+    const int64_t kk = kg + v;
+    if (kvalid && kk >= G.slo[2] && kk <= G.shi[2]) colS |= 1u << v;
+    if (kk == 0 || kk == G.n2 - 1) colShell |= 1u << v;
+    const int rc = pa_row_case(G, 2, kk, G.n2, G.treat);
+    if (rc == 1) colLo |= 1u << v;
+    if (rc == 2) colHi |= 1u << v;
+  }
+  // halo duty of this wave: wave 0 -> row above the tile, wave 3 -> row below (vector loads);
+  // wave 1, lanes < 2*TJ -> the single cells left / right of each tile row (scalar loads)
+  const int64_t hrow = (wv == 0) ? pa_wrapmod(j0 - 1, G.n1) : pa_wrapmod(j0 + TJ, G.n1);
+  const bool hvec = (wv == 0 || wv == 3);
+  const bool hsc = (wv == 1 && lane < 2 * TJ);
+  const int hs_row = lane >> 1, hs_side = lane & 1;
+  const int64_t hs_off = pa_wrapmod(j0 + hs_row, G.n1) * G.s1 +
+                         (hs_side ? pa_wrapmod(k0 + TK, G.n2) : pa_wrapmod(k0 - 1, G.n2));
+
+  T beta = (T)0, alpha = (T)0;
+  if (PHASE == 0) beta = (T)A.sc->beta; else alpha = (T)A.sc->alpha;
+
+  auto plane_of = [&](int q) -> int64_t { return rev ? (i1 - 1 - q) : (i0 + q); };
+  auto pptr = [&](const Vec<T>& v, int64_t ii) -> const T* {
+    return ii < 0 ? v.glo : (ii >= G.n0 ? v.ghi : v.p + ii * G.s0);
+  };
+
+  // e = r + beta d (phase A) or d (phase B) of the thread's own cells on local plane ii
+  auto load_own = [&](int64_t ii, V (&e)[RJ]) {
+    const T* dp = pptr(A.d, ii);
+    if (PHASE == 0) {
+      const T* rp = pptr(A.r, ii);
+#pragma unroll
+      for (int jj = 0; jj < RJ; ++jj) {
+        const int64_t o = jrow[jj] * G.s1 + kc;
+        V rv = *reinterpret_cast<const V*>(rp + o);
+        V dv = *reinterpret_cast<const V*>(dp + o);
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) {
+          T bd = beta * dv[v];
+          e[jj][v] = rv[v] + bd;
+        }
+      }
+    } else {
+#pragma unroll
+      for (int jj = 0; jj < RJ; ++jj) e[jj] = *reinterpret_cast<const V*>(dp + jrow[jj] * G.s1 + kc);
+    }
+  };
+  auto load_halo = [&](int64_t ii, V& hv, T& hs) {
+    const T* dp = pptr(A.d, ii);
+    const T* rp = PHASE == 0 ? pptr(A.r, ii) : nullptr;
+    if (hvec) {
+      const int64_t o = hrow * G.s1 + kc;
+      V dv = *reinterpret_cast<const V*>(dp + o);
+      if (PHASE == 0) {
+        V rv = *reinterpret_cast<const V*>(rp + o);
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) {
+          T bd = beta * dv[v];
+          hv[v] = rv[v] + bd;
+        }
+      } else {
+        hv = dv;
+      }
+    }
+    if (hsc) {
+      T dvs = dp[hs_off];
+      if (PHASE == 0) {
+        T bd = beta * dvs;
+        hs = rp[hs_off] + bd;
+      } else {
+        hs = dvs;
+      }
+    }
+  };
+  auto stage = [&](int buf, const V (&e)[RJ], const V& hv, const T& hs) {
+#pragma unroll
+    for (int jj = 0; jj < RJ; ++jj)
+      *reinterpret_cast<V*>(&tile[buf][wv * RJ + jj + 1][VEC + lane * VEC]) = e[jj];
+    if (hvec) *reinterpret_cast<V*>(&tile[buf][wv == 0 ? 0 : TJ + 1][VEC + lane * VEC]) = hv;
+    if (hsc) tile[buf][hs_row + 1][hs_side ? VEC + TK : VEC - 1] = hs;
+  };
+
+  V ea[RJ], ec[RJ], eb[RJ];  // behind / current / ahead in march order
+  V hv;
+  T hs = (T)0;
+#pragma unroll
+  for (int v = 0; v < VEC; ++v) hv[v] = (T)0;
+
+  // ---- prologue -----------------------------------------------------------------------
+  load_own(plane_of(-1), ea);
+  load_own(plane_of(0), ec);
+  load_halo(plane_of(0), hv, hs);
+  stage(0, ec, hv, hs);
+  load_own(plane_of(1), eb);
+  if (CI > 1) load_halo(plane_of(1), hv, hs);
+  __syncthreads();
+
+  double s0 = 0.0, s1 = 0.0;
+  const T sgn = A.sign, cf = A.coeff;
+  const int hasc = A.has_coeff;
+
+  for (int m = 0; m < CI; ++m) {
+    const int buf = m & 1;
+    const int64_t ii = plane_of(m);
+    // plane m+1 into the other LDS buffer (its last readers passed the barrier of step m-1)
+    if (m + 1 < CI) stage(buf ^ 1, eb, hv, hs);
+    // issue the loads of plane m+2 (own) and its halo: in flight during the stencil below
+    V en[RJ];
+#pragma unroll
+    for (int jj = 0; jj < RJ; ++jj) en[jj] = eb[jj];
+    V hvn = hv;
+    T hsn = hs;
+    if (m + 1 < CI) {
+      load_own(plane_of(m + 2), en);
+      if (m + 2 < CI) load_halo(plane_of(m + 2), hvn, hsn);
+    }
+    // phase B: the thread's x and r of this plane
+    V xv[RJ], rv[RJ];
+    if (PHASE == 1) {
+#pragma unroll
+      for (int jj = 0; jj < RJ; ++jj) {
+        const int64_t o = ii * G.s0 + jrow[jj] * G.s1 + kc;
+        xv[jj] = *reinterpret_cast<const V*>(A.x + o);
+        rv[jj] = *reinterpret_cast<const V*>(A.rw + o);
+      }
+    }
+
+    // ---- stencil on plane ii ------------------------------------------------------------
+    const int64_t gi = ii + G.off0;
+    const bool iS = gi >= G.slo[0] && gi <= G.shi[0];
+    const bool iShell = (gi == 0 || gi == G.g0 - 1);
+    T cPi = A.lap.inv[0], cCi = A.lap.m2inv[0], cMi = A.lap.inv[0];
+    {
+      const int rc = pa_row_case(G, 0, gi, G.g0, G.treat);
+      if (rc == 1) { cPi = A.lap.c23[0]; cCi = -A.lap.c23[0]; cMi = (T)0; }
+      if (rc == 2) { cPi = (T)0; cCi = -A.lap.c23[0]; cMi = A.lap.c23[0]; }
+    }
+#pragma unroll
+    for (int jj = 0; jj < RJ; ++jj) {
+      const int R = wv * RJ + jj + 1;
+      T cPj = A.lap.inv[1], cCj = A.lap.m2inv[1], cMj = A.lap.inv[1];
+      if (rowLo >> jj & 1) { cPj = A.lap.c23[1]; cCj = -A.lap.c23[1]; cMj = (T)0; }
+      if (rowHi >> jj & 1) { cPj = (T)0; cCj = -A.lap.c23[1]; cMj = A.lap.c23[1]; }
+      // j-1 / j+1: registers inside the thread's row block, LDS across it
+      V up, dn;
+      if (jj > 0) up = ec[jj - 1]; else up = *reinterpret_cast<const V*>(&tile[buf][R - 1][VEC + lane * VEC]);
+      if (jj < RJ - 1) dn = ec[jj + 1]; else dn = *reinterpret_cast<const V*>(&tile[buf][R + 1][VEC + lane * VEC]);
+      const T left = tile[buf][R][VEC + lane * VEC - 1];
+      const T right = tile[buf][R][VEC + lane * VEC + VEC];
+      V outd;   // phase A: d' ; phase B: new r
+      V outx;   // phase B: new x
+#pragma unroll
+      for (int v = 0; v < VEC; ++v) {
+        const T xc = ec[jj][v];
+        const bool inS = iS && (rowS >> jj & 1) && (colS >> v & 1);
+        T res = (T)0;
+        if (inS) {
+          const T xpi = rev ? ea[jj][v] : eb[jj][v];
+          const T xmi = rev ? eb[jj][v] : ea[jj][v];
+          T s = cPi * xpi;
+          T mm = cCi * xc;
+          s = s + mm;
+          mm = cMi * xmi;
+          s = s + mm;
+          T ax = s;
+          s = cPj * dn[v];
+          mm = cCj * xc;
+          s = s + mm;
+          mm = cMj * up[v];
+          s = s + mm;
+          ax = ax + s;
+          T cPk = A.lap.inv[2], cCk = A.lap.m2inv[2], cMk = A.lap.inv[2];
+          if (colLo >> v & 1) { cPk = A.lap.c23[2]; cCk = -A.lap.c23[2]; cMk = (T)0; }
+          if (colHi >> v & 1) { cPk = (T)0; cCk = -A.lap.c23[2]; cMk = A.lap.c23[2]; }
+          const T xpk = (v < VEC - 1) ? ec[jj][v + 1 < VEC ? v + 1 : v] : right;
+          const T xmk = (v > 0) ? ec[jj][v > 0 ? v - 1 : 0] : left;
+          s = cPk * xpk;
+          mm = cCk * xc;
+          s = s + mm;
+          mm = cMk * xmk;
+          s = s + mm;
+          ax = ax + s;
+          if (hasc) ax = ax * cf;
+          ax = ax * sgn;
+          res = ax;
+        }
+        if (PHASE == 0) {
+          const T e = inS ? xc : (T)0;
+          outd[v] = e;
+          if (inS) {
+            T p = e * res;
+            s0 += (double)p;
+          }
+        } else {
+          T xo = xv[jj][v];
+          T rn = (T)0;
+          T xn = xo;
+          if (inS) {
+            T ad = alpha * xc;
+            xn = xo + ad;
+            T aAd = alpha * res;
+            rn = rv[jj][v] - aAd;
+            T p = rn * rn;
+            s0 += (double)p;
+            if (!(iShell || (rowShell >> jj & 1) || (colShell >> v & 1))) {
+              T df = xn - xo;
+              T p2 = df * df;
+              s1 += (double)p2;
+            }
+          }
+          outd[v] = rn;
+          outx[v] = xn;
+        }
+      }
+      if (kvalid && (rowValid >> jj & 1)) {
+        const int64_t o = ii * G.s0 + jrow[jj] * G.s1 + kc;
+        if (PHASE == 0) {
+          *reinterpret_cast<V*>(A.dnew + o) = outd;
+        } else {
+          *reinterpret_cast<V*>(A.x + o) = outx;
+          *reinterpret_cast<V*>(A.rw + o) = outd;
+          if (A.send_lo && ii == 0) *reinterpret_cast<V*>(A.send_lo + jrow[jj] * G.s1 + kc) = outd;
+          if (A.send_hi && ii == G.n0 - 1) *reinterpret_cast<V*>(A.send_hi + jrow[jj] * G.s1 + kc) = outd;
+        }
+      }
+    }
+    // ---- shift the register planes ----------------------------------------------------------
+#pragma unroll
+    for (int jj = 0; jj < RJ; ++jj) {
+      ea[jj] = ec[jj];
+      ec[jj] = eb[jj];
+      eb[jj] = en[jj];
+    }
+    hv = hvn;
+    hs = hsn;
+    __syncthreads();
+  }
+
+  if (PHASE == 0) {
+    double s[1] = {s0};
+    pa_block_reduce_store<1>(s, A.partials);
+  } else {
+    double s[2] = {s0, s1};
+    pa_block_reduce_store<2>(s, A.partials);
+  }
+}
+
+// ---- host side -------------------------------------------------------------------------------
 template <typename T>
-int pa_cg3d_phase_b(pa_ctx*, const DevEq<T>&, Vec<T>, T*, T*, double*) { return 0; }
+static bool cg3d_covered(const pa_ctx* c, const DevEq<T>& E, const void* p0, const void* p1, const void* p2) {
+  if (!c->fastpath) return false;
+  if (c->ndim != 3) return false;
+  if (E.nterms != 1 || E.t[0].kind != PA_OP_LAPLACIAN || E.t[0].coeff_f) return false;
+  constexpr int VEC = VecOf<T>::N;
+  if (c->G.n2 % VEC != 0) return false;
+  if (c->G.n0 < 3 || c->G.n1 < 3 || c->G.n2 < 2 * VEC) return false;
+  const uintptr_t m = 15;
+  if (((uintptr_t)p0 & m) || ((uintptr_t)p1 & m) || ((uintptr_t)p2 & m)) return false;
+  return true;
+}
+
+static int cus_of(pa_ctx* c) {
+  static int cus = 0;
+  if (!cus) {
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, c->device) == hipSuccess) cus = prop.multiProcessorCount;
+    if (cus <= 0) cus = 256;
+  }
+  return cus;
+}
+
+template <typename T, int RJ, int PHASE>
+static int blocks_per_cu() {
+  static int cached = 0;
+  if (!cached) {
+    const char* e = getenv(PHASE == 0 ? "PYAPES_HIP_BPC_A" : "PYAPES_HIP_BPC_B");
+    int n = e ? atoi(e) : 0;
+    if (n <= 0) {
+      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_cg3d<T, RJ, PHASE>, 256, 0) != hipSuccess || n <= 0) n = 2;
+    }
+    cached = n;
+  }
+  return cached;
+}
+
+template <typename T, int RJ, int PHASE>
+static int launch_cg3d(pa_ctx* c, Cg3dArgs<T>& A) {
+  constexpr int VEC = VecOf<T>::N;
+  constexpr int TJ = 4 * RJ, TK = 64 * VEC;
+  const DevGeom& G = c->G;
+  A.tiles_j = (int)((G.n1 + TJ - 1) / TJ);
+  A.tiles_k = (int)((G.n2 + TK - 1) / TK);
+  const int tiles = A.tiles_j * A.tiles_k;
+  const int capacity = cus_of(c) * blocks_per_cu<T, RJ, PHASE>();
+  int chunks = capacity / tiles;
+  if (chunks < 1) chunks = 1;
+  if (chunks > G.n0) chunks = (int)G.n0;
+  A.chunks = chunks;
+  const int nblk = tiles * chunks;
+  if (nblk > PA_MAX_GRID) return 0;
+  hipLaunchKernelGGL((k_cg3d<T, RJ, PHASE>), dim3(nblk), dim3(256), 0, c->stream, A);
+  return nblk;
+}
+
+template <typename T>
+static void fill_common(pa_ctx* c, const DevEq<T>& E, Cg3dArgs<T>& A) {
+  A.G = c->G;
+  A.lap = E.lap;
+  A.coeff = E.t[0].coeff;
+  A.sign = E.t[0].sign;
+  A.has_coeff = E.t[0].has_coeff;
+  A.sc = c->sc;
+}
+
+template <typename T>
+int pa_cg3d_phase_a(pa_ctx* c, const DevEq<T>& E, Vec<T> r, Vec<T> d, T* dnew, double* partials) {
+  if (!cg3d_covered<T>(c, E, r.p, d.p, dnew)) return 0;
+  if (((uintptr_t)r.glo | (uintptr_t)r.ghi | (uintptr_t)d.glo | (uintptr_t)d.ghi) & 15) return 0;
+  Cg3dArgs<T> A;
+  memset(&A, 0, sizeof(A));
+  fill_common<T>(c, E, A);
+  A.r = r; A.d = d; A.dnew = dnew; A.partials = partials;
+  A.reverse = 0;
+  int n = launch_cg3d<T, 4, 0>(c, A);
+  if (n > 0 && hipGetLastError() != hipSuccess) { pa_set_err(c, "k_cg3d phase A launch failed"); return PA_E_HIP; }
+  return n;
+}
+
+template <typename T>
+int pa_cg3d_phase_b(pa_ctx* c, const DevEq<T>& E, Vec<T> d, T* x, T* r, double* partials) {
+  if (!cg3d_covered<T>(c, E, d.p, x, r)) return 0;
+  if (((uintptr_t)d.glo | (uintptr_t)d.ghi) & 15) return 0;
+  if (((uintptr_t)c->r_send_lo | (uintptr_t)c->r_send_hi) & 15) return 0;
+  Cg3dArgs<T> A;
+  memset(&A, 0, sizeof(A));
+  fill_common<T>(c, E, A);
+  A.d = d; A.x = x; A.rw = r; A.partials = partials;
+  A.send_lo = (T*)c->r_send_lo; A.send_hi = (T*)c->r_send_hi;
+  A.reverse = 1;
+  int n = launch_cg3d<T, 4, 1>(c, A);
+  if (n > 0 && hipGetLastError() != hipSuccess) { pa_set_err(c, "k_cg3d phase B launch failed"); return PA_E_HIP; }
+  return n;
+}
 
 template int pa_cg3d_phase_a<float>(pa_ctx*, const DevEq<float>&, Vec<float>, Vec<float>, float*, double*);
 template int pa_cg3d_phase_a<double>(pa_ctx*, const DevEq<double>&, Vec<double>, Vec<double>, double*, double*);

@@ -6,6 +6,7 @@
 #include "pa_host.h"
 
 #include <math.h>
+#include <stdlib.h>
 #include <stdio.h>
 #include <string.h>
 
@@ -273,13 +274,6 @@ __global__ void __launch_bounds__(PA_BLOCK) k_rhs_adjust(DevGeom G, DevEq<T> E, 
   }
 }
 
-// ---- device-resident solver scalars ---------------------------------------------------
-struct SolverScalars {
-  double rr, rr_old, dAd, alpha, beta, tol, tolerance;
-  double rho, omega, rho_next, r0v, ts, tt, r0t;  // bicgstab
-  long long itr, max_it;
-  int done, err, finished_early;
-};
 
 // ---- CG: r = (b - A x) on S, d = r, partial sum r.r (linalg.py:98-107) ---------------
 template <typename T>
@@ -965,6 +959,7 @@ int pa_ctx_create(int device, void* hip_stream, pa_ctx** out) {
   c->device = device;
   c->stream = (hipStream_t)hip_stream;
   c->err[0] = 0;
+  if (const char* fp = getenv("PYAPES_HIP_FASTPATH")) c->fastpath = atoi(fp) != 0;
   if (hipMalloc((void**)&c->sc, sizeof(SolverScalars)) != hipSuccess ||
       hipMalloc((void**)&c->sums, PA_NSUM * sizeof(double)) != hipSuccess ||
       hipHostMalloc((void**)&c->h_sc, sizeof(SolverScalars)) != hipSuccess ||

@@ -9,7 +9,14 @@
 
 #define PA_MAX_GRID 2048  // 256 CUs x 8 resident workgroups of 256 threads
 
-struct SolverScalars;
+// device-resident solver scalars: alpha, beta, the stop test and the iteration count never
+// leave the GPU inside a solve; the host only polls `done`
+struct SolverScalars {
+  double rr, rr_old, dAd, alpha, beta, tol, tolerance;
+  double rho, omega, rho_next, r0v, ts, tt, r0t;  // bicgstab
+  long long itr, max_it;
+  int done, err, finished_early;
+};
 
 struct HostBC {
   int type = PA_BC_NONE;

@@ -106,3 +106,19 @@ def summation_sensitivity(case, rhs0, K):
     x0, r0 = oracle_solve(case, rhs0, K, False)
     x1, r1 = oracle_solve(case, rhs0, K, True)
     return rel_err(x1, x0), abs(r1["itr"] - r0["itr"])
+
+
+def true_residual(case, rhs0, x):
+    """|| (b_adj - A x) ||_2 over the interior set, evaluated by the product's own operator."""
+    from pyapes_amd.mesh.tools import boundary_slicer
+    mesh = product_mesh(case)
+    var = product_field(case, mesh, x)
+    rhs = torch.as_tensor(rhs0).to(mesh.device).clone()
+    solver = Solver({"fdm": {"method": "cg", "tol": 1e-6, "max_it": 1, "report": False}})
+    fdm = FDM()
+    coeff, sign = case.get("coeff", 1.0), case.get("sign", 1.0)
+    eq = fdm.laplacian(coeff, var) if sign > 0 else -fdm.laplacian(coeff, var)
+    solver.set_eq(eq == rhs)
+    S = tuple(boundary_slicer(mesh.dim, var.bcs))
+    r = (solver.rhs - solver.Aop(var))[0][S]
+    return float(torch.linalg.norm(r))

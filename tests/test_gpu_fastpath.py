@@ -1,0 +1,83 @@
+"""-m gpu: the 3-D fast-path CG kernels (pa_cg3d.hip) against the generic kernels and the oracle,
+on shapes that exercise partial tiles, every BC type and both dtypes."""
+import os
+import warnings
+
+import pytest
+import torch
+
+import pyapes_oracle as O
+from helpers import rel_err
+
+pytestmark = pytest.mark.gpu
+
+from pyapes_amd.geometry import Box
+from pyapes_amd.mesh import Mesh
+from pyapes_amd.solver.fdm import FDM
+from pyapes_amd.solver.ops import Solver
+from pyapes_amd.variables import Field
+
+D = lambda v=0.0: ("dirichlet", v)   # noqa: E731
+N = lambda v=0.0: ("neumann", v)     # noqa: E731
+SY = ("symmetry", None)
+PE = ("periodic", None)
+
+SHAPES = [
+    ((20, 37, 50), "double"), ((9, 16, 128), "double"), ((33, 33, 34), "double"), ((40, 40, 40), "double"),
+    ((17, 70, 260), "double"), ((12, 18, 132), "single"), ((24, 40, 64), "single"),
+]
+BCS = {
+    "dir": [D(0.0)] * 6,
+    "mix": [D(0.0), N(0.5), D(0.3), N(0.0), D(1.0), N(-0.25)],
+    "sym": [N(0.3), N(0.0), SY, SY, SY, D(2.0)],
+    "per": [PE] * 6,
+    "zper": [D(0.5), N(0.1), SY, D(0.0), PE, PE],
+    "xper": [PE, PE, D(0.0), D(1.0), N(0.0), N(0.2)],
+}
+
+
+def _cfg(bcs):
+    return [{"bc_face": O.FACES[i], "bc_type": t, "bc_val": v, "bc_val_opt": None} for i, (t, v) in enumerate(bcs)]
+
+
+def _solve(n, dtype, bcs, rhs0, K, fast, coeff=1.0, sign=1.0):
+    os.environ["PYAPES_HIP_FASTPATH"] = "1" if fast else "0"
+    mesh = Mesh(Box[0:1, 0:1, 0:0.5], None, list(n), "cuda", dtype)   # new mesh -> new ctx reads the env
+    var = Field("p", 1, mesh, {"domain": _cfg(bcs), "obstacle": None})
+    rhs = rhs0.to("cuda").clone()
+    solver = Solver({"fdm": {"method": "cg", "tol": 1e-30, "max_it": K, "report": False}})
+    fdm = FDM()
+    eq = fdm.laplacian(coeff, var) if sign > 0 else -fdm.laplacian(coeff, var)
+    solver.set_eq(eq == rhs)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        rep = solver.solve()
+    os.environ.pop("PYAPES_HIP_FASTPATH", None)
+    return var().cpu(), rep
+
+
+@pytest.mark.parametrize("bc", list(BCS), ids=list(BCS))
+@pytest.mark.parametrize("shape", SHAPES, ids=lambda s: "x".join(map(str, s[0])) + s[1][0])
+def test_fast_vs_generic_vs_oracle(shape, bc):
+    n, dtype = shape
+    tdt = torch.float64 if dtype == "double" else torch.float32
+    g = torch.Generator().manual_seed(hash((n, bc)) % 1000)
+    rhs0 = torch.randn((1, *n), generator=g, dtype=torch.float64).to(tdt)
+    if bc == "per":
+        rhs0 -= rhs0.mean()
+    K = 6
+    xf, rf = _solve(n, dtype, BCS[bc], rhs0, K, True, coeff=0.7, sign=-1.0)
+    xg, rg = _solve(n, dtype, BCS[bc], rhs0, K, False, coeff=0.7, sign=-1.0)
+    tol = 1e-12 if dtype == "double" else 2e-5
+    assert rf["itr"] == rg["itr"] == K + 1
+    assert rel_err(xf, xg) <= tol, (rel_err(xf, xg))
+    # oracle (checker)
+    mesh = O.OMesh([0, 0, 0], [1, 1, 0.5], list(n), dtype)
+    cfg = [{"bc_face": O.FACES[i], "bc_type": t, "bc_val": v} for i, (t, v) in enumerate(BCS[bc])]
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        xo, ro = O.solve_poisson(mesh, cfg, rhs0.clone(), method="cg", tol=1e-30, max_it=K, coeff=0.7, sign=-1.0)
+    tol_o = 1e-10 if dtype == "double" else 1e-5
+    assert ro["itr"] == rf["itr"]
+    assert rel_err(xf, xo) <= tol_o, rel_err(xf, xo)
+    assert abs(rf["tol"] - ro["tol"]) <= (1e-6 if dtype == "double" else 1e-4) * abs(ro["tol"]) + 1e-12
