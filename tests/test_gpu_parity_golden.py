@@ -55,9 +55,9 @@ def test_ops_bit_exact(case):
 def test_solve_vs_reference(case):
     """tolerance: 1e-10 rel (fp64) / 1e-5 (fp32) and identical iteration counts.  Cases flagged
     ``sensitive`` (BiCGSTAB, CG on the periodic operator) are held to that bar for the short fixed
-    iteration counts; for their long runs the bar is the reference algorithm's own sensitivity to
-    the summation order (helpers.summation_sensitivity), which bounds what ANY reordering can reach."""
-    from helpers import summation_sensitivity
+    iteration counts; for their long runs the bar is the reference algorithm's own spread over
+    summation orders (helpers.summation_band), which bounds what ANY reordering can reach."""
+    from helpers import summation_band
     g = golden_load(case["name"])
     rtol = 1e-10 if case["dtype"] == "double" else 1e-5
     for K in case["max_its"]:
@@ -65,13 +65,16 @@ def test_solve_vs_reference(case):
         x, rep, _ = product_solve(case, g["rhs0"], K)
         err = rel_err(x, g[f"x_K{K}"])
         if case.get("sensitive") and K > 10:
-            sens, ditr = summation_sensitivity(case, g["rhs0"], K)
-            assert abs(rep["itr"] - ref["itr"]) <= max(5, 3 * ditr, ref["itr"] // 4), (case["name"], K, rep, ref)
+            band, its = summation_band(case, g["rhs0"], K)
+            slack = max(3, max(its) - min(its))
+            assert min(its) - slack <= rep["itr"] <= max(its) + slack, (case["name"], K, rep, its)
             assert rep["converge"] == ref["converge"]
-            if rep["converge"]:
+            assert err <= max(rtol, 5 * band), (case["name"], K, err, band)
+            periodic = any(t == "periodic" for t, _ in case["bcs"])
+            if rep["converge"] and not periodic:
                 # converged: the true residual of the returned iterate must be at the stop-test level
-                res = true_residual(case, g["rhs0"], x)
-                assert res <= 1e3 * case["tol"], (case["name"], K, res)
+                # (not meaningful with periodic faces: their BC fill edits nodes of the interior set, Q5)
+                assert true_residual(case, g["rhs0"], x) <= 1e3 * case["tol"], (case["name"], K)
             continue
         assert rep["itr"] == ref["itr"], (case["name"], K, rep, ref)
         assert rep["converge"] == ref["converge"]

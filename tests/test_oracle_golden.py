@@ -125,11 +125,12 @@ def test_reference_algorithm_is_summation_order_sensitive():
     """Documents WHY long BiCGSTAB / periodic-CG runs cannot be pinned to 1e-10: the reference
     algorithm itself moves by far more than that when only the order of its dot-product
     summations changes (same inputs, same arithmetic otherwise).  SPD CG is stable."""
-    from helpers import summation_sensitivity
+    from helpers import summation_band
     from conftest import golden_cases, golden_load
     cases = {c["name"]: c for c in golden_cases("solve")}
-    s_bicg, _ = summation_sensitivity(cases["bicg2d_xper_f64"], golden_load("bicg2d_xper_f64")["rhs0"], 1000)
-    s_pcg, _ = summation_sensitivity(cases["cg2d_xper101_f64"], golden_load("cg2d_xper101_f64")["rhs0"], 30)
-    s_cg, d_cg = summation_sensitivity(cases["cg3d_mix33_f64"], golden_load("cg3d_mix33_f64")["rhs0"], 1000)
-    assert s_bicg > 1e-8 and s_pcg > 1e-8
-    assert s_cg < 1e-13 and d_cg == 0
+    b_bicg, its_bicg = summation_band(cases["bicg2d_xper_f64"], golden_load("bicg2d_xper_f64")["rhs0"], 1000)
+    b_pcg, _ = summation_band(cases["cg2d_xper101_f64"], golden_load("cg2d_xper101_f64")["rhs0"], 30)
+    b_cg, its_cg = summation_band(cases["cg3d_mix33_f64"], golden_load("cg3d_mix33_f64")["rhs0"], 1000)
+    assert b_bicg > 1e-6 and len(set(its_bicg)) > 1
+    assert b_pcg > 1e-6
+    assert b_cg < 1e-13 and len(set(its_cg)) == 1
