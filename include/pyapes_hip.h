@@ -139,11 +139,13 @@ int pa_euler_step(pa_ctx* ctx, const void* phi_in, void* phi_out, int div_kind, 
  * between the phases of one iteration:
  *   begin -> [exchange r planes] -> [all-reduce sums] -> per iteration:
  *     phase_a   d' = r + beta d, local sum d'.(A d')        -> [all-reduce sums]
- *     phase_b   alpha; x += alpha d'; r -= alpha A d'; BC fill; local sums
- *               -> [exchange r planes] -> [all-reduce sums]
+ *     phase_b   alpha; x += alpha d'; r -= alpha A d'   -> [exchange r planes, periodic x planes]
+ *     bc        BC fill of x, boundary part of the stop test, local sums -> [all-reduce sums]
  *     finish_iter   beta, stop test, iteration count (device side)
- * With no slab set (P = 1) the reductions and scalar logic run inside the phases
- * and finish_iter is a no-op.  Nothing here synchronises the stream. */
+ * With no slab set (P = 1) the BC fill, reductions and scalar logic run inside the phases
+ * and bc / finish_iter are no-ops.  On a slab pa_cg_begin does NOT fill the BCs: the driver
+ * calls pa_apply_bc first and then exchanges the ghost planes of x.  Nothing here
+ * synchronises the stream. */
 #define PA_NSUM 8
 enum { PA_SUM_DAD = 0, PA_SUM_RR = 1, PA_SUM_DX2 = 2 };
 
@@ -160,13 +162,15 @@ typedef struct {
   const void* x_ghost_hi;
   const void* bc_far_lo0;  /* periodic axis-0 BC fill on the lower end rank: x[N-1], x[N-2] */
   const void* bc_far_lo1;
-  const void* bc_far_hi0;  /* ... on the upper end rank: the new x[0] */
+  const void* bc_far_hi0;  /* ... on the upper end rank: x[1] of the lower end rank (the new x[0] is
+                              recomputed there bit for bit as x[1] - x[N-1] + x[N-2]) */
 } pa_slab;
 int pa_slab_set(pa_ctx* ctx, const pa_slab* slab); /* NULL: back to single GPU */
 
 int pa_cg_begin(pa_ctx* ctx, void* x, const void* rhs, double tol, int64_t max_it);
 int pa_cg_phase_a(pa_ctx* ctx);
 int pa_cg_phase_b(pa_ctx* ctx);
+int pa_cg_bc(pa_ctx* ctx);
 int pa_cg_finish_iter(pa_ctx* ctx);
 /* P = 1 only: enqueue n whole iterations back to back */
 int pa_cg_iterate(pa_ctx* ctx, int64_t n);

@@ -90,8 +90,13 @@ __global__ void __launch_bounds__(PA_BLOCK) k_bc_face(DevGeom G, T* __restrict__
         }
         T t1 = vp - vf;
         *xf = t1 + vff;
+      } else if (B.far0) {
+        // slab: the lower end rank lives elsewhere; far0 = its x[1], and the new x[0] it computes,
+        // x1 - x[N-1] + x[N-2], is recomputed here bit for bit from the planes this rank owns
+        T t1 = B.far0[q] - x[base + (N - 1 - off) * st];
+        *xf = t1 + x[base + (pa_wrap(N - 2, N) - off) * st];
       } else {
-        *xf = B.far0 ? B.far0[q] : x[base + (0 - off) * st];
+        *xf = x[base + (0 - off) * st];
       }
     }
   }
@@ -279,7 +284,8 @@ __global__ void __launch_bounds__(PA_BLOCK) k_rhs_adjust(DevGeom G, DevEq<T> E, 
 template <typename T>
 __global__ void __launch_bounds__(PA_BLOCK) k_cg_init(DevGeom G, DevEq<T> E, Vec<T> xv,
                                                        const T* __restrict__ rhs, T* __restrict__ r,
-                                                       T* __restrict__ d, double* __restrict__ partials) {
+                                                       T* __restrict__ d, T* __restrict__ send_lo,
+                                                       T* __restrict__ send_hi, double* __restrict__ partials) {
   FieldAcc<T> acc{xv};
   double s[1] = {0.0};
   for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < G.ncell;
@@ -295,6 +301,8 @@ __global__ void __launch_bounds__(PA_BLOCK) k_cg_init(DevGeom G, DevEq<T> E, Vec
     }
     r[idx] = rv;
     if (d) d[idx] = rv;
+    if (send_lo && i == 0) send_lo[j * G.s1 + k] = rv;
+    if (send_hi && i == G.n0 - 1) send_hi[j * G.s1 + k] = rv;
   }
   pa_block_reduce_store<1>(s, partials);
 }
@@ -586,6 +594,21 @@ __global__ void __launch_bounds__(PA_BLOCK) k_euler(DevGeom G, DevEq<T> Elap, De
       v = pc + a;
     }
     out[idx] = v;
+  }
+}
+
+// slab: ghost planes of the new direction, d'_g = r_g + beta d_g -- bitwise what the neighbour
+// rank computes for its own boundary plane, so no direction planes are ever exchanged
+template <typename T>
+__global__ void __launch_bounds__(PA_BLOCK) k_ghost_dir(const SolverScalars* __restrict__ sc, int64_t n,
+                                                         const T* __restrict__ r_lo, const T* __restrict__ r_hi,
+                                                         const T* __restrict__ d_lo, const T* __restrict__ d_hi,
+                                                         T* __restrict__ o_lo, T* __restrict__ o_hi) {
+  if (sc->done) return;
+  const T beta = (T)sc->beta;
+  for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < n; q += (int64_t)gridDim.x * blockDim.x) {
+    if (r_lo) { T b = beta * d_lo[q]; o_lo[q] = r_lo[q] + b; }
+    if (r_hi) { T b = beta * d_hi[q]; o_hi[q] = r_hi[q] + b; }
   }
 }
 
@@ -1376,15 +1399,27 @@ static int cg_begin_t(pa_ctx* c, T* x, const T* rhs, double tol, int64_t max_it)
   c->solver_live = 1;
   DevEq<T> E;
   pa_build_eq<T>(c, c->nterms, c->terms, E);
-  if ((rc = bc_apply_t<T>(c, x))) return rc;  // linalg.py:97
+  // linalg.py:97.  On a slab the driver fills the BCs itself (pa_apply_bc) BEFORE it exchanges
+  // the ghost planes of x, so the fill must not run again here.
+  if (!c->slab && (rc = bc_apply_t<T>(c, x))) return rc;
   T* r = (T*)c->scr[SCR_R];
   T* d = (T*)c->scr[SCR_D0];
   double* part = (double*)c->scr[SCR_PART];
   Vec<T> xv = pa_vec_self<T>(c, x);
   if (c->slab) { xv.glo = (const T*)c->x_glo; xv.ghi = (const T*)c->x_ghi; }
-  hipLaunchKernelGGL(k_cg_init<T>, dim3(nblk), dim3(PA_BLOCK), 0, c->stream, G, E, xv, rhs, r, d, part);
+  hipLaunchKernelGGL(k_cg_init<T>, dim3(nblk), dim3(PA_BLOCK), 0, c->stream, G, E, xv, rhs, r, d,
+                     (T*)c->r_send_lo, (T*)c->r_send_hi, part);
   hipLaunchKernelGGL(k_cg_post_init<T>, dim3(1), dim3(PA_BLOCK), 0, c->stream, c->sc, part, nblk, pa_sums(c),
                      c->slab ? 0 : 2);
+  c->pending_init_logic = c->slab ? 1 : 0;
+  if (c->slab) {
+    // ghost planes of the two direction buffers: lo/hi x ping/pong, zero = "d = r" with beta = 0
+    const size_t pb = (size_t)G.s0 * sizeof(T);
+    if ((rc = pa_scratch(c, &c->scr[SCR_GHOST], &c->cap[SCR_GHOST], 4 * pb))) return rc;
+    PA_HIP(c, hipMemsetAsync(c->scr[SCR_GHOST], 0, 4 * pb, c->stream));
+    char* g = (char*)c->scr[SCR_GHOST];
+    c->d_glo[0] = g; c->d_ghi[0] = g + pb; c->d_glo[1] = g + 2 * pb; c->d_ghi[1] = g + 3 * pb;
+  }
   hipLaunchKernelGGL(k_shell<T>, dim3(shell_blocks(c)), dim3(PA_BLOCK), 0, c->stream, G, c->sc, (const T*)x,
                      (T*)c->scr[SCR_SHELL], (double*)c->scr[SCR_PART2], 0);
   PA_HIP(c, hipGetLastError());
@@ -1408,8 +1443,15 @@ template <typename T>
 static Vec<T> cg_vec(pa_ctx* c, const T* p, int which /*0 r, 1 d cur*/) {
   Vec<T> v = pa_vec_self<T>(c, p);
   if (c->slab) {
-    if (which == 0) { v.glo = (const T*)c->r_recv_lo; v.ghi = (const T*)c->r_recv_hi; }
-    else { v.glo = (const T*)c->d_glo[c->cur]; v.ghi = (const T*)c->d_ghi[c->cur]; }
+    // a NULL recv pointer marks a physical (non-periodic) end: that ghost plane is never used in a
+    // result, the field's own plane stands in so that speculative loads stay inside valid memory
+    if (which == 0) {
+      if (c->r_recv_lo) v.glo = (const T*)c->r_recv_lo;
+      if (c->r_recv_hi) v.ghi = (const T*)c->r_recv_hi;
+    } else {
+      if (c->r_recv_lo) v.glo = (const T*)c->d_glo[c->cur];
+      if (c->r_recv_hi) v.ghi = (const T*)c->d_ghi[c->cur];
+    }
   }
   return v;
 }
@@ -1424,7 +1466,17 @@ int pa_cg_phase_a_t(pa_ctx* c, int stage_post) {
   T* dold = (T*)c->scr[c->cur ? SCR_D1 : SCR_D0];
   T* dnew = (T*)c->scr[c->cur ? SCR_D0 : SCR_D1];
   double* part = (double*)c->scr[SCR_PART];
+  if (c->pending_init_logic) {  // slab: sum r.r has been all-reduced by the driver
+    hipLaunchKernelGGL(k_cg_post_init<T>, dim3(1), dim3(PA_BLOCK), 0, c->stream, c->sc, (const double*)nullptr, 0,
+                       pa_sums(c), 1);
+    c->pending_init_logic = 0;
+  }
   Vec<T> rv = cg_vec<T>(c, r, 0), dv = cg_vec<T>(c, dold, 1);
+  if (c->slab && (c->r_recv_lo || c->r_recv_hi)) {
+    hipLaunchKernelGGL(k_ghost_dir<T>, dim3(pa_grid_blocks(G.s0)), dim3(PA_BLOCK), 0, c->stream, c->sc, G.s0,
+                       (const T*)c->r_recv_lo, (const T*)c->r_recv_hi, (const T*)c->d_glo[c->cur],
+                       (const T*)c->d_ghi[c->cur], (T*)c->d_glo[c->cur ^ 1], (T*)c->d_ghi[c->cur ^ 1]);
+  }
   if (c->profile) (void)hipEventRecord(c->pev[0], c->stream);
   int rc = pa_cg3d_phase_a<T>(c, E, rv, dv, dnew, part);
   if (rc < 0) return rc;
@@ -1463,6 +1515,11 @@ int pa_cg_phase_b_t(pa_ctx* c, int stage_post) {
     used_blocks = nblk;
   }
   if (c->profile) pa_profile_stop(c, 1);
+  c->b_blocks = used_blocks;
+  if (c->slab) {  // BC fill + shell + reduction happen in pa_cg_bc, after the driver's plane exchange
+    PA_HIP(c, hipGetLastError());
+    return PA_OK;
+  }
   int nsh = 0;
   if (!c->bc_static) {
     if ((rc = bc_apply_t<T>(c, x, true))) return rc;
@@ -1472,6 +1529,27 @@ int pa_cg_phase_b_t(pa_ctx* c, int stage_post) {
   }
   hipLaunchKernelGGL(k_cg_post_b<T>, dim3(1), dim3(PA_BLOCK), 0, c->stream, c->sc, part, used_blocks, part2, nsh,
                      pa_sums(c), stage_post);
+  PA_HIP(c, hipGetLastError());
+  return PA_OK;
+}
+
+// slab: BC fill of x (needs the far planes the driver just exchanged when axis 0 is periodic),
+// boundary-shell part of the stop test, local partial sums -> sums[1], sums[2]
+template <typename T>
+int pa_cg_bc_t(pa_ctx* c) {
+  const DevGeom& G = c->G;
+  T* x = (T*)c->cg_x;
+  double* part = (double*)c->scr[SCR_PART];
+  double* part2 = (double*)c->scr[SCR_PART2];
+  int nsh = 0, rc;
+  if (!c->bc_static) {
+    if ((rc = bc_apply_t<T>(c, x, true))) return rc;
+    nsh = shell_blocks(c);
+    hipLaunchKernelGGL(k_shell<T>, dim3(nsh), dim3(PA_BLOCK), 0, c->stream, G, c->sc, (const T*)x,
+                       (T*)c->scr[SCR_SHELL], part2, 1);
+  }
+  hipLaunchKernelGGL(k_cg_post_b<T>, dim3(1), dim3(PA_BLOCK), 0, c->stream, c->sc, part, c->b_blocks, part2, nsh,
+                     pa_sums(c), 0);
   PA_HIP(c, hipGetLastError());
   return PA_OK;
 }
@@ -1592,7 +1670,8 @@ static int bicg_run_t(pa_ctx* c, T* x, const T* rhs, double tol, int64_t max_it,
   T* t = (T*)c->scr[SCR_TT];
   double* part = (double*)c->scr[SCR_PART];
   Vec<T> xv = pa_vec_self<T>(c, x);
-  hipLaunchKernelGGL(k_cg_init<T>, dim3(nblk), dim3(PA_BLOCK), 0, c->stream, G, E, xv, rhs, r0, r, part);
+  hipLaunchKernelGGL(k_cg_init<T>, dim3(nblk), dim3(PA_BLOCK), 0, c->stream, G, E, xv, rhs, r0, r, (T*)nullptr,
+                     (T*)nullptr, part);
   PA_HIP(c, hipMemsetAsync(p[0], 0, fb, c->stream));
   PA_HIP(c, hipMemsetAsync(v[0], 0, fb, c->stream));
   // rho_next = sum r0.r0 ; tol0 = sqrt(rho_next) ; first beta = rho_next / 1 * 1 / 1 (linalg.py:201-212)
@@ -1709,6 +1788,12 @@ int pa_cg_phase_b(pa_ctx* c) {
   }
   const int st = c->slab ? 0 : 2;
   return c->dtype == PA_F64 ? pa_cg_phase_b_t<double>(c, st) : pa_cg_phase_b_t<float>(c, st);
+}
+
+int pa_cg_bc(pa_ctx* c) {
+  if (!c || !c->solver_live) { if (c) pa_set_err(c, "pa_cg_bc without pa_cg_begin"); return PA_E_STATE; }
+  if (!c->slab) return PA_OK;  // done inside phase_b
+  return c->dtype == PA_F64 ? pa_cg_bc_t<double>(c) : pa_cg_bc_t<float>(c);
 }
 
 int pa_cg_finish_iter(pa_ctx* c) {

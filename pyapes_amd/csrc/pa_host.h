@@ -54,7 +54,7 @@ struct pa_ctx {
   double* ext_sums = nullptr;     // slab: caller-owned sums buffer (all-reduced by the host driver)
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   // CG state
-  int solver_live = 0, cur = 0, bc_static = 0;
+  int solver_live = 0, cur = 0, bc_static = 0, pending_init_logic = 0, b_blocks = 0;
   void* cg_x = nullptr;
   // slab decomposition (P > 1): externally owned exchange buffers
   int slab = 0;
@@ -68,7 +68,7 @@ struct pa_ctx {
   void* d_ghi[2] = {nullptr, nullptr};
   const void* bc_far_lo0 = nullptr;  // periodic axis-0 fill: x[N-1] (for the lower end rank)
   const void* bc_far_lo1 = nullptr;  //                       x[N-2]
-  const void* bc_far_hi0 = nullptr;  //                       x[0]   (for the upper end rank)
+  const void* bc_far_hi0 = nullptr;  //                       x[1] of the lower end rank (for the upper end rank)
   // per-kernel timing of the two dominant CG kernels (pa_profile_set): HIP events on the ctx stream
   int profile = 0;
   hipEvent_t pev[4] = {nullptr, nullptr, nullptr, nullptr};

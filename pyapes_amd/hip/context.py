@@ -95,6 +95,10 @@ class HipContext:
             self.bind_bcs(var, bcs, d)
             self._rc(self.lib.pa_apply_bc(self.h, self._ptr(self._field(var[d], "BC fill"))))
 
+    def apply_bc_bound(self, x: Tensor) -> None:
+        """BC fill with the list already bound by ``bind_bcs`` (one scalar field)."""
+        self._rc(self.lib.pa_apply_bc(self.h, self._ptr(self._field(x, "BC fill"))))
+
     # -- equation -------------------------------------------------------------------
     def set_terms(self, terms: Sequence[dict]) -> None:
         """terms: dicts with kind, sign, coeff (None|float|Tensor), u (float|Tensor)."""
@@ -205,6 +209,9 @@ class HipContext:
 
     def cg_phase_b(self) -> None:
         self._rc(self.lib.pa_cg_phase_b(self.h))
+
+    def cg_bc(self) -> None:
+        self._rc(self.lib.pa_cg_bc(self.h))
 
     def cg_finish_iter(self) -> None:
         self._rc(self.lib.pa_cg_finish_iter(self.h))

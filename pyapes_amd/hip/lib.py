@@ -73,6 +73,7 @@ SIGNATURES: dict[str, tuple[Any, list[Any]]] = {
     "pa_cg_begin": (C.c_int, [_VP, _VP, _VP, C.c_double, C.c_int64]),
     "pa_cg_phase_a": (C.c_int, [_VP]),
     "pa_cg_phase_b": (C.c_int, [_VP]),
+    "pa_cg_bc": (C.c_int, [_VP]),
     "pa_cg_finish_iter": (C.c_int, [_VP]),
     "pa_cg_iterate": (C.c_int, [_VP, C.c_int64]),
     "pa_cg_end": (C.c_int, [_VP, C.POINTER(PaReport)]),

@@ -1,5 +1,26 @@
-"""Slab decomposition along axis 0 (new).  Host logic only."""
+"""Slab decomposition along axis 0 and the multi-GPU CG driver (new).
+
+The reference is single-device.  Here the 3-D grid is cut into P slabs of whole
+(n1 x n2) planes, one per rank / GPU.  Per CG iteration the ranks exchange
+
+  * one boundary plane of the residual r with each axis-0 neighbour (ring wrap when
+    axis 0 is periodic) -- the ghost planes of the search direction are NOT sent: each
+    rank advances them with the same recurrence d' = r + beta d the owner uses, bit for bit;
+  * when axis 0 is periodic, the three planes of x its BC fill reads across the ring
+    (x[N-1], x[N-2] to the lower end rank, x[1] to the upper end rank);
+  * two all-reduces of scalars (sum d.Ad, then sum r.r + the stop-test sum).
+
+Everything else is rank-local.  Communication goes through ``torch.distributed``
+(backend "nccl" = RCCL over xGMI on the GPUs; "gloo" in the CPU tests), compute through
+a *backend* object with the stepwise C-ABI calls (``HipContext`` in the product; the tests
+substitute an oracle-backed stand-in to exercise this driver on CPU with world_size 2).
+"""
 from __future__ import annotations
+
+from typing import Any, Sequence
+
+import torch
+from torch import Tensor
 
 
 def slab_extent(n0: int, rank: int, world: int) -> tuple[int, int]:
@@ -11,3 +32,158 @@ def slab_extent(n0: int, rank: int, world: int) -> tuple[int, int]:
     base, rem = divmod(n0, world)
     off = rank * base + min(rank, rem)
     return off, base + (1 if rank < rem else 0)
+
+
+class SlabCG:
+    """Stepwise CG over P slabs.  ``begin`` / ``iterate(n)`` / ``end`` mirror pa_cg_begin /
+    pa_cg_iterate / pa_cg_end of the single-GPU path; nothing in ``iterate`` synchronises
+    the host with the device."""
+
+    def __init__(self, mesh: Any, var: Any, rhs: Tensor, terms: Sequence[dict], dist: Any,
+                 backend: Any = None, group: Any = None):
+        assert mesh.slab is not None, "SlabCG needs a Mesh(..., slab=(rank, world))"
+        self.mesh, self.var, self.dist, self.group = mesh, var, dist, group
+        self.rank, self.world = mesh.slab
+        if backend is None:
+            from .hip.context import context_for
+            backend = context_for(mesh)
+        self.be = backend
+        types = {bc.bc_face: bc.bc_type for bc in var.bcs}
+        self.periodic0 = types.get("xl") == "periodic" or types.get("xu") == "periodic"
+        if self.periodic0 and not (types.get("xl") == "periodic" and types.get("xu") == "periodic"):
+            raise ValueError("SlabCG: axis 0 must be periodic on both faces or on none")
+        order = [bc.bc_face for bc in var.bcs]
+        if order[:2] != ["xl", "xu"]:
+            raise ValueError("SlabCG: the BC list must start with xl, xu (factory order)")
+        P, r = self.world, self.rank
+        self.nb_lo = r - 1 if r > 0 else (P - 1 if self.periodic0 else None)
+        self.nb_hi = r + 1 if r < P - 1 else (0 if self.periodic0 else None)
+        self.x = var()[0]
+        self.rhs = rhs[0] if rhs.dim() == 4 else rhs
+        dev, f = self.x.device, self.x.dtype
+        plane = tuple(self.x.shape[1:])
+
+        def buf(cond=True):
+            return torch.zeros(plane, dtype=f, device=dev) if cond else None
+
+        self.sums = torch.zeros(8, dtype=torch.float64, device=dev)
+        self.bufs = {
+            "sums": self.sums,
+            "r_send_lo": buf(self.nb_lo is not None), "r_send_hi": buf(self.nb_hi is not None),
+            "r_recv_lo": buf(self.nb_lo is not None), "r_recv_hi": buf(self.nb_hi is not None),
+            "x_ghost_lo": buf(self.nb_lo is not None), "x_ghost_hi": buf(self.nb_hi is not None),
+            "bc_far_lo0": buf(self.periodic0 and r == 0), "bc_far_lo1": buf(self.periodic0 and r == 0),
+            "bc_far_hi0": buf(self.periodic0 and r == P - 1),
+        }
+        self.terms = list(terms)
+        self._stage = None  # pinned CPU staging when the process group cannot move GPU tensors
+
+    # -- communication -----------------------------------------------------------
+    def _p2p(self, sends: list[tuple[Tensor, int, int]], recvs: list[tuple[Tensor, int, int]]) -> None:
+        """sends/recvs: (tensor, peer, tag).  One batched, ordered exchange."""
+        if not sends and not recvs:
+            return
+        d = self.dist
+        gpu = bool(sends and sends[0][0].is_cuda) or bool(recvs and recvs[0][0].is_cuda)
+        staged = gpu and d.get_backend(self.group) != "nccl"
+        if staged:  # gloo with GPU tensors (2-rank rehearsal on one card): go through the host
+            torch.cuda.synchronize()
+            s2 = [(t.cpu(), p, tag) for t, p, tag in sends]
+            r2 = [(torch.empty(t.shape, dtype=t.dtype), p, tag) for t, p, tag in recvs]
+        else:
+            s2, r2 = sends, recvs
+        ops = [d.P2POp(d.isend, t, p, self.group, tag) for t, p, tag in s2]
+        ops += [d.P2POp(d.irecv, t, p, self.group, tag) for t, p, tag in r2]
+        for w in d.batch_isend_irecv(ops):
+            w.wait()
+        if staged:
+            for (dst, _, _), (src, _, _) in zip(recvs, r2):
+                dst.copy_(src)
+
+    def _exchange_planes(self, lo_send: Tensor | None, hi_send: Tensor | None,
+                         lo_recv: Tensor | None, hi_recv: Tensor | None) -> None:
+        """Send my first plane down / last plane up, receive the ghosts.  Tag 0 = travelling up
+        (lands in a lower ghost), tag 1 = travelling down.  Receives are posted hi first so that
+        with P = 2 and a periodic ring (both neighbours are the same peer) the two messages pair
+        correctly even on a backend that ignores tags."""
+        sends, recvs = [], []
+        if self.nb_lo is not None and lo_send is not None:
+            sends.append((lo_send, self.nb_lo, 1))
+        if self.nb_hi is not None and hi_send is not None:
+            sends.append((hi_send, self.nb_hi, 0))
+        if self.nb_hi is not None and hi_recv is not None:
+            recvs.append((hi_recv, self.nb_hi, 1))
+        if self.nb_lo is not None and lo_recv is not None:
+            recvs.append((lo_recv, self.nb_lo, 0))
+        self._p2p(sends, recvs)
+
+    def _exchange_bc_far(self) -> None:
+        """Periodic axis 0: planes of x the end ranks' BC fill reads across the ring."""
+        if not self.periodic0:
+            return
+        P, r = self.world, self.rank
+        sends, recvs = [], []
+        if r == P - 1:
+            sends += [(self.x[-1].contiguous(), 0, 2), (self.x[-2].contiguous(), 0, 3)]
+            recvs += [(self.bufs["bc_far_hi0"], 0, 4)]
+        if r == 0:
+            sends += [(self.x[1].contiguous(), P - 1, 4)]
+            recvs += [(self.bufs["bc_far_lo0"], P - 1, 2), (self.bufs["bc_far_lo1"], P - 1, 3)]
+        self._p2p(sends, recvs)
+
+    def _allreduce(self, lo: int, hi: int) -> None:
+        self.dist.all_reduce(self.sums[lo:hi], op=self.dist.ReduceOp.SUM, group=self.group)
+
+    # -- solve ------------------------------------------------------------------------
+    def begin(self, tol: float, max_it: int, adjust_rhs: bool = True) -> None:
+        be = self.be
+        be.slab_set(self.bufs)
+        be.bind_bcs(self.var(), self.var.bcs, 0)
+        be.set_terms(self.terms)
+        if adjust_rhs:
+            be.rhs_adjust(self.rhs)
+        self._exchange_bc_far()
+        be.apply_bc_bound(self.x)                      # linalg.py:97, before the ghosts of x move
+        self._exchange_planes(self.x[0], self.x[-1], self.bufs["x_ghost_lo"], self.bufs["x_ghost_hi"])
+        be.cg_begin(self.x, self.rhs, tol, max_it)      # r, d = r, local sum r.r -> sums[1], r planes
+        self._exchange_planes(self.bufs["r_send_lo"], self.bufs["r_send_hi"],
+                              self.bufs["r_recv_lo"], self.bufs["r_recv_hi"])
+        self._allreduce(1, 2)
+
+    def iterate(self, n: int) -> None:
+        be = self.be
+        for _ in range(n):
+            be.cg_phase_a()                              # d' = r + beta d ; local sum d'.Ad'
+            self._allreduce(0, 1)
+            be.cg_phase_b()                              # alpha ; x, r update ; r planes out
+            self._exchange_planes(self.bufs["r_send_lo"], self.bufs["r_send_hi"],
+                                  self.bufs["r_recv_lo"], self.bufs["r_recv_hi"])
+            self._exchange_bc_far()
+            be.cg_bc()                                   # BC fill of x ; local sums r.r, |dx|^2
+            self._allreduce(1, 3)
+            be.cg_finish_iter()                          # beta, stop test, itr (device side)
+
+    def solve(self, tol: float, max_it: int, poll: int = 8) -> Any:
+        """Run to the reference's stop rule (tol / max_it + 1 iterations); polls the device-side
+        done flag every ``poll`` iterations -- iterations enqueued after it is set are no-ops."""
+        self.begin(tol, max_it)
+        done = 0
+        while done <= max_it:
+            n = min(poll, max_it + 1 - done)
+            self.iterate(n)
+            done += n
+            if self.be.report().itr < done:
+                break
+        return self.end()
+
+    def profile(self, n: int) -> dict[str, float]:
+        self.be.profile(True)
+        self.iterate(n)
+        out = self.be.profile_read()
+        self.be.profile(False)
+        return out
+
+    def end(self) -> Any:
+        rep = self.be.cg_end()
+        self.be.slab_set(None)
+        return rep

@@ -1,0 +1,73 @@
+"""-m gpu: the real HIP kernels in slab mode.  Two ranks share cuda:0 (gloo process group, planes
+staged through the host by the driver) -- a rehearsal of the P > 1 path on the one-GPU box: slab
+extents, ghost planes, direction-ghost recurrence, periodic far planes, split reductions.
+Checked against the single-domain oracle."""
+import os
+import socket
+import warnings
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import pyapes_oracle as O
+from test_slab_gloo import CASES, _free_port
+
+pytestmark = pytest.mark.gpu
+
+
+def _worker(rank, world, port, name, n, K, dtype, out):
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    sys.path.insert(0, here)
+    sys.path.insert(0, os.path.dirname(here))
+    warnings.filterwarnings("ignore")
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from pyapes_amd.geometry import Box
+        from pyapes_amd.mesh import Mesh
+        from pyapes_amd.slab import SlabCG
+        from pyapes_amd.variables import Field
+        torch.cuda.set_device(0)
+        bcs = [{"bc_face": O.FACES[i], "bc_type": t, "bc_val": v, "bc_val_opt": None}
+               for i, (t, v) in enumerate(CASES[name])]
+        mesh = Mesh(Box[0:1, 0:1, 0:0.5], None, list(n), "cuda", dtype, slab=(rank, world))
+        var = Field("p", 1, mesh, {"domain": bcs, "obstacle": None})
+        g = torch.Generator().manual_seed(7)
+        rhs_g = torch.randn((1, *n), generator=g, dtype=torch.float64).to(mesh.dtype.float)
+        if name == "per":
+            rhs_g -= rhs_g.mean()
+        rhs = rhs_g[:, mesh.i_off:mesh.i_off + mesh.nx[0]].contiguous().cuda()
+        drv = SlabCG(mesh, var, rhs, [{"kind": 0, "sign": -1.0, "coeff": 0.7}], dist)
+        rep = drv.solve(1e-30, K, poll=3)
+        parts = [None] * world
+        dist.all_gather_object(parts, var().cpu())
+        if rank == 0:
+            torch.save({"x": torch.cat(parts, dim=1), "itr": int(rep.itr), "tol": float(rep.tol)}, out)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("shape", [((24, 20, 132), "double"), ((12, 9, 11), "double"), ((16, 12, 136), "single")],
+                         ids=["fast_f64", "generic_f64", "fast_f32"])
+@pytest.mark.parametrize("name", list(CASES), ids=list(CASES))
+def test_two_slabs_on_one_gpu(name, shape, tmp_path):
+    (n, dtype), K = shape, 6
+    out = str(tmp_path / "x.pt")
+    mp.spawn(_worker, args=(2, _free_port(), name, n, K, dtype, out), nprocs=2, join=True)
+    res = torch.load(out)
+    mesh = O.OMesh([0, 0, 0], [1, 1, 0.5], list(n), dtype)
+    cfg = [{"bc_face": O.FACES[i], "bc_type": t, "bc_val": v} for i, (t, v) in enumerate(CASES[name])]
+    g = torch.Generator().manual_seed(7)
+    rhs = torch.randn((1, *n), generator=g, dtype=torch.float64).to(mesh.dtype)
+    if name == "per":
+        rhs -= rhs.mean()
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        xo, ro = O.solve_poisson(mesh, cfg, rhs, method="cg", tol=1e-30, max_it=K, coeff=0.7, sign=-1.0)
+    assert res["itr"] == ro["itr"] == K + 1
+    err = float(torch.linalg.norm(res["x"].double() - xo.double()) / torch.linalg.norm(xo.double()))
+    assert err < (1e-10 if dtype == "double" else 1e-5), err

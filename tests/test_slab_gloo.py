@@ -1,0 +1,103 @@
+"""CPU, world_size 2, gloo: the slab driver (pyapes_amd/slab.py: halo exchange of r planes, ring
+wrap, periodic far planes, scalar all-reduces, phase order) with the torch stand-in backend,
+against the single-domain oracle.  Also the host-side partitioning logic."""
+import os
+import socket
+import warnings
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import pyapes_oracle as O
+from pyapes_amd.slab import slab_extent
+
+D = lambda v=0.0: ("dirichlet", v)   # noqa: E731
+N = lambda v=0.0: ("neumann", v)     # noqa: E731
+SY = ("symmetry", None)
+PE = ("periodic", None)
+CASES = {
+    "dir": [D(0.0), D(0.5), D(0.0), D(0.0), D(1.0), D(0.0)],
+    "mix": [N(0.3), D(0.0), D(0.3), N(0.0), SY, N(-0.25)],
+    "neu_hi": [D(0.2), N(0.0), SY, SY, D(1.0), D(0.0)],
+    "per": [PE] * 6,
+    "xper": [PE, PE, D(0.0), D(1.0), N(0.0), SY],
+}
+
+
+def test_slab_extent_partitions_exactly():
+    for n0 in (6, 7, 12, 512, 1024, 33):
+        for world in (1, 2, 3, 4, 8):
+            if n0 < 3 * world:
+                with pytest.raises(ValueError):
+                    slab_extent(n0, 0, world)
+                continue
+            ext = [slab_extent(n0, r, world) for r in range(world)]
+            assert ext[0][0] == 0 and sum(e[1] for e in ext) == n0
+            for a, b in zip(ext, ext[1:]):
+                assert a[0] + a[1] == b[0]
+            assert max(e[1] for e in ext) - min(e[1] for e in ext) <= 1
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, name, n, K, dtype, out):
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    sys.path.insert(0, here)
+    sys.path.insert(0, os.path.dirname(here))
+    warnings.filterwarnings("ignore")
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from pyapes_amd.geometry import Box
+        from pyapes_amd.mesh import Mesh
+        from pyapes_amd.slab import SlabCG
+        from pyapes_amd.variables import Field
+        from slab_torch_backend import TorchSlabBackend
+        bcs = [{"bc_face": O.FACES[i], "bc_type": t, "bc_val": v, "bc_val_opt": None}
+               for i, (t, v) in enumerate(CASES[name])]
+        mesh = Mesh(Box[0:1, 0:1, 0:0.5], None, list(n), "cpu", dtype, slab=(rank, world))
+        var = Field("p", 1, mesh, {"domain": bcs, "obstacle": None})
+        g = torch.Generator().manual_seed(7)
+        rhs_g = torch.randn((1, *n), generator=g, dtype=torch.float64).to(mesh.dtype.float)
+        if name == "per":
+            rhs_g -= rhs_g.mean()
+        rhs = rhs_g[:, mesh.i_off:mesh.i_off + mesh.nx[0]].clone()
+        drv = SlabCG(mesh, var, rhs, [{"kind": 0, "sign": -1.0, "coeff": 0.7}], dist, backend=TorchSlabBackend(mesh))
+        rep = drv.solve(1e-30, K, poll=3)
+        parts = [None] * world
+        dist.all_gather_object(parts, var().clone())
+        if rank == 0:
+            torch.save({"x": torch.cat(parts, dim=1), "itr": rep.itr, "tol": rep.tol}, out)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("name", list(CASES), ids=list(CASES))
+def test_slab_driver_two_ranks_matches_oracle(name, tmp_path):
+    n, K, dtype = (12, 9, 10), 7, "double"
+    out = str(tmp_path / "x.pt")
+    mp.spawn(_worker, args=(2, _free_port(), name, n, K, dtype, out), nprocs=2, join=True)
+    res = torch.load(out)
+    mesh = O.OMesh([0, 0, 0], [1, 1, 0.5], list(n), dtype)
+    cfg = [{"bc_face": O.FACES[i], "bc_type": t, "bc_val": v} for i, (t, v) in enumerate(CASES[name])]
+    g = torch.Generator().manual_seed(7)
+    rhs = torch.randn((1, *n), generator=g, dtype=torch.float64)
+    if name == "per":
+        rhs -= rhs.mean()
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        xo, ro = O.solve_poisson(mesh, cfg, rhs, method="cg", tol=1e-30, max_it=K, coeff=0.7, sign=-1.0)
+    assert res["itr"] == ro["itr"] == K + 1
+    err = float(torch.linalg.norm(res["x"] - xo) / torch.linalg.norm(xo))
+    assert err < 1e-12, err
+    assert abs(res["tol"] - ro["tol"]) <= 1e-10 * abs(ro["tol"])
