@@ -1,0 +1,33 @@
+"""Explicit time marching (new; the reference's ``Ddt`` is a stub).
+
+``euler_step(phi, u, nu, dt, fdm_config)``:  phi <- B( phi + dt * ( nu * lap(phi) - div(u phi) ) )
+on the interior set, lap / div being the explicit operators (edge=False) evaluated on the current,
+BC-filled phi.  One fused kernel (``k_euler``) + the ordered BC fill.
+"""
+from __future__ import annotations
+
+from typing import Any
+
+import torch
+from torch import Tensor
+
+from ..backend import require_gpu
+from ..hip.context import context_for
+from ..variables import Field
+from .fdc import _adv_of, div_kind
+
+
+def euler_step(phi: Field, u: float | Tensor | Field, nu: float, dt: float,
+               config: dict | None = None) -> Field:
+    """Advance ``phi`` in place by one explicit Euler step; returns ``phi``."""
+    require_gpu(phi(), "euler_step")
+    if phi.dim != 1:
+        raise NotImplementedError("pyapes_amd: euler_step is for scalar fields")
+    cfg = (config or {}).get("div", {"limiter": "upwind"})
+    kind = div_kind(cfg.get("limiter", "upwind").lower(), bool(cfg.get("compat", False)))
+    ctx = context_for(phi.mesh)
+    ctx.bind_bcs(phi(), phi.bcs, 0)
+    out = torch.empty_like(phi())
+    ctx.euler_step(phi()[0], out[0], kind, _adv_of(u, phi), nu, dt)
+    phi.set_var_tensor(out)
+    return phi

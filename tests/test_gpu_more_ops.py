@@ -1,0 +1,184 @@
+"""-m gpu: the entry points the golden vectors do not reach -- Jacobi, explicit Euler, intended
+upwind, tensor coefficients, callable / per-node BC values, error behaviour -- against the oracle."""
+import warnings
+from math import pi
+
+import pytest
+import torch
+
+import pyapes_oracle as O
+from helpers import bit_equal, rel_err
+
+pytestmark = pytest.mark.gpu
+
+from pyapes_amd.geometry import Box
+from pyapes_amd.mesh import Mesh
+from pyapes_amd.solver.fdc import FDC
+from pyapes_amd.solver.fdm import FDM
+from pyapes_amd.solver.march import euler_step
+from pyapes_amd.solver.ops import Solver
+from pyapes_amd.testing.poisson import poisson_bcs, poisson_exact_nd, poisson_rhs_nd
+from pyapes_amd.variables import Field
+from pyapes_amd.variables.bcs import homogeneous_bcs, mixed_bcs
+
+
+def _cfgs(bcs):
+    prod = [{"bc_face": O.FACES[i], "bc_type": t, "bc_val": v, "bc_val_opt": None} for i, (t, v) in enumerate(bcs)]
+    orc = [{"bc_face": O.FACES[i], "bc_type": t, "bc_val": v} for i, (t, v) in enumerate(bcs)]
+    return prod, orc
+
+
+@pytest.mark.parametrize("nd,n", [(1, [33]), (2, [17, 20]), (3, [12, 10, 14])])
+def test_jacobi_matches_oracle(nd, n):
+    bcs = [("dirichlet", 0.2), ("neumann", 0.1), ("dirichlet", 0.0), ("symmetry", None), ("dirichlet", 1.0),
+           ("neumann", 0.0)][:2 * nd]
+    prod, orc = _cfgs(bcs)
+    lo, up = [0.0] * nd, [1.0] * nd
+    g = torch.Generator().manual_seed(3)
+    rhs0 = torch.randn((1, *n), generator=g, dtype=torch.float64)
+    for K, omega in ((0, 1.0), (25, 0.8)):
+        mesh = Mesh(Box(lo, up), None, n, "cuda", "double")
+        var = Field("p", 1, mesh, {"domain": prod, "obstacle": None})
+        rhs = rhs0.cuda().clone()
+        solver = Solver({"fdm": {"method": "jacobi", "tol": 1e-30, "max_it": K, "report": False, "omega": omega}})
+        solver.set_eq(FDM().laplacian(0.9, var) == rhs)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            rep = solver.solve()
+            om = O.OMesh(lo, up, n, "double")
+            xo, ro = O.solve_poisson(om, orc, rhs0.clone(), method="jacobi", tol=1e-30, max_it=K, coeff=0.9,
+                                     omega=omega)
+        assert rep["itr"] == ro["itr"] == K + 1
+        assert rel_err(var().cpu(), xo) < 1e-13
+        assert abs(rep["tol"] - ro["tol"]) <= 1e-10 * abs(ro["tol"])
+
+
+def test_jacobi_converges_to_cg_solution_config1():
+    """BASELINE config 1: 2-D Poisson 128x128 fp64, Dirichlet, Jacobi -- no reference Jacobi exists
+    (SURVEY Q1); the converged iterate must equal the reference CG solution to solver tolerance."""
+    mesh = Mesh(Box[0:1, 0:1], None, [128, 128], "cuda", "double")
+    out = {}
+    for method, tol, mx in (("cg", 1e-10, 2000), ("jacobi", 1e-9, 100000)):
+        var = Field("p", 1, mesh, {"domain": poisson_bcs(2), "obstacle": None})
+        rhs = poisson_rhs_nd(mesh, var)
+        solver = Solver({"fdm": {"method": method, "tol": tol, "max_it": mx, "report": False}})
+        solver.set_eq(FDM().laplacian(1.0, var) == rhs)
+        rep = solver.solve()
+        assert rep["converge"], (method, rep)
+        out[method] = var().clone()
+    assert float((out["cg"] - out["jacobi"]).abs().max()) < 5e-5
+    assert float((out["cg"][0] - poisson_exact_nd(mesh)).abs().max()) < 1e-3
+
+
+def test_callable_bcs_128_known_answer():
+    """BASELINE config 1 inputs with the reference solver: CG 271 iterations."""
+    mesh = Mesh(Box[0:1, 0:1], None, [128, 128], "cuda", "double")
+    var = Field("p", 1, mesh, {"domain": poisson_bcs(2), "obstacle": None})
+    rhs = poisson_rhs_nd(mesh, var)
+    solver = Solver({"fdm": {"method": "cg", "tol": 1e-6, "max_it": 1000, "report": False}})
+    solver.set_eq(FDM().laplacian(1.0, var) == rhs)
+    rep = solver.solve()
+    assert rep["itr"] == 271 and abs(rep["tol"] - 9.195241388276045e-07) < 1e-15
+
+
+@pytest.mark.parametrize("limiter", ["upwind", "none"])
+@pytest.mark.parametrize("dtype", ["double", "single"])
+def test_euler_step_matches_oracle(limiter, dtype):
+    """BASELINE config 4 family at small size: explicit adv-diff march, Neumann/Symmetry BCs (upwind)
+    or Dirichlet/periodic (central: the reference's central Div cannot take neumann faces)."""
+    n = [14, 12, 16]
+    if limiter == "upwind":
+        bcs = [("neumann", 0.0), ("neumann", 0.0), ("symmetry", None), ("symmetry", None), ("symmetry", None),
+               ("symmetry", None)]
+    else:
+        bcs = [("dirichlet", 0.0), ("dirichlet", 0.0), ("periodic", None), ("periodic", None), ("dirichlet", 0.1),
+               ("dirichlet", 0.0)]
+    prod, orc = _cfgs(bcs)
+    mesh = Mesh(Box[0:1, 0:1, 0:1], None, n, "cuda", dtype)
+    om = O.OMesh([0, 0, 0], [1, 1, 1], n, dtype)
+    gx = om.grid
+    phi0 = torch.exp(-((gx[0] - 0.5) ** 2 + (gx[1] - 0.5) ** 2 + (gx[2] - 0.5) ** 2) / 0.02).unsqueeze(0)
+    g = torch.Generator().manual_seed(5)
+    ut = (1.0 + 0.3 * torch.randn((1, *n), generator=g, dtype=torch.float64)).to(om.dtype)
+    nu, dt = 1e-3, 2e-3
+    for u in (1.0, ut):
+        var = Field("phi", 1, mesh, {"domain": prod, "obstacle": None})
+        var.set_var_tensor(phi0.cuda().clone())
+        var.apply_bcs()
+        po = phi0.clone()
+        bo = O.make_bcs(om, orc)
+        O.bc_fill(po, bo)
+        for _ in range(5):
+            euler_step(var, u if isinstance(u, float) else u.cuda(), nu, dt, {"div": {"limiter": limiter}})
+            po = O.euler_step(po, u, nu, dt, om, bo, limiter)
+        assert rel_err(var().cpu(), po) < (1e-13 if dtype == "double" else 1e-5)
+
+
+def test_upwind_intended_and_compat():
+    mesh = Mesh(Box[0:1], None, [11], "cuda", "double")
+    var = Field("U", 1, mesh, {"domain": homogeneous_bcs(1, 0.0, "dirichlet"), "obstacle": None})
+    var.set_var_tensor((mesh.X ** 2).unsqueeze(0).clone())
+    out = FDC({"div": {"limiter": "upwind", "edge": False}}).div(2.0, var)
+    phi = var()[0]
+    expect = 2.0 * (phi[1:-1] - phi[:-2]) / mesh.dx[0]      # reference tests/test_fdm.py:239
+    assert torch.allclose(out[0][1:-1], expect, rtol=0, atol=1e-13)
+    om = O.OMesh([0], [1], [11], "double")
+    assert bit_equal(out, O.div_upwind_intended(2.0, var().cpu(), om))
+
+
+def test_central_div_with_neumann_raises_like_reference():
+    mesh = Mesh(Box[0:1, 0:1], None, [8, 8], "cuda", "double")
+    var = Field("U", 1, mesh, {"domain": homogeneous_bcs(2, 0.0, "neumann"), "obstacle": None})
+    from pyapes_amd.hip.lib import PaError
+    with pytest.raises(PaError, match="IndexError"):
+        FDC({"div": {"limiter": "none", "edge": False}}).div(1.0, var)
+
+
+def test_tensor_coefficient_laplacian_and_per_node_bc_values():
+    n = [9, 11, 10]
+    mesh = Mesh(Box[0:1, 0:1, 0:1], None, n, "cuda", "double")
+    om = O.OMesh([0, 0, 0], [1, 1, 1], n, "double")
+    g = torch.Generator().manual_seed(11)
+    face_vals = torch.randn(n[1] * n[2], generator=g, dtype=torch.float64)   # xl: gather order = C order
+    grad_vals = torch.randn(n[0] * n[1], generator=g, dtype=torch.float64)   # zu
+    bcs = [("dirichlet", face_vals), ("dirichlet", 0.0), ("dirichlet", 0.0), ("dirichlet", 0.0),
+           ("dirichlet", 0.0), ("neumann", grad_vals)]
+    prod, orc = _cfgs(bcs)
+    for c in prod:
+        if isinstance(c["bc_val"], torch.Tensor):
+            c["bc_val"] = c["bc_val"].cuda()
+    x0 = torch.randn((1, *n), generator=g, dtype=torch.float64)
+    gamma = 1.0 + 0.1 * torch.randn((1, *n), generator=g, dtype=torch.float64)
+    var = Field("p", 1, mesh, {"domain": prod, "obstacle": None})
+    var.set_var_tensor(x0.cuda().clone())
+    var.apply_bcs()
+    bo = O.make_bcs(om, orc)
+    xo = x0.clone()
+    O.bc_fill(xo, bo)
+    assert bit_equal(var(), xo)
+    rhs = torch.zeros_like(var())
+    solver = Solver({"fdm": {"method": "cg", "tol": 1e-6, "max_it": 3, "report": False}})
+    solver.set_eq(FDM().laplacian(gamma.cuda(), var) == rhs)
+    tabs = O.laplacian_tables(xo, om, bo)
+    assert bit_equal(solver.Aop(var), O.Aop(xo, [O.OTerm("laplacian", tabs, gamma, 1.0)], 3))
+    assert bit_equal(rhs, O.laplacian_rhs_adjust(xo, om, bo))
+
+
+def test_unknown_method_and_vector_field_errors():
+    mesh = Mesh(Box[0:1], None, [11], "cuda", "double")
+    var = Field("U", 1, mesh, {"domain": homogeneous_bcs(1, 0.0, "dirichlet"), "obstacle": None})
+    solver = Solver({"fdm": {"method": "gmres", "tol": 1e-6, "max_it": 3, "report": False}})
+    solver.set_eq(FDM().laplacian(1.0, var) == 1.0)
+    with pytest.raises(RuntimeError, match="only supports"):
+        solver.solve()
+
+
+def test_nonfinite_tolerance_raises_runtime_error():
+    mesh = Mesh(Box[0:1, 0:1], None, [9, 9], "cuda", "double")
+    var = Field("U", 1, mesh, {"domain": homogeneous_bcs(2, 0.0, "neumann"), "obstacle": None})
+    rhs = torch.full((1, 9, 9), float("inf"), dtype=torch.float64, device="cuda")
+    solver = Solver({"fdm": {"method": "cg", "tol": 1e-6, "max_it": 5, "report": False}})
+    solver.set_eq(FDM().laplacian(1.0, var) == rhs)
+    # reference: alpha = nan_to_num(nan) = 0 keeps x finite -> tol 0 -> converged after one iteration
+    rep = solver.solve()
+    assert rep["itr"] == 1

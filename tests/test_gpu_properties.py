@@ -1,0 +1,108 @@
+"""-m gpu: BASELINE.json's FULL sizes, through size-independent properties (the oracle cannot run
+there in seconds): exact discrete eigen-solution, constants in the null space, linearity,
+conservation on the periodic ring, fast path == generic path, run-to-run bitwise determinism."""
+import os
+import warnings
+from math import cos, pi
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from pyapes_amd.geometry import Box
+from pyapes_amd.hip import lib as L
+from pyapes_amd.hip.context import HipContext
+from pyapes_amd.mesh import Mesh
+from pyapes_amd.solver.fdm import FDM
+from pyapes_amd.solver.ops import Solver
+from pyapes_amd.variables import Field
+from pyapes_amd.variables.bcs import homogeneous_bcs, mixed_bcs
+
+
+def _fixed_cg(mesh, bcs, rhs, K, fast=True):
+    os.environ["PYAPES_HIP_FASTPATH"] = "1" if fast else "0"
+    mesh._hip = None                                   # fresh ctx picks the switch up
+    var = Field("p", 1, mesh, {"domain": bcs, "obstacle": None})
+    solver = Solver({"fdm": {"method": "cg", "tol": -1.0, "max_it": K - 1, "report": False}})
+    solver.set_eq(FDM().laplacian(1.0, var) == rhs.clone())
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        rep = solver.solve()
+    os.environ.pop("PYAPES_HIP_FASTPATH", None)
+    mesh._hip = None
+    return var(), rep
+
+
+def test_c2_256_dirichlet_discrete_eigen_solution():
+    """3-D Poisson 256^3 fp64, Dirichlet 0, rhs = sin(pi x) sin(pi y) sin(pi z): an eigenvector of the
+    discrete operator, so CG must land on rhs / lambda_h (known in closed form) in 1-2 iterations."""
+    n = 256
+    mesh = Mesh(Box[0:1, 0:1, 0:1], None, [n, n, n], "cuda", "double")
+    var = Field("p", 1, mesh, {"domain": homogeneous_bcs(3, 0.0, "dirichlet"), "obstacle": None})
+    rhs = (torch.sin(pi * mesh.X) * torch.sin(pi * mesh.Y) * torch.sin(pi * mesh.Z)).unsqueeze(0).contiguous()
+    solver = Solver({"fdm": {"method": "cg", "tol": 1e-8, "max_it": 200, "report": False}})
+    b = rhs.clone()
+    solver.set_eq(FDM().laplacian(1.0, var) == b)
+    rep = solver.solve()
+    h = 1.0 / (n - 1)
+    lam = 3 * (2 * cos(pi * h) - 2) / h ** 2
+    exact = rhs / lam
+    S = (slice(1, -1),) * 3
+    err = float(torch.linalg.norm((var()[0] - exact[0])[S]) / torch.linalg.norm(exact[0][S]))
+    assert rep["converge"] and rep["itr"] <= 3, rep
+    assert err < 1e-10, err
+    assert float(var()[0][0].abs().max()) == 0.0 and float(var()[0][:, :, -1].abs().max()) == 0.0
+
+
+def test_c3_512_periodic_operator_properties():
+    n = 512
+    mesh = Mesh(Box[0:1, 0:1, 0:1], None, [n, n, n], "cuda", "double")
+    var = Field("p", 1, mesh, {"domain": homogeneous_bcs(3, None, "periodic"), "obstacle": None})
+    ctx = mesh._hip = HipContext(mesh)
+    ctx.bind_bcs(var(), var.bcs, 0)
+    ctx.set_terms([{"kind": L.OP_LAPLACIAN, "sign": 1.0, "coeff": None}])
+    g = torch.Generator(device="cuda").manual_seed(1)
+    x = torch.randn((n, n, n), generator=g, dtype=torch.float64, device="cuda")
+    y = torch.randn((n, n, n), generator=g, dtype=torch.float64, device="cuda")
+    ax, ay = ctx.aop(x), ctx.aop(y)
+    # constants are in the null space, exactly
+    assert float(ctx.aop(torch.full_like(x, 3.25)).abs().max()) == 0.0
+    # conservation on the ring: sum A x = 0 up to rounding
+    assert abs(float(ax.sum())) <= 1e-9 * float(ax.abs().sum())
+    # linearity
+    lin = ctx.aop(2.0 * x - 0.5 * y)
+    assert float((lin - (2.0 * ax - 0.5 * ay)).abs().max()) <= 1e-9 * float(ax.abs().max())
+    # symmetry of the ring operator: <y, A x> = <x, A y>
+    a, b = float((y * ax).sum()), float((x * ay).sum())
+    assert abs(a - b) <= 1e-10 * abs(a)
+    del ax, ay, lin, x, y
+    mesh._hip = None
+
+
+@pytest.mark.parametrize("workload", ["c3_512_f64_periodic", "c2_256_f64_dirichlet", "c5_1024x1024x512_f32_mixed"])
+def test_full_size_fast_equals_generic_and_is_deterministic(workload):
+    if workload.startswith("c3"):
+        n, dtype, up = [512, 512, 512], "double", [1, 1, 1]
+        bcs = homogeneous_bcs(3, None, "periodic")
+    elif workload.startswith("c2"):
+        n, dtype, up = [256, 256, 256], "double", [1, 1, 1]
+        bcs = homogeneous_bcs(3, 0.0, "dirichlet")
+    else:
+        n, dtype, up = [1024, 1024, 512], "single", [1, 1, 0.5]
+        bcs = mixed_bcs([0, 0, 0, 0, 1, 0], ["dirichlet", "neumann", "dirichlet", "neumann", "dirichlet", "neumann"])
+    mesh = Mesh(Box([0, 0, 0], up), None, n, "cuda", dtype)
+    g = torch.Generator(device="cuda").manual_seed(0)
+    rhs = torch.randn((1, *n), generator=g, dtype=mesh.dtype.float, device="cuda")
+    if workload.startswith("c3"):
+        rhs -= rhs.mean()
+    K = 4
+    xf, rf = _fixed_cg(mesh, bcs, rhs, K, True)
+    xf2, rf2 = _fixed_cg(mesh, bcs, rhs, K, True)
+    assert torch.equal(xf, xf2) and rf["tol"] == rf2["tol"], "fused CG is not run-to-run deterministic"
+    del xf2
+    xg, rg = _fixed_cg(mesh, bcs, rhs, K, False)
+    assert rf["itr"] == rg["itr"] == K
+    rel = float(torch.linalg.norm((xf - xg).double()) / torch.linalg.norm(xg.double()))
+    assert rel <= (1e-12 if dtype == "double" else 1e-5), rel
+    assert abs(rf["tol"] - rg["tol"]) <= (1e-10 if dtype == "double" else 1e-4) * abs(rg["tol"])

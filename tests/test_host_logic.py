@@ -1,0 +1,147 @@
+"""CPU: the C-ABI library loads and exports every symbol include/pyapes_hip.h declares; the
+pyapes-compatible host layer (mesh, fields, BC factories, equation DSL) behaves like the
+reference's; compute entry points refuse to run without the GPU (no CPU fallback)."""
+import os
+import re
+import warnings
+
+import pytest
+import torch
+
+import pyapes_oracle as O
+from conftest import ROOT
+from pyapes_amd.geometry import Box
+from pyapes_amd.hip import lib as L
+from pyapes_amd.mesh import Mesh
+from pyapes_amd.mesh.tools import boundary_slicer, inner_slicer
+from pyapes_amd.solver.fdc import FDC
+from pyapes_amd.solver.fdm import FDM
+from pyapes_amd.solver.linalg import terms_of
+from pyapes_amd.solver.ops import Solver
+from pyapes_amd.testing.poisson import poisson_bcs, poisson_rhs_nd
+from pyapes_amd.variables import Field
+from pyapes_amd.variables.bcs import BoxBoundary, homogeneous_bcs, mixed_bcs
+
+
+def _declared_symbols():
+    txt = open(os.path.join(ROOT, "include", "pyapes_hip.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(pa_[a-z0-9_]+)\s*\(", txt)))
+
+
+def test_library_exports_every_declared_symbol():
+    lib = L.load_library()
+    names = _declared_symbols()
+    assert len(names) >= 25
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/pyapes_hip.h but not exported"
+    assert set(names) == set(L.SIGNATURES), set(names) ^ set(L.SIGNATURES)
+    assert b"gfx950" in lib.pa_version()
+
+
+@pytest.mark.skipif(torch.cuda.is_available(), reason="only meaningful without a GPU")
+def test_ctx_create_fails_loudly_without_gpu():
+    import ctypes as C
+    lib = L.load_library()
+    h = C.c_void_p()
+    rc = lib.pa_ctx_create(0, None, C.byref(h))
+    assert rc == L.PA_E_HIP and b"no HIP device" in lib.pa_last_error(None)
+
+
+def test_missing_library_is_a_hard_error(tmp_path):
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        L.load_library(str(tmp_path / "nope.so"))
+
+
+@pytest.mark.parametrize("spacing", [[11, 17, 9], [0.1, 0.05, 0.125]])
+@pytest.mark.parametrize("dtype", ["double", "single"])
+def test_mesh_matches_reference_conventions(spacing, dtype):
+    mesh = Mesh(Box[0:1, 0:2, -1:0.5], None, spacing, "cpu", dtype)
+    om = O.OMesh([0, 0, -1], [1, 2, 0.5], spacing, dtype)   # oracle mesh is pinned to the reference
+    assert list(mesh.nx) == om.nx
+    assert mesh.dx_list == om.dx_list
+    for a in range(3):
+        assert torch.equal(mesh.x[a], om.x[a])
+        assert torch.equal(mesh.grid[a], om.grid[a])
+    assert mesh.dim == 3 and mesh.coord_sys == "xyz" and mesh.N == om.nx[0] * om.nx[1] * om.nx[2]
+    assert torch.equal(mesh.d_mask["yu"], om.face_mask("yu"))
+    assert float(mesh.face_dxf("xl")) == float(om.x[0][0] - om.x[0][1])
+    assert float(mesh.face_dxf("zu")) == float(om.x[2][-1] - om.x[2][-2])
+
+
+def test_box_face_order_and_geometry():
+    assert Box[0:1].face == ["xl", "xu"]
+    assert Box[0:1, 0:1].face == ["yl", "yu", "xl", "xu"]          # geometry/basis.py:163-180
+    assert Box[0:1, 0:1, 0:1].face == ["xl", "xu", "yl", "yu", "zl", "zu"]
+    b = Box([0, 0], [2, 3])
+    assert b.dim == 2 and b.size == 6.0 and b.type == "box" and b.lower == [0.0, 0.0]
+    with pytest.raises(AssertionError):
+        Box[0:1:2]
+
+
+def test_bc_factories_and_field():
+    assert [c["bc_face"] for c in homogeneous_bcs(2, 0.0, "dirichlet")] == ["xl", "xu", "yl", "yu"]
+    m = mixed_bcs([0, 1, None, None], ["dirichlet", "neumann", "periodic", "periodic"])
+    assert m[1] == {"bc_face": "xu", "bc_type": "neumann", "bc_val": 1, "bc_val_opt": None}
+    bb = BoxBoundary(xl={"bc_type": "dirichlet", "bc_val": 0.4}, yu={"bc_type": "symmetry", "bc_val": None})()
+    assert [c["bc_face"] for c in bb] == ["xl", "yu"]
+    mesh = Mesh(Box[0:1, 0:1], None, [5, 6], "cpu", "double")
+    var = Field("p", 1, mesh, {"domain": m, "obstacle": None}, init_val=0.5)
+    assert var().shape == (1, 5, 6) and float(var()[0, 2, 3]) == 0.5
+    assert [bc.bc_type for bc in var.bcs] == ["dirichlet", "neumann", "periodic", "periodic"]
+    assert var.bcs[1].bc_n_dir == 1 and var.bcs[1].bc_face_dim == 0 and var.bcs[1].bc_treat
+    assert torch.equal(var.bcs[0].bc_mask_prev, torch.roll(mesh.d_mask["xl"], 1, 0))
+    assert boundary_slicer(2, var.bcs) == [slice(1, -1), slice(None, None)]
+    assert inner_slicer(2, 2) == [slice(2, -2), slice(2, -2)]
+    with pytest.raises(AssertionError):
+        Field("q", 1, mesh, {"domain": m[:3], "obstacle": None})
+    w = var.copy("w")
+    w += 1.0
+    assert float(var()[0, 0, 0]) == 0.5 and float(w()[0, 0, 0]) == 1.5 and w.name == "w"
+    var <<= torch.ones(1, 5, 6, dtype=torch.float64)
+    assert float(var().sum()) == 30.0
+
+
+def test_equation_dsl_mirrors_reference():
+    mesh = Mesh(Box[0:1], None, [11], "cpu", "double")
+    var = Field("U", 1, mesh, {"domain": homogeneous_bcs(1, 0.0, "dirichlet"), "obstacle": None}, init_val=0.5)
+    fdm = FDM({"div": {"limiter": "upwind", "edge": False}})
+    eq = fdm.grad(var) - fdm.laplacian(0.5, var) == 1.0
+    assert [eq.ops[k]["name"] for k in eq.ops] == ["Grad", "Laplacian"]
+    assert eq.ops[0]["sign"] == 1.0 and eq.ops[1]["sign"] == -1 and eq.ops[1]["param"] == (0.5,)
+    assert eq.rhs.shape == var().shape and float(eq.rhs[0, 3]) == 1.0
+    assert set(eq.ops[0]) == {"name", "Aop", "target", "param", "sign", "other", "A_coeffs", "adjust_rhs"}
+    terms, bcs = terms_of(eq.ops)
+    assert [t["kind"] for t in terms] == [L.OP_GRAD, L.OP_LAPLACIAN] and terms[1]["sign"] == -1
+    neg = -FDM().laplacian(var)
+    assert neg.ops[0]["sign"] == -1 and neg.ops[0]["param"] == (None,)
+    d = fdm.div(2.0, var)
+    t, _ = terms_of(d.ops)
+    assert t[0]["kind"] == L.OP_DIV_UPWIND and t[0]["u"] == 2.0
+    fdm2 = FDM({"div": {"limiter": "upwind", "edge": False, "compat": True}})
+    assert terms_of(fdm2.div(var).ops)[0][0]["kind"] == L.OP_DIV_UPWIND_COMPAT
+    with pytest.raises(AssertionError):
+        FDM().laplacian(1.0, var) == torch.zeros(2, 11)
+    # operator objects are per instance (reference shares class-level singletons)
+    assert FDM().laplacian is not FDM().laplacian
+
+
+def test_no_cpu_compute_path():
+    mesh = Mesh(Box[0:1, 0:1, 0:1], None, [0.1, 0.1, 0.1], "cpu", "double")
+    var = Field("p", 1, mesh, {"domain": poisson_bcs(3), "obstacle": None})
+    rhs = poisson_rhs_nd(mesh, var)
+    solver = Solver({"fdm": {"method": "cg", "tol": 1e-6, "max_it": 10, "report": False}})
+    with pytest.raises(RuntimeError, match="no CPU"):
+        solver.set_eq(FDM().laplacian(1.0, var) == rhs)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        with pytest.raises(RuntimeError, match="no CPU"):
+            FDC({"laplacian": {"edge": False}}).laplacian(var)
+    with pytest.raises(RuntimeError, match="no CPU"):
+        var.apply_bcs()
+
+
+def test_product_does_not_import_the_oracle():
+    import pathlib
+    for p in pathlib.Path(ROOT, "pyapes_amd").rglob("*.py"):
+        assert "pyapes_oracle" not in p.read_text(), p
