@@ -27,6 +27,7 @@
 // CU carries the same number of identical work items and nothing queues behind a tail.
 #include "pa_host.h"
 
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -126,52 +127,63 @@ __global__ void __launch_bounds__(256) k_cg3d(Cg3dArgs<T> A) {
     return ii < 0 ? v.glo : (ii >= G.n0 ? v.ghi : v.p + ii * G.s0);
   };
 
-  // e = r + beta d (phase A) or d (phase B) of the thread's own cells on local plane ii
-  auto load_own = [&](int64_t ii, V (&e)[RJ]) {
+  // Raw loads of one plane (own cells + this wave's share of the halo ring).  They are only
+  // ISSUED here; the arithmetic that consumes them (finish_*) is placed after the stencil of the
+  // current plane, so the s_waitcnt lands there and the loads fly during the stencil.
+  struct Raw {
+    V d[RJ];
+    V r[RJ];   // phase A only
+    V hd, hr;  // halo row (waves 0 and 3)
+    T sd, sr;  // halo cell (wave 1)
+  };
+  auto issue = [&](int64_t ii, Raw& w, bool with_halo) {
     const T* dp = pptr(A.d, ii);
-    if (PHASE == 0) {
-      const T* rp = pptr(A.r, ii);
+    const T* rp = PHASE == 0 ? pptr(A.r, ii) : dp;
 #pragma unroll
-      for (int jj = 0; jj < RJ; ++jj) {
-        const int64_t o = jrow[jj] * G.s1 + kc;
-        V rv = *reinterpret_cast<const V*>(rp + o);
-        V dv = *reinterpret_cast<const V*>(dp + o);
-#pragma unroll
-        for (int v = 0; v < VEC; ++v) {
-          T bd = beta * dv[v];
-          e[jj][v] = rv[v] + bd;
-        }
+    for (int jj = 0; jj < RJ; ++jj) {
+      const int64_t o = jrow[jj] * G.s1 + kc;
+      w.d[jj] = *reinterpret_cast<const V*>(dp + o);
+      if (PHASE == 0) w.r[jj] = *reinterpret_cast<const V*>(rp + o);
+    }
+    if (with_halo) {
+      if (hvec) {
+        const int64_t o = hrow * G.s1 + kc;
+        w.hd = *reinterpret_cast<const V*>(dp + o);
+        if (PHASE == 0) w.hr = *reinterpret_cast<const V*>(rp + o);
       }
-    } else {
-#pragma unroll
-      for (int jj = 0; jj < RJ; ++jj) e[jj] = *reinterpret_cast<const V*>(dp + jrow[jj] * G.s1 + kc);
+      if (hsc) {
+        w.sd = dp[hs_off];
+        if (PHASE == 0) w.sr = rp[hs_off];
+      }
     }
   };
-  auto load_halo = [&](int64_t ii, V& hv, T& hs) {
-    const T* dp = pptr(A.d, ii);
-    const T* rp = PHASE == 0 ? pptr(A.r, ii) : nullptr;
-    if (hvec) {
-      const int64_t o = hrow * G.s1 + kc;
-      V dv = *reinterpret_cast<const V*>(dp + o);
+  // e = r + beta d (phase A, linalg.py:141) or d (phase B)
+  auto finish_own = [&](const Raw& w, V (&e)[RJ]) {
+#pragma unroll
+    for (int jj = 0; jj < RJ; ++jj) {
       if (PHASE == 0) {
-        V rv = *reinterpret_cast<const V*>(rp + o);
 #pragma unroll
         for (int v = 0; v < VEC; ++v) {
-          T bd = beta * dv[v];
-          hv[v] = rv[v] + bd;
+          T bd = beta * w.d[jj][v];
+          e[jj][v] = w.r[jj][v] + bd;
         }
       } else {
-        hv = dv;
+        e[jj] = w.d[jj];
       }
     }
-    if (hsc) {
-      T dvs = dp[hs_off];
-      if (PHASE == 0) {
-        T bd = beta * dvs;
-        hs = rp[hs_off] + bd;
-      } else {
-        hs = dvs;
+  };
+  auto finish_halo = [&](const Raw& w, V& hv, T& hs) {
+    if (PHASE == 0) {
+#pragma unroll
+      for (int v = 0; v < VEC; ++v) {
+        T bd = beta * w.hd[v];
+        hv[v] = w.hr[v] + bd;
       }
+      T bs = beta * w.sd;
+      hs = w.sr + bs;
+    } else {
+      hv = w.hd;
+      hs = w.sd;
     }
   };
   auto stage = [&](int buf, const V (&e)[RJ], const V& hv, const T& hs) {
@@ -185,16 +197,21 @@ __global__ void __launch_bounds__(256) k_cg3d(Cg3dArgs<T> A) {
   V ea[RJ], ec[RJ], eb[RJ];  // behind / current / ahead in march order
   V hv;
   T hs = (T)0;
+  Raw w;
 #pragma unroll
-  for (int v = 0; v < VEC; ++v) hv[v] = (T)0;
+  for (int v = 0; v < VEC; ++v) { hv[v] = (T)0; w.hd[v] = (T)0; w.hr[v] = (T)0; }
+  w.sd = (T)0; w.sr = (T)0;
 
   // ---- prologue -----------------------------------------------------------------------
-  load_own(plane_of(-1), ea);
-  load_own(plane_of(0), ec);
-  load_halo(plane_of(0), hv, hs);
+  issue(plane_of(-1), w, false);
+  finish_own(w, ea);
+  issue(plane_of(0), w, true);
+  finish_own(w, ec);
+  finish_halo(w, hv, hs);
   stage(0, ec, hv, hs);
-  load_own(plane_of(1), eb);
-  if (CI > 1) load_halo(plane_of(1), hv, hs);
+  issue(plane_of(1), w, CI > 1);
+  finish_own(w, eb);
+  finish_halo(w, hv, hs);
   __syncthreads();
 
   double s0 = 0.0, s1 = 0.0;
@@ -204,19 +221,11 @@ __global__ void __launch_bounds__(256) k_cg3d(Cg3dArgs<T> A) {
   for (int m = 0; m < CI; ++m) {
     const int buf = m & 1;
     const int64_t ii = plane_of(m);
+    const bool more = m + 1 < CI;
     // plane m+1 into the other LDS buffer (its last readers passed the barrier of step m-1)
-    if (m + 1 < CI) stage(buf ^ 1, eb, hv, hs);
-    // issue the loads of plane m+2 (own) and its halo: in flight during the stencil below
-    V en[RJ];
-#pragma unroll
-    for (int jj = 0; jj < RJ; ++jj) en[jj] = eb[jj];
-    V hvn = hv;
-    T hsn = hs;
-    if (m + 1 < CI) {
-      load_own(plane_of(m + 2), en);
-      if (m + 2 < CI) load_halo(plane_of(m + 2), hvn, hsn);
-    }
-    // phase B: the thread's x and r of this plane
+    if (more) stage(buf ^ 1, eb, hv, hs);
+    // phase B: the thread's x and r of THIS plane, issued first so that their wait (at the update,
+    // below the stencil) does not have to cover the younger loads of plane m+2
     V xv[RJ], rv[RJ];
     if (PHASE == 1) {
 #pragma unroll
@@ -226,8 +235,10 @@ __global__ void __launch_bounds__(256) k_cg3d(Cg3dArgs<T> A) {
         rv[jj] = *reinterpret_cast<const V*>(A.rw + o);
       }
     }
+    // loads of plane m+2 (own cells + halo): in flight during the stencil below
+    if (more) issue(plane_of(m + 2), w, m + 2 < CI);
 
-    // ---- stencil on plane ii ------------------------------------------------------------
+    // ---- stencil on plane ii, every cell of the thread (masks are applied afterwards) --------
     const int64_t gi = ii + G.off0;
     const bool iS = gi >= G.slo[0] && gi <= G.shi[0];
     const bool iShell = (gi == 0 || gi == G.g0 - 1);
@@ -237,6 +248,7 @@ __global__ void __launch_bounds__(256) k_cg3d(Cg3dArgs<T> A) {
       if (rc == 1) { cPi = A.lap.c23[0]; cCi = -A.lap.c23[0]; cMi = (T)0; }
       if (rc == 2) { cPi = (T)0; cCi = -A.lap.c23[0]; cMi = A.lap.c23[0]; }
     }
+    V res[RJ];
 #pragma unroll
     for (int jj = 0; jj < RJ; ++jj) {
       const int R = wv * RJ + jj + 1;
@@ -249,67 +261,68 @@ __global__ void __launch_bounds__(256) k_cg3d(Cg3dArgs<T> A) {
       if (jj < RJ - 1) dn = ec[jj + 1]; else dn = *reinterpret_cast<const V*>(&tile[buf][R + 1][VEC + lane * VEC]);
       const T left = tile[buf][R][VEC + lane * VEC - 1];
       const T right = tile[buf][R][VEC + lane * VEC + VEC];
+#pragma unroll
+      for (int v = 0; v < VEC; ++v) {
+        const T xc = ec[jj][v];
+        const T xpi = rev ? ea[jj][v] : eb[jj][v];
+        const T xmi = rev ? eb[jj][v] : ea[jj][v];
+        T s = cPi * xpi;
+        T mm = cCi * xc;
+        s = s + mm;
+        mm = cMi * xmi;
+        s = s + mm;
+        T ax = s;
+        s = cPj * dn[v];
+        mm = cCj * xc;
+        s = s + mm;
+        mm = cMj * up[v];
+        s = s + mm;
+        ax = ax + s;
+        T cPk = A.lap.inv[2], cCk = A.lap.m2inv[2], cMk = A.lap.inv[2];
+        if (colLo >> v & 1) { cPk = A.lap.c23[2]; cCk = -A.lap.c23[2]; cMk = (T)0; }
+        if (colHi >> v & 1) { cPk = (T)0; cCk = -A.lap.c23[2]; cMk = A.lap.c23[2]; }
+        const T xpk = (v < VEC - 1) ? ec[jj][v + 1 < VEC ? v + 1 : v] : right;
+        const T xmk = (v > 0) ? ec[jj][v > 0 ? v - 1 : 0] : left;
+        s = cPk * xpk;
+        mm = cCk * xc;
+        s = s + mm;
+        mm = cMk * xmk;
+        s = s + mm;
+        ax = ax + s;
+        if (hasc) ax = ax * cf;
+        ax = ax * sgn;
+        res[jj][v] = ax;
+      }
+    }
+
+    // ---- outputs of plane ii --------------------------------------------------------------------
+#pragma unroll
+    for (int jj = 0; jj < RJ; ++jj) {
       V outd;   // phase A: d' ; phase B: new r
       V outx;   // phase B: new x
 #pragma unroll
       for (int v = 0; v < VEC; ++v) {
-        const T xc = ec[jj][v];
         const bool inS = iS && (rowS >> jj & 1) && (colS >> v & 1);
-        T res = (T)0;
-        if (inS) {
-          const T xpi = rev ? ea[jj][v] : eb[jj][v];
-          const T xmi = rev ? eb[jj][v] : ea[jj][v];
-          T s = cPi * xpi;
-          T mm = cCi * xc;
-          s = s + mm;
-          mm = cMi * xmi;
-          s = s + mm;
-          T ax = s;
-          s = cPj * dn[v];
-          mm = cCj * xc;
-          s = s + mm;
-          mm = cMj * up[v];
-          s = s + mm;
-          ax = ax + s;
-          T cPk = A.lap.inv[2], cCk = A.lap.m2inv[2], cMk = A.lap.inv[2];
-          if (colLo >> v & 1) { cPk = A.lap.c23[2]; cCk = -A.lap.c23[2]; cMk = (T)0; }
-          if (colHi >> v & 1) { cPk = (T)0; cCk = -A.lap.c23[2]; cMk = A.lap.c23[2]; }
-          const T xpk = (v < VEC - 1) ? ec[jj][v + 1 < VEC ? v + 1 : v] : right;
-          const T xmk = (v > 0) ? ec[jj][v > 0 ? v - 1 : 0] : left;
-          s = cPk * xpk;
-          mm = cCk * xc;
-          s = s + mm;
-          mm = cMk * xmk;
-          s = s + mm;
-          ax = ax + s;
-          if (hasc) ax = ax * cf;
-          ax = ax * sgn;
-          res = ax;
-        }
+        const T xc = ec[jj][v];
         if (PHASE == 0) {
           const T e = inS ? xc : (T)0;
           outd[v] = e;
-          if (inS) {
-            T p = e * res;
-            s0 += (double)p;
-          }
+          T p = e * res[jj][v];
+          s0 += inS ? (double)p : 0.0;
         } else {
-          T xo = xv[jj][v];
-          T rn = (T)0;
-          T xn = xo;
-          if (inS) {
-            T ad = alpha * xc;
-            xn = xo + ad;
-            T aAd = alpha * res;
-            rn = rv[jj][v] - aAd;
-            T p = rn * rn;
-            s0 += (double)p;
-            if (!(iShell || (rowShell >> jj & 1) || (colShell >> v & 1))) {
-              T df = xn - xo;
-              T p2 = df * df;
-              s1 += (double)p2;
-            }
-          }
+          const T xo = xv[jj][v];
+          T ad = alpha * xc;
+          T xn = xo + ad;
+          T aAd = alpha * res[jj][v];
+          T rn = rv[jj][v] - aAd;
+          xn = inS ? xn : xo;
+          rn = inS ? rn : (T)0;
+          T p = rn * rn;
+          s0 += inS ? (double)p : 0.0;
+          const bool offshell = inS && !(iShell || (rowShell >> jj & 1) || (colShell >> v & 1));
+          T df = xn - xo;
+          T p2 = df * df;
+          s1 += offshell ? (double)p2 : 0.0;
           outd[v] = rn;
           outx[v] = xn;
         }
@@ -326,15 +339,17 @@ __global__ void __launch_bounds__(256) k_cg3d(Cg3dArgs<T> A) {
         }
       }
     }
-    // ---- shift the register planes ----------------------------------------------------------
+
+    // ---- rotate the register planes; plane m+2 becomes "ahead" (first use of its loads) --------
 #pragma unroll
     for (int jj = 0; jj < RJ; ++jj) {
       ea[jj] = ec[jj];
       ec[jj] = eb[jj];
-      eb[jj] = en[jj];
     }
-    hv = hvn;
-    hs = hsn;
+    if (more) {
+      finish_own(w, eb);
+      finish_halo(w, hv, hs);
+    }
     __syncthreads();
   }
 
@@ -400,6 +415,14 @@ static int launch_cg3d(pa_ctx* c, Cg3dArgs<T>& A) {
   A.chunks = chunks;
   const int nblk = tiles * chunks;
   if (nblk > PA_MAX_GRID) return 0;
+  static int dbg = -1;
+  if (dbg < 0) dbg = getenv("PYAPES_HIP_DEBUG") ? 8 : 0;
+  if (dbg > 0) {
+    --dbg;
+    fprintf(stderr, "[pyapes_hip] k_cg3d phase %c: tiles %dx%d chunks %d (CI ~%lld) blocks %d, %d blocks/CU x %d CUs\n",
+            PHASE == 0 ? 'A' : 'B', A.tiles_j, A.tiles_k, chunks, (long long)(G.n0 / chunks), nblk,
+            blocks_per_cu<T, RJ, PHASE>(), cus_of(c));
+  }
   hipLaunchKernelGGL((k_cg3d<T, RJ, PHASE>), dim3(nblk), dim3(256), 0, c->stream, A);
   return nblk;
 }

@@ -425,6 +425,221 @@ __global__ void __launch_bounds__(PA_BLOCK) k_shell(DevGeom G, const SolverScala
   if (mode == 1) pa_block_reduce_store<1>(s, partials);
 }
 
+
+// ---- fused BC fill + boundary-shell stop-test term ---------------------------------------------
+// The reference applies the faces one after the other (linalg.py:295-297); a later face reads, on
+// the shared edges, what an earlier face wrote.  For the factory order xl,xu,yl,yu,zl,zu the final
+// value of a shell node is a closed form of ORIGINAL interior values: v3 = zfill(v2), v2 =
+// yfill(v1), v1 = xfill(v0).  k_bc_compute evaluates that per shell node from the unmodified
+// field into a compact shell buffer (and accumulates (new - old)^2 against the previous
+// iteration's shell for the stop test); k_bc_scatter writes the shell back.  2 launches instead
+// of 6 face fills + 1 shell pass, same values bit for bit.
+template <typename T>
+struct BCFaceDev {
+  int type;
+  T sval;          // dirichlet value / neumann additive constant for scalar V
+  const T* vals;   // per-node g or V
+  T dxf, ndir;
+};
+template <typename T>
+struct BCAll {
+  BCFaceDev<T> f[6];
+  T c43, c13, c23;
+  const T* far_lo0;  // slab, periodic axis 0: x[N-1], x[N-2] (lower end rank), x[1] (upper end rank)
+  const T* far_lo1;
+  const T* far_hi0;
+  int slab_periodic0;
+};
+
+template <typename T>
+__device__ __forceinline__ T pa_bc_const(const BCAll<T>& B, int f, int64_t q) {
+  const BCFaceDev<T>& F = B.f[f];
+  if (!F.vals) return F.sval;
+  T ct = B.c23 * F.vals[q];
+  ct = ct * F.dxf;
+  return ct * F.ndir;
+}
+
+// Closed-form evaluation, one stage per axis.  stage<A>(i,j,k) = value of the node after the
+// faces of axes 0..A have been applied, expressed through stage<A-1> of the nodes that face reads.
+template <typename T>
+struct BCEval {
+  const DevGeom& G;
+  const BCAll<T>& B;
+  const T* __restrict__ x;
+
+  // axis-0 neighbour of (., j, k) at GLOBAL plane g before any fill; on a slab whose ring is cut the
+  // planes of the other end rank come from the exchanged far buffers
+  __device__ __forceinline__ T raw0(int f, int64_t g, int64_t base) const {
+    // one pointer select, one load (an if/return ladder here was miscompiled by hipcc 7.2 when fully
+    // inlined: tests/test_gpu_bc_fused.py is the regression test)
+    const T* p = x + (g - G.off0) * G.s0;
+    if (B.slab_periodic0 && B.f[f].type == 4) {
+      if (f == 0) {
+        p = (g == G.g0 - 1) ? B.far_lo0 : ((g == G.g0 - 2) ? B.far_lo1 : p);
+      } else {
+        p = (g == 1) ? B.far_hi0 : p;
+      }
+    }
+    return p[base];
+  }
+
+  // the value face f writes, from the three pre-axis values it can read:
+  //   p1 = prev, p2 = prev2 (neumann / symmetry); periodic: a = x[1], b = x[N-1], c = x[N-2]
+  __device__ __forceinline__ T stage0(int64_t i, int64_t j, int64_t k) const {
+    const int64_t gi = i + G.off0;
+    const int64_t base = j * G.s1 + k;
+    int f = -1;
+    if (G.act[0]) {
+      if (gi == 0 && B.f[0].type) f = 0;
+      else if (gi == G.g0 - 1 && B.f[1].type) f = 1;
+    }
+    if (f < 0) return x[i * G.s0 + base];
+    const int type = B.f[f].type;
+    const bool lower = f == 0;
+    const int64_t N = G.g0;
+    if (type == 1) return B.f[f].vals ? B.f[f].vals[base] : B.f[f].sval;
+    if (type == 2) {
+      T t1 = B.c43 * raw0(f, lower ? 1 : N - 2, base);
+      T t2 = B.c13 * raw0(f, lower ? 2 : N - 3, base);
+      t1 = t1 - t2;
+      return t1 + pa_bc_const<T>(B, f, base);
+    }
+    if (type == 3) return raw0(f, lower ? 1 : N - 2, base);
+    T t1 = raw0(f, 1, base) - raw0(f, N - 1, base);
+    return t1 + raw0(f, N - 2, base);
+  }
+
+  __device__ __forceinline__ T stage1(int64_t i, int64_t j, int64_t k) const {
+    int f = -1;
+    if (G.act[1]) {
+      if (j == 0 && B.f[2].type) f = 2;
+      else if (j == G.n1 - 1 && B.f[3].type) f = 3;
+    }
+    if (f < 0) return stage0(i, j, k);
+    const int type = B.f[f].type;
+    const bool lower = f == 2;
+    const int64_t N = G.n1, q = i * G.n2 + k;
+    if (type == 1) return B.f[f].vals ? B.f[f].vals[q] : B.f[f].sval;
+    if (type == 2) {
+      T t1 = B.c43 * stage0(i, lower ? 1 : N - 2, k);
+      T t2 = B.c13 * stage0(i, lower ? 2 : N - 3, k);
+      t1 = t1 - t2;
+      return t1 + pa_bc_const<T>(B, f, q);
+    }
+    if (type == 3) return stage0(i, lower ? 1 : N - 2, k);
+    T t1 = stage0(i, 1, k) - stage0(i, N - 1, k);
+    return t1 + stage0(i, N - 2, k);
+  }
+
+  __device__ __forceinline__ T stage2(int64_t i, int64_t j, int64_t k) const {
+    int f = -1;
+    if (G.act[2]) {
+      if (k == 0 && B.f[4].type) f = 4;
+      else if (k == G.n2 - 1 && B.f[5].type) f = 5;
+    }
+    if (f < 0) return stage1(i, j, k);
+    const int type = B.f[f].type;
+    const bool lower = f == 4;
+    const int64_t N = G.n2, q = i * G.n1 + j;
+    if (type == 1) return B.f[f].vals ? B.f[f].vals[q] : B.f[f].sval;
+    if (type == 2) {
+      T t1 = B.c43 * stage1(i, j, lower ? 1 : N - 2);
+      T t2 = B.c13 * stage1(i, j, lower ? 2 : N - 3);
+      t1 = t1 - t2;
+      return t1 + pa_bc_const<T>(B, f, q);
+    }
+    if (type == 3) return stage1(i, j, lower ? 1 : N - 2);
+    T t1 = stage1(i, j, 1) - stage1(i, j, N - 1);
+    return t1 + stage1(i, j, N - 2);
+  }
+};
+
+template <typename T>
+__device__ __forceinline__ T pa_bc_v3(const DevGeom& G, const BCAll<T>& B, const T* __restrict__ x, int64_t i,
+                                      int64_t j, int64_t k) {
+  BCEval<T> ev{G, B, x};
+  return ev.stage2(i, j, k);
+}
+
+// enumerate the shell nodes this rank owns exactly once (same layout as k_shell)
+__device__ __forceinline__ bool pa_shell_node(const DevGeom& G, int64_t q, const int64_t* start, int64_t& i,
+                                              int64_t& j, int64_t& k) {
+  int f = 0;
+  for (int w = 1; w < 6; ++w)
+    if (G.act[w >> 1] && q >= start[w]) f = w;
+  const int a = f >> 1, side = f & 1;
+  const int64_t local = q - start[f];
+  if (a == 0) {
+    int64_t gi = side == 0 ? 0 : G.g0 - 1;
+    i = gi - G.off0;
+    if (i < 0 || i >= G.n0) return false;
+    j = local / G.n2; k = local - j * G.n2;
+  } else if (a == 1) {
+    i = local / G.n2; k = local - i * G.n2;
+    j = side == 0 ? 0 : G.n1 - 1;
+    int64_t gi = i + G.off0;
+    if (G.act[0] && (gi == 0 || gi == G.g0 - 1)) return false;
+  } else {
+    i = local / G.n1; j = local - i * G.n1;
+    k = side == 0 ? 0 : G.n2 - 1;
+    int64_t gi = i + G.off0;
+    if (G.act[0] && (gi == 0 || gi == G.g0 - 1)) return false;
+    if (G.act[1] && (j == 0 || j == G.n1 - 1)) return false;
+  }
+  return true;
+}
+
+template <typename T>
+__global__ void __launch_bounds__(PA_BLOCK) k_bc_compute(DevGeom G, BCAll<T> B, const int* __restrict__ done,
+                                                          const T* __restrict__ x, const T* __restrict__ shell_old,
+                                                          T* __restrict__ shell_new, double* __restrict__ partials,
+                                                          int with_delta) {
+  if (done && *done) return;
+  const int64_t sz[3] = {G.n1 * G.n2, G.n0 * G.n2, G.n0 * G.n1};
+  int64_t total = 0, start[6];
+  for (int f = 0; f < 6; ++f) { start[f] = total; total += G.act[f >> 1] ? sz[f >> 1] : 0; }
+  double s[1] = {0.0};
+  for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < total;
+       q += (int64_t)gridDim.x * blockDim.x) {
+    int64_t i, j, k;
+    if (!pa_shell_node(G, q, start, i, j, k)) continue;
+    T v = pa_bc_v3<T>(G, B, x, i, j, k);
+#ifdef PA_DEBUG_BC
+    if (i == 0 && j == 1 && k == G.n2 - 1) {
+      BCEval<T> ev{G, B, x};
+      printf("DBG node(0,1,%lld) v=%g stage1(0,1,n2-2)=%g stage0=%g types %d %d %d %d %d %d slabp %d far %p %p %p raw1 %g rawN1 %g rawN2 %g\n",
+             (long long)k, (double)v, (double)ev.stage1(0, 1, G.n2 - 2), (double)ev.stage0(0, 1, G.n2 - 2),
+             B.f[0].type, B.f[1].type, B.f[2].type, B.f[3].type, B.f[4].type, B.f[5].type, B.slab_periodic0,
+             (void*)B.far_lo0, (void*)B.far_lo1, (void*)B.far_hi0, (double)ev.raw0(0, 1, 1 * G.s1 + G.n2 - 2),
+             (double)ev.raw0(0, G.g0 - 1, 1 * G.s1 + G.n2 - 2), (double)ev.raw0(0, G.g0 - 2, 1 * G.s1 + G.n2 - 2));
+    }
+#endif
+    shell_new[q] = v;
+    if (with_delta) {
+      T df = v - shell_old[q];
+      T p = df * df;
+      s[0] += (double)p;
+    }
+  }
+  if (with_delta) pa_block_reduce_store<1>(s, partials);
+}
+
+template <typename T>
+__global__ void __launch_bounds__(PA_BLOCK) k_bc_scatter(DevGeom G, const int* __restrict__ done,
+                                                          T* __restrict__ x, const T* __restrict__ shell_new) {
+  if (done && *done) return;
+  const int64_t sz[3] = {G.n1 * G.n2, G.n0 * G.n2, G.n0 * G.n1};
+  int64_t total = 0, start[6];
+  for (int f = 0; f < 6; ++f) { start[f] = total; total += G.act[f >> 1] ? sz[f >> 1] : 0; }
+  for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < total;
+       q += (int64_t)gridDim.x * blockDim.x) {
+    int64_t i, j, k;
+    if (!pa_shell_node(G, q, start, i, j, k)) continue;
+    x[i * G.s0 + j * G.s1 + k] = shell_new[q];
+  }
+}
+
 // ---- reductions of per-block partials + scalar logic ------------------------------------
 // sums[slot[s]] (+)= sum over blocks of partials[b*ns + s]
 __device__ __forceinline__ double pa_reduce_partials(const double* __restrict__ partials, int nblk, int ns,
@@ -954,7 +1169,21 @@ static int bc_apply_t(pa_ctx* c, T* x, bool guarded = false) {
   return PA_OK;
 }
 
+static bool bc_fusable(const pa_ctx* c);
+template <typename T>
+static int bc_shell_fused(pa_ctx* c, T* x, double* part2, int with_delta, bool guarded, int* nsh, bool standalone);
+
+// ordered BC fill of one field: fused (2 launches) when the list allows it, else face by face
+template <typename T>
+static int bc_apply_auto(pa_ctx* c, T* x, bool guarded) {
+  if (bc_fusable(c)) return bc_shell_fused<T>(c, x, nullptr, 0, guarded, nullptr, true);
+  return bc_apply_t<T>(c, x, guarded);
+}
+
 int pa_bc_apply_any(pa_ctx* c, void* x) {
+  if (bc_fusable(c))
+    return c->dtype == PA_F64 ? bc_shell_fused<double>(c, (double*)x, nullptr, 0, false, nullptr, true)
+                              : bc_shell_fused<float>(c, (float*)x, nullptr, 0, false, nullptr, true);
   return c->dtype == PA_F64 ? bc_apply_t<double>(c, (double*)x) : bc_apply_t<float>(c, (float*)x);
 }
 
@@ -1237,7 +1466,7 @@ static int euler_t(pa_ctx* c, const T* in, T* out, int kind, double u, const voi
   hipLaunchKernelGGL(k_euler<T>, dim3(pa_grid_blocks(c->G.ncell)), dim3(PA_BLOCK), 0, c->stream, c->G, El, Ea, pv,
                      out, (T)nu, (T)dt);
   PA_HIP(c, hipGetLastError());
-  return bc_apply_t<T>(c, out);
+  return bc_apply_auto<T>(c, out, false);
 }
 
 extern "C" {
@@ -1343,6 +1572,102 @@ static bool bc_is_static(const pa_ctx* c) {
   return true;
 }
 
+
+// ---- fused BC fill (+ shell stop-test term) ------------------------------------------------------
+// usable when the faces are listed in the factory order and every mesh axis has >= 5 nodes
+static bool bc_fusable(const pa_ctx* c) {
+  if (getenv("PYAPES_HIP_BC_UNFUSED")) return false;
+  // Measured on MI355X (512^3 fp64 periodic): the closed form costs 86 + 40 us against 62 + 19 us for
+  // six face launches + the shell pass, so it only wins where launches, not bytes, set the time.
+  // PYAPES_HIP_BC_FUSED=1 forces it (tests do).
+  if (!getenv("PYAPES_HIP_BC_FUSED") &&
+      2 * (c->G.n1 * c->G.n2 + c->G.n0 * c->G.n2 + c->G.n0 * c->G.n1) > 400000)
+    return false;
+  int last = -1;
+  for (int w = 0; w < c->nbc; ++w) {
+    if (c->bc[c->bc_order[w]].type == PA_BC_NONE) continue;
+    if (c->bc_order[w] <= last) return false;
+    last = c->bc_order[w];
+  }
+  const DevGeom& G = c->G;
+  const int64_t N[3] = {G.g0, G.n1, G.n2};
+  const int64_t nloc[3] = {G.n0, G.n1, G.n2};
+  for (int a = 0; a < 3; ++a)
+    if (G.act[a] && (N[a] < 5 || (a == 0 && nloc[0] < 3))) return false;
+  // periodic must be declared on both faces of an axis for the closed form
+  for (int a = 0; a < 3; ++a)
+    if ((c->bc[2 * a].type == PA_BC_PERIODIC) != (c->bc[2 * a + 1].type == PA_BC_PERIODIC)) return false;
+  return true;
+}
+
+template <typename T>
+static int bc_fill_all(pa_ctx* c, BCAll<T>& B) {
+  memset(&B, 0, sizeof(B));
+  const DevGeom& G = c->G;
+  for (int f = 0; f < 6; ++f) {
+    const HostBC& b = c->bc[f];
+    BCFaceDev<T>& F = B.f[f];
+    F.type = b.type;
+    F.vals = (const T*)b.vals;
+    F.dxf = (T)b.dxf;
+    F.ndir = (f & 1) == 0 ? (T)-1 : (T)1;
+    if (b.type == PA_BC_DIRICHLET) F.sval = (T)b.value;
+    if (b.type == PA_BC_NEUMANN) {
+      T pre = (T)((2.0 / 3.0) * b.value);
+      pre = pre * F.dxf;
+      pre = pre * F.ndir;
+      F.sval = pre;
+    }
+    if ((f >> 1) == 0 && G.act[0]) {  // slab: a rank only applies the axis-0 face it holds
+      if (f == 0 && G.off0 != 0) F.type = PA_BC_NONE;
+      if (f == 1 && G.off0 + G.n0 != G.g0) F.type = PA_BC_NONE;
+    }
+  }
+  B.c43 = (T)(4.0 / 3.0);
+  B.c13 = (T)(1.0 / 3.0);
+  B.c23 = (T)(2.0 / 3.0);
+  B.slab_periodic0 = (G.n0 != G.g0 && c->bc[0].type == PA_BC_PERIODIC) ? 1 : 0;
+  if (B.slab_periodic0) {
+    B.far_lo0 = (const T*)c->bc_far_lo0;
+    B.far_lo1 = (const T*)c->bc_far_lo1;
+    B.far_hi0 = (const T*)c->bc_far_hi0;
+    if ((B.f[0].type == PA_BC_PERIODIC && (!B.far_lo0 || !B.far_lo1)) ||
+        (B.f[1].type == PA_BC_PERIODIC && !B.far_hi0)) {
+      pa_set_err(c, "periodic axis-0 BC on a slab needs the far planes (pa_slab_set)");
+      return PA_E_STATE;
+    }
+  }
+  return PA_OK;
+}
+
+// fills x; with_delta: partial sums of (new - old)^2 over the shell -> part2 (returns #blocks via *nsh)
+template <typename T>
+static int bc_shell_fused(pa_ctx* c, T* x, double* part2, int with_delta, bool guarded, int* nsh,
+                          bool standalone) {
+  BCAll<T> B;
+  int rc = bc_fill_all<T>(c, B);
+  if (rc) return rc;
+  const int nb = shell_blocks(c);
+  const size_t half = (size_t)shell_elems(c);
+  T *so, *sn;
+  if (standalone) {  // plain pa_apply_bc: private staging, the solver's x_old shell is left alone
+    if ((rc = pa_scratch(c, &c->scr[SCR_SHELL2], &c->cap[SCR_SHELL2], half * sizeof(T)))) return rc;
+    so = sn = (T*)c->scr[SCR_SHELL2];
+  } else {
+    T* base = (T*)c->scr[SCR_SHELL];
+    so = base + (c->shell_cur ? half : 0);
+    sn = base + (c->shell_cur ? 0 : half);
+  }
+  const int* done = guarded ? pa_done_flag(c) : nullptr;
+  hipLaunchKernelGGL(k_bc_compute<T>, dim3(nb), dim3(PA_BLOCK), 0, c->stream, c->G, B, done, (const T*)x,
+                     (const T*)so, sn, part2, with_delta);
+  hipLaunchKernelGGL(k_bc_scatter<T>, dim3(nb), dim3(PA_BLOCK), 0, c->stream, c->G, done, x, (const T*)sn);
+  if (!standalone) c->shell_cur ^= 1;
+  if (nsh) *nsh = nb;
+  PA_HIP(c, hipGetLastError());
+  return PA_OK;
+}
+
 static int init_scalars(pa_ctx* c, double tol, int64_t max_it) {
   SolverScalars h;
   memset(&h, 0, sizeof(h));
@@ -1391,17 +1716,27 @@ static int cg_begin_t(pa_ctx* c, T* x, const T* rhs, double tol, int64_t max_it)
   if ((rc = pa_scratch(c, &c->scr[SCR_D1], &c->cap[SCR_D1], fb))) return rc;
   if ((rc = pa_scratch(c, &c->scr[SCR_PART], &c->cap[SCR_PART], (size_t)PA_MAX_GRID * 4 * sizeof(double)))) return rc;
   if ((rc = pa_scratch(c, &c->scr[SCR_PART2], &c->cap[SCR_PART2], (size_t)PA_MAX_GRID * sizeof(double)))) return rc;
-  if ((rc = pa_scratch(c, &c->scr[SCR_SHELL], &c->cap[SCR_SHELL], (size_t)shell_elems(c) * sizeof(T)))) return rc;
+  if ((rc = pa_scratch(c, &c->scr[SCR_SHELL], &c->cap[SCR_SHELL], 2 * (size_t)shell_elems(c) * sizeof(T)))) return rc;
   if ((rc = init_scalars(c, tol, max_it))) return rc;
   c->cg_x = x;
   c->cur = 0;
   c->bc_static = bc_is_static(c);
+  c->bc_fused = bc_fusable(c);
+  c->shell_cur = 0;
   c->solver_live = 1;
   DevEq<T> E;
   pa_build_eq<T>(c, c->nterms, c->terms, E);
   // linalg.py:97.  On a slab the driver fills the BCs itself (pa_apply_bc) BEFORE it exchanges
   // the ghost planes of x, so the fill must not run again here.
-  if (!c->slab && (rc = bc_apply_t<T>(c, x))) return rc;
+  bool shell_ready = false;
+  if (!c->slab) {
+    if (c->bc_fused) {  // fill + remember the filled shell as x_old in one go
+      if ((rc = bc_shell_fused<T>(c, x, nullptr, 0, false, nullptr, false))) return rc;
+      shell_ready = true;
+    } else if ((rc = bc_apply_t<T>(c, x))) {
+      return rc;
+    }
+  }
   T* r = (T*)c->scr[SCR_R];
   T* d = (T*)c->scr[SCR_D0];
   double* part = (double*)c->scr[SCR_PART];
@@ -1420,8 +1755,9 @@ static int cg_begin_t(pa_ctx* c, T* x, const T* rhs, double tol, int64_t max_it)
     char* g = (char*)c->scr[SCR_GHOST];
     c->d_glo[0] = g; c->d_ghi[0] = g + pb; c->d_glo[1] = g + 2 * pb; c->d_ghi[1] = g + 3 * pb;
   }
-  hipLaunchKernelGGL(k_shell<T>, dim3(shell_blocks(c)), dim3(PA_BLOCK), 0, c->stream, G, c->sc, (const T*)x,
-                     (T*)c->scr[SCR_SHELL], (double*)c->scr[SCR_PART2], 0);
+  if (!shell_ready)
+    hipLaunchKernelGGL(k_shell<T>, dim3(shell_blocks(c)), dim3(PA_BLOCK), 0, c->stream, G, c->sc, (const T*)x,
+                       (T*)c->scr[SCR_SHELL] + (c->shell_cur ? shell_elems(c) : 0), (double*)c->scr[SCR_PART2], 0);
   PA_HIP(c, hipGetLastError());
   return PA_OK;
 }
@@ -1522,10 +1858,14 @@ int pa_cg_phase_b_t(pa_ctx* c, int stage_post) {
   }
   int nsh = 0;
   if (!c->bc_static) {
-    if ((rc = bc_apply_t<T>(c, x, true))) return rc;
-    nsh = shell_blocks(c);
-    hipLaunchKernelGGL(k_shell<T>, dim3(nsh), dim3(PA_BLOCK), 0, c->stream, G, c->sc, (const T*)x,
-                       (T*)c->scr[SCR_SHELL], part2, 1);
+    if (c->bc_fused) {
+      if ((rc = bc_shell_fused<T>(c, x, part2, 1, true, &nsh, false))) return rc;
+    } else {
+      if ((rc = bc_apply_t<T>(c, x, true))) return rc;
+      nsh = shell_blocks(c);
+      hipLaunchKernelGGL(k_shell<T>, dim3(nsh), dim3(PA_BLOCK), 0, c->stream, G, c->sc, (const T*)x,
+                         (T*)c->scr[SCR_SHELL], part2, 1);
+    }
   }
   hipLaunchKernelGGL(k_cg_post_b<T>, dim3(1), dim3(PA_BLOCK), 0, c->stream, c->sc, part, used_blocks, part2, nsh,
                      pa_sums(c), stage_post);
@@ -1543,10 +1883,14 @@ int pa_cg_bc_t(pa_ctx* c) {
   double* part2 = (double*)c->scr[SCR_PART2];
   int nsh = 0, rc;
   if (!c->bc_static) {
-    if ((rc = bc_apply_t<T>(c, x, true))) return rc;
-    nsh = shell_blocks(c);
-    hipLaunchKernelGGL(k_shell<T>, dim3(nsh), dim3(PA_BLOCK), 0, c->stream, G, c->sc, (const T*)x,
-                       (T*)c->scr[SCR_SHELL], part2, 1);
+    if (c->bc_fused) {
+      if ((rc = bc_shell_fused<T>(c, x, part2, 1, true, &nsh, false))) return rc;
+    } else {
+      if ((rc = bc_apply_t<T>(c, x, true))) return rc;
+      nsh = shell_blocks(c);
+      hipLaunchKernelGGL(k_shell<T>, dim3(nsh), dim3(PA_BLOCK), 0, c->stream, G, c->sc, (const T*)x,
+                         (T*)c->scr[SCR_SHELL], part2, 1);
+    }
   }
   hipLaunchKernelGGL(k_cg_post_b<T>, dim3(1), dim3(PA_BLOCK), 0, c->stream, c->sc, part, c->b_blocks, part2, nsh,
                      pa_sums(c), 0);
@@ -1709,7 +2053,7 @@ static int bicg_run_t(pa_ctx* c, T* x, const T* rhs, double tol, int64_t max_it,
     hipLaunchKernelGGL(k_bicg_post<T>, dim3(1), dim3(PA_BLOCK), 0, c->stream, c->sc, part, nblk, 2);
     hipLaunchKernelGGL(k_bicg_x<T>, dim3(nblk), dim3(PA_BLOCK), 0, c->stream, G, c->sc, x, (const T*)p[cur ^ 1],
                        (const T*)s, (const T*)t, r, part);
-    if ((rc = bc_apply_t<T>(c, x, true))) return rc;
+    if ((rc = bc_apply_auto<T>(c, x, true))) return rc;
     hipLaunchKernelGGL(k_bicg_post<T>, dim3(1), dim3(PA_BLOCK), 0, c->stream, c->sc, part, nblk, 3);
     cur ^= 1;
     ++enq;

@@ -27,7 +27,7 @@ struct HostBC {
 
 enum {
   SCR_R = 0, SCR_D0, SCR_D1, SCR_PART, SCR_PART2, SCR_SHELL, SCR_R0, SCR_V0, SCR_V1, SCR_S, SCR_TT,
-  SCR_GHOST, PA_NSCRATCH
+  SCR_GHOST, SCR_SHELL2, PA_NSCRATCH
 };
 
 struct pa_ctx {
@@ -55,6 +55,7 @@ struct pa_ctx {
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   // CG state
   int solver_live = 0, cur = 0, bc_static = 0, pending_init_logic = 0, b_blocks = 0;
+  int bc_fused = 0, shell_cur = 0;  // fused BC fill: which half of SCR_SHELL holds x_old on the shell
   void* cg_x = nullptr;
   // slab decomposition (P > 1): externally owned exchange buffers
   int slab = 0;

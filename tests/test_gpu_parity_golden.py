@@ -17,6 +17,43 @@ from pyapes_amd.solver.fdm import FDM
 from pyapes_amd.solver.ops import Solver
 
 
+@pytest.mark.parametrize("case", [c for c in golden_cases("ops") if c["dtype"] == "double"], ids=lambda c: c["name"])
+def test_bc_fill_face_by_face_path(case, monkeypatch):
+    """The unfused BC fill (one launch per face in list order) must give the same bits as the fused
+    closed form that the factory order normally takes."""
+    monkeypatch.setenv("PYAPES_HIP_BC_UNFUSED", "1")
+    g = golden_load(case["name"])
+    mesh = product_mesh(case)
+    var = product_field(case, mesh, g["x0"])
+    var.apply_bcs()
+    assert bit_equal(var(), g["bc_fill"]), "bc_fill (face by face)"
+
+
+def test_bc_fill_non_factory_order_matches_oracle():
+    """A BC list that is NOT in factory order takes the face-by-face path; order dependence on the
+    shared edges must follow the list (oracle = literal sequential fill)."""
+    import pyapes_oracle as O
+    from pyapes_amd.geometry import Box
+    from pyapes_amd.mesh import Mesh
+    from pyapes_amd.variables import Field
+    n = [7, 8, 9]
+    order = ["zu", "xl", "yu", "xu", "zl", "yl"]
+    spec = {"xl": ("neumann", 0.3), "xu": ("dirichlet", 1.0), "yl": ("symmetry", None), "yu": ("neumann", -0.2),
+            "zl": ("dirichlet", 0.5), "zu": ("neumann", 0.1)}
+    prod = [{"bc_face": f, "bc_type": spec[f][0], "bc_val": spec[f][1], "bc_val_opt": None} for f in order]
+    orc = [{"bc_face": f, "bc_type": spec[f][0], "bc_val": spec[f][1]} for f in order]
+    g = torch.Generator().manual_seed(2)
+    x0 = torch.randn((1, *n), generator=g, dtype=torch.float64)
+    mesh = Mesh(Box[0:1, 0:1, 0:1], None, n, "cuda", "double")
+    var = Field("p", 1, mesh, {"domain": prod, "obstacle": None})
+    var.set_var_tensor(x0.cuda().clone())
+    var.apply_bcs()
+    om = O.OMesh([0, 0, 0], [1, 1, 1], n, "double")
+    xo = x0.clone()
+    O.bc_fill(xo, O.make_bcs(om, orc))
+    assert bit_equal(var(), xo)
+
+
 @pytest.mark.parametrize("case", golden_cases("ops"), ids=lambda c: c["name"])
 def test_ops_bit_exact(case):
     g = golden_load(case["name"])
