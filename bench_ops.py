@@ -1,0 +1,133 @@
+#!/usr/bin/env python3
+"""bench_ops.py -- secondary measurements for the other rows of SURVEY section 8 (not the driver's
+contract; bench.py is).  One JSON line per workload: explicit Laplacian apply, the explicit
+adv-diff Euler march (BASELINE config 4), Jacobi (config 1 and 3-D), BiCGSTAB, 2-D CG.
+achieved GB/s uses the ALGORITHMIC bytes of SURVEY 8d (apply 2 passes, Euler 2-3, Jacobi 3,
+CG 10, BiCGSTAB 22 = 2 applies x 2 + 9 axpy/dot passes x 2) against the 8 TB/s HBM peak.
+
+    python bench_ops.py [--quick]
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+import warnings
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+PEAK = 8000.0
+
+
+def timed(fn, iters, warm=2):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters
+
+
+def emit(name, cells, ms, passes, esize, extra=None):
+    gbs = passes * esize * cells / (ms * 1e-3) / 1e9
+    out = {"workload": name, "ms": ms, "cell_updates_per_s": cells / (ms * 1e-3), "alg_passes": passes,
+           "alg_GBs": gbs, "frac_of_hbm_peak": gbs / PEAK}
+    if extra:
+        out.update(extra)
+    print(json.dumps(out), flush=True)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--quick", action="store_true")
+    args = ap.parse_args()
+    from pyapes_amd.geometry import Box
+    from pyapes_amd.mesh import Mesh
+    from pyapes_amd.solver.fdc import FDC
+    from pyapes_amd.solver.fdm import FDM
+    from pyapes_amd.solver.march import euler_march, euler_step
+    from pyapes_amd.solver.ops import Solver
+    from pyapes_amd.testing.poisson import poisson_bcs, poisson_rhs_nd
+    from pyapes_amd.variables import Field
+    from pyapes_amd.variables.bcs import homogeneous_bcs, mixed_bcs
+    warnings.simplefilter("ignore")
+    q = args.quick
+
+    # --- explicit Laplacian apply, 512^3 fp64 (2 passes = 16 B/cell) -----------------------------
+    n = 256 if q else 512
+    mesh = Mesh(Box[0:1, 0:1, 0:1], None, [n, n, n], "cuda", "double")
+    var = Field("p", 1, mesh, {"domain": homogeneous_bcs(3, 0.0, "neumann"), "obstacle": None}, init_val="random")
+    fdc = FDC({"laplacian": {"edge": False}})
+    ms = timed(lambda: fdc.laplacian(var), 10)
+    emit(f"laplacian apply {n}^3 f64 neumann (incl. output alloc)", n ** 3, ms, 2, 8)
+    del var, mesh
+
+    # --- config 4: explicit adv-diff march 256^3 fp32, upwind, Neumann / Symmetry ------------------
+    n = 128 if q else 256
+    mesh = Mesh(Box[0:1, 0:1, 0:1], None, [n, n, n], "cuda", "single")
+    bcs = mixed_bcs([0.0, 0.0, None, None, None, None],
+                    ["neumann", "neumann", "symmetry", "symmetry", "symmetry", "symmetry"])
+    phi = Field("phi", 1, mesh, {"domain": bcs, "obstacle": None})
+    phi.set_var_tensor(torch.exp(-((mesh.X - 0.5) ** 2 + (mesh.Y - 0.5) ** 2 + (mesh.Z - 0.5) ** 2) / 0.02)
+                       .unsqueeze(0).contiguous())
+    phi.apply_bcs()
+    nu = 1e-3
+    dx = mesh.dx_list[0]
+    dt = 0.2 * min(dx * dx / (6 * nu), dx / 1.0)
+    cfg = {"div": {"limiter": "upwind"}}
+    ms = timed(lambda: euler_step(phi, 1.0, nu, dt, cfg), 100)
+    emit(f"euler adv-diff step {n}^3 f32 upwind scalar u, neumann/symmetry (config 4)", n ** 3, ms, 2, 4)
+    ut = torch.ones_like(phi()) * 0.7
+    ms = timed(lambda: euler_step(phi, ut, nu, dt, cfg), 100)
+    emit(f"euler adv-diff step {n}^3 f32 upwind speed tensor (config 4)", n ** 3, ms, 3, 4)
+    ms = timed(lambda: euler_march(phi, 1.0, nu, dt, 50, cfg), 4) / 50
+    emit(f"euler_march (50 steps per call) {n}^3 f32 upwind scalar u (config 4)", n ** 3, ms, 2, 4)
+    ms = timed(lambda: euler_march(phi, ut, nu, dt, 50, cfg), 4) / 50
+    emit(f"euler_march (50 steps per call) {n}^3 f32 upwind speed tensor (config 4)", n ** 3, ms, 3, 4)
+    assert bool(torch.isfinite(phi()).all())
+    del phi, mesh, ut
+
+    # --- solvers: ms per iteration from fixed-iteration solves ------------------------------------
+    def solver_ms(meshf, bcsf, method, K, rhs_fn=None, extra_cfg=None):
+        mesh = meshf()
+        var = Field("p", 1, mesh, {"domain": bcsf, "obstacle": None})
+        rhs = rhs_fn(mesh, var) if rhs_fn else torch.randn_like(var())
+        cfg = {"method": method, "tol": -1.0, "max_it": K - 1, "report": False}
+        cfg.update(extra_cfg or {})
+        s = Solver({"fdm": cfg})
+        s.set_eq(FDM().laplacian(1.0, var) == rhs)
+        t0 = time.perf_counter()
+        rep = s.solve()
+        wall = (time.perf_counter() - t0) * 1e3
+        return var.last_gpu_ms / rep["itr"], wall / rep["itr"], rep["itr"], mesh.N
+
+    K = 200
+    ms, wall, itr, N = solver_ms(lambda: Mesh(Box[0:1, 0:1], None, [128, 128], "cuda", "double"), poisson_bcs(2),
+                                 "jacobi", 1000, poisson_rhs_nd)
+    emit("jacobi 2-D 128x128 f64 dirichlet (config 1)", N, ms, 3, 8, {"wall_ms_per_iter": wall, "iters": itr})
+    ms, wall, itr, N = solver_ms(lambda: Mesh(Box[0:1, 0:1], None, [128, 128], "cuda", "double"), poisson_bcs(2),
+                                 "cg", 271, poisson_rhs_nd)
+    emit("cg 2-D 128x128 f64 dirichlet (config 1 inputs)", N, ms, 10, 8, {"wall_ms_per_iter": wall, "iters": itr})
+    n = 128 if q else 256
+    ms, wall, itr, N = solver_ms(lambda: Mesh(Box[0:1, 0:1, 0:1], None, [n, n, n], "cuda", "double"),
+                                 homogeneous_bcs(3, 0.0, "dirichlet"), "jacobi", K)
+    emit(f"jacobi 3-D {n}^3 f64 dirichlet", N, ms, 3, 8, {"wall_ms_per_iter": wall, "iters": itr})
+    ms, wall, itr, N = solver_ms(lambda: Mesh(Box[0:1, 0:1, 0:1], None, [n, n, n], "cuda", "double"),
+                                 mixed_bcs([0, 0, 0, 0, 1, 0], ["dirichlet", "neumann"] * 3), "bicgstab", 100)
+    emit(f"bicgstab 3-D {n}^3 f64 mixed", N, ms, 22, 8, {"wall_ms_per_iter": wall, "iters": itr})
+    m2 = 1024 if q else 4096
+    ms, wall, itr, N = solver_ms(lambda: Mesh(Box[0:1, 0:1], None, [m2, m2], "cuda", "double"),
+                                 homogeneous_bcs(2, 0.0, "dirichlet"), "cg", 100)
+    emit(f"cg 2-D {m2}x{m2} f64 dirichlet (generic kernels)", N, ms, 10, 8, {"wall_ms_per_iter": wall, "iters": itr})
+
+
+if __name__ == "__main__":
+    main()

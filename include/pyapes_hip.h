@@ -133,6 +133,11 @@ int pa_jacobi(pa_ctx* ctx, void* x, const void* rhs, double tol, int64_t max_it,
 int pa_euler_step(pa_ctx* ctx, const void* phi_in, void* phi_out, int div_kind, double u,
                   const void* u_field, double nu, double dt);
 
+/* nsteps Euler steps enqueued back to back, ping-ponging phi <-> tmp (final state in phi if nsteps
+ * is even, else in tmp); no host synchronisation */
+int pa_euler_march(pa_ctx* ctx, void* phi, void* tmp, int div_kind, double u, const void* u_field,
+                   double nu, double dt, int64_t nsteps);
+
 /* ---- stepwise CG (slab-decomposed multi-GPU driver and bench.py) -------
  * pa_cg above is the single-GPU loop.  The stepwise form lets a host driver put
  * the halo exchange and the scalar all-reduces (RCCL through torch.distributed)

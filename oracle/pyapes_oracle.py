@@ -640,6 +640,8 @@ def div_upwind_intended(u: float | Tensor, var: Tensor, mesh: OMesh) -> Tensor:
     """[NEW] first-order upwind advection as the reference's own test states it
     (tests/test_fdm.py:239):  sum_a [ u+ (phi_i - phi_{i-1}) + u- (phi_{i+1} - phi_i) ] / dx_a,
     u+ = max(u,0), u- = min(u,0); scalar phi uses adv[0] on every axis.
+    Evaluated in flux-difference form with the reciprocal spacing fl(1/dx_a) (one multiply per
+    axis instead of two divisions per node; the product path uses the same operation order).
     Wrap-around neighbours like every other roll stencil; boundary rows are
     meaningless and overwritten by the BC fill of the time-march."""
     adv = adv_tensor(u, var)
@@ -651,9 +653,10 @@ def div_upwind_intended(u: float | Tensor, var: Tensor, mesh: OMesh) -> Tensor:
         up = torch.max(adv[ai], zeros)
         um = torch.min(adv[ai], zeros)
         phi = var[ai]
-        bwd = (phi - torch.roll(phi, 1, a)) / dx[a]
-        fwd = (torch.roll(phi, -1, a) - phi) / dx[a]
-        out[0] += up * bwd + um * fwd
+        inv = torch.ones((), dtype=var.dtype) / dx[a]
+        bwd = phi - torch.roll(phi, 1, a)
+        fwd = torch.roll(phi, -1, a) - phi
+        out[0] += (up * bwd + um * fwd) * inv
     return out
 
 

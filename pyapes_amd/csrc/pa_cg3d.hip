@@ -50,6 +50,13 @@ struct Cg3dArgs {
   T* send_hi;
   double* partials;
   int tiles_j, tiles_k, chunks, reverse;
+  // single-field phases (2 = A x, 3 = explicit Euler step, 4 = Jacobi sweep): the field is `d`
+  const T* aux;         // Jacobi: rhs ; Euler: advection field u (or null -> scalar u)
+  T* out;               // result field
+  T p0, p1, u;          // Euler: nu, dt, scalar u ; Jacobi: omega
+  T hh[3], h2[3], ih[3];  // h, fl(2h), fl(1/h) per axis
+  int kind;             // Euler: PA_OP_DIV_*
+  int interior_only;    // A x: zero outside the interior set
 };
 
 __device__ __forceinline__ int pa_xcd_remap(int b, int nb) {
@@ -70,7 +77,7 @@ __global__ void __launch_bounds__(256) k_cg3d(Cg3dArgs<T> A) {
   constexpr int TJ = 4 * RJ, TK = 64 * VEC, TKP = TK + 2 * VEC;
   __shared__ __attribute__((aligned(16))) T tile[2][TJ + 2][TKP];
 
-  if (A.sc->done) return;
+  if (PHASE != 2 && PHASE != 3 && A.sc->done) return;
   const DevGeom& G = A.G;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int vb = pa_xcd_remap(blockIdx.x, gridDim.x);
@@ -100,6 +107,20 @@ __global__ void __launch_bounds__(256) k_cg3d(Cg3dArgs<T> A) {
     if (rc == 1) rowLo |= 1u << jj;
     if (rc == 2) rowHi |= 1u << jj;
   }
+  unsigned rowPLo = 0, rowPHi = 0, colPLo = 0, colPHi = 0;  // periodic rows of the central Div (fdc.py:596-602)
+  if (PHASE == 3) {
+#pragma unroll
+    for (int jj = 0; jj < RJ; ++jj) {
+      const int64_t jg = j0 + wv * RJ + jj;
+      if (G.bct[2] == 4 && jg == 1) rowPLo |= 1u << jj;
+      if (G.bct[3] == 4 && jg == G.n1 - 2) rowPHi |= 1u << jj;
+    }
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) {
+      if (G.bct[4] == 4 && kg + v == 1) colPLo |= 1u << v;
+      if (G.bct[5] == 4 && kg + v == G.n2 - 2) colPHi |= 1u << v;
+    }
+  }
   unsigned colS = 0, colShell = 0, colLo = 0, colHi = 0;
 #pragma unroll
   for (int v = 0; v < VEC; ++v) {
@@ -120,7 +141,8 @@ __global__ void __launch_bounds__(256) k_cg3d(Cg3dArgs<T> A) {
                          (hs_side ? pa_wrapmod(k0 + TK, G.n2) : pa_wrapmod(k0 - 1, G.n2));
 
   T beta = (T)0, alpha = (T)0;
-  if (PHASE == 0) beta = (T)A.sc->beta; else alpha = (T)A.sc->alpha;
+  if (PHASE == 0) beta = (T)A.sc->beta;
+  if (PHASE == 1) alpha = (T)A.sc->alpha;
 
   auto plane_of = [&](int q) -> int64_t { return rev ? (i1 - 1 - q) : (i0 + q); };
   auto pptr = [&](const Vec<T>& v, int64_t ii) -> const T* {
@@ -235,6 +257,11 @@ __global__ void __launch_bounds__(256) k_cg3d(Cg3dArgs<T> A) {
         rv[jj] = *reinterpret_cast<const V*>(A.rw + o);
       }
     }
+    if (PHASE == 4 || (PHASE == 3 && A.aux)) {  // Jacobi rhs / Euler advection field of this plane
+#pragma unroll
+      for (int jj = 0; jj < RJ; ++jj)
+        xv[jj] = *reinterpret_cast<const V*>(A.aux + ii * G.s0 + jrow[jj] * G.s1 + kc);
+    }
     // loads of plane m+2 (own cells + halo): in flight during the stencil below
     if (more) issue(plane_of(m + 2), w, m + 2 < CI);
 
@@ -248,6 +275,8 @@ __global__ void __launch_bounds__(256) k_cg3d(Cg3dArgs<T> A) {
       if (rc == 1) { cPi = A.lap.c23[0]; cCi = -A.lap.c23[0]; cMi = (T)0; }
       if (rc == 2) { cPi = (T)0; cCi = -A.lap.c23[0]; cMi = A.lap.c23[0]; }
     }
+    const bool iPLo = PHASE == 3 && G.bct[0] == 4 && gi == 1;
+    const bool iPHi = PHASE == 3 && G.bct[1] == 4 && gi == G.g0 - 2;
     V res[RJ];
 #pragma unroll
     for (int jj = 0; jj < RJ; ++jj) {
@@ -291,6 +320,65 @@ __global__ void __launch_bounds__(256) k_cg3d(Cg3dArgs<T> A) {
         ax = ax + s;
         if (hasc) ax = ax * cf;
         ax = ax * sgn;
+        if (PHASE == 3) {
+          // explicit Euler:  phi + dt (nu lap - adv)   (k_euler, pa_core.hip; ax = plain Laplacian)
+          const T uc = A.aux ? xv[jj][v] : A.u;
+          const T xp3[3] = {xpi, dn[v], xpk}, xm3[3] = {xmi, up[v], xmk};
+          const bool plo[3] = {iPLo, (bool)(rowPLo >> jj & 1), (bool)(colPLo >> v & 1)};
+          const bool phi_[3] = {iPHi, (bool)(rowPHi >> jj & 1), (bool)(colPHi >> v & 1)};
+          T adv = (T)0;
+#pragma unroll
+          for (int a = 0; a < 3; ++a) {
+            T t;
+            if (A.kind == 4) {  // upwind as the reference's test states it
+              const T upl = uc > (T)0 ? uc : (T)0, umi = uc < (T)0 ? uc : (T)0;
+              T bwd = xc - xm3[a];
+              T fwd = xp3[a] - xc;
+              t = upl * bwd;
+              T m2 = umi * fwd;
+              t = t + m2;
+              t = t * A.ih[a];
+            } else if (A.kind == 3) {  // literal reference upwind
+              const T cP = (T)2 * (uc < (T)0 ? uc : (T)0);
+              const T cC = (T)0 * ((T)2 * uc);
+              const T cM = (T)2 * (uc > (T)0 ? uc : (T)0);
+              t = cP * xp3[a];
+              T m2 = cC * xc;
+              t = t + m2;
+              m2 = cM * xm3[a];
+              t = t + m2;
+            } else {  // central, scalar u
+              T cP = uc, cC = (T)0 * uc, cM = -uc;
+              if (plo[a]) cM = (T)0;
+              if (phi_[a]) cP = (T)0;
+              cP = cP / A.h2[a];
+              cC = cC / A.h2[a];
+              cM = cM / A.h2[a];
+              t = cP * xp3[a];
+              T m2 = cC * xc;
+              t = t + m2;
+              m2 = cM * xm3[a];
+              t = t + m2;
+            }
+            adv = adv + t;
+          }
+          T q = A.p0 * ax;
+          q = q - adv;
+          q = A.p1 * q;
+          ax = xc + q;
+        }
+        if (PHASE == 4) {
+          // Jacobi:  x + omega (b - A x) / diag(A)   (k_jacobi, pa_core.hip)
+          T dg = cCi;
+          dg = dg + cCj;
+          dg = dg + cCk;
+          if (hasc) dg = dg * cf;
+          dg = dg * sgn;
+          T q = xv[jj][v] - ax;
+          q = q / dg;
+          q = A.p0 * q;
+          ax = xc + q;
+        }
         res[jj][v] = ax;
       }
     }
@@ -304,7 +392,18 @@ __global__ void __launch_bounds__(256) k_cg3d(Cg3dArgs<T> A) {
       for (int v = 0; v < VEC; ++v) {
         const bool inS = iS && (rowS >> jj & 1) && (colS >> v & 1);
         const T xc = ec[jj][v];
-        if (PHASE == 0) {
+        if (PHASE == 2) {
+          outd[v] = (inS || !A.interior_only) ? res[jj][v] : (T)0;
+        } else if (PHASE == 3) {
+          outd[v] = inS ? res[jj][v] : xc;
+        } else if (PHASE == 4) {
+          const T xn = inS ? res[jj][v] : xc;
+          const bool offshell = inS && !(iShell || (rowShell >> jj & 1) || (colShell >> v & 1));
+          T df = xn - xc;
+          T p2 = df * df;
+          s1 += offshell ? (double)p2 : 0.0;
+          outd[v] = xn;
+        } else if (PHASE == 0) {
           const T e = inS ? xc : (T)0;
           outd[v] = e;
           T p = e * res[jj][v];
@@ -329,7 +428,9 @@ __global__ void __launch_bounds__(256) k_cg3d(Cg3dArgs<T> A) {
       }
       if (kvalid && (rowValid >> jj & 1)) {
         const int64_t o = ii * G.s0 + jrow[jj] * G.s1 + kc;
-        if (PHASE == 0) {
+        if (PHASE >= 2) {
+          *reinterpret_cast<V*>(A.out + o) = outd;
+        } else if (PHASE == 0) {
           *reinterpret_cast<V*>(A.dnew + o) = outd;
         } else {
           *reinterpret_cast<V*>(A.x + o) = outx;
@@ -356,7 +457,7 @@ __global__ void __launch_bounds__(256) k_cg3d(Cg3dArgs<T> A) {
   if (PHASE == 0) {
     double s[1] = {s0};
     pa_block_reduce_store<1>(s, A.partials);
-  } else {
+  } else if (PHASE == 1 || PHASE == 4) {
     double s[2] = {s0, s1};
     pa_block_reduce_store<2>(s, A.partials);
   }
@@ -390,7 +491,7 @@ template <typename T, int RJ, int PHASE>
 static int blocks_per_cu() {
   static int cached = 0;
   if (!cached) {
-    const char* e = getenv(PHASE == 0 ? "PYAPES_HIP_BPC_A" : "PYAPES_HIP_BPC_B");
+    const char* e = getenv(PHASE == 0 ? "PYAPES_HIP_BPC_A" : (PHASE == 1 ? "PYAPES_HIP_BPC_B" : "PYAPES_HIP_BPC_X"));
     int n = e ? atoi(e) : 0;
     if (n <= 0) {
       if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_cg3d<T, RJ, PHASE>, 256, 0) != hipSuccess || n <= 0) n = 2;
@@ -420,11 +521,40 @@ static int launch_cg3d(pa_ctx* c, Cg3dArgs<T>& A) {
   if (dbg > 0) {
     --dbg;
     fprintf(stderr, "[pyapes_hip] k_cg3d phase %c: tiles %dx%d chunks %d (CI ~%lld) blocks %d, %d blocks/CU x %d CUs\n",
-            PHASE == 0 ? 'A' : 'B', A.tiles_j, A.tiles_k, chunks, (long long)(G.n0 / chunks), nblk,
+            (char)('A' + PHASE), A.tiles_j, A.tiles_k, chunks, (long long)(G.n0 / chunks), nblk,
             blocks_per_cu<T, RJ, PHASE>(), cus_of(c));
   }
   hipLaunchKernelGGL((k_cg3d<T, RJ, PHASE>), dim3(nblk), dim3(256), 0, c->stream, A);
   return nblk;
+}
+
+// rows per thread: 4 (16-row tiles) for big planes; fewer rows = more tiles = longer marching chunks
+// when a plane has too few 16-row tiles to give every resident workgroup >= 32 planes
+template <typename T>
+static int pick_rj(pa_ctx* c) {
+  if (const char* e = getenv("PYAPES_HIP_RJ")) {
+    int v = atoi(e);
+    if (v == 1 || v == 2 || v == 4) return v;
+  }
+  constexpr int VEC = VecOf<T>::N;
+  const DevGeom& G = c->G;
+  const int64_t tk = (G.n2 + 64 * VEC - 1) / (64 * VEC);
+  const int cap = cus_of(c) * 2;
+  for (int rj = 4; rj >= 2; rj >>= 1) {
+    const int64_t tiles = ((G.n1 + 4 * rj - 1) / (4 * rj)) * tk;
+    const int64_t chunks = cap / tiles > 0 ? cap / tiles : 1;
+    if (G.n0 / chunks >= 24) return rj;
+  }
+  return 1;
+}
+
+template <typename T, int PHASE>
+static int launch_any(pa_ctx* c, Cg3dArgs<T>& A) {
+  switch (pick_rj<T>(c)) {
+    case 1: return launch_cg3d<T, 1, PHASE>(c, A);
+    case 2: return launch_cg3d<T, 2, PHASE>(c, A);
+    default: return launch_cg3d<T, 4, PHASE>(c, A);
+  }
 }
 
 template <typename T>
@@ -446,7 +576,7 @@ int pa_cg3d_phase_a(pa_ctx* c, const DevEq<T>& E, Vec<T> r, Vec<T> d, T* dnew, d
   fill_common<T>(c, E, A);
   A.r = r; A.d = d; A.dnew = dnew; A.partials = partials;
   A.reverse = 0;
-  int n = launch_cg3d<T, 4, 0>(c, A);
+  int n = launch_any<T, 0>(c, A);
   if (n > 0 && hipGetLastError() != hipSuccess) { pa_set_err(c, "k_cg3d phase A launch failed"); return PA_E_HIP; }
   return n;
 }
@@ -462,10 +592,74 @@ int pa_cg3d_phase_b(pa_ctx* c, const DevEq<T>& E, Vec<T> d, T* x, T* r, double* 
   A.d = d; A.x = x; A.rw = r; A.partials = partials;
   A.send_lo = (T*)c->r_send_lo; A.send_hi = (T*)c->r_send_hi;
   A.reverse = 1;
-  int n = launch_cg3d<T, 4, 1>(c, A);
+  int n = launch_any<T, 1>(c, A);
   if (n > 0 && hipGetLastError() != hipSuccess) { pa_set_err(c, "k_cg3d phase B launch failed"); return PA_E_HIP; }
   return n;
 }
+
+// ---- single-field phases: A x (one Laplacian term), explicit Euler step, Jacobi sweep -----------
+template <typename T>
+static void fill_h(const pa_ctx* c, Cg3dArgs<T>& A) {
+  for (int a = 0; a < 3; ++a) {
+    T h = (T)c->dx[a];
+    A.hh[a] = h;
+    A.h2[a] = (T)2 * h;
+    A.ih[a] = (T)1 / h;
+  }
+}
+
+template <typename T>
+int pa_tile3d_aop(pa_ctx* c, const DevEq<T>& E, Vec<T> x, T* y, int interior_only) {
+  if (!cg3d_covered<T>(c, E, x.p, y, y)) return 0;
+  if (((uintptr_t)x.glo | (uintptr_t)x.ghi) & 15) return 0;
+  Cg3dArgs<T> A;
+  memset(&A, 0, sizeof(A));
+  fill_common<T>(c, E, A);
+  A.d = x; A.out = y; A.interior_only = interior_only;
+  int n = launch_any<T, 2>(c, A);
+  if (n > 0 && hipGetLastError() != hipSuccess) { pa_set_err(c, "k_cg3d A x launch failed"); return PA_E_HIP; }
+  return n;
+}
+
+template <typename T>
+int pa_tile3d_euler(pa_ctx* c, Vec<T> phi, T* out, int kind, double u, const void* u_field, double nu, double dt) {
+  DevEq<T> E;
+  pa_term t;
+  memset(&t, 0, sizeof(t));
+  t.kind = PA_OP_LAPLACIAN; t.sign = 1.0;
+  pa_build_eq<T>(c, 1, &t, E);
+  if (!cg3d_covered<T>(c, E, phi.p, out, u_field ? u_field : out)) return 0;
+  if (((uintptr_t)phi.glo | (uintptr_t)phi.ghi) & 15) return 0;
+  if (kind == PA_OP_DIV_CENTRAL && u_field) return 0;  // needs u at the neighbours: generic kernel
+  Cg3dArgs<T> A;
+  memset(&A, 0, sizeof(A));
+  fill_common<T>(c, E, A);
+  fill_h<T>(c, A);
+  A.d = phi; A.out = out; A.aux = (const T*)u_field; A.u = (T)u; A.p0 = (T)nu; A.p1 = (T)dt; A.kind = kind;
+  int n = launch_any<T, 3>(c, A);
+  if (n > 0 && hipGetLastError() != hipSuccess) { pa_set_err(c, "k_cg3d Euler launch failed"); return PA_E_HIP; }
+  return n;
+}
+
+template <typename T>
+int pa_tile3d_jacobi(pa_ctx* c, const DevEq<T>& E, Vec<T> x, const T* rhs, T* xnew, double omega, double* partials) {
+  if (!cg3d_covered<T>(c, E, x.p, rhs, xnew)) return 0;
+  if (((uintptr_t)x.glo | (uintptr_t)x.ghi) & 15) return 0;
+  Cg3dArgs<T> A;
+  memset(&A, 0, sizeof(A));
+  fill_common<T>(c, E, A);
+  A.d = x; A.out = xnew; A.aux = rhs; A.p0 = (T)omega; A.partials = partials;
+  int n = launch_any<T, 4>(c, A);
+  if (n > 0 && hipGetLastError() != hipSuccess) { pa_set_err(c, "k_cg3d Jacobi launch failed"); return PA_E_HIP; }
+  return n;
+}
+
+template int pa_tile3d_aop<float>(pa_ctx*, const DevEq<float>&, Vec<float>, float*, int);
+template int pa_tile3d_aop<double>(pa_ctx*, const DevEq<double>&, Vec<double>, double*, int);
+template int pa_tile3d_euler<float>(pa_ctx*, Vec<float>, float*, int, double, const void*, double, double);
+template int pa_tile3d_euler<double>(pa_ctx*, Vec<double>, double*, int, double, const void*, double, double);
+template int pa_tile3d_jacobi<float>(pa_ctx*, const DevEq<float>&, Vec<float>, const float*, float*, double, double*);
+template int pa_tile3d_jacobi<double>(pa_ctx*, const DevEq<double>&, Vec<double>, const double*, double*, double, double*);
 
 template int pa_cg3d_phase_a<float>(pa_ctx*, const DevEq<float>&, Vec<float>, Vec<float>, float*, double*);
 template int pa_cg3d_phase_a<double>(pa_ctx*, const DevEq<double>&, Vec<double>, Vec<double>, double*, double*);

@@ -1054,6 +1054,7 @@ static void fill_coefs(const pa_ctx* c, DevEq<T>& E) {
     T th = (T)2 * h;
     T third = (T)(1.0 / 3.0);
     E.grd.h[a] = h;
+    E.grd.ih[a] = (T)1 / h;
     E.grd.h2[a] = th;
     E.grd.g[a] = (T)1 / th;
     E.grd.mg[a] = (T)-1 / th;
@@ -1358,8 +1359,11 @@ static int aop_t(pa_ctx* c, const T* x, T* y, int interior_only, int nterms, con
     xv.glo = (const T*)c->x_glo;
     xv.ghi = (const T*)c->x_ghi;
   }
-  hipLaunchKernelGGL(k_aop<T>, dim3(pa_grid_blocks(c->G.ncell)), dim3(PA_BLOCK), 0, c->stream, c->G, E, xv, y,
-                     interior_only);
+  int fr = pa_tile3d_aop<T>(c, E, xv, y, interior_only);
+  if (fr < 0) return fr;
+  if (fr == 0)
+    hipLaunchKernelGGL(k_aop<T>, dim3(pa_grid_blocks(c->G.ncell)), dim3(PA_BLOCK), 0, c->stream, c->G, E, xv, y,
+                       interior_only);
   PA_HIP(c, hipGetLastError());
   return PA_OK;
 }
@@ -1463,8 +1467,11 @@ static int euler_t(pa_ctx* c, const T* in, T* out, int kind, double u, const voi
     if (!c->x_glo || !c->x_ghi) { pa_set_err(c, "pa_euler_step on a slab needs ghost planes"); return PA_E_STATE; }
     pv.glo = (const T*)c->x_glo; pv.ghi = (const T*)c->x_ghi;
   }
-  hipLaunchKernelGGL(k_euler<T>, dim3(pa_grid_blocks(c->G.ncell)), dim3(PA_BLOCK), 0, c->stream, c->G, El, Ea, pv,
-                     out, (T)nu, (T)dt);
+  int fr = pa_tile3d_euler<T>(c, pv, out, kind, u, u_field, nu, dt);
+  if (fr < 0) return fr;
+  if (fr == 0)
+    hipLaunchKernelGGL(k_euler<T>, dim3(pa_grid_blocks(c->G.ncell)), dim3(PA_BLOCK), 0, c->stream, c->G, El, Ea, pv,
+                       out, (T)nu, (T)dt);
   PA_HIP(c, hipGetLastError());
   return bc_apply_auto<T>(c, out, false);
 }
@@ -1543,6 +1550,23 @@ int pa_euler_step(pa_ctx* c, const void* in, void* out, int kind, double u, cons
   PA_HIP(c, hipSetDevice(c->device));
   return c->dtype == PA_F64 ? euler_t<double>(c, (const double*)in, (double*)out, kind, u, u_field, nu, dt)
                             : euler_t<float>(c, (const float*)in, (float*)out, kind, u, u_field, nu, dt);
+}
+
+int pa_euler_march(pa_ctx* c, void* phi, void* tmp, int kind, double u, const void* u_field, double nu, double dt,
+                   int64_t nsteps) {
+  if (!c || !c->grid_set) return PA_E_STATE;
+  int rc = check_div_kind(c, kind);
+  if (rc) return rc;
+  if (phi == tmp || nsteps < 0) { pa_set_err(c, "pa_euler_march: bad buffers / step count"); return PA_E_ARG; }
+  PA_HIP(c, hipSetDevice(c->device));
+  void* buf[2] = {phi, tmp};
+  for (int64_t s = 0; s < nsteps; ++s) {
+    rc = c->dtype == PA_F64
+             ? euler_t<double>(c, (const double*)buf[s & 1], (double*)buf[(s + 1) & 1], kind, u, u_field, nu, dt)
+             : euler_t<float>(c, (const float*)buf[s & 1], (float*)buf[(s + 1) & 1], kind, u, u_field, nu, dt);
+    if (rc) return rc;
+  }
+  return PA_OK;
 }
 
 }  // extern "C"
@@ -1957,8 +1981,13 @@ static int jacobi_run_t(pa_ctx* c, T* x, const T* rhs, double tol, int64_t max_i
     // two sweeps per round so that the iterate is back in the caller's buffer at every poll
     for (int half = 0; half < 2; ++half) {
       Vec<T> xv = pa_vec_self<T>(c, buf[cur]);
-      hipLaunchKernelGGL(k_jacobi<T>, dim3(nblk), dim3(PA_BLOCK), 0, c->stream, G, E, c->sc, xv, rhs, buf[cur ^ 1],
-                         (T)omega, part);
+      int used = pa_tile3d_jacobi<T>(c, E, xv, rhs, buf[cur ^ 1], omega, part);
+      if (used < 0) return used;
+      if (used == 0) {
+        hipLaunchKernelGGL(k_jacobi<T>, dim3(nblk), dim3(PA_BLOCK), 0, c->stream, G, E, c->sc, xv, rhs, buf[cur ^ 1],
+                           (T)omega, part);
+        used = nblk;
+      }
       int nsh = 0;
       // NOTE: when done is set the sweep kernels return early, so buf[cur^1] is stale: the copy-back
       // below is guarded by the iteration parity recorded on the device (itr).
@@ -1968,7 +1997,7 @@ static int jacobi_run_t(pa_ctx* c, T* x, const T* rhs, double tol, int64_t max_i
         hipLaunchKernelGGL(k_shell<T>, dim3(nsh), dim3(PA_BLOCK), 0, c->stream, G, c->sc, (const T*)buf[cur ^ 1],
                            (T*)c->scr[SCR_SHELL], part2, 1);
       }
-      hipLaunchKernelGGL(k_jacobi_post<T>, dim3(1), dim3(PA_BLOCK), 0, c->stream, c->sc, part, nblk, part2, nsh,
+      hipLaunchKernelGGL(k_jacobi_post<T>, dim3(1), dim3(PA_BLOCK), 0, c->stream, c->sc, part, used, part2, nsh,
                          pa_sums(c));
       cur ^= 1;
       ++enq;

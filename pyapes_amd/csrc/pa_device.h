@@ -48,6 +48,7 @@ struct GradCoef {  // fdc.py:543-609 with gamma = 1
   T hi_m[3];   // fl(fl(-1 - 1/3) / 2h)             Am
   T h2[3];     // fl(2h)
   T h[3];      // h
+  T ih[3];     // fl(1 / h)
 };
 
 template <typename T>
@@ -266,11 +267,12 @@ __device__ __forceinline__ T pa_apply_terms(const DevGeom& G, const DevEq<T>& E,
         if (!G.act[a]) continue;
         T xp, xm;
         pa_nbrs<T>(G, acc, a, i, j, k, xp, xm);
-        T bwd = (xc - xm) / E.grd.h[a];
-        T fwd = (xp - xc) / E.grd.h[a];
+        T bwd = xc - xm;
+        T fwd = xp - xc;
         T s = upl * bwd;
         T m = umi * fwd;
         s = s + m;
+        s = s * E.grd.ih[a];
         ax = ax + s;
       }
     }

@@ -129,9 +129,9 @@ class HipContext:
         self._keep["terms"] = (arr, keep)
         self._rc(self.lib.pa_eq_set(self.h, len(terms), arr))
 
-    def aop(self, x: Tensor, interior_only: bool = False) -> Tensor:
+    def aop(self, x: Tensor, interior_only: bool = False, out: Tensor | None = None) -> Tensor:
         x = self._field(x, "Aop")
-        y = torch.empty_like(x)
+        y = torch.empty_like(x) if out is None else self._field(out, "Aop out")
         self._rc(self.lib.pa_aop(self.h, self._ptr(x), self._ptr(y), 1 if interior_only else 0))
         return y
 
@@ -139,21 +139,23 @@ class HipContext:
         self._rc(self.lib.pa_rhs_adjust(self.h, self._ptr(self._field(rhs, "rhs"))))
 
     # -- explicit operators ------------------------------------------------------------
-    def laplacian(self, x: Tensor, edge: bool) -> Tensor:
+    def laplacian(self, x: Tensor, edge: bool, out: Tensor | None = None) -> Tensor:
         x = self._field(x, "laplacian")
-        y = torch.empty_like(x)
+        y = torch.empty_like(x) if out is None else self._field(out, "laplacian out")
         self._rc(self.lib.pa_laplacian(self.h, self._ptr(x), self._ptr(y), int(edge)))
         return y
 
-    def grad(self, x: Tensor, edge: bool) -> Tensor:
+    def grad(self, x: Tensor, edge: bool, out: Tensor | None = None) -> Tensor:
         x = self._field(x, "grad")
-        y = torch.empty((self.mesh.dim, *self.mesh.nx), dtype=self.dtype, device=self.device)
+        y = out if out is not None else torch.empty((self.mesh.dim, *self.mesh.nx), dtype=self.dtype,
+                                                    device=self.device)
+        assert y.is_contiguous() and y.numel() == self.mesh.dim * self.mesh.N
         self._rc(self.lib.pa_grad(self.h, self._ptr(x), self._ptr(y), int(edge)))
         return y
 
-    def div(self, kind: int, u: float | Tensor, x: Tensor) -> Tensor:
+    def div(self, kind: int, u: float | Tensor, x: Tensor, out: Tensor | None = None) -> Tensor:
         x = self._field(x, "div")
-        y = torch.empty_like(x)
+        y = torch.empty_like(x) if out is None else self._field(out, "div out")
         uf = None
         us = 0.0
         if isinstance(u, Tensor):
@@ -162,6 +164,21 @@ class HipContext:
             us = float(u)
         self._rc(self.lib.pa_div(self.h, kind, us, self._ptr(uf), self._ptr(x), self._ptr(y)))
         return y
+
+    def euler_march(self, phi: Tensor, tmp: Tensor, kind: int, u: float | Tensor, nu: float, dt: float,
+                    nsteps: int) -> Tensor:
+        """``nsteps`` explicit Euler steps enqueued back to back, ping-ponging phi <-> tmp; returns the
+        tensor that holds the final state."""
+        phi = self._field(phi, "euler_march")
+        tmp = self._field(tmp, "euler_march")
+        uf, us = None, 0.0
+        if isinstance(u, Tensor):
+            uf = self._field(u if u.dim() == self.mesh.dim else u[0], "advection tensor")
+        else:
+            us = float(u)
+        self._rc(self.lib.pa_euler_march(self.h, self._ptr(phi), self._ptr(tmp), kind, us, self._ptr(uf),
+                                         float(nu), float(dt), int(nsteps)))
+        return phi if nsteps % 2 == 0 else tmp
 
     def euler_step(self, phi: Tensor, out: Tensor, kind: int, u: float | Tensor, nu: float, dt: float) -> None:
         phi = self._field(phi, "euler_step")

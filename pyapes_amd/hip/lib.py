@@ -70,6 +70,7 @@ SIGNATURES: dict[str, tuple[Any, list[Any]]] = {
     "pa_bicgstab": (C.c_int, [_VP, _VP, _VP, C.c_double, C.c_int64, C.POINTER(PaReport)]),
     "pa_jacobi": (C.c_int, [_VP, _VP, _VP, C.c_double, C.c_int64, C.c_double, C.POINTER(PaReport)]),
     "pa_euler_step": (C.c_int, [_VP, _VP, _VP, C.c_int, C.c_double, _VP, C.c_double, C.c_double]),
+    "pa_euler_march": (C.c_int, [_VP, _VP, _VP, C.c_int, C.c_double, _VP, C.c_double, C.c_double, C.c_int64]),
     "pa_cg_begin": (C.c_int, [_VP, _VP, _VP, C.c_double, C.c_int64]),
     "pa_cg_phase_a": (C.c_int, [_VP]),
     "pa_cg_phase_b": (C.c_int, [_VP]),

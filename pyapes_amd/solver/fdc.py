@@ -136,7 +136,7 @@ class Laplacian(Discretizer):
         out = torch.empty_like(var())
         for d in range(var.dim):
             ctx.bind_bcs(var(), A_coeffs.bcs, d)
-            out[d] = ctx.laplacian(var()[d], edge)
+            ctx.laplacian(var()[d], edge, out=out[d])
         return out
 
 
@@ -158,11 +158,11 @@ class Grad(Discretizer):
         require_gpu(var(), "FDC.grad")
         ctx = context_for(var.mesh)
         edge = self._edge()
-        comps = []
+        out = torch.empty((var.dim, var.mesh.dim, *var.mesh.nx), dtype=var().dtype, device=var().device)
         for d in range(var.dim):
             ctx.bind_bcs(var(), A_coeffs.bcs, d)
-            comps.append(ctx.grad(var()[d], edge))
-        return torch.stack(comps)
+            ctx.grad(var()[d], edge, out=out[d])
+        return out
 
 
 class Div(Discretizer):
@@ -199,8 +199,9 @@ class Div(Discretizer):
         ctx = context_for(var.mesh)
         ctx.bind_bcs(var(), A_coeffs.bcs, 0)
         u = _adv_of(A_coeffs.var_j, var)
-        out = ctx.div(div_kind(A_coeffs.limiter, A_coeffs.compat), u, var()[0])
-        return out.unsqueeze(0)
+        out = torch.empty_like(var())
+        ctx.div(div_kind(A_coeffs.limiter, A_coeffs.compat), u, var()[0], out=out[0])
+        return out
 
 
 class FDC:

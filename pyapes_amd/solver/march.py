@@ -31,3 +31,25 @@ def euler_step(phi: Field, u: float | Tensor | Field, nu: float, dt: float,
     ctx.euler_step(phi()[0], out[0], kind, _adv_of(u, phi), nu, dt)
     phi.set_var_tensor(out)
     return phi
+
+
+def euler_march(phi: Field, u: float | Tensor | Field, nu: float, dt: float, nsteps: int,
+                config: dict | None = None) -> Field:
+    """``nsteps`` explicit Euler steps with no host work in between (the whole march is enqueued by one
+    C-ABI call: fused step kernel + ordered BC fill per step, ping-pong buffers)."""
+    require_gpu(phi(), "euler_march")
+    if phi.dim != 1:
+        raise NotImplementedError("pyapes_amd: euler_march is for scalar fields")
+    cfg = (config or {}).get("div", {"limiter": "upwind"})
+    kind = div_kind(cfg.get("limiter", "upwind").lower(), bool(cfg.get("compat", False)))
+    ctx = context_for(phi.mesh)
+    ctx.bind_bcs(phi(), phi.bcs, 0)
+    if not phi().is_contiguous():
+        phi.set_var_tensor(phi().contiguous())
+    tmp = torch.empty_like(phi())
+    final = ctx.euler_march(phi()[0], tmp[0], kind, _adv_of(u, phi), nu, dt, nsteps)
+    if final.data_ptr() == tmp[0].data_ptr():
+        phi.set_var_tensor(tmp)
+    if hasattr(phi, "_t"):
+        phi.update_time(dt * nsteps)
+    return phi

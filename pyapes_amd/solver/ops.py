@@ -71,4 +71,6 @@ def _Aop(target: Field, eqs: dict[int, OPStype]) -> Tensor:
     terms, bcs = terms_of(eqs)
     ctx.bind_bcs(target(), bcs, 0)
     ctx.set_terms(terms)
-    return ctx.aop(target()[0], interior_only=False).unsqueeze(0)
+    out = torch.empty_like(target())
+    ctx.aop(target()[0], interior_only=False, out=out[0])
+    return out
