@@ -712,6 +712,45 @@ __global__ void __launch_bounds__(PA_BLOCK) k_cg_post_b(SolverScalars* sc, const
   }
 }
 
+// overlap mode: the part of post_b the next phase A needs (sum r.r -> beta) ...
+template <typename T>
+__global__ void __launch_bounds__(PA_BLOCK) k_cg_post_b1(SolverScalars* sc, const double* partials, int nblk,
+                                                          double* sums) {
+  __shared__ double sm[PA_BLOCK / 64];
+  if (sc->done) return;
+  double rr = pa_reduce_partials(partials, nblk, 2, 0, sm);
+  double dx2 = pa_reduce_partials(partials, nblk, 2, 1, sm);
+  if (threadIdx.x == 0) {
+    sums[1] = rr;
+    sums[2] = dx2;
+    T rr_new = (T)rr;
+    T rr_old = (T)sc->rr;
+    sc->rr_old = (double)rr_old;
+    sc->beta = (double)(rr_new / rr_old);
+    sc->rr = (double)rr_new;
+  }
+}
+
+// ... and the part that needs the BC-filled boundary shell (stop test, iteration count, done)
+template <typename T>
+__global__ void __launch_bounds__(PA_BLOCK) k_cg_post_b2(SolverScalars* sc, const double* partials_shell,
+                                                          int nblk_shell, const double* sums) {
+  __shared__ double sm[PA_BLOCK / 64];
+  if (sc->done) return;
+  double sh = nblk_shell > 0 ? pa_reduce_partials(partials_shell, nblk_shell, 1, 0, sm) : 0.0;
+  if (threadIdx.x == 0) {
+    T tol = (T)sqrt(sums[2] + sh);
+    sc->tol = (double)tol;
+    if (isnan(tol) || isinf(tol)) {
+      sc->err = 1;
+      sc->done = 1;
+      return;
+    }
+    sc->itr += 1;
+    if (sc->itr > sc->max_it || !(sc->tol > sc->tolerance)) sc->done = 1;
+  }
+}
+
 template <typename T>
 __global__ void __launch_bounds__(PA_BLOCK) k_cg_post_init(SolverScalars* sc, const double* partials, int nblk,
                                                             double* sums, int stage) {
@@ -1012,6 +1051,9 @@ __global__ void __launch_bounds__(PA_BLOCK) k_bicg_post(SolverScalars* sc, const
 
 static thread_local char g_create_err[512] = "";
 
+// stream for the BC / shell helpers: the ctx stream, or the side stream while overlapping
+static inline hipStream_t pa_ls(const pa_ctx* c) { return c->launch_stream ? c->launch_stream : c->stream; }
+
 static inline const int* pa_done_flag(const pa_ctx* c) { return &c->sc->done; }
 
 void pa_set_err(pa_ctx* c, const char* fmt, ...) {
@@ -1164,7 +1206,7 @@ static int bc_apply_t(pa_ctx* c, T* x, bool guarded = false) {
     }
     int64_t nu = (a == 0) ? G.n1 : G.n0;
     int64_t nv = (a == 2) ? G.n1 : G.n2;
-    hipLaunchKernelGGL(k_bc_face<T>, dim3(pa_grid_blocks(nu * nv)), dim3(PA_BLOCK), 0, c->stream, G, x, B);
+    hipLaunchKernelGGL(k_bc_face<T>, dim3(pa_grid_blocks(nu * nv)), dim3(PA_BLOCK), 0, pa_ls(c), G, x, B);
   }
   PA_HIP(c, hipGetLastError());
   return PA_OK;
@@ -1240,6 +1282,9 @@ int pa_ctx_destroy(pa_ctx* c) {
   if (c->ev1) (void)hipEventDestroy(c->ev1);
   for (int q = 0; q < 4; ++q)
     if (c->pev[q]) (void)hipEventDestroy(c->pev[q]);
+  if (c->side) { (void)hipStreamSynchronize(c->side); (void)hipStreamDestroy(c->side); }
+  if (c->ev_k2) (void)hipEventDestroy(c->ev_k2);
+  if (c->ev_bc) (void)hipEventDestroy(c->ev_bc);
   delete c;
   return PA_OK;
 }
@@ -1683,9 +1728,9 @@ static int bc_shell_fused(pa_ctx* c, T* x, double* part2, int with_delta, bool g
     sn = base + (c->shell_cur ? 0 : half);
   }
   const int* done = guarded ? pa_done_flag(c) : nullptr;
-  hipLaunchKernelGGL(k_bc_compute<T>, dim3(nb), dim3(PA_BLOCK), 0, c->stream, c->G, B, done, (const T*)x,
+  hipLaunchKernelGGL(k_bc_compute<T>, dim3(nb), dim3(PA_BLOCK), 0, pa_ls(c), c->G, B, done, (const T*)x,
                      (const T*)so, sn, part2, with_delta);
-  hipLaunchKernelGGL(k_bc_scatter<T>, dim3(nb), dim3(PA_BLOCK), 0, c->stream, c->G, done, x, (const T*)sn);
+  hipLaunchKernelGGL(k_bc_scatter<T>, dim3(nb), dim3(PA_BLOCK), 0, pa_ls(c), c->G, done, x, (const T*)sn);
   if (!standalone) c->shell_cur ^= 1;
   if (nsh) *nsh = nb;
   PA_HIP(c, hipGetLastError());
@@ -1706,7 +1751,16 @@ static int init_scalars(pa_ctx* c, double tol, int64_t max_it) {
   return PA_OK;
 }
 
+static int pa_join_side(pa_ctx* c) {
+  if (c->side_pending) {
+    PA_HIP(c, hipStreamWaitEvent(c->stream, c->ev_bc, 0));
+    c->side_pending = 0;
+  }
+  return PA_OK;
+}
+
 static int read_scalars(pa_ctx* c) {
+  if (int rcj = pa_join_side(c)) return rcj;
   PA_HIP(c, hipMemcpyAsync(c->h_sc, c->sc, sizeof(SolverScalars), hipMemcpyDeviceToHost, c->stream));
   PA_HIP(c, hipStreamSynchronize(c->stream));
   return PA_OK;
@@ -1747,6 +1801,23 @@ static int cg_begin_t(pa_ctx* c, T* x, const T* rhs, double tol, int64_t max_it)
   c->bc_static = bc_is_static(c);
   c->bc_fused = bc_fusable(c);
   c->shell_cur = 0;
+  c->side_pending = 0;
+  c->launch_stream = nullptr;
+  {
+    // Opt-in (PYAPES_HIP_OVERLAP=1).  Measured on MI355X at 512^3 fp64 periodic: no gain (1.72 vs
+    // 1.71 ms / iteration) -- the chip is bandwidth-bound either way and the strided face kernels
+    // take their HBM time from phase A instead of from the critical path.
+    const char* ov = getenv("PYAPES_HIP_OVERLAP");
+    c->overlap = (!c->slab && !c->bc_static && ov && atoi(ov) != 0) ? 1 : 0;
+    if (c->overlap && !c->side) {
+      if (hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking) != hipSuccess ||
+          hipEventCreateWithFlags(&c->ev_k2, hipEventDisableTiming) != hipSuccess ||
+          hipEventCreateWithFlags(&c->ev_bc, hipEventDisableTiming) != hipSuccess) {
+        c->overlap = 0;
+        (void)hipGetLastError();
+      }
+    }
+  }
   c->solver_live = 1;
   DevEq<T> E;
   pa_build_eq<T>(c, c->nterms, c->terms, E);
@@ -1865,6 +1936,7 @@ int pa_cg_phase_b_t(pa_ctx* c, int stage_post) {
   double* part = (double*)c->scr[SCR_PART];
   double* part2 = (double*)c->scr[SCR_PART2];
   Vec<T> dv = cg_vec<T>(c, d, 1);
+  if (int rcj = pa_join_side(c)) return rcj;  // x and the done flag of the previous iteration are final
   if (c->profile) (void)hipEventRecord(c->pev[2], c->stream);
   int rc = pa_cg3d_phase_b<T>(c, E, dv, x, r, part);
   if (rc < 0) return rc;
@@ -1877,6 +1949,32 @@ int pa_cg_phase_b_t(pa_ctx* c, int stage_post) {
   if (c->profile) pa_profile_stop(c, 1);
   c->b_blocks = used_blocks;
   if (c->slab) {  // BC fill + shell + reduction happen in pa_cg_bc, after the driver's plane exchange
+    PA_HIP(c, hipGetLastError());
+    return PA_OK;
+  }
+  if (c->overlap && stage_post == 2) {
+    // main stream: beta for the next phase A.  side stream: BC fill, shell term, stop test -- they
+    // overlap phase A of the next iteration and are joined in front of its phase B / any read-back.
+    hipLaunchKernelGGL(k_cg_post_b1<T>, dim3(1), dim3(PA_BLOCK), 0, c->stream, c->sc, part, used_blocks, pa_sums(c));
+    PA_HIP(c, hipEventRecord(c->ev_k2, c->stream));
+    PA_HIP(c, hipStreamWaitEvent(c->side, c->ev_k2, 0));
+    c->launch_stream = c->side;
+    int nsh2 = 0;
+    if (c->bc_fused) {
+      rc = bc_shell_fused<T>(c, x, part2, 1, true, &nsh2, false);
+    } else {
+      rc = bc_apply_t<T>(c, x, true);
+      nsh2 = shell_blocks(c);
+      if (!rc)
+        hipLaunchKernelGGL(k_shell<T>, dim3(nsh2), dim3(PA_BLOCK), 0, c->side, G, c->sc, (const T*)x,
+                           (T*)c->scr[SCR_SHELL], part2, 1);
+    }
+    c->launch_stream = nullptr;
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_cg_post_b2<T>, dim3(1), dim3(PA_BLOCK), 0, c->side, c->sc, (const double*)part2, nsh2,
+                       (const double*)pa_sums(c));
+    PA_HIP(c, hipEventRecord(c->ev_bc, c->side));
+    c->side_pending = 1;
     PA_HIP(c, hipGetLastError());
     return PA_OK;
   }
@@ -2191,7 +2289,7 @@ int pa_cg_iterate(pa_ctx* c, int64_t n) {
     rc = c->dtype == PA_F64 ? pa_cg_phase_b_t<double>(c, 2) : pa_cg_phase_b_t<float>(c, 2);
     if (rc) return rc;
   }
-  return PA_OK;
+  return pa_join_side(c);  // the ctx stream now covers everything that was enqueued
 }
 
 int pa_profile_set(pa_ctx* c, int on) {

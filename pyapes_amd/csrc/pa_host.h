@@ -56,6 +56,12 @@ struct pa_ctx {
   // CG state
   int solver_live = 0, cur = 0, bc_static = 0, pending_init_logic = 0, b_blocks = 0;
   int bc_fused = 0, shell_cur = 0;  // fused BC fill: which half of SCR_SHELL holds x_old on the shell
+  // overlap: the BC fill + boundary-shell part of the stop test of iteration k run on a second
+  // stream beside phase A of iteration k+1 (they touch x / the shell only; phase A touches r, d)
+  int overlap = 0, side_pending = 0;
+  hipStream_t side = nullptr;
+  hipStream_t launch_stream = nullptr;  // stream the BC helpers launch on (main unless overlapping)
+  hipEvent_t ev_k2 = nullptr, ev_bc = nullptr;
   void* cg_x = nullptr;
   // slab decomposition (P > 1): externally owned exchange buffers
   int slab = 0;
