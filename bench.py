@@ -8,7 +8,7 @@ stop test) over the whole grid.  Default workload at every N: BASELINE config 3,
 configuration the metric is quoted on -- 3-D Poisson 512^3 fp64, periodic BCs, CG --
 slab-decomposed along axis 0 for N > 1 (strong scaling: the global grid is fixed).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c3|c2|c5] [--n n0,n1,n2]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c3|c2|c5] [--size n0,n1,n2]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 Prints ONE JSON line on rank 0.
@@ -133,7 +133,7 @@ def main():
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="c3", choices=list(WORKLOADS))
-    ap.add_argument("--n", default=None, help="override global node counts n0,n1,n2 (testing)")
+    ap.add_argument("--size", dest="n", default=None, help="override global node counts n0,n1,n2 (testing)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline-probe", action="store_true")
     args = ap.parse_args()
@@ -147,6 +147,10 @@ def main():
         args.gpus = world
 
     assert torch.cuda.is_available(), "bench.py needs the MI355X; there is no CPU path"
+    # rehearsal switches (one-GPU box): BENCH_SINGLE_DEVICE=1 puts every rank on cuda:0,
+    # BENCH_BACKEND=gloo moves the planes through the host instead of RCCL
+    if os.environ.get("BENCH_SINGLE_DEVICE"):
+        local_rank = 0
     torch.cuda.set_device(local_rank)
 
     from pyapes_amd.geometry import Box
@@ -164,7 +168,11 @@ def main():
     if world > 1:
         import torch.distributed as dist_mod
         dist = dist_mod
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        backend = os.environ.get("BENCH_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
 
     mesh = Mesh(Box([0.0, 0.0, 0.0], list(upper)), None, list(gn), "cuda", dtype,
                 slab=(rank, world) if world > 1 else None)
@@ -234,8 +242,9 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         secs = float(t.item())
         ev_ms = secs * 1e3
-        rep = drv.end()
+        rep = drv.be.report()
         assert rep.itr == W + K and rep.status == 0, f"work was skipped: itr={rep.itr} status={rep.status}"
+        assert bool(torch.isfinite(var()).all()), "iterate became non-finite inside the timed region"
         roof = None
         if not args.no_roofline_probe:
             pr = drv.profile(min(K, 10))
@@ -247,6 +256,7 @@ def main():
                     "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
                     "phase_a_ms": pr["phase_a_ms"], "phase_b_ms": pr["phase_b_ms"],
                     "alg_bytes_per_launch": alg_bytes, "scope": "rank 0, per GPU"}
+        drv.end()
 
     if rank == 0:
         value = cells_global * K / secs
@@ -286,6 +296,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline(kind, dtype)
         print(json.dumps(out))
     if dist is not None:
+        dist.barrier()
         dist.destroy_process_group()
 
 
