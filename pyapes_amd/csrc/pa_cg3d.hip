@@ -225,15 +225,30 @@ __global__ void __launch_bounds__(256) k_cg3d(Cg3dArgs<T> A) {
   w.sd = (T)0; w.sr = (T)0;
 
   // ---- prologue -----------------------------------------------------------------------
-  issue(plane_of(-1), w, false);
-  finish_own(w, ea);
+  const bool act0 = G.act[0] != 0;   // 2-D meshes occupy internal axes 1,2: a single plane, no i-neighbours
+  if (act0) {
+    issue(plane_of(-1), w, false);
+    finish_own(w, ea);
+  } else {
+#pragma unroll
+    for (int jj = 0; jj < RJ; ++jj)
+#pragma unroll
+      for (int v = 0; v < VEC; ++v) ea[jj][v] = (T)0;
+  }
   issue(plane_of(0), w, true);
   finish_own(w, ec);
   finish_halo(w, hv, hs);
   stage(0, ec, hv, hs);
-  issue(plane_of(1), w, CI > 1);
-  finish_own(w, eb);
-  finish_halo(w, hv, hs);
+  if (act0) {
+    issue(plane_of(1), w, CI > 1);
+    finish_own(w, eb);
+    finish_halo(w, hv, hs);
+  } else {
+#pragma unroll
+    for (int jj = 0; jj < RJ; ++jj)
+#pragma unroll
+      for (int v = 0; v < VEC; ++v) eb[jj][v] = (T)0;
+  }
   __syncthreads();
 
   double s0 = 0.0, s1 = 0.0;
@@ -268,7 +283,7 @@ __global__ void __launch_bounds__(256) k_cg3d(Cg3dArgs<T> A) {
     // ---- stencil on plane ii, every cell of the thread (masks are applied afterwards) --------
     const int64_t gi = ii + G.off0;
     const bool iS = gi >= G.slo[0] && gi <= G.shi[0];
-    const bool iShell = (gi == 0 || gi == G.g0 - 1);
+    const bool iShell = act0 && (gi == 0 || gi == G.g0 - 1);
     T cPi = A.lap.inv[0], cCi = A.lap.m2inv[0], cMi = A.lap.inv[0];
     {
       const int rc = pa_row_case(G, 0, gi, G.g0, G.treat);
@@ -300,7 +315,7 @@ __global__ void __launch_bounds__(256) k_cg3d(Cg3dArgs<T> A) {
         s = s + mm;
         mm = cMi * xmi;
         s = s + mm;
-        T ax = s;
+        T ax = act0 ? s : (T)0;
         s = cPj * dn[v];
         mm = cCj * xc;
         s = s + mm;
@@ -329,6 +344,7 @@ __global__ void __launch_bounds__(256) k_cg3d(Cg3dArgs<T> A) {
           T adv = (T)0;
 #pragma unroll
           for (int a = 0; a < 3; ++a) {
+            if (a == 0 && !act0) continue;
             T t;
             if (A.kind == 4) {  // upwind as the reference's test states it
               const T upl = uc > (T)0 ? uc : (T)0, umi = uc < (T)0 ? uc : (T)0;
@@ -369,7 +385,7 @@ __global__ void __launch_bounds__(256) k_cg3d(Cg3dArgs<T> A) {
         }
         if (PHASE == 4) {
           // Jacobi:  x + omega (b - A x) / diag(A)   (k_jacobi, pa_core.hip)
-          T dg = cCi;
+          T dg = act0 ? cCi : (T)0;
           dg = dg + cCj;
           dg = dg + cCk;
           if (hasc) dg = dg * cf;
@@ -467,11 +483,11 @@ __global__ void __launch_bounds__(256) k_cg3d(Cg3dArgs<T> A) {
 template <typename T>
 static bool cg3d_covered(const pa_ctx* c, const DevEq<T>& E, const void* p0, const void* p1, const void* p2) {
   if (!c->fastpath) return false;
-  if (c->ndim != 3) return false;
+  if (c->ndim != 3 && c->ndim != 2) return false;
   if (E.nterms != 1 || E.t[0].kind != PA_OP_LAPLACIAN || E.t[0].coeff_f) return false;
   constexpr int VEC = VecOf<T>::N;
   if (c->G.n2 % VEC != 0) return false;
-  if (c->G.n0 < 3 || c->G.n1 < 3 || c->G.n2 < 2 * VEC) return false;
+  if ((c->ndim == 3 && c->G.n0 < 3) || c->G.n1 < 3 || c->G.n2 < 2 * VEC) return false;
   const uintptr_t m = 15;
   if (((uintptr_t)p0 & m) || ((uintptr_t)p1 & m) || ((uintptr_t)p2 & m)) return false;
   return true;
@@ -515,7 +531,7 @@ static int launch_cg3d(pa_ctx* c, Cg3dArgs<T>& A) {
   if (chunks > G.n0) chunks = (int)G.n0;
   A.chunks = chunks;
   const int nblk = tiles * chunks;
-  if (nblk > PA_MAX_GRID) return 0;
+  if (nblk > PA_MAX_PARTIALS) return 0;
   static int dbg = -1;
   if (dbg < 0) dbg = getenv("PYAPES_HIP_DEBUG") ? 8 : 0;
   if (dbg > 0) {
@@ -538,6 +554,7 @@ static int pick_rj(pa_ctx* c) {
   }
   constexpr int VEC = VecOf<T>::N;
   const DevGeom& G = c->G;
+  if (!G.act[0]) return 4;  // 2-D: one plane, nothing to march; the biggest tile has the least halo
   const int64_t tk = (G.n2 + 64 * VEC - 1) / (64 * VEC);
   const int cap = cus_of(c) * 2;
   for (int rj = 4; rj >= 2; rj >>= 1) {
