@@ -51,8 +51,11 @@ struct Cg3dArgs {
   double* partials;
   int tiles_j, tiles_k, chunks, reverse;
   // single-field phases (2 = A x, 3 = explicit Euler step, 4 = Jacobi sweep): the field is `d`
-  const T* aux;         // Jacobi: rhs ; Euler: advection field u (or null -> scalar u)
+  const T* aux;         // Jacobi: rhs ; Euler: advection field u (or null) ; BiCGSTAB: r0
   T* out;               // result field
+  // BiCGSTAB phases (5: p' = r + beta (p - omega v), v' = A p' ; 6: s = r - alpha v, t = A s)
+  Vec<T> v;             // third input field of phase 5 (v) ; phase 6 uses r and d (= v)
+  T* out2;              // second result field (v' / t)
   T p0, p1, u;          // Euler: nu, dt, scalar u ; Jacobi: omega
   T hh[3], h2[3], ih[3];  // h, fl(2h), fl(1/h) per axis
   int kind;             // Euler: PA_OP_DIV_*
@@ -78,6 +81,7 @@ __global__ void __launch_bounds__(256) k_cg3d(Cg3dArgs<T> A) {
   __shared__ __attribute__((aligned(16))) T tile[2][TJ + 2][TKP];
 
   if (PHASE != 2 && PHASE != 3 && A.sc->done) return;
+  (void)sizeof(int[PHASE >= 0 && PHASE <= 6 ? 1 : -1]);
   const DevGeom& G = A.G;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int vb = pa_xcd_remap(blockIdx.x, gridDim.x);
@@ -141,8 +145,11 @@ __global__ void __launch_bounds__(256) k_cg3d(Cg3dArgs<T> A) {
                          (hs_side ? pa_wrapmod(k0 + TK, G.n2) : pa_wrapmod(k0 - 1, G.n2));
 
   T beta = (T)0, alpha = (T)0;
+  T omega = (T)0;
   if (PHASE == 0) beta = (T)A.sc->beta;
   if (PHASE == 1) alpha = (T)A.sc->alpha;
+  if (PHASE == 5) { beta = (T)A.sc->beta; omega = (T)A.sc->omega; }
+  if (PHASE == 6) alpha = (T)A.sc->alpha;
 
   auto plane_of = [&](int q) -> int64_t { return rev ? (i1 - 1 - q) : (i0 + q); };
   auto pptr = [&](const Vec<T>& v, int64_t ii) -> const T* {
@@ -154,59 +161,67 @@ __global__ void __launch_bounds__(256) k_cg3d(Cg3dArgs<T> A) {
   // current plane, so the s_waitcnt lands there and the loads fly during the stencil.
   struct Raw {
     V d[RJ];
-    V r[RJ];   // phase A only
-    V hd, hr;  // halo row (waves 0 and 3)
-    T sd, sr;  // halo cell (wave 1)
+    V r[RJ];   // phases A, 5, 6
+    V q[RJ];   // phase 5 (v)
+    V hd, hr, hq;  // halo row (waves 0 and 3)
+    T sd, sr, sq;  // halo cell (wave 1)
   };
+  constexpr bool HAS_R = (PHASE == 0 || PHASE == 5 || PHASE == 6);
+  constexpr bool HAS_Q = (PHASE == 5);
   auto issue = [&](int64_t ii, Raw& w, bool with_halo) {
     const T* dp = pptr(A.d, ii);
-    const T* rp = PHASE == 0 ? pptr(A.r, ii) : dp;
+    const T* rp = HAS_R ? pptr(A.r, ii) : dp;
+    const T* qp = HAS_Q ? pptr(A.v, ii) : dp;
 #pragma unroll
     for (int jj = 0; jj < RJ; ++jj) {
       const int64_t o = jrow[jj] * G.s1 + kc;
       w.d[jj] = *reinterpret_cast<const V*>(dp + o);
-      if (PHASE == 0) w.r[jj] = *reinterpret_cast<const V*>(rp + o);
+      if (HAS_R) w.r[jj] = *reinterpret_cast<const V*>(rp + o);
+      if (HAS_Q) w.q[jj] = *reinterpret_cast<const V*>(qp + o);
     }
     if (with_halo) {
       if (hvec) {
         const int64_t o = hrow * G.s1 + kc;
         w.hd = *reinterpret_cast<const V*>(dp + o);
-        if (PHASE == 0) w.hr = *reinterpret_cast<const V*>(rp + o);
+        if (HAS_R) w.hr = *reinterpret_cast<const V*>(rp + o);
+        if (HAS_Q) w.hq = *reinterpret_cast<const V*>(qp + o);
       }
       if (hsc) {
         w.sd = dp[hs_off];
-        if (PHASE == 0) w.sr = rp[hs_off];
+        if (HAS_R) w.sr = rp[hs_off];
+        if (HAS_Q) w.sq = qp[hs_off];
       }
     }
   };
-  // e = r + beta d (phase A, linalg.py:141) or d (phase B)
+  // the staged field from the raw loads: phase A r + beta d ; phase 5 r + beta (p - omega v)
+  // (linalg.py:217) ; phase 6 r - alpha v (linalg.py:230) ; else the field itself
+  auto combine = [&](T rr_, T dd_, T qq_) -> T {
+    if (PHASE == 0) {
+      T bd = beta * dd_;
+      return rr_ + bd;
+    } else if (PHASE == 5) {
+      T t = omega * qq_;
+      t = dd_ - t;
+      t = beta * t;
+      return rr_ + t;
+    } else if (PHASE == 6) {
+      T av = alpha * dd_;
+      return rr_ - av;
+    }
+    return dd_;
+  };
   auto finish_own = [&](const Raw& w, V (&e)[RJ]) {
 #pragma unroll
     for (int jj = 0; jj < RJ; ++jj) {
-      if (PHASE == 0) {
 #pragma unroll
-        for (int v = 0; v < VEC; ++v) {
-          T bd = beta * w.d[jj][v];
-          e[jj][v] = w.r[jj][v] + bd;
-        }
-      } else {
-        e[jj] = w.d[jj];
-      }
+      for (int v = 0; v < VEC; ++v)
+        e[jj][v] = combine(HAS_R ? w.r[jj][v] : (T)0, w.d[jj][v], HAS_Q ? w.q[jj][v] : (T)0);
     }
   };
   auto finish_halo = [&](const Raw& w, V& hv, T& hs) {
-    if (PHASE == 0) {
 #pragma unroll
-      for (int v = 0; v < VEC; ++v) {
-        T bd = beta * w.hd[v];
-        hv[v] = w.hr[v] + bd;
-      }
-      T bs = beta * w.sd;
-      hs = w.sr + bs;
-    } else {
-      hv = w.hd;
-      hs = w.sd;
-    }
+    for (int v = 0; v < VEC; ++v) hv[v] = combine(HAS_R ? w.hr[v] : (T)0, w.hd[v], HAS_Q ? w.hq[v] : (T)0);
+    hs = combine(HAS_R ? w.sr : (T)0, w.sd, HAS_Q ? w.sq : (T)0);
   };
   auto stage = [&](int buf, const V (&e)[RJ], const V& hv, const T& hs) {
 #pragma unroll
@@ -221,8 +236,8 @@ __global__ void __launch_bounds__(256) k_cg3d(Cg3dArgs<T> A) {
   T hs = (T)0;
   Raw w;
 #pragma unroll
-  for (int v = 0; v < VEC; ++v) { hv[v] = (T)0; w.hd[v] = (T)0; w.hr[v] = (T)0; }
-  w.sd = (T)0; w.sr = (T)0;
+  for (int v = 0; v < VEC; ++v) { hv[v] = (T)0; w.hd[v] = (T)0; w.hr[v] = (T)0; w.hq[v] = (T)0; }
+  w.sd = (T)0; w.sr = (T)0; w.sq = (T)0;
 
   // ---- prologue -----------------------------------------------------------------------
   const bool act0 = G.act[0] != 0;   // 2-D meshes occupy internal axes 1,2: a single plane, no i-neighbours
@@ -251,7 +266,7 @@ __global__ void __launch_bounds__(256) k_cg3d(Cg3dArgs<T> A) {
   }
   __syncthreads();
 
-  double s0 = 0.0, s1 = 0.0;
+  double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
   const T sgn = A.sign, cf = A.coeff;
   const int hasc = A.has_coeff;
 
@@ -272,7 +287,7 @@ __global__ void __launch_bounds__(256) k_cg3d(Cg3dArgs<T> A) {
         rv[jj] = *reinterpret_cast<const V*>(A.rw + o);
       }
     }
-    if (PHASE == 4 || (PHASE == 3 && A.aux)) {  // Jacobi rhs / Euler advection field of this plane
+    if (PHASE == 4 || PHASE == 5 || PHASE == 6 || (PHASE == 3 && A.aux)) {  // rhs / u / r0 of this plane
 #pragma unroll
       for (int jj = 0; jj < RJ; ++jj)
         xv[jj] = *reinterpret_cast<const V*>(A.aux + ii * G.s0 + jrow[jj] * G.s1 + kc);
@@ -408,7 +423,25 @@ __global__ void __launch_bounds__(256) k_cg3d(Cg3dArgs<T> A) {
       for (int v = 0; v < VEC; ++v) {
         const bool inS = iS && (rowS >> jj & 1) && (colS >> v & 1);
         const T xc = ec[jj][v];
-        if (PHASE == 2) {
+        if (PHASE == 5 || PHASE == 6) {
+          // own cells: p' (or s) everywhere, v' = A p' (or t = A s) on the interior set
+          const bool mine = kvalid && (rowValid >> jj & 1);
+          const T an = inS ? res[jj][v] : (T)0;
+          outd[v] = xc;
+          outx[v] = an;
+          const T r0c = xv[jj][v];
+          if (PHASE == 5) {
+            T p = r0c * an;
+            s0 += inS ? (double)p : 0.0;
+          } else {
+            T p = xc * xc;
+            s0 += mine ? (double)p : 0.0;   // |s|^2 over every node (tol of linalg.py:233)
+            T a = an * xc, b = an * an, cc = r0c * an;
+            s1 += inS ? (double)a : 0.0;
+            s2 += inS ? (double)b : 0.0;
+            s3 += inS ? (double)cc : 0.0;
+          }
+        } else if (PHASE == 2) {
           outd[v] = (inS || !A.interior_only) ? res[jj][v] : (T)0;
         } else if (PHASE == 3) {
           outd[v] = inS ? res[jj][v] : xc;
@@ -444,7 +477,10 @@ __global__ void __launch_bounds__(256) k_cg3d(Cg3dArgs<T> A) {
       }
       if (kvalid && (rowValid >> jj & 1)) {
         const int64_t o = ii * G.s0 + jrow[jj] * G.s1 + kc;
-        if (PHASE >= 2) {
+        if (PHASE == 5 || PHASE == 6) {
+          *reinterpret_cast<V*>(A.out + o) = outd;
+          *reinterpret_cast<V*>(A.out2 + o) = outx;
+        } else if (PHASE >= 2) {
           *reinterpret_cast<V*>(A.out + o) = outd;
         } else if (PHASE == 0) {
           *reinterpret_cast<V*>(A.dnew + o) = outd;
@@ -476,6 +512,12 @@ __global__ void __launch_bounds__(256) k_cg3d(Cg3dArgs<T> A) {
   } else if (PHASE == 1 || PHASE == 4) {
     double s[2] = {s0, s1};
     pa_block_reduce_store<2>(s, A.partials);
+  } else if (PHASE == 5) {
+    double s[1] = {s0};
+    pa_block_reduce_store<1>(s, A.partials);
+  } else if (PHASE == 6) {
+    double s[4] = {s0, s1, s2, s3};
+    pa_block_reduce_store<4>(s, A.partials);
   }
 }
 
@@ -670,6 +712,37 @@ int pa_tile3d_jacobi(pa_ctx* c, const DevEq<T>& E, Vec<T> x, const T* rhs, T* xn
   if (n > 0 && hipGetLastError() != hipSuccess) { pa_set_err(c, "k_cg3d Jacobi launch failed"); return PA_E_HIP; }
   return n;
 }
+
+template <typename T>
+int pa_tile3d_bicg_pv(pa_ctx* c, const DevEq<T>& E, Vec<T> r, Vec<T> p, Vec<T> v, const T* r0, T* pnew, T* vnew,
+                      double* partials) {
+  if (!cg3d_covered<T>(c, E, r.p, p.p, v.p) || !cg3d_covered<T>(c, E, r0, pnew, vnew)) return 0;
+  Cg3dArgs<T> A;
+  memset(&A, 0, sizeof(A));
+  fill_common<T>(c, E, A);
+  A.r = r; A.d = p; A.v = v; A.aux = r0; A.out = pnew; A.out2 = vnew; A.partials = partials;
+  int n = launch_any<T, 5>(c, A);
+  if (n > 0 && hipGetLastError() != hipSuccess) { pa_set_err(c, "k_cg3d BiCGSTAB p/v launch failed"); return PA_E_HIP; }
+  return n;
+}
+
+template <typename T>
+int pa_tile3d_bicg_st(pa_ctx* c, const DevEq<T>& E, Vec<T> r, Vec<T> v, const T* r0, T* s_out, T* t_out,
+                      double* partials) {
+  if (!cg3d_covered<T>(c, E, r.p, v.p, r0) || !cg3d_covered<T>(c, E, s_out, t_out, t_out)) return 0;
+  Cg3dArgs<T> A;
+  memset(&A, 0, sizeof(A));
+  fill_common<T>(c, E, A);
+  A.r = r; A.d = v; A.aux = r0; A.out = s_out; A.out2 = t_out; A.partials = partials;
+  int n = launch_any<T, 6>(c, A);
+  if (n > 0 && hipGetLastError() != hipSuccess) { pa_set_err(c, "k_cg3d BiCGSTAB s/t launch failed"); return PA_E_HIP; }
+  return n;
+}
+
+template int pa_tile3d_bicg_pv<float>(pa_ctx*, const DevEq<float>&, Vec<float>, Vec<float>, Vec<float>, const float*, float*, float*, double*);
+template int pa_tile3d_bicg_pv<double>(pa_ctx*, const DevEq<double>&, Vec<double>, Vec<double>, Vec<double>, const double*, double*, double*, double*);
+template int pa_tile3d_bicg_st<float>(pa_ctx*, const DevEq<float>&, Vec<float>, Vec<float>, const float*, float*, float*, double*);
+template int pa_tile3d_bicg_st<double>(pa_ctx*, const DevEq<double>&, Vec<double>, Vec<double>, const double*, double*, double*, double*);
 
 template int pa_tile3d_aop<float>(pa_ctx*, const DevEq<float>&, Vec<float>, float*, int);
 template int pa_tile3d_aop<double>(pa_ctx*, const DevEq<double>&, Vec<double>, double*, int);

@@ -1026,6 +1026,25 @@ __global__ void __launch_bounds__(PA_BLOCK) k_bicg_post(SolverScalars* sc, const
       rn = rn * (T)r0t;
       sc->rho_next = (double)rn;
     }
+  } else if (stage == 12) {
+    // fused s / t kernel: partial rows are {|s|^2, t.s, t.t, r0.t}: stop test 1, then omega, rho_next
+    double ss = pa_reduce_partials(partials, nblk, 4, 0, sm);
+    double ts = pa_reduce_partials(partials, nblk, 4, 1, sm);
+    double tt = pa_reduce_partials(partials, nblk, 4, 2, sm);
+    double r0t = pa_reduce_partials(partials, nblk, 4, 3, sm);
+    if (threadIdx.x == 0) {
+      T tol = (T)sqrt(ss);
+      sc->tol = (double)tol;
+      if (isnan(tol) || isinf(tol)) { sc->err = 1; sc->done = 1; return; }
+      sc->finished_early = (sc->tol <= sc->tolerance) ? 1 : 0;
+      if (!sc->finished_early) {
+        T om = (T)pa_nan_to_num<T>((T)ts / (T)tt);
+        sc->omega = (double)om;
+        T rn = -om;
+        rn = rn * (T)r0t;
+        sc->rho_next = (double)rn;
+      }
+    }
   } else {
     double v = pa_reduce_partials(partials, nblk, 1, 0, sm);
     if (threadIdx.x == 0) {
@@ -2169,15 +2188,27 @@ static int bicg_run_t(pa_ctx* c, T* x, const T* rhs, double tol, int64_t max_it,
   int next_poll = 1;
   for (;;) {
     Vec<T> rv = pa_vec_self<T>(c, r), pv = pa_vec_self<T>(c, p[cur]), vv = pa_vec_self<T>(c, v[cur]);
-    hipLaunchKernelGGL(k_bicg_pv<T>, dim3(nblk), dim3(PA_BLOCK), 0, c->stream, G, E, c->sc, rv, pv, vv, (const T*)r0,
-                       p[cur ^ 1], v[cur ^ 1], part);
-    hipLaunchKernelGGL(k_bicg_post<T>, dim3(1), dim3(PA_BLOCK), 0, c->stream, c->sc, part, nblk, 0);
-    hipLaunchKernelGGL(k_bicg_s<T>, dim3(nblk), dim3(PA_BLOCK), 0, c->stream, G, c->sc, (const T*)r,
-                       (const T*)v[cur ^ 1], s, part);
-    hipLaunchKernelGGL(k_bicg_post<T>, dim3(1), dim3(PA_BLOCK), 0, c->stream, c->sc, part, nblk, 1);
-    Vec<T> sv = pa_vec_self<T>(c, s);
-    hipLaunchKernelGGL(k_bicg_t<T>, dim3(nblk), dim3(PA_BLOCK), 0, c->stream, G, E, c->sc, sv, (const T*)r0, t, part);
-    hipLaunchKernelGGL(k_bicg_post<T>, dim3(1), dim3(PA_BLOCK), 0, c->stream, c->sc, part, nblk, 2);
+    int used = pa_tile3d_bicg_pv<T>(c, E, rv, pv, vv, (const T*)r0, p[cur ^ 1], v[cur ^ 1], part);
+    if (used < 0) return used;
+    if (used == 0) {
+      hipLaunchKernelGGL(k_bicg_pv<T>, dim3(nblk), dim3(PA_BLOCK), 0, c->stream, G, E, c->sc, rv, pv, vv, (const T*)r0,
+                         p[cur ^ 1], v[cur ^ 1], part);
+      used = nblk;
+    }
+    hipLaunchKernelGGL(k_bicg_post<T>, dim3(1), dim3(PA_BLOCK), 0, c->stream, c->sc, part, used, 0);
+    Vec<T> vnv = pa_vec_self<T>(c, v[cur ^ 1]);
+    used = pa_tile3d_bicg_st<T>(c, E, rv, vnv, (const T*)r0, s, t, part);
+    if (used < 0) return used;
+    if (used > 0) {
+      hipLaunchKernelGGL(k_bicg_post<T>, dim3(1), dim3(PA_BLOCK), 0, c->stream, c->sc, part, used, 12);
+    } else {
+      hipLaunchKernelGGL(k_bicg_s<T>, dim3(nblk), dim3(PA_BLOCK), 0, c->stream, G, c->sc, (const T*)r,
+                         (const T*)v[cur ^ 1], s, part);
+      hipLaunchKernelGGL(k_bicg_post<T>, dim3(1), dim3(PA_BLOCK), 0, c->stream, c->sc, part, nblk, 1);
+      Vec<T> sv = pa_vec_self<T>(c, s);
+      hipLaunchKernelGGL(k_bicg_t<T>, dim3(nblk), dim3(PA_BLOCK), 0, c->stream, G, E, c->sc, sv, (const T*)r0, t, part);
+      hipLaunchKernelGGL(k_bicg_post<T>, dim3(1), dim3(PA_BLOCK), 0, c->stream, c->sc, part, nblk, 2);
+    }
     hipLaunchKernelGGL(k_bicg_x<T>, dim3(nblk), dim3(PA_BLOCK), 0, c->stream, G, c->sc, x, (const T*)p[cur ^ 1],
                        (const T*)s, (const T*)t, r, part);
     if ((rc = bc_apply_auto<T>(c, x, true))) return rc;

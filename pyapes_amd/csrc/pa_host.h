@@ -121,3 +121,9 @@ template <typename T>
 int pa_tile3d_euler(pa_ctx* c, Vec<T> phi, T* out, int kind, double u, const void* u_field, double nu, double dt);
 template <typename T>
 int pa_tile3d_jacobi(pa_ctx* c, const DevEq<T>& E, Vec<T> x, const T* rhs, T* xnew, double omega, double* partials);
+template <typename T>
+int pa_tile3d_bicg_pv(pa_ctx* c, const DevEq<T>& E, Vec<T> r, Vec<T> p, Vec<T> v, const T* r0, T* pnew, T* vnew,
+                      double* partials);
+template <typename T>
+int pa_tile3d_bicg_st(pa_ctx* c, const DevEq<T>& E, Vec<T> r, Vec<T> v, const T* r0, T* s_out, T* t_out,
+                      double* partials);
