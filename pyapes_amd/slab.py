@@ -100,12 +100,11 @@ class SlabCG:
             for (dst, _, _), (src, _, _) in zip(recvs, r2):
                 dst.copy_(src)
 
-    def _exchange_planes(self, lo_send: Tensor | None, hi_send: Tensor | None,
-                         lo_recv: Tensor | None, hi_recv: Tensor | None) -> None:
-        """Send my first plane down / last plane up, receive the ghosts.  Tag 0 = travelling up
-        (lands in a lower ghost), tag 1 = travelling down.  Receives are posted hi first so that
-        with P = 2 and a periodic ring (both neighbours are the same peer) the two messages pair
-        correctly even on a backend that ignores tags."""
+    def _plane_ops(self, lo_send, hi_send, lo_recv, hi_recv):
+        """(sends, recvs) for: my first plane down / my last plane up, ghosts in.  Tag 0 = travelling up
+        (lands in a lower ghost), tag 1 = travelling down.  Receives are listed hi first so that with
+        P = 2 and a periodic ring (both neighbours are the same peer) the two messages pair correctly
+        even on a backend that ignores tags (NCCL matches same-peer operations in order)."""
         sends, recvs = [], []
         if self.nb_lo is not None and lo_send is not None:
             sends.append((lo_send, self.nb_lo, 1))
@@ -115,21 +114,35 @@ class SlabCG:
             recvs.append((hi_recv, self.nb_hi, 1))
         if self.nb_lo is not None and lo_recv is not None:
             recvs.append((lo_recv, self.nb_lo, 0))
-        self._p2p(sends, recvs)
+        return sends, recvs
+
+    def _bc_far_ops(self):
+        """Periodic axis 0: planes of x the end ranks' BC fill reads across the ring."""
+        sends, recvs = [], []
+        if self.periodic0:
+            P, r = self.world, self.rank
+            if r == P - 1:
+                sends += [(self.x[-1], 0, 2), (self.x[-2], 0, 3)]
+                recvs += [(self.bufs["bc_far_hi0"], 0, 4)]
+            if r == 0:
+                sends += [(self.x[1], P - 1, 4)]
+                recvs += [(self.bufs["bc_far_lo0"], P - 1, 2), (self.bufs["bc_far_lo1"], P - 1, 3)]
+        return sends, recvs
+
+    def _exchange_planes(self, lo_send, hi_send, lo_recv, hi_recv) -> None:
+        self._p2p(*self._plane_ops(lo_send, hi_send, lo_recv, hi_recv))
 
     def _exchange_bc_far(self) -> None:
-        """Periodic axis 0: planes of x the end ranks' BC fill reads across the ring."""
-        if not self.periodic0:
-            return
-        P, r = self.world, self.rank
-        sends, recvs = [], []
-        if r == P - 1:
-            sends += [(self.x[-1].contiguous(), 0, 2), (self.x[-2].contiguous(), 0, 3)]
-            recvs += [(self.bufs["bc_far_hi0"], 0, 4)]
-        if r == 0:
-            sends += [(self.x[1].contiguous(), P - 1, 4)]
-            recvs += [(self.bufs["bc_far_lo0"], P - 1, 2), (self.bufs["bc_far_lo1"], P - 1, 3)]
-        self._p2p(sends, recvs)
+        self._p2p(*self._bc_far_ops())
+
+    def _exchange_iter(self) -> None:
+        """The one batched exchange of an iteration: residual planes + periodic far planes of x.
+        With P = 2 and a ring, rank 0 <-> rank 1 carry up to 5 messages each way; same-peer order is
+        sends [r_lo, r_hi, x...] against recvs [r_hi-ghost, r_lo-ghost, x...] on both sides."""
+        b = self.bufs
+        s1, r1 = self._plane_ops(b["r_send_lo"], b["r_send_hi"], b["r_recv_lo"], b["r_recv_hi"])
+        s2, r2 = self._bc_far_ops()
+        self._p2p(s1 + s2, r1 + r2)
 
     def _allreduce(self, lo: int, hi: int) -> None:
         self.dist.all_reduce(self.sums[lo:hi], op=self.dist.ReduceOp.SUM, group=self.group)
@@ -156,9 +169,7 @@ class SlabCG:
             be.cg_phase_a()                              # d' = r + beta d ; local sum d'.Ad'
             self._allreduce(0, 1)
             be.cg_phase_b()                              # alpha ; x, r update ; r planes out
-            self._exchange_planes(self.bufs["r_send_lo"], self.bufs["r_send_hi"],
-                                  self.bufs["r_recv_lo"], self.bufs["r_recv_hi"])
-            self._exchange_bc_far()
+            self._exchange_iter()
             be.cg_bc()                                   # BC fill of x ; local sums r.r, |dx|^2
             self._allreduce(1, 3)
             be.cg_finish_iter()                          # beta, stop test, itr (device side)
