@@ -204,6 +204,19 @@ class Mesh:
     def is_cuda(self) -> bool:
         return self.device.type == "cuda"
 
+    @property
+    def dg(self) -> list[Tensor]:
+        """Half the sum of the forward and backward node distances, one-sided on the boundary
+        (`_mesh.py:262-293`): dx in the interior, dx/2 on the boundary nodes."""
+        out = []
+        for a, g in enumerate(self.grid):
+            fw = torch.roll(g, -1, a) - g
+            bw = g - torch.roll(g, 1, a)
+            fw = torch.where(fw < 0, torch.zeros_like(fw), fw)
+            bw = torch.where(bw < 0, torch.zeros_like(bw), bw)
+            out.append((fw + bw) / 2)
+        return out
+
     def face_dxf(self, face: str) -> float:
         """``grid[face] - grid[prev]`` of ``Neumann.apply`` (bcs.py:228-231): the literal
         difference of the two outermost node coordinates, in the mesh dtype."""
