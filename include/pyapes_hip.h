@@ -122,6 +122,9 @@ int pa_laplacian(pa_ctx* ctx, const void* x, void* y, int edge);
 int pa_grad(pa_ctx* ctx, const void* x, void* y, int edge);
 /* kind = PA_OP_DIV_*; u_field NULL -> scalar u */
 int pa_div(pa_ctx* ctx, int kind, double u, const void* u_field, const void* x, void* y);
+/* edge=True post-pass of Div (fdc.py:290-361): overwrites the two end nodes of y with the one-sided
+ * 2nd-order formula times the advection value.  1-D only, like the reference for scalar fields. */
+int pa_div_edge(pa_ctx* ctx, double u, const void* u_field, const void* x, void* y);
 
 /* ---- solvers (linalg.solve -> cg | bicgstab, linalg.py:33-279) --------- */
 int pa_cg(pa_ctx* ctx, void* x, const void* rhs, double tol, int64_t max_it, pa_report* out);

@@ -156,7 +156,8 @@ __global__ void __launch_bounds__(PA_BLOCK) k_grad(DevGeom G, DevEq<T> E, Vec<T>
 // because the reference overwrites faces axis by axis); mode 1: grad (y[a] on faces normal to a).
 template <typename T>
 __global__ void __launch_bounds__(PA_BLOCK) k_edge(DevGeom G, DevEq<T> E, const T* __restrict__ x,
-                                                    T* __restrict__ y, int nd, int mode) {
+                                                    T* __restrict__ y, int nd, int mode, T u = (T)0,
+                                                    const T* __restrict__ u_f = nullptr) {
   for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < G.ncell;
        idx += (int64_t)gridDim.x * blockDim.x) {
     int64_t i, j, k;
@@ -180,7 +181,7 @@ __global__ void __launch_bounds__(PA_BLOCK) k_edge(DevGeom G, DevEq<T> E, const 
       s = s - v3;
       T h2 = E.grd.h[sel] * E.grd.h[sel];
       y[idx] = s / h2;
-    } else {
+    } else if (mode == 1) {
       for (int a = 3 - nd; a < 3; ++a) {
         if (!(c[a] == 0 || c[a] == n[a] - 1)) continue;
         int64_t dir = (c[a] == 0) ? 1 : -1;
@@ -193,6 +194,20 @@ __global__ void __launch_bounds__(PA_BLOCK) k_edge(DevGeom G, DevEq<T> E, const 
         if (c[a] == 0) s = -s;
         y[(int64_t)(a - (3 - nd)) * G.ncell + idx] = s / E.grd.h[a];
       }
+    } else {
+      // Div, 1-D (fdc.py:316-348): -+(3/2 v0 - 2 v1 + 1/2 v2) / dx * adv on the two end nodes
+      const int a = 2;
+      if (!(c[a] == 0 || c[a] == n[a] - 1)) continue;
+      int64_t dir = (c[a] == 0) ? 1 : -1;
+      T v0 = x[idx], v1 = x[idx + dir], v2 = x[idx + 2 * dir];
+      T s = (T)1.5 * v0;
+      T m = (T)2 * v1;
+      s = s - m;
+      m = (T)0.5 * v2;
+      s = s + m;
+      if (c[a] == 0) s = -s;
+      s = s / E.grd.h[a];
+      y[idx] = s * (u_f ? u_f[idx] : u);
     }
   }
 }
@@ -1603,6 +1618,32 @@ int pa_div(pa_ctx* c, int kind, double u, const void* u_field, const void* x, vo
   t.kind = kind; t.sign = 1.0; t.u = u; t.u_field = u_field;
   return c->dtype == PA_F64 ? aop_t<double>(c, (const double*)x, (double*)y, 0, 1, &t)
                             : aop_t<float>(c, (const float*)x, (float*)y, 0, 1, &t);
+}
+
+int pa_div_edge(pa_ctx* c, double u, const void* u_field, const void* x, void* y) {
+  if (!c || !c->grid_set) return PA_E_STATE;
+  if (c->ndim != 1) {
+    pa_set_err(c, "edge=True Div of a scalar field is 1-D only (the reference raises IndexError, fdc.py:296-303)");
+    return PA_E_ARG;
+  }
+  if (c->G.n2 < 3) { pa_set_err(c, "edge Div needs >= 3 nodes"); return PA_E_ARG; }
+  PA_HIP(c, hipSetDevice(c->device));
+  pa_term t;
+  memset(&t, 0, sizeof(t));
+  t.kind = PA_OP_GRAD; t.sign = 1.0;
+  if (c->dtype == PA_F64) {
+    DevEq<double> E;
+    pa_build_eq<double>(c, 1, &t, E);
+    hipLaunchKernelGGL(k_edge<double>, dim3(pa_grid_blocks(c->G.ncell)), dim3(PA_BLOCK), 0, c->stream, c->G, E,
+                       (const double*)x, (double*)y, c->ndim, 2, (double)u, (const double*)u_field);
+  } else {
+    DevEq<float> E;
+    pa_build_eq<float>(c, 1, &t, E);
+    hipLaunchKernelGGL(k_edge<float>, dim3(pa_grid_blocks(c->G.ncell)), dim3(PA_BLOCK), 0, c->stream, c->G, E,
+                       (const float*)x, (float*)y, c->ndim, 2, (float)u, (const float*)u_field);
+  }
+  PA_HIP(c, hipGetLastError());
+  return PA_OK;
 }
 
 int pa_euler_step(pa_ctx* c, const void* in, void* out, int kind, double u, const void* u_field, double nu,

@@ -165,6 +165,15 @@ class HipContext:
         self._rc(self.lib.pa_div(self.h, kind, us, self._ptr(uf), self._ptr(x), self._ptr(y)))
         return y
 
+    def div_edge(self, u: float | Tensor, x: Tensor, y: Tensor) -> None:
+        uf, us = None, 0.0
+        if isinstance(u, Tensor):
+            uf = self._field(u if u.dim() == self.mesh.dim else u[0], "advection tensor")
+        else:
+            us = float(u)
+        self._rc(self.lib.pa_div_edge(self.h, us, self._ptr(uf), self._ptr(self._field(x, "div edge")),
+                                      self._ptr(self._field(y, "div edge out"))))
+
     def euler_march(self, phi: Tensor, tmp: Tensor, kind: int, u: float | Tensor, nu: float, dt: float,
                     nsteps: int) -> Tensor:
         """``nsteps`` explicit Euler steps enqueued back to back, ping-ponging phi <-> tmp; returns the

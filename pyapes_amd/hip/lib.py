@@ -66,6 +66,7 @@ SIGNATURES: dict[str, tuple[Any, list[Any]]] = {
     "pa_laplacian": (C.c_int, [_VP, _VP, _VP, C.c_int]),
     "pa_grad": (C.c_int, [_VP, _VP, _VP, C.c_int]),
     "pa_div": (C.c_int, [_VP, C.c_int, C.c_double, _VP, _VP, _VP]),
+    "pa_div_edge": (C.c_int, [_VP, C.c_double, _VP, _VP, _VP]),
     "pa_cg": (C.c_int, [_VP, _VP, _VP, C.c_double, C.c_int64, C.POINTER(PaReport)]),
     "pa_bicgstab": (C.c_int, [_VP, _VP, _VP, C.c_double, C.c_int64, C.POINTER(PaReport)]),
     "pa_jacobi": (C.c_int, [_VP, _VP, _VP, C.c_double, C.c_int64, C.c_double, C.POINTER(PaReport)]),

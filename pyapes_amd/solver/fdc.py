@@ -17,7 +17,9 @@ from torch import Tensor
 from ..backend import require_gpu
 from ..hip import lib as L
 from ..hip.context import context_for
+from ..geometry.basis import n2d_coord
 from ..variables import Field
+from ..variables.container import Hess, Jac
 from .tools import StencilSpec
 from .types import DiscretizerConfigType
 
@@ -194,13 +196,17 @@ class Div(Discretizer):
         require_gpu(var(), "FDC.div")
         if var.dim != 1:
             raise NotImplementedError("pyapes_amd: Div of a vector field is not covered (scalar fields only)")
-        if self._edge():
-            raise NotImplementedError("pyapes_amd: edge=True Div is not covered yet")
+        edge = self._edge()
+        if edge and var.mesh.dim != 1:
+            raise IndexError("pyapes_amd: edge=True Div of a scalar field works in 1-D only "
+                             "(the reference indexes var[dim] / adv[dim] and raises IndexError, fdc.py:296-303)")
         ctx = context_for(var.mesh)
         ctx.bind_bcs(var(), A_coeffs.bcs, 0)
         u = _adv_of(A_coeffs.var_j, var)
         out = torch.empty_like(var())
         ctx.div(div_kind(A_coeffs.limiter, A_coeffs.compat), u, var()[0], out=out[0])
+        if edge:
+            ctx.div_edge(u, var()[0], out[0])
         return out
 
 
@@ -224,3 +230,35 @@ class FDC:
             self.config = {scheme: {target: val}}  # type: ignore[assignment,misc]
         for c in self.config:  # type: ignore[union-attr]
             getattr(self, c).set_config(self.config)
+
+
+def _edge_grad_of(mesh, field_nd: Tensor) -> Tensor:
+    """``(mesh.dim, *nx)``: central gradient with the one-sided 2nd-order boundary formulas of
+    ``_treat_edge`` (fdc.py:260-288) of one scalar array -- no BC rows (container field without BCs)."""
+    require_gpu(field_nd, "jacobian / hessian")
+    ctx = context_for(mesh)
+    ctx.bind_bcs(field_nd, [], 0)
+    return ctx.grad(field_nd.contiguous(), True)
+
+
+def jacobian(var: Field) -> Jac:
+    """First derivatives of a scalar field (fdc.py:896-914): ``Jac(x=.., y=.., z=..)``."""
+    assert var().shape[0] == 1, "Scalar: var must be a scalar field."
+    n2d = n2d_coord(var.mesh.coord_sys)
+    g = _edge_grad_of(var.mesh, var()[0])
+    return Jac(**{n2d[i]: g[i] for i in range(var.mesh.dim)})
+
+
+def hessian(var: Field) -> Hess:
+    """Second derivatives of a scalar field as the gradient of each Jacobian component, upper
+    triangle only (fdc.py:917-944): ``Hess(xx=.., xy=.., ...)``."""
+    assert var().shape[0] == 1, "Scalar: var must be a scalar field."
+    n2d = n2d_coord(var.mesh.coord_sys)
+    nd = var.mesh.dim
+    g = _edge_grad_of(var.mesh, var()[0])
+    data = {}
+    for i in range(nd):
+        gi = _edge_grad_of(var.mesh, g[i])
+        for j in range(i, nd):
+            data[n2d[i] + n2d[j]] = gi[j]
+    return Hess(**data)

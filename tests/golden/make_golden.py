@@ -234,6 +234,36 @@ def run_solve(case):
     return out
 
 
+def run_spatial(case):
+    """jacobian / hessian of a scalar field (fdc.py:896-944) and, in 1-D, Div with edge=True
+    (fdc.py:290-361; for scalar fields the reference's edge Div only works in 1-D)."""
+    from pyapes.solver.fdc import hessian, jacobian
+    mr = ref_mesh(case)
+    nd = mr.dim
+    x0 = rand_field(case, mr)
+    out = {"x0": npy(x0)}
+    var = Field("p", 1, mr, {"domain": None, "obstacle": None})
+    var.set_var_tensor(x0.clone())
+    jac = jacobian(var)
+    hess = hessian(var)
+    names = "xyz"
+    for i in range(nd):
+        out["jac_" + names[i]] = npy(jac[names[i]])
+        for j in range(i, nd):
+            out["hess_" + names[i] + names[j]] = npy(hess[names[i] + names[j]])
+    if nd == 1:
+        cr, _ = bc_cfg(case)
+        v2 = Field("q", 1, mr, {"domain": cr, "obstacle": None})
+        v2.set_var_tensor(x0.clone())
+        g = torch.Generator().manual_seed(case.get("seed", 0) + 7)
+        ut = torch.randn((1, *mr.nx), generator=g, dtype=torch.float64).to(mr.dtype.float)
+        out["u_tensor"] = npy(ut)
+        out["div_edge_none_f"] = npy(FDC({"div": {"limiter": "none", "edge": True}}).div(1.5, v2))
+        out["div_edge_none_t"] = npy(FDC({"div": {"limiter": "none", "edge": True}}).div(ut, v2))
+        out["div_edge_upwind_f"] = npy(FDC({"div": {"limiter": "upwind", "edge": True}}).div(1.5, v2))
+    return out
+
+
 # ---------------------------------------------------------------- case list
 def D(v=0.0):
     return ["dirichlet", v]
@@ -322,13 +352,23 @@ CASES += [
 ]
 
 
+for dt in ("double", "single"):
+    s_ = "f64" if dt == "double" else "f32"
+    CASES += [
+        mk(f"spatial1d_{s_}", "spatial", 1, [12], dt, [D(0.3), D(-0.2)]),
+        mk(f"spatial2d_{s_}", "spatial", 2, [7, 9], dt, [D(0.0)] * 4),
+        mk(f"spatial3d_{s_}", "spatial", 3, [5, 6, 8], dt, [D(0.0)] * 6),
+        mk(f"spatial3d_min_{s_}", "spatial", 3, [3, 3, 3], dt, [D(0.0)] * 6),
+    ]
+
+
 def main():
     torch.set_num_threads(8)
     index = []
     total = 0
     for case in CASES:
         print(f"[golden] {case['name']}")
-        out = run_ops(case) if case["kind"] == "ops" else run_solve(case)
+        out = {"ops": run_ops, "solve": run_solve, "spatial": run_spatial}[case["kind"]](case)
         path = os.path.join(HERE, case["name"] + ".npz")
         np.savez_compressed(path, **out)
         total += os.path.getsize(path)

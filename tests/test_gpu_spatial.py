@@ -1,0 +1,65 @@
+"""-m gpu: jacobian / hessian and the 1-D edge=True Div (8a7) against the golden
+vectors the reference produced -- bit-exact."""
+import warnings
+
+import pytest
+import torch
+
+from conftest import golden_cases, golden_load
+from helpers import bit_equal, product_cfg, product_mesh
+
+pytestmark = pytest.mark.gpu
+
+from pyapes_amd.solver.fdc import FDC, hessian, jacobian
+from pyapes_amd.variables import Field
+
+
+@pytest.mark.parametrize("case", golden_cases("spatial"), ids=lambda c: c["name"])
+def test_jacobian_hessian_div_edge(case):
+    g = golden_load(case["name"])
+    mesh = product_mesh(case)
+    nd = mesh.dim
+    var = Field("p", 1, mesh, {"domain": None, "obstacle": None})
+    var.set_var_tensor(torch.as_tensor(g["x0"]).cuda().clone())
+    jac, hess = jacobian(var), hessian(var)
+    names = "xyz"
+    assert len(jac) == nd and len(hess) == nd * (nd + 1) // 2
+    for i in range(nd):
+        assert bit_equal(jac[names[i]], g["jac_" + names[i]]), "jac_" + names[i]
+        for j in range(i, nd):
+            assert bit_equal(hess[names[i] + names[j]], g["hess_" + names[i] + names[j]]), names[i] + names[j]
+            assert hess[names[j] + names[i]] is hess[names[i] + names[j]]
+    if nd < 3:
+        with pytest.raises(KeyError):
+            jac["z"]
+    if nd == 1:
+        v2 = Field("q", 1, mesh, {"domain": product_cfg(case), "obstacle": None})
+        v2.set_var_tensor(torch.as_tensor(g["x0"]).cuda().clone())
+        ut = torch.as_tensor(g["u_tensor"]).cuda()
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            assert bit_equal(FDC({"div": {"limiter": "none", "edge": True}}).div(1.5, v2), g["div_edge_none_f"])
+            assert bit_equal(FDC({"div": {"limiter": "none", "edge": True}}).div(ut, v2), g["div_edge_none_t"])
+            assert bit_equal(FDC({"div": {"limiter": "upwind", "edge": True, "compat": True}}).div(1.5, v2),
+                             g["div_edge_upwind_f"])
+    else:
+        v2 = Field("q", 1, mesh, {"domain": product_cfg(case), "obstacle": None})
+        with pytest.raises(IndexError):
+            FDC({"div": {"limiter": "none", "edge": True}}).div(1.5, v2)
+
+
+def test_jacobian_hessian_closed_forms():
+    """reference tests/test_spatial.py::test_jac_and_hess"""
+    from pyapes_amd.geometry import Box
+    from pyapes_amd.mesh import Mesh
+    mesh = Mesh(Box[0:1, 0:1, 0:1], None, [3, 3, 3], "cuda", "double")
+    var = Field("t", 1, mesh, {"domain": None, "obstacle": None})
+    var.set_var_tensor((mesh.grid[0] ** 2 + 2 * mesh.grid[2] ** 2).unsqueeze(0).contiguous())
+    jac = jacobian(var)
+    assert torch.allclose(jac.x, 2 * mesh.grid[0]) and torch.allclose(jac.z, 4 * mesh.grid[2])
+    assert torch.allclose(jac.y, torch.zeros_like(jac.y))
+    var.set_var_tensor(((mesh.grid[0] ** 2) * (mesh.grid[2] ** 2)).unsqueeze(0).contiguous())
+    hess = hessian(var)
+    assert torch.allclose(hess.xx, 2 * mesh.grid[2] ** 2)
+    assert torch.allclose(hess.xz, 4 * mesh.grid[0] * mesh.grid[2])
+    assert torch.allclose(hess.xy, torch.zeros_like(hess.xy))
