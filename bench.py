@@ -165,7 +165,8 @@ def main():
     esize = 8 if dtype == "double" else 4
 
     dist = None
-    if world > 1:
+    force_slab = bool(os.environ.get("BENCH_FORCE_SLAB"))  # rehearsal: drive the slab path with one rank
+    if world > 1 or force_slab:
         import torch.distributed as dist_mod
         dist = dist_mod
         backend = os.environ.get("BENCH_BACKEND", "nccl")
@@ -175,7 +176,7 @@ def main():
             dist.init_process_group(backend)
 
     mesh = Mesh(Box([0.0, 0.0, 0.0], list(upper)), None, list(gn), "cuda", dtype,
-                slab=(rank, world) if world > 1 else None)
+                slab=(rank, world) if (world > 1 or force_slab) else None)
     var = Field("p", 1, mesh, {"domain": make_bcs(kind), "obstacle": None})
     rhs = synth_rhs(mesh, kind)
     log(f"rank {rank}/{world}: workload {args.workload} global {gn} local {tuple(mesh.nx)} {dtype} {kind}")
@@ -183,7 +184,7 @@ def main():
     W, K = args.warmup, args.steps
     terms = [{"kind": L.OP_LAPLACIAN, "sign": 1.0, "coeff": 1.0}]
 
-    if world == 1:
+    if world == 1 and not force_slab:
         ctx = context_for(mesh)
         ctx.bind_bcs(var(), var.bcs, 0)
         ctx.set_terms(terms)

@@ -172,6 +172,12 @@ typedef struct {
   const void* bc_far_lo1;
   const void* bc_far_hi0;  /* ... on the upper end rank: x[1] of the lower end rank (the new x[0] is
                               recomputed there bit for bit as x[1] - x[N-1] + x[N-2]) */
+  /* optional packing of the periodic x planes next to the residual planes, so that one message per
+   * neighbour carries everything: after phase_b the library copies x[1] to x_pack_lo1 (lower end
+   * rank) and x[n0-1], x[n0-2] to x_pack_hi0 / x_pack_hi1 (upper end rank); NULL = not wanted */
+  void* x_pack_lo1;
+  void* x_pack_hi0;
+  void* x_pack_hi1;
 } pa_slab;
 int pa_slab_set(pa_ctx* ctx, const pa_slab* slab); /* NULL: back to single GPU */
 

@@ -881,6 +881,21 @@ __global__ void __launch_bounds__(PA_BLOCK) k_ghost_dir(const SolverScalars* __r
   }
 }
 
+// slab, periodic axis 0: copies of the x planes the other end rank's BC fill needs, placed next to
+// the residual planes in the packed send buffers (one message per neighbour and iteration)
+template <typename T>
+__global__ void __launch_bounds__(PA_BLOCK) k_pack_planes(const SolverScalars* __restrict__ sc, int64_t n,
+                                                           const T* __restrict__ s0, T* __restrict__ d0,
+                                                           const T* __restrict__ s1, T* __restrict__ d1,
+                                                           const T* __restrict__ s2, T* __restrict__ d2) {
+  if (sc->done) return;
+  for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < n; q += (int64_t)gridDim.x * blockDim.x) {
+    if (d0) d0[q] = s0[q];
+    if (d1) d1[q] = s1[q];
+    if (d2) d2[q] = s2[q];
+  }
+}
+
 template <typename T>
 __global__ void k_copy(const T* __restrict__ a, T* __restrict__ b, int64_t n) {
   for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < n;
@@ -1567,6 +1582,7 @@ int pa_slab_set(pa_ctx* c, const pa_slab* s) {
     c->r_send_lo = c->r_send_hi = nullptr;
     c->r_recv_lo = c->r_recv_hi = nullptr;
     c->bc_far_lo0 = c->bc_far_lo1 = c->bc_far_hi0 = nullptr;
+    c->x_pack_lo1 = c->x_pack_hi0 = c->x_pack_hi1 = nullptr;
     return PA_OK;
   }
   if (c->ndim != 3) { pa_set_err(c, "pa_slab_set: slabs are for 3-D meshes"); return PA_E_ARG; }
@@ -1577,6 +1593,7 @@ int pa_slab_set(pa_ctx* c, const pa_slab* s) {
   c->r_recv_lo = s->r_recv_lo; c->r_recv_hi = s->r_recv_hi;
   c->x_glo = s->x_ghost_lo; c->x_ghi = s->x_ghost_hi;
   c->bc_far_lo0 = s->bc_far_lo0; c->bc_far_lo1 = s->bc_far_lo1; c->bc_far_hi0 = s->bc_far_hi0;
+  c->x_pack_lo1 = s->x_pack_lo1; c->x_pack_hi0 = s->x_pack_hi0; c->x_pack_hi1 = s->x_pack_hi1;
   return PA_OK;
 }
 
@@ -2009,6 +2026,12 @@ int pa_cg_phase_b_t(pa_ctx* c, int stage_post) {
   if (c->profile) pa_profile_stop(c, 1);
   c->b_blocks = used_blocks;
   if (c->slab) {  // BC fill + shell + reduction happen in pa_cg_bc, after the driver's plane exchange
+    if (c->x_pack_lo1 || c->x_pack_hi0 || c->x_pack_hi1) {
+      const T* xr = (const T*)x;
+      hipLaunchKernelGGL(k_pack_planes<T>, dim3(pa_grid_blocks(G.s0)), dim3(PA_BLOCK), 0, c->stream, c->sc, G.s0,
+                         xr + 1 * G.s0, (T*)c->x_pack_lo1, xr + (G.n0 - 1) * G.s0, (T*)c->x_pack_hi0,
+                         xr + (G.n0 - 2) * G.s0, (T*)c->x_pack_hi1);
+    }
     PA_HIP(c, hipGetLastError());
     return PA_OK;
   }

@@ -77,6 +77,9 @@ struct pa_ctx {
   const void* bc_far_lo0 = nullptr;  // periodic axis-0 fill: x[N-1] (for the lower end rank)
   const void* bc_far_lo1 = nullptr;  //                       x[N-2]
   const void* bc_far_hi0 = nullptr;  //                       x[1] of the lower end rank (for the upper end rank)
+  void* x_pack_lo1 = nullptr;        // pack destinations of x[1] / x[n0-1] / x[n0-2] (periodic end ranks)
+  void* x_pack_hi0 = nullptr;
+  void* x_pack_hi1 = nullptr;
   // per-kernel timing of the two dominant CG kernels (pa_profile_set): HIP events on the ctx stream
   int profile = 0;
   hipEvent_t pev[4] = {nullptr, nullptr, nullptr, nullptr};

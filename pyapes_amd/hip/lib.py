@@ -44,7 +44,7 @@ class PaTerm(C.Structure):
 class PaSlab(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in (
         "sums", "r_send_lo", "r_send_hi", "r_recv_lo", "r_recv_hi", "x_ghost_lo", "x_ghost_hi",
-        "bc_far_lo0", "bc_far_lo1", "bc_far_hi0")]
+        "bc_far_lo0", "bc_far_lo1", "bc_far_hi0", "x_pack_lo1", "x_pack_hi0", "x_pack_hi1")]
 
 
 # name -> (restype, argtypes); every symbol include/pyapes_hip.h declares

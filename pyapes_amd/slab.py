@@ -67,14 +67,34 @@ class SlabCG:
             return torch.zeros(plane, dtype=f, device=dev) if cond else None
 
         self.sums = torch.zeros(8, dtype=torch.float64, device=dev)
+        # Packed exchange buffers, one message per neighbour and iteration:
+        #   down (to nb_lo):  [ r first plane | x[1] if I am the lower end of a periodic ring ]
+        #   up   (to nb_hi):  [ r last plane  | x[n0-1], x[n0-2] if I am the upper end of the ring ]
+        # and the mirror-image receive buffers; the C side gets plane views of them.
+        first, last = self.periodic0 and r == 0, self.periodic0 and r == P - 1
+        self.k_lo, self.k_hi = 1 + (1 if first else 0), 1 + (2 if last else 0)   # planes I send down / up
+        self.m_lo, self.m_hi = 1 + (2 if first else 0), 1 + (1 if last else 0)   # planes I get from below / above
+
+        def pack(k, cond):
+            return torch.zeros((k, *plane), dtype=f, device=dev) if cond else None
+
+        self.send_lo, self.send_hi = pack(self.k_lo, self.nb_lo is not None), pack(self.k_hi, self.nb_hi is not None)
+        self.recv_lo, self.recv_hi = pack(self.m_lo, self.nb_lo is not None), pack(self.m_hi, self.nb_hi is not None)
+
+        def pl(t, i, cond=True):
+            return t[i] if (t is not None and cond) else None
+
         self.bufs = {
             "sums": self.sums,
-            "r_send_lo": buf(self.nb_lo is not None), "r_send_hi": buf(self.nb_hi is not None),
-            "r_recv_lo": buf(self.nb_lo is not None), "r_recv_hi": buf(self.nb_hi is not None),
+            "r_send_lo": pl(self.send_lo, 0), "r_send_hi": pl(self.send_hi, 0),
+            "r_recv_lo": pl(self.recv_lo, 0), "r_recv_hi": pl(self.recv_hi, 0),
             "x_ghost_lo": buf(self.nb_lo is not None), "x_ghost_hi": buf(self.nb_hi is not None),
-            "bc_far_lo0": buf(self.periodic0 and r == 0), "bc_far_lo1": buf(self.periodic0 and r == 0),
-            "bc_far_hi0": buf(self.periodic0 and r == P - 1),
+            "bc_far_lo0": pl(self.recv_lo, 1, first), "bc_far_lo1": pl(self.recv_lo, 2, first),
+            "bc_far_hi0": pl(self.recv_hi, 1, last),
+            "x_pack_lo1": pl(self.send_lo, 1, first), "x_pack_hi0": pl(self.send_hi, 1, last),
+            "x_pack_hi1": pl(self.send_hi, 2, last),
         }
+        self._iter_ops = None
         self.terms = list(terms)
         self._stage = None  # pinned CPU staging when the process group cannot move GPU tensors
 
@@ -136,13 +156,10 @@ class SlabCG:
         self._p2p(*self._bc_far_ops())
 
     def _exchange_iter(self) -> None:
-        """The one batched exchange of an iteration: residual planes + periodic far planes of x.
-        With P = 2 and a ring, rank 0 <-> rank 1 carry up to 5 messages each way; same-peer order is
-        sends [r_lo, r_hi, x...] against recvs [r_hi-ghost, r_lo-ghost, x...] on both sides."""
-        b = self.bufs
-        s1, r1 = self._plane_ops(b["r_send_lo"], b["r_send_hi"], b["r_recv_lo"], b["r_recv_hi"])
-        s2, r2 = self._bc_far_ops()
-        self._p2p(s1 + s2, r1 + r2)
+        """The one batched exchange of an iteration: ONE packed message to each neighbour (residual
+        plane + the periodic x planes phase_b packed behind it) and one from each.  Same-peer order
+        (P = 2 ring): sends [down, up] against receives [from above, from below] on both sides."""
+        self._p2p(*self._plane_ops(self.send_lo, self.send_hi, self.recv_lo, self.recv_hi))
 
     def _allreduce(self, lo: int, hi: int) -> None:
         self.dist.all_reduce(self.sums[lo:hi], op=self.dist.ReduceOp.SUM, group=self.group)

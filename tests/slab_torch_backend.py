@@ -195,6 +195,9 @@ class TorchSlabBackend:
         self.x.copy_(torch.where(self.S, self.x + self.alpha * self.d, self.x))
         self.r = torch.where(self.S, self.r - self.alpha * self.Ad, torch.zeros_like(self.r))
         self._send_r()
+        for key, plane in (("x_pack_lo1", 1), ("x_pack_hi0", -1), ("x_pack_hi1", -2)):
+            if b.get(key) is not None:
+                b[key].copy_(self.x[plane])
 
     def cg_bc(self):
         if self.done:
