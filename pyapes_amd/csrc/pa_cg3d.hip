@@ -41,6 +41,7 @@ struct Cg3dArgs {
   LapCoef<T> lap;
   T coeff, sign;
   int has_coeff;
+  const T* coeff_f;     // tensor coefficient Gamma(x) of laplacian(Gamma, phi) (fdm.py:166-169) or null
   const SolverScalars* sc;
   Vec<T> r, d;          // phase A: r and the old direction; phase B: d = new direction
   T* dnew;              // phase A output
@@ -290,6 +291,12 @@ __global__ void __launch_bounds__(256) k_cg3d(Cg3dArgs<T> A) {
         rv[jj] = __builtin_nontemporal_load(reinterpret_cast<const V*>(A.rw + o));
       }
     }
+    V cv[RJ];
+    if (A.coeff_f) {
+#pragma unroll
+      for (int jj = 0; jj < RJ; ++jj)
+        cv[jj] = *reinterpret_cast<const V*>(A.coeff_f + ii * G.s0 + jrow[jj] * G.s1 + kc);
+    }
     if (PHASE == 4 || PHASE == 5 || PHASE == 6 || (PHASE == 3 && A.aux)) {  // rhs / u / r0 of this plane
 #pragma unroll
       for (int jj = 0; jj < RJ; ++jj)
@@ -351,7 +358,7 @@ __global__ void __launch_bounds__(256) k_cg3d(Cg3dArgs<T> A) {
         mm = cMk * xmk;
         s = s + mm;
         ax = ax + s;
-        if (hasc) ax = ax * cf;
+        if (hasc) ax = ax * (A.coeff_f ? cv[jj][v] : cf);
         ax = ax * sgn;
         if (PHASE == 3) {
           // explicit Euler:  phi + dt (nu lap - adv)   (k_euler, pa_core.hip; ax = plain Laplacian)
@@ -406,7 +413,7 @@ __global__ void __launch_bounds__(256) k_cg3d(Cg3dArgs<T> A) {
           T dg = act0 ? cCi : (T)0;
           dg = dg + cCj;
           dg = dg + cCk;
-          if (hasc) dg = dg * cf;
+          if (hasc) dg = dg * (A.coeff_f ? cv[jj][v] : cf);
           dg = dg * sgn;
           T q = xv[jj][v] - ax;
           q = q / dg;
@@ -529,7 +536,8 @@ template <typename T>
 static bool cg3d_covered(const pa_ctx* c, const DevEq<T>& E, const void* p0, const void* p1, const void* p2) {
   if (!c->fastpath) return false;
   if (c->ndim != 3 && c->ndim != 2) return false;
-  if (E.nterms != 1 || E.t[0].kind != PA_OP_LAPLACIAN || E.t[0].coeff_f) return false;
+  if (E.nterms != 1 || E.t[0].kind != PA_OP_LAPLACIAN) return false;
+  if (E.t[0].coeff_f && ((uintptr_t)E.t[0].coeff_f & 15)) return false;
   constexpr int VEC = VecOf<T>::N;
   if (c->G.n2 % VEC != 0) return false;
   if ((c->ndim == 3 && c->G.n0 < 3) || c->G.n1 < 3 || c->G.n2 < 2 * VEC) return false;
@@ -624,6 +632,7 @@ static void fill_common(pa_ctx* c, const DevEq<T>& E, Cg3dArgs<T>& A) {
   A.G = c->G;
   A.lap = E.lap;
   A.coeff = E.t[0].coeff;
+  A.coeff_f = E.t[0].coeff_f;
   A.sign = E.t[0].sign;
   A.has_coeff = E.t[0].has_coeff;
   A.sc = c->sc;

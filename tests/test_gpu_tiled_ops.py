@@ -129,3 +129,47 @@ def test_euler_march_equals_repeated_steps():
             euler_step(a, 0.8, 1e-3, 1e-3, {"div": {"limiter": "upwind"}})
         euler_march(b, 0.8, 1e-3, 1e-3, nsteps, {"div": {"limiter": "upwind"}})
         assert torch.equal(a(), b()), nsteps
+
+
+@pytest.mark.parametrize("shape", [((12, 18, 20), "double"), ((40, 44), "double"), ((10, 12, 136), "single")],
+                         ids=["3d", "2d", "3d_f32"])
+def test_tensor_coefficient_laplacian_tiled(shape, monkeypatch):
+    """laplacian(Gamma(x), phi): A x, CG and Jacobi with a tensor coefficient on the
+    tiled kernels vs the generic kernels (bit-exact A x) and the oracle."""
+    n, dtype = shape
+    nd = len(n)
+    tdt = torch.float64 if dtype == "double" else torch.float32
+    g = torch.Generator().manual_seed(17)
+    x0 = torch.randn((1, *n), generator=g, dtype=torch.float64).to(tdt)
+    rhs0 = torch.randn((1, *n), generator=g, dtype=torch.float64).to(tdt)
+    gamma = (1.0 + 0.2 * torch.rand((1, *n), generator=g, dtype=torch.float64)).to(tdt)
+    bcs = [D(0.0), N(0.5), D(0.3), N(0.0), D(1.0), N(-0.25)][:2 * nd]
+    out = {}
+    for fast in (True, False):
+        monkeypatch.setenv("PYAPES_HIP_FASTPATH", "1" if fast else "0")
+        mesh = Mesh(Box([0.0] * nd, [1.0] * nd), None, list(n), "cuda", dtype)
+        var = Field("p", 1, mesh, {"domain": _cfg(bcs), "obstacle": None})
+        var.set_var_tensor(x0.cuda().clone())
+        var.apply_bcs()
+        solver = Solver({"fdm": {"method": "cg", "tol": 1e-30, "max_it": 5, "report": False}})
+        solver.set_eq(FDM().laplacian(gamma.cuda(), var) == rhs0.cuda().clone())
+        res = {"aop": solver.Aop(var).cpu()}
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            rep = solver.solve()
+        res["cg"], res["rep"] = var().cpu(), rep
+        out[fast] = res
+    assert torch.equal(out[True]["aop"], out[False]["aop"])
+    assert out[True]["rep"]["itr"] == out[False]["rep"]["itr"] == 6
+    assert rel_err(out[True]["cg"], out[False]["cg"]) <= (1e-12 if dtype == "double" else 2e-5)
+    om = O.OMesh([0.0] * nd, [1.0] * nd, list(n), dtype)
+    orc = [{"bc_face": O.FACES[i], "bc_type": t, "bc_val": v} for i, (t, v) in enumerate(bcs)]
+    bo = O.make_bcs(om, orc)
+    xo = x0.clone()
+    tabs = O.laplacian_tables(xo, om, bo)
+    rhs = rhs0.clone() + O.laplacian_rhs_adjust(xo, om, bo)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        xs, ro = O.cg(xo, rhs, [O.OTerm("laplacian", tabs, gamma, 1.0)], om, bo, 1e-30, 5)
+    assert ro["itr"] == 6
+    assert rel_err(out[True]["cg"], xs) <= (1e-10 if dtype == "double" else 1e-5)
