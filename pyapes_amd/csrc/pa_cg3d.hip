@@ -74,7 +74,7 @@ __device__ __forceinline__ int64_t pa_wrapmod(int64_t v, int64_t n) {
   return v < 0 ? v + n : v;
 }
 
-template <typename T, int RJ, int PHASE>
+template <typename T, int RJ, int PHASE, bool CF = false>
 __global__ void __launch_bounds__(256) k_cg3d(Cg3dArgs<T> A) {
   typedef typename VecOf<T>::type V;
   constexpr int VEC = VecOf<T>::N;
@@ -292,7 +292,7 @@ __global__ void __launch_bounds__(256) k_cg3d(Cg3dArgs<T> A) {
       }
     }
     V cv[RJ];
-    if (A.coeff_f) {
+    if (CF) {
 #pragma unroll
       for (int jj = 0; jj < RJ; ++jj)
         cv[jj] = *reinterpret_cast<const V*>(A.coeff_f + ii * G.s0 + jrow[jj] * G.s1 + kc);
@@ -358,7 +358,7 @@ __global__ void __launch_bounds__(256) k_cg3d(Cg3dArgs<T> A) {
         mm = cMk * xmk;
         s = s + mm;
         ax = ax + s;
-        if (hasc) ax = ax * (A.coeff_f ? cv[jj][v] : cf);
+        if (hasc) ax = ax * (CF ? cv[jj][v] : cf);
         ax = ax * sgn;
         if (PHASE == 3) {
           // explicit Euler:  phi + dt (nu lap - adv)   (k_euler, pa_core.hip; ax = plain Laplacian)
@@ -413,7 +413,7 @@ __global__ void __launch_bounds__(256) k_cg3d(Cg3dArgs<T> A) {
           T dg = act0 ? cCi : (T)0;
           dg = dg + cCj;
           dg = dg + cCk;
-          if (hasc) dg = dg * (A.coeff_f ? cv[jj][v] : cf);
+          if (hasc) dg = dg * (CF ? cv[jj][v] : cf);
           dg = dg * sgn;
           T q = xv[jj][v] - ax;
           q = q / dg;
@@ -556,21 +556,21 @@ static int cus_of(pa_ctx* c) {
   return cus;
 }
 
-template <typename T, int RJ, int PHASE>
+template <typename T, int RJ, int PHASE, bool CF>
 static int blocks_per_cu() {
   static int cached = 0;
   if (!cached) {
     const char* e = getenv(PHASE == 0 ? "PYAPES_HIP_BPC_A" : (PHASE == 1 ? "PYAPES_HIP_BPC_B" : "PYAPES_HIP_BPC_X"));
     int n = e ? atoi(e) : 0;
     if (n <= 0) {
-      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_cg3d<T, RJ, PHASE>, 256, 0) != hipSuccess || n <= 0) n = 2;
+      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_cg3d<T, RJ, PHASE, CF>, 256, 0) != hipSuccess || n <= 0) n = 2;
     }
     cached = n;
   }
   return cached;
 }
 
-template <typename T, int RJ, int PHASE>
+template <typename T, int RJ, int PHASE, bool CF = false>
 static int launch_cg3d(pa_ctx* c, Cg3dArgs<T>& A) {
   constexpr int VEC = VecOf<T>::N;
   constexpr int TJ = 4 * RJ, TK = 64 * VEC;
@@ -578,7 +578,7 @@ static int launch_cg3d(pa_ctx* c, Cg3dArgs<T>& A) {
   A.tiles_j = (int)((G.n1 + TJ - 1) / TJ);
   A.tiles_k = (int)((G.n2 + TK - 1) / TK);
   const int tiles = A.tiles_j * A.tiles_k;
-  const int capacity = cus_of(c) * blocks_per_cu<T, RJ, PHASE>();
+  const int capacity = cus_of(c) * blocks_per_cu<T, RJ, PHASE, CF>();
   int chunks = capacity / tiles;
   if (chunks < 1) chunks = 1;
   if (chunks > G.n0) chunks = (int)G.n0;
@@ -591,9 +591,9 @@ static int launch_cg3d(pa_ctx* c, Cg3dArgs<T>& A) {
     --dbg;
     fprintf(stderr, "[pyapes_hip] k_cg3d phase %c: tiles %dx%d chunks %d (CI ~%lld) blocks %d, %d blocks/CU x %d CUs\n",
             (char)('A' + PHASE), A.tiles_j, A.tiles_k, chunks, (long long)(G.n0 / chunks), nblk,
-            blocks_per_cu<T, RJ, PHASE>(), cus_of(c));
+            blocks_per_cu<T, RJ, PHASE, CF>(), cus_of(c));
   }
-  hipLaunchKernelGGL((k_cg3d<T, RJ, PHASE>), dim3(nblk), dim3(256), 0, c->stream, A);
+  hipLaunchKernelGGL((k_cg3d<T, RJ, PHASE, CF>), dim3(nblk), dim3(256), 0, c->stream, A);
   return nblk;
 }
 
@@ -620,6 +620,17 @@ static int pick_rj(pa_ctx* c) {
 
 template <typename T, int PHASE>
 static int launch_any(pa_ctx* c, Cg3dArgs<T>& A) {
+  constexpr bool CF_OK = (PHASE == 0 || PHASE == 1 || PHASE == 2 || PHASE == 4);
+  if (A.coeff_f) {  // tensor coefficient: separate instantiation, so the scalar-coefficient kernels stay lean
+    if (!CF_OK) return 0;
+    if constexpr (CF_OK) {
+      switch (pick_rj<T>(c)) {
+        case 1: return launch_cg3d<T, 1, PHASE, true>(c, A);
+        case 2: return launch_cg3d<T, 2, PHASE, true>(c, A);
+        default: return launch_cg3d<T, 4, PHASE, true>(c, A);
+      }
+    }
+  }
   switch (pick_rj<T>(c)) {
     case 1: return launch_cg3d<T, 1, PHASE>(c, A);
     case 2: return launch_cg3d<T, 2, PHASE>(c, A);
