@@ -293,7 +293,7 @@ def main():
                 except Exception:
                     pass
             out["roofline"] = roof
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:   # reported baseline: rank 0 at N = 1 only
             out["cpu_baseline"] = cpu_baseline(kind, dtype)
         print(json.dumps(out))
     if dist is not None:
