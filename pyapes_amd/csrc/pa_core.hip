@@ -655,6 +655,128 @@ __global__ void __launch_bounds__(PA_BLOCK) k_bc_scatter(DevGeom G, const int* _
   }
 }
 
+
+// ---- BC fill, one launch per AXIS (lower then upper face in the same thread) + the boundary-shell
+//      part of the stop test in the same pass ------------------------------------------------------
+// Valid for the factory order xl,xu,yl,yu,zl,zu: within an axis the upper fill only depends on the
+// lower fill through the periodic copy x[N-1] = x[0], which the same thread has just computed;
+// across axes the launches are still sequential.  Halves the strided passes over the z faces and
+// removes the separate k_shell pass: every shell node is charged to the LAST face that writes it
+// (z over y over x), which is where its final value is known.
+template <typename T>
+struct BCPairArgs {
+  BCArgs<T> lo, hi;   // .type == 0: face absent on this rank
+  int axis;
+  int64_t pos_lo, pos_hi;  // offsets of the two faces in the shell buffer
+};
+
+template <typename T>
+__device__ __forceinline__ T pa_bc_face_value(const BCArgs<T>& B, const T* __restrict__ x, int64_t base, int64_t st,
+                                              int64_t off, int64_t N, int64_t q, T x0_new) {
+  const bool lower = B.side == 0;
+  const int64_t p1 = lower ? 1 : N - 2, p2 = lower ? 2 : N - 3;
+  if (B.type == 1) return B.vals ? B.vals[q] : B.sval;
+  if (B.type == 2) {
+    T ct;
+    if (B.vals) {
+      ct = B.c23 * B.vals[q];
+      ct = ct * B.dxf;
+      ct = ct * B.ndir;
+    } else {
+      ct = B.sval;
+    }
+    T t1 = B.c43 * x[base + (p1 - off) * st];
+    T t2 = B.c13 * x[base + (p2 - off) * st];
+    t1 = t1 - t2;
+    return t1 + ct;
+  }
+  if (B.type == 3) return x[base + (p1 - off) * st];
+  // periodic
+  if (lower) {
+    T vp = x[base + (1 - off) * st];
+    T vf = B.far0 ? B.far0[q] : x[base + (N - 1 - off) * st];
+    T vff = B.far0 ? B.far1[q] : x[base + (N - 2 - off) * st];
+    T t1 = vp - vf;
+    return t1 + vff;
+  }
+  if (B.far0) {  // slab: x[1] of the lower end rank arrived in far0; recompute its new x[0] bit for bit
+    T t1 = B.far0[q] - x[base + (N - 1 - off) * st];
+    return t1 + x[base + (N - 2 - off) * st];
+  }
+  return x0_new;
+}
+
+template <typename T>
+__global__ void __launch_bounds__(PA_BLOCK) k_bc_pair(DevGeom G, T* __restrict__ x, BCPairArgs<T> P,
+                                                       const int* __restrict__ done, T* __restrict__ shell_old,
+                                                       double* __restrict__ partials, int mode) {
+  if (done && *done) return;
+  const int a = P.axis;
+  const int64_t nu = (a == 0) ? G.n1 : G.n0;
+  const int64_t nv = (a == 2) ? G.n1 : G.n2;
+  const int64_t N = (a == 0) ? G.g0 : (a == 1 ? G.n1 : G.n2);
+  const int64_t off = (a == 0) ? G.off0 : 0;
+  const int64_t st = (a == 0) ? G.s0 : (a == 1 ? G.s1 : 1);
+  double s[1] = {0.0};
+  for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < nu * nv;
+       q += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t u = q / nv, v = q - u * nv;
+    int64_t base;
+    bool owned = true;  // is this axis the last one whose faces contain the node?
+    if (a == 0) {
+      base = u * G.s1 + v;
+      if (G.act[1] && (u == 0 || u == G.n1 - 1)) owned = false;
+      if (G.act[2] && (v == 0 || v == G.n2 - 1)) owned = false;
+    } else if (a == 1) {
+      base = u * G.s0 + v;
+      if (G.act[2] && (v == 0 || v == G.n2 - 1)) owned = false;
+    } else {
+      base = u * G.s0 + v * G.s1;
+    }
+    T x0_new = (T)0;
+    if (P.lo.type) {
+      T* xf = x + base + (0 - off) * st;
+      T val;
+      if (mode == 3) {
+        val = *xf;
+      } else {
+        val = pa_bc_face_value<T>(P.lo, x, base, st, off, N, q, (T)0);
+        *xf = val;
+      }
+      x0_new = val;
+      if (mode && owned) {
+        if (mode == 1) {
+          T df = val - shell_old[P.pos_lo + q];
+          T p = df * df;
+          s[0] += (double)p;
+        }
+        shell_old[P.pos_lo + q] = val;
+      }
+    } else if (P.hi.type == 4 && !P.hi.far0) {
+      x0_new = x[base + (0 - off) * st];
+    }
+    if (P.hi.type) {
+      T* xf = x + base + (N - 1 - off) * st;
+      T val;
+      if (mode == 3) {
+        val = *xf;
+      } else {
+        val = pa_bc_face_value<T>(P.hi, x, base, st, off, N, q, x0_new);
+        *xf = val;
+      }
+      if (mode && owned) {
+        if (mode == 1) {
+          T df = val - shell_old[P.pos_hi + q];
+          T p = df * df;
+          s[0] += (double)p;
+        }
+        shell_old[P.pos_hi + q] = val;
+      }
+    }
+  }
+  if (mode == 1) pa_block_reduce_store<1>(s, partials);
+}
+
 // ---- reductions of per-block partials + scalar logic ------------------------------------
 // sums[slot[s]] (+)= sum over blocks of partials[b*ns + s]
 __device__ __forceinline__ double pa_reduce_partials(const double* __restrict__ partials, int nblk, int ns,
@@ -1814,6 +1936,96 @@ static int bc_shell_fused(pa_ctx* c, T* x, double* part2, int with_delta, bool g
   return PA_OK;
 }
 
+// BC list in factory order with both faces of every mesh axis present (what the BC factories emit),
+// >= 5 nodes per axis: the per-axis pair kernels apply
+static bool bc_pairable(const pa_ctx* c) {
+  if (getenv("PYAPES_HIP_BC_UNPAIRED")) return false;
+  int last = -1, cnt = 0;
+  for (int w = 0; w < c->nbc; ++w) {
+    if (c->bc[c->bc_order[w]].type == PA_BC_NONE) continue;
+    if (c->bc_order[w] <= last) return false;
+    last = c->bc_order[w];
+    ++cnt;
+  }
+  const DevGeom& G = c->G;
+  const int64_t N[3] = {G.g0, G.n1, G.n2};
+  int need = 0;
+  for (int a = 0; a < 3; ++a) {
+    if (!G.act[a]) continue;
+    need += 2;
+    if (N[a] < 5 || (a == 0 && G.n0 < 3)) return false;
+    if (c->bc[2 * a].type == PA_BC_NONE || c->bc[2 * a + 1].type == PA_BC_NONE) return false;
+    if ((c->bc[2 * a].type == PA_BC_PERIODIC) != (c->bc[2 * a + 1].type == PA_BC_PERIODIC)) return false;
+  }
+  return cnt == need;
+}
+
+template <typename T>
+static void bc_face_args(pa_ctx* c, int f, BCArgs<T>& B, bool guarded) {
+  const DevGeom& G = c->G;
+  const HostBC& b = c->bc[f];
+  memset(&B, 0, sizeof(B));
+  const int a = f >> 1, side = f & 1;
+  B.axis = a; B.side = side; B.type = b.type;
+  if (a == 0) {  // slab: only the rank holding the global boundary plane
+    if (side == 0 && G.off0 != 0) B.type = 0;
+    if (side == 1 && G.off0 + G.n0 != G.g0) B.type = 0;
+  }
+  B.vals = (const T*)b.vals;
+  B.c43 = (T)(4.0 / 3.0);
+  B.c13 = (T)(1.0 / 3.0);
+  B.c23 = (T)(2.0 / 3.0);
+  B.dxf = (T)b.dxf;
+  B.ndir = side == 0 ? (T)-1 : (T)1;
+  B.done = guarded ? pa_done_flag(c) : nullptr;
+  if (b.type == PA_BC_DIRICHLET) B.sval = (T)b.value;
+  if (b.type == PA_BC_NEUMANN) {
+    T pre = (T)((2.0 / 3.0) * b.value);
+    pre = pre * B.dxf;
+    pre = pre * B.ndir;
+    B.sval = pre;
+  }
+  if (b.type == PA_BC_PERIODIC && a == 0 && G.n0 != G.g0) {
+    B.far0 = (const T*)(side == 0 ? c->bc_far_lo0 : c->bc_far_hi0);
+    B.far1 = (const T*)c->bc_far_lo1;
+  }
+}
+
+// mode 0: fill only; 1: fill + shell delta (partials -> part2, rows returned in *nsh) + save; 2: fill + save;
+// 3: save only (slab: the driver has filled the BCs itself)
+template <typename T>
+static int bc_pair_apply(pa_ctx* c, T* x, double* part2, int mode, bool guarded, int* nsh) {
+  const DevGeom& G = c->G;
+  const int64_t sz[3] = {G.n1 * G.n2, G.n0 * G.n2, G.n0 * G.n1};
+  int64_t start[6], total = 0;
+  for (int f = 0; f < 6; ++f) { start[f] = total; total += G.act[f >> 1] ? sz[f >> 1] : 0; }
+  T* shell = (T*)c->scr[SCR_SHELL];
+  int rows = 0;
+  for (int a = 0; a < 3; ++a) {
+    if (!G.act[a]) continue;
+    BCPairArgs<T> P;
+    bc_face_args<T>(c, 2 * a, P.lo, guarded);
+    bc_face_args<T>(c, 2 * a + 1, P.hi, guarded);
+    if (mode != 3 && ((P.lo.type == PA_BC_PERIODIC && a == 0 && G.n0 != G.g0 && !P.lo.far0) ||
+                      (P.hi.type == PA_BC_PERIODIC && a == 0 && G.n0 != G.g0 && !P.hi.far0))) {
+      pa_set_err(c, "periodic axis-0 BC on a slab needs the far planes (pa_slab_set)");
+      return PA_E_STATE;
+    }
+    if (!P.lo.type && !P.hi.type) continue;
+    P.axis = a;
+    P.pos_lo = start[2 * a];
+    P.pos_hi = start[2 * a + 1];
+    const int nb = pa_grid_blocks(sz[a]);
+    hipLaunchKernelGGL(k_bc_pair<T>, dim3(nb), dim3(PA_BLOCK), 0, pa_ls(c), G, x, P,
+                       guarded ? pa_done_flag(c) : (const int*)nullptr, shell, part2 ? part2 + rows : nullptr,
+                       mode);
+    if (mode == 1) rows += nb;
+  }
+  if (nsh) *nsh = rows;
+  PA_HIP(c, hipGetLastError());
+  return PA_OK;
+}
+
 static int init_scalars(pa_ctx* c, double tol, int64_t max_it) {
   SolverScalars h;
   memset(&h, 0, sizeof(h));
@@ -1870,13 +2082,14 @@ static int cg_begin_t(pa_ctx* c, T* x, const T* rhs, double tol, int64_t max_it)
   if ((rc = pa_scratch(c, &c->scr[SCR_D0], &c->cap[SCR_D0], fb))) return rc;
   if ((rc = pa_scratch(c, &c->scr[SCR_D1], &c->cap[SCR_D1], fb))) return rc;
   if ((rc = pa_scratch(c, &c->scr[SCR_PART], &c->cap[SCR_PART], (size_t)PA_MAX_PARTIALS * 4 * sizeof(double)))) return rc;
-  if ((rc = pa_scratch(c, &c->scr[SCR_PART2], &c->cap[SCR_PART2], (size_t)PA_MAX_GRID * sizeof(double)))) return rc;
+  if ((rc = pa_scratch(c, &c->scr[SCR_PART2], &c->cap[SCR_PART2], (size_t)3 * PA_MAX_GRID * sizeof(double)))) return rc;
   if ((rc = pa_scratch(c, &c->scr[SCR_SHELL], &c->cap[SCR_SHELL], 2 * (size_t)shell_elems(c) * sizeof(T)))) return rc;
   if ((rc = init_scalars(c, tol, max_it))) return rc;
   c->cg_x = x;
   c->cur = 0;
   c->bc_static = bc_is_static(c);
   c->bc_fused = bc_fusable(c);
+  c->bc_pair = (!c->bc_fused && bc_pairable(c)) ? 1 : 0;
   c->shell_cur = 0;
   c->side_pending = 0;
   c->launch_stream = nullptr;
@@ -1894,6 +2107,7 @@ static int cg_begin_t(pa_ctx* c, T* x, const T* rhs, double tol, int64_t max_it)
         (void)hipGetLastError();
       }
     }
+    if (c->overlap) c->bc_pair = 0;
   }
   c->solver_live = 1;
   DevEq<T> E;
@@ -1905,9 +2119,15 @@ static int cg_begin_t(pa_ctx* c, T* x, const T* rhs, double tol, int64_t max_it)
     if (c->bc_fused) {  // fill + remember the filled shell as x_old in one go
       if ((rc = bc_shell_fused<T>(c, x, nullptr, 0, false, nullptr, false))) return rc;
       shell_ready = true;
+    } else if (c->bc_pair) {
+      if ((rc = bc_pair_apply<T>(c, x, nullptr, 2, false, nullptr))) return rc;
+      shell_ready = true;
     } else if ((rc = bc_apply_t<T>(c, x))) {
       return rc;
     }
+  } else if (c->bc_pair) {  // slab: the driver has filled the BCs already; only record the shell
+    if ((rc = bc_pair_apply<T>(c, x, nullptr, 3, false, nullptr))) return rc;
+    shell_ready = true;
   }
   T* r = (T*)c->scr[SCR_R];
   T* d = (T*)c->scr[SCR_D0];
@@ -2065,6 +2285,8 @@ int pa_cg_phase_b_t(pa_ctx* c, int stage_post) {
   if (!c->bc_static) {
     if (c->bc_fused) {
       if ((rc = bc_shell_fused<T>(c, x, part2, 1, true, &nsh, false))) return rc;
+    } else if (c->bc_pair) {
+      if ((rc = bc_pair_apply<T>(c, x, part2, 1, true, &nsh))) return rc;
     } else {
       if ((rc = bc_apply_t<T>(c, x, true))) return rc;
       nsh = shell_blocks(c);
@@ -2090,6 +2312,8 @@ int pa_cg_bc_t(pa_ctx* c) {
   if (!c->bc_static) {
     if (c->bc_fused) {
       if ((rc = bc_shell_fused<T>(c, x, part2, 1, true, &nsh, false))) return rc;
+    } else if (c->bc_pair) {
+      if ((rc = bc_pair_apply<T>(c, x, part2, 1, true, &nsh))) return rc;
     } else {
       if ((rc = bc_apply_t<T>(c, x, true))) return rc;
       nsh = shell_blocks(c);
@@ -2141,7 +2365,7 @@ static int jacobi_run_t(pa_ctx* c, T* x, const T* rhs, double tol, int64_t max_i
   int rc;
   if ((rc = pa_scratch(c, &c->scr[SCR_D0], &c->cap[SCR_D0], fb))) return rc;
   if ((rc = pa_scratch(c, &c->scr[SCR_PART], &c->cap[SCR_PART], (size_t)PA_MAX_PARTIALS * 4 * sizeof(double)))) return rc;
-  if ((rc = pa_scratch(c, &c->scr[SCR_PART2], &c->cap[SCR_PART2], (size_t)PA_MAX_GRID * sizeof(double)))) return rc;
+  if ((rc = pa_scratch(c, &c->scr[SCR_PART2], &c->cap[SCR_PART2], (size_t)3 * PA_MAX_GRID * sizeof(double)))) return rc;
   if ((rc = pa_scratch(c, &c->scr[SCR_SHELL], &c->cap[SCR_SHELL], (size_t)shell_elems(c) * sizeof(T)))) return rc;
   if ((rc = init_scalars(c, tol, max_it))) return rc;
   DevEq<T> E;

@@ -56,6 +56,7 @@ struct pa_ctx {
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   // CG state
   int solver_live = 0, cur = 0, bc_static = 0, pending_init_logic = 0, b_blocks = 0;
+  int bc_pair = 0;  // per-axis pair kernels (lower + upper face + shell stop-test term in one launch)
   int bc_fused = 0, shell_cur = 0;  // fused BC fill: which half of SCR_SHELL holds x_old on the shell
   // overlap: the BC fill + boundary-shell part of the stop test of iteration k run on a second
   // stream beside phase A of iteration k+1 (they touch x / the shell only; phase A touches r, d)

@@ -71,3 +71,16 @@ def test_two_slabs_on_one_gpu(name, shape, tmp_path):
     assert res["itr"] == ro["itr"] == K + 1
     err = float(torch.linalg.norm(res["x"].double() - xo.double()) / torch.linalg.norm(xo.double()))
     assert err < (1e-10 if dtype == "double" else 1e-5), err
+
+
+@pytest.mark.parametrize("name", list(CASES), ids=list(CASES))
+def test_two_slabs_pair_bc_kernels(name, tmp_path, monkeypatch):
+    """same, with the per-axis BC pair kernels (what a large slab uses) instead of the fused fill"""
+    monkeypatch.setenv("PYAPES_HIP_BC_UNFUSED", "1")
+    test_two_slabs_on_one_gpu(name, ((24, 20, 132), "double"), tmp_path)
+    paired = torch.load(str(tmp_path / "x.pt"))
+    monkeypatch.setenv("PYAPES_HIP_BC_UNPAIRED", "1")
+    test_two_slabs_on_one_gpu(name, ((24, 20, 132), "double"), tmp_path)
+    plain = torch.load(str(tmp_path / "x.pt"))
+    assert torch.equal(paired["x"], plain["x"])
+    assert abs(paired["tol"] - plain["tol"]) <= 1e-12 * abs(plain["tol"])
