@@ -43,7 +43,9 @@ import torch
 from torch import Tensor
 
 FACES = ["xl", "xu", "yl", "yu", "zl", "zu"]
+FACES_RZ = ["rl", "ru", "zl", "zu"]          # geometry/basis.py:18 (Cylinder: axis 0 = r, axis 1 = z)
 _AXIS = {"x": 0, "y": 1, "z": 2}
+_AXIS_RZ = {"r": 0, "z": 1}                   # geometry/basis.py:10
 
 
 def _tdtype(dtype: str | int) -> torch.dtype:
@@ -58,10 +60,15 @@ def _tdtype(dtype: str | int) -> torch.dtype:
 # mesh (pyapes/mesh/_mesh.py:30-117)
 # --------------------------------------------------------------------------
 class OMesh:
-    """Node-based equidistant box mesh; ``spacing`` = node counts (ints) or dx (floats)."""
+    """Node-based equidistant box mesh; ``spacing`` = node counts (ints) or dx (floats).
+    ``coord="rz"``: axisymmetric (Cylinder) mesh, 2-D, axis 0 = r >= 0 (_mesh.py:48-49, 121-131)."""
 
     def __init__(self, lower: Sequence[float], upper: Sequence[float],
-                 spacing: Sequence[int | float], dtype: str | int = "double"):
+                 spacing: Sequence[int | float], dtype: str | int = "double", coord: str = "xyz"):
+        assert coord in ("xyz", "rz")
+        self.coord = coord
+        if coord == "rz":
+            assert len(lower) == 2 and lower[0] >= 0
         self.dtype = _tdtype(dtype)
         self.lower = [float(v) for v in lower]
         self.upper = [float(v) for v in upper]
@@ -85,9 +92,21 @@ class OMesh:
     def dx(self) -> Tensor:
         return torch.tensor(self.dx_list, dtype=self.dtype)
 
+    @property
+    def faces(self) -> list[str]:
+        return FACES_RZ if self.coord == "rz" else FACES[:2 * self.dim]
+
+    def axis_of(self, face: str) -> int:
+        return (_AXIS_RZ if self.coord == "rz" else _AXIS)[face[0]]
+
+    @property
+    def R(self) -> Tensor:
+        assert self.coord == "rz"
+        return self.grid[0]
+
     def face_mask(self, face: str) -> Tensor:
         """Whole boundary plane incl. edges/corners (_mesh.py:321-399)."""
-        a = _AXIS[face[0]]
+        a = self.axis_of(face)
         m = torch.zeros(*self.nx, dtype=torch.bool)
         idx: list[Any] = [slice(None)] * self.dim
         idx[a] = 0 if face[1] == "l" else self.nx[a] - 1
@@ -110,7 +129,7 @@ class OBC:
 
     def __post_init__(self):
         self.type = self.type.lower()
-        self.axis = _AXIS[self.face[0]]
+        self.axis = self.mesh.axis_of(self.face)
         self.n_dir = -1 if self.face[1] == "l" else 1
         self.mask = self.mesh.face_mask(self.face)
         # bcs.py:84-93: rolled copies of the face mask along the face normal
@@ -172,13 +191,13 @@ def make_bcs(mesh: OMesh, cfg: Sequence[dict]) -> list[OBC]:
             for c in cfg]
 
 
-def homogeneous_cfg(dim: int, val: Any, typ: str) -> list[dict]:
-    return [{"bc_face": FACES[i], "bc_type": typ,
+def homogeneous_cfg(dim: int, val: Any, typ: str, faces: Sequence[str] = FACES) -> list[dict]:
+    return [{"bc_face": faces[i], "bc_type": typ,
              "bc_val": val[i] if isinstance(val, list) else val} for i in range(2 * dim)]
 
 
-def mixed_cfg(vals: Sequence[Any], types: Sequence[str]) -> list[dict]:
-    return [{"bc_face": FACES[i], "bc_type": t, "bc_val": v}
+def mixed_cfg(vals: Sequence[Any], types: Sequence[str], faces: Sequence[str] = FACES) -> list[dict]:
+    return [{"bc_face": faces[i], "bc_type": t, "bc_val": v}
             for i, (v, t) in enumerate(zip(vals, types))]
 
 
@@ -191,11 +210,12 @@ def bc_fill(var: Tensor, bcs: Sequence[OBC]) -> Tensor:
 
 
 def interior_slicer(ndim: int, bcs: Sequence[OBC]) -> tuple[slice, ...]:
-    """mesh/tools.py:7-20."""
+    """mesh/tools.py:7-20.  Literal: the face letter goes through the xyz table whatever the mesh is,
+    so a periodic face of an rz mesh raises here (KeyError 'r' / IndexError for 'z' -> 2)."""
     lim: list[list[int | None]] = [[1, -1] for _ in range(ndim)]
     for bc in bcs:
         if bc.type == "periodic":
-            lim[bc.axis][0 if bc.face[1] == "l" else 1] = None
+            lim[_AXIS[bc.face[0]]][0 if bc.face[1] == "l" else 1] = None
     return tuple(slice(*l) for l in lim)
 
 
@@ -217,6 +237,10 @@ def _bc_value(bc: OBC, var: Tensor, d: int) -> Any:
 # coefficient tables [App, Ap, Ac, Am, Amm], each a list over mesh axes of
 # tensors shaped like var (dim, *nx)         (solver/tools.py:29-108)
 # --------------------------------------------------------------------------
+def _nn(t: Tensor) -> Tensor:
+    return torch.nan_to_num(t, nan=0.0, posinf=0.0, neginf=0.0)
+
+
 def _base_tables(var: Tensor, ndim: int, p: float, c: float, m: float):
     z = lambda: [torch.zeros_like(var) for _ in range(ndim)]  # noqa: E731
     return [z(),
@@ -227,8 +251,13 @@ def _base_tables(var: Tensor, ndim: int, p: float, c: float, m: float):
 
 
 def laplacian_tables(var: Tensor, mesh: OMesh, bcs: Sequence[OBC] | None):
-    """fdc.py:376-423 (xyz only)."""
+    """fdc.py:376-423; rz base rows tools.py:86-107."""
     App, Ap, Ac, Am, Amm = _base_tables(var, mesh.dim, 1.0, -2.0, 1.0)
+    if mesh.coord == "rz":
+        dr = mesh.dx[0]
+        scale = _nn(dr / (2 * mesh.R))
+        Ap[0] = (1 + scale) * torch.ones_like(var)
+        Am[0] = (1 - scale) * torch.ones_like(var)
     dx = mesh.dx
     for i in range(var.shape[0]):
         for j in range(mesh.dim):
@@ -238,7 +267,9 @@ def laplacian_tables(var: Tensor, mesh: OMesh, bcs: Sequence[OBC] | None):
                 if bc.n_vec[j] == 0:
                     continue
                 if bc.type in ("neumann", "symmetry"):
-                    alpha = torch.zeros_like(mesh.grid[j][bc.prev])
+                    dr = mesh.dx[j] if j == 0 else 0.0
+                    r = mesh.grid[j][bc.prev]
+                    alpha = _nn(2 / 3 * dr / r) if mesh.coord == "rz" else torch.zeros_like(r)
                     if bc.n_dir < 0:
                         Ap[j][i][bc.prev] = 2 / 3 + alpha
                         Ac[j][i][bc.prev] = -(2 / 3 + alpha)
@@ -263,7 +294,9 @@ def laplacian_rhs_adjust(var: Tensor, mesh: OMesh, bcs: Sequence[OBC] | None) ->
         for j in range(mesh.dim):
             for bc in bcs:
                 if bc.type == "neumann":
-                    alpha = torch.zeros_like(mesh.grid[j][bc.prev])
+                    dr = mesh.dx[j] if j == 0 else 0.0
+                    r = mesh.grid[j][bc.prev]
+                    alpha = _nn(1 / 3 * dr / r) if mesh.coord == "rz" else torch.zeros_like(r)
                     at_bc = _bc_value(bc, var, i)
                     adj[i][bc.prev] += (2 / 3 - alpha) * (at_bc * bc.n_vec[j]) / dx[j]
     return adj
@@ -352,6 +385,8 @@ def div_tables(u: float | Tensor, var: Tensor, mesh: OMesh, bcs: Sequence[OBC] |
     """fdc.py:623-664, 708-772 (literal; 'upwind' is the reference's defective form, Q3)."""
     adv = adv_tensor(u, var)
     App, Ap, Ac, Am, Amm = _base_tables(var, mesh.dim, 1.0, 0.0, -1.0)
+    if mesh.coord == "rz":  # tools.py:64-78: the u phi / r term of the axisymmetric divergence
+        Ac[0] = _nn(2 * mesh.dx[0] / mesh.R) * torch.ones_like(var)
     limiter = limiter.lower()
     if limiter == "none":
         advection = torch.zeros_like(var[0])
@@ -657,6 +692,11 @@ def div_upwind_intended(u: float | Tensor, var: Tensor, mesh: OMesh) -> Tensor:
         bwd = phi - torch.roll(phi, 1, a)
         fwd = torch.roll(phi, -1, a) - phi
         out[0] += (up * bwd + um * fwd) * inv
+    if mesh.coord == "rz":  # + u phi / r, written like the central scheme's Ac row (tools.py:64-78)
+        ac = _nn(2 * dx[0] / mesh.R) * torch.ones_like(var[0])
+        ac = ac * adv[0]
+        ac = ac / (2.0 * dx[0])
+        out[0] += ac * var[0]
     return out
 
 
@@ -717,6 +757,39 @@ def _p2(grid, mask, *_):
 def poisson_cfg(dim: int) -> list[dict]:
     val: Any = _p1 if dim == 1 else (_p2 if dim == 2 else 0.0)
     return [{"bc_face": FACES[i], "bc_type": "dirichlet", "bc_val": val} for i in range(2 * dim)]
+
+
+# axisymmetric Poisson problem of the reference's tests/test_solver.py:309-358:
+# u = exp(-z) cos(r) on Cylinder[0:1, 0:1]; rl neumann 0, the other faces dirichlet (exact values)
+def _rz_ru(grid, mask, *_):
+    return torch.exp(-grid[1][mask]) * math.cos(1)
+
+
+def _rz_zl(grid, mask, *_):
+    return torch.cos(grid[0][mask])
+
+
+def _rz_zu(grid, mask, *_):
+    return torch.cos(grid[0][mask]) * math.exp(-1)
+
+
+def poisson_rz_cfg() -> list[dict]:
+    return [{"bc_face": "rl", "bc_type": "neumann", "bc_val": 0.0},
+            {"bc_face": "ru", "bc_type": "dirichlet", "bc_val": _rz_ru},
+            {"bc_face": "zl", "bc_type": "dirichlet", "bc_val": _rz_zl},
+            {"bc_face": "zu", "bc_type": "dirichlet", "bc_val": _rz_zu}]
+
+
+def poisson_rz_rhs(mesh: OMesh) -> Tensor:
+    R, Z = mesh.grid
+    rhs = torch.zeros(1, *mesh.nx, dtype=mesh.dtype)
+    rhs[0] = -torch.sin(R) / (R * torch.exp(Z))
+    rhs[0][R.eq(0.0)] = -1.0 / torch.exp(Z[R.eq(0.0)])
+    return rhs
+
+
+def poisson_rz_exact(mesh: OMesh) -> Tensor:
+    return torch.exp(-mesh.grid[1]) * torch.cos(mesh.grid[0])
 
 
 # --------------------------------------------------------------------------

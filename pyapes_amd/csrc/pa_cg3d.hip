@@ -535,6 +535,7 @@ __global__ void __launch_bounds__(256) k_cg3d(Cg3dArgs<T> A) {
 template <typename T>
 static bool cg3d_covered(const pa_ctx* c, const DevEq<T>& E, const void* p0, const void* p1, const void* p2) {
   if (!c->fastpath) return false;
+  if (c->coord != PA_COORD_XYZ) return false;  // r-dependent rows: generic kernels
   if (c->ndim != 3 && c->ndim != 2) return false;
   if (E.nterms != 1 || E.t[0].kind != PA_OP_LAPLACIAN) return false;
   if (E.t[0].coeff_f && ((uintptr_t)E.t[0].coeff_f & 15)) return false;

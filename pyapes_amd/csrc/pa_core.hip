@@ -265,8 +265,9 @@ __global__ void __launch_bounds__(PA_BLOCK) k_rhs_adjust(DevGeom G, DevEq<T> E, 
           T V = pa_face_val<T>(G, R.f[fc], a, i, j, k);
           T nv = side == 0 ? (T)-1 : (T)1;
           T vn = V * nv;
-          if (t.kind == 0) {            // laplacian: += (2/3)(V n)/h   (fdc.py:450-453)
-            T s = R.c23 * vn;
+          if (t.kind == 0) {            // laplacian: += (2/3 - alpha)(V n)/h   (fdc.py:440-453)
+            T f23 = (E.rz && a == PA_RZ_AXIS) ? E.rz[3 * E.rz_n + g[a]] : R.c23;
+            T s = f23 * vn;
             s = s / R.h[a];
             adj = adj + s;
           } else if (t.kind == 1) {     // grad: -= (1/3)(V n) * 1      (fdc.py:526-537)
@@ -924,7 +925,8 @@ __global__ void __launch_bounds__(PA_BLOCK) k_jacobi(DevGeom G, DevEq<T> E, cons
         for (int a = 0; a < 3; ++a) {
           if (!G.act[a]) continue;
           int rc = pa_row_case(G, a, g[a], N[a], G.treat);
-          T cC = rc == 0 ? E.lap.m2inv[a] : -E.lap.c23[a];
+          T cB = (E.rz && a == PA_RZ_AXIS) ? E.rz[2 * E.rz_n + g[a]] : E.lap.c23[a];
+          T cC = rc == 0 ? E.lap.m2inv[a] : -cB;
           dg = dg + cC;
         }
         if (t.has_coeff) dg = dg * (t.coeff_f ? t.coeff_f[idx] : t.coeff);
@@ -1296,6 +1298,8 @@ void pa_build_eq(const pa_ctx* c, int nterms, const pa_term* terms, DevEq<T>& E)
     E.t[q].u_f = (const T*)terms[q].u_field;
   }
   fill_coefs<T>(c, E);
+  E.rz = c->coord == PA_COORD_RZ ? (const T*)c->rz_tab : nullptr;
+  E.rz_n = c->G.n1;
 }
 template void pa_build_eq<float>(const pa_ctx*, int, const pa_term*, DevEq<float>&);
 template void pa_build_eq<double>(const pa_ctx*, int, const pa_term*, DevEq<double>&);
@@ -1495,7 +1499,21 @@ int pa_grid_set(pa_ctx* c, int ndim, const int64_t* n, const double* dx, int dty
   c->solver_live = 0;
   for (int f = 0; f < 6; ++f) c->bc[f] = HostBC();
   c->nbc = 0;
+  c->coord = PA_COORD_XYZ;
+  c->rz_tab = nullptr;
   pa_refresh_geom(c);
+  return PA_OK;
+}
+
+int pa_coord_set(pa_ctx* c, int coord_sys, const void* r_tables) {
+  if (!c || !c->grid_set) { if (c) pa_set_err(c, "pa_coord_set before pa_grid_set"); return PA_E_STATE; }
+  if (coord_sys == PA_COORD_XYZ) { c->coord = PA_COORD_XYZ; c->rz_tab = nullptr; return PA_OK; }
+  if (coord_sys != PA_COORD_RZ) { pa_set_err(c, "pa_coord_set: unknown coordinate system %d", coord_sys); return PA_E_ARG; }
+  if (c->ndim != 2) { pa_set_err(c, "pa_coord_set: rz coordinate system only accepts 2-D grids (_mesh.py:48-49)"); return PA_E_ARG; }
+  if (!r_tables) { pa_set_err(c, "pa_coord_set: rz needs the r tables"); return PA_E_ARG; }
+  c->coord = PA_COORD_RZ;
+  c->rz_tab = r_tables;
+  c->solver_live = 0;
   return PA_OK;
 }
 

@@ -68,7 +68,12 @@ struct DevEq {
   DevTerm<T> t[PA_MAX_TERMS];
   LapCoef<T> lap;
   GradCoef<T> grd;
+  // axisymmetric (rz) mesh: 5 x rz_n table of pa_coord_set, r = internal axis 1; null on xyz meshes
+  const T* rz;
+  int64_t rz_n;
 };
+
+#define PA_RZ_AXIS 1  // 2-D meshes are right-aligned in the 3 internal axes: r -> 1, z -> 2
 
 // a field plus the two ghost planes that complete it along internal axis 0
 // (slab neighbours, or the wrap-around planes of the field itself when P = 1)
@@ -177,9 +182,15 @@ __device__ __forceinline__ T pa_apply_terms(const DevGeom& G, const DevEq<T>& E,
       for (int a = 0; a < 3; ++a) {
         if (!G.act[a]) continue;
         T cP = E.lap.inv[a], cC = E.lap.m2inv[a], cM = E.lap.inv[a];
+        T cB = E.lap.c23[a];
+        if (E.rz && a == PA_RZ_AXIS) {  // tools.py:86-107, fdc.py:395-417
+          cP = E.rz[g[a]];
+          cM = E.rz[E.rz_n + g[a]];
+          cB = E.rz[2 * E.rz_n + g[a]];
+        }
         int rc = pa_row_case(G, a, g[a], N[a], G.treat);
-        if (rc == 1) { cP = E.lap.c23[a]; cC = -E.lap.c23[a]; cM = (T)0; }
-        if (rc == 2) { cP = (T)0; cC = -E.lap.c23[a]; cM = E.lap.c23[a]; }
+        if (rc == 1) { cP = cB; cC = -cB; cM = (T)0; }
+        if (rc == 2) { cP = (T)0; cC = -cB; cM = cB; }
         T xp, xm;
         pa_nbrs<T>(G, acc, a, i, j, k, xp, xm);
         T s = cP * xp;
@@ -227,6 +238,7 @@ __device__ __forceinline__ T pa_apply_terms(const DevGeom& G, const DevEq<T>& E,
         }
         T ucen = t.u_f ? t.u_f[o] : t.u;
         T cP = up, cC = (T)0 * ucen, cM = -um;
+        if (E.rz && a == PA_RZ_AXIS) cC = E.rz[4 * E.rz_n + g[a]] * ucen;  // tools.py:64-78
         if (G.bct[2 * a] == 4 && g[a] == 1) cM = (T)0;
         if (G.bct[2 * a + 1] == 4 && g[a] == N[a] - 2) cP = (T)0;
         cP = cP / E.grd.h2[a];
@@ -244,11 +256,13 @@ __device__ __forceinline__ T pa_apply_terms(const DevGeom& G, const DevEq<T>& E,
     } else if (t.kind == 3) {  // PA_OP_DIV_UPWIND_COMPAT (literal fdc.py:746-772)
       T ucen = t.u_f ? t.u_f[o] : t.u;
       T cP = (T)2 * (ucen < (T)0 ? ucen : (T)0);
-      T cC = (T)0 * ((T)2 * ucen);
+      T cC0 = (T)0 * ((T)2 * ucen);
       T cM = (T)2 * (ucen > (T)0 ? ucen : (T)0);
 #pragma unroll
       for (int a = 0; a < 3; ++a) {
         if (!G.act[a]) continue;
+        T cC = cC0;
+        if (E.rz && a == PA_RZ_AXIS) cC = E.rz[4 * E.rz_n + g[a]] * ((T)2 * ucen);
         T xp, xm;
         pa_nbrs<T>(G, acc, a, i, j, k, xp, xm);
         T s = cP * xp;
@@ -274,6 +288,12 @@ __device__ __forceinline__ T pa_apply_terms(const DevGeom& G, const DevEq<T>& E,
         s = s + m;
         s = s * E.grd.ih[a];
         ax = ax + s;
+      }
+      if (E.rz) {  // + u phi / r, written like the central scheme's Ac row
+        T cC = E.rz[4 * E.rz_n + g[PA_RZ_AXIS]] * ucen;
+        cC = cC / E.grd.h2[PA_RZ_AXIS];
+        T m = cC * xc;
+        ax = ax + m;
       }
     }
     ax = ax * t.sign;

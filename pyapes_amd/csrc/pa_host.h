@@ -88,6 +88,8 @@ struct pa_ctx {
   int64_t prof_n[2] = {0, 0};
   // 3-D fast path switch (PYAPES_HIP_FASTPATH=0 disables; tests compare both)
   int fastpath = 1;
+  int coord = 0;                 // PA_COORD_*
+  const void* rz_tab = nullptr;  // 5 x n_r table of pa_coord_set (device, caller-owned)
 };
 
 static inline double* pa_sums(const pa_ctx* c) { return (c->slab && c->ext_sums) ? c->ext_sums : c->sums; }

@@ -1,4 +1,5 @@
 from .basis import GeoTypeIdentifier
 from .box import Box
+from .cylinder import Cylinder
 
-__all__ = ["Box", "GeoTypeIdentifier"]
+__all__ = ["Box", "Cylinder", "GeoTypeIdentifier"]

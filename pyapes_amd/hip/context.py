@@ -14,7 +14,6 @@ import torch
 from torch import Tensor
 
 from ..backend import require_gpu
-from ..geometry.basis import FDIR
 from . import lib as L
 
 
@@ -48,6 +47,10 @@ class HipContext:
                                       int(mesh.i_off), n0g))
         self._keep: dict[str, Any] = {}
         self._bc_sig: Any = None
+        if mesh.coord_sys == "rz":
+            tab = mesh.rz_tables().to(self.device)
+            self._keep["rz"] = tab
+            self._rc(self.lib.pa_coord_set(self.h, L.PA_COORD_RZ, self._ptr(tab)))
 
     def __del__(self):
         try:
@@ -84,7 +87,7 @@ class HipContext:
             if arr is not None:
                 keep.append(arr)
             dxf = self.mesh.face_dxf(bc.bc_face) if bc.bc_type == "neumann" else 0.0
-            self._rc(self.lib.pa_bc_set(self.h, FDIR.index(bc.bc_face), pos, L.BC_CODE[bc.bc_type],
+            self._rc(self.lib.pa_bc_set(self.h, self.mesh.face_index(bc.bc_face), pos, L.BC_CODE[bc.bc_type],
                                         float(scalar), self._ptr(arr), float(dxf)))
         self._keep["bc"] = keep
 

@@ -18,6 +18,7 @@ BC_NONE, BC_DIRICHLET, BC_NEUMANN, BC_SYMMETRY, BC_PERIODIC = 0, 1, 2, 3, 4
 BC_CODE = {"dirichlet": BC_DIRICHLET, "neumann": BC_NEUMANN, "symmetry": BC_SYMMETRY,
            "periodic": BC_PERIODIC}
 OP_LAPLACIAN, OP_GRAD, OP_DIV_CENTRAL, OP_DIV_UPWIND_COMPAT, OP_DIV_UPWIND = 0, 1, 2, 3, 4
+PA_COORD_XYZ, PA_COORD_RZ = 0, 1
 PA_OK, PA_E_ARG, PA_E_HIP, PA_E_STATE, PA_E_NONFINITE = 0, -1, -2, -3, -4
 PA_NSUM = 8
 
@@ -67,6 +68,7 @@ SIGNATURES: dict[str, tuple[Any, list[Any]]] = {
     "pa_grad": (C.c_int, [_VP, _VP, _VP, C.c_int]),
     "pa_div": (C.c_int, [_VP, C.c_int, C.c_double, _VP, _VP, _VP]),
     "pa_div_edge": (C.c_int, [_VP, C.c_double, _VP, _VP, _VP]),
+    "pa_coord_set": (C.c_int, [_VP, C.c_int, _VP]),
     "pa_cg": (C.c_int, [_VP, _VP, _VP, C.c_double, C.c_int64, C.POINTER(PaReport)]),
     "pa_bicgstab": (C.c_int, [_VP, _VP, _VP, C.c_double, C.c_int64, C.POINTER(PaReport)]),
     "pa_jacobi": (C.c_int, [_VP, _VP, _VP, C.c_double, C.c_int64, C.c_double, C.POINTER(PaReport)]),

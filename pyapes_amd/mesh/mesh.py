@@ -14,7 +14,7 @@ from torch import Tensor
 
 from ..backend import DTYPE_DOUBLE, DTYPE_SINGLE, TORCH_DEVICE, DType, TorchDevice
 from ..geometry import GeoTypeIdentifier
-from ..geometry.basis import DIR_TO_NUM, Geometry
+from ..geometry.basis import Geometry, d2n_coord
 
 
 class _LazyMasks(dict):
@@ -31,7 +31,7 @@ class _LazyMasks(dict):
         m = self._mesh
         mask = torch.zeros(*m.nx, dtype=torch.bool, device=m.device)
         idx: list = [slice(None)] * m.dim
-        a = DIR_TO_NUM[face[0]]
+        a = m.d_mask_dim(face)
         if m.owns_face(face):
             idx[a] = 0 if face[1] == "l" else m.nx[a] - 1
             mask[tuple(idx)] = True
@@ -52,7 +52,7 @@ class Mesh:
     """``Mesh(Box[0:1, 0:1], None, [128, 128], "cuda", "double")``.
 
     Args:
-        domain: ``Box`` geometry.
+        domain: ``Box`` or ``Cylinder`` geometry.
         obstacle: must be ``None`` (obstacles raise downstream in the reference too,
             linalg.py:287-292).
         spacing: node counts (ints) or spacings (floats) per axis (_mesh.py:67-80).
@@ -72,8 +72,10 @@ class Mesh:
         assert dtype in DTYPE_DOUBLE or dtype in DTYPE_SINGLE, "Mesh: dtype only accept double or single"
         self.dtype = DType(dtype)
         self.domain = domain
-        if domain.type != "box":
-            raise TypeError("pyapes_amd: only Box domains are in scope")
+        if domain.type not in ("box", "cylinder"):
+            raise TypeError(f"Mesh: domain type ({domain.type=}) not identifiable")
+        if self.coord_sys == "rz":
+            assert self.dim == 2, "Mesh: rz coordinate system only accept 2D domain"
         self.obstacle = obstacle
         f = self.dtype.float
         self._lower = torch.tensor(domain.lower, dtype=f, device=self.device)
@@ -116,7 +118,14 @@ class Mesh:
     # -- geometry ---------------------------------------------------------
     @property
     def coord_sys(self) -> str:
-        return "xyz"
+        """"xyz" (Box) or "rz" (Cylinder: axis 0 = r, axis 1 = z) (_mesh.py:121-131)."""
+        return "rz" if self.domain.type == "cylinder" else "xyz"
+
+    @property
+    def R(self) -> Tensor:
+        if self.coord_sys != "rz":
+            raise KeyError("Mesh: R coordinate only available in axisymmetric case.")
+        return self.grid[0]
 
     @property
     def dim(self) -> int:
@@ -138,7 +147,7 @@ class Mesh:
 
     def owns_face(self, face: str) -> bool:
         """False only on slab ranks that do not hold that global axis-0 boundary plane."""
-        if self.slab is None or face[0] != "x":
+        if self.slab is None or self.d_mask_dim(face) != 0:
             return True
         if face[1] == "l":
             return self.i_off == 0
@@ -150,10 +159,14 @@ class Mesh:
 
     @property
     def Y(self) -> Tensor:
-        return self.grid[1] if self.dim > 1 else torch.tensor([], dtype=self.dtype.float, device=self.device)
+        if self.coord_sys == "rz" or self.dim < 2:   # _mesh.py:206-222
+            return torch.tensor([], dtype=self.dtype.float, device=self.device)
+        return self.grid[1]
 
     @property
     def Z(self) -> Tensor:
+        if self.coord_sys == "rz":                   # _mesh.py:224-238: the second axis of an rz mesh
+            return self.grid[1]
         return self.grid[2] if self.dim > 2 else torch.tensor([], dtype=self.dtype.float, device=self.device)
 
     @property
@@ -220,11 +233,44 @@ class Mesh:
     def face_dxf(self, face: str) -> float:
         """``grid[face] - grid[prev]`` of ``Neumann.apply`` (bcs.py:228-231): the literal
         difference of the two outermost node coordinates, in the mesh dtype."""
-        g = self._gx_host[DIR_TO_NUM[face[0]]]
+        g = self._gx_host[self.d_mask_dim(face)]
         return float(g[0] - g[1]) if face[1] == "l" else float(g[-1] - g[-2])
 
     def d_mask_dim(self, d_face: str) -> int:
-        return DIR_TO_NUM[d_face[0]]
+        return d2n_coord(self.coord_sys)[d_face[0]]
+
+    def face_index(self, face: str) -> int:
+        """0..5 = lower / upper face of mesh axis 0, 1, 2 (the C ABI's face id)"""
+        return 2 * self.d_mask_dim(face) + (0 if face[1] == "l" else 1)
+
+    def rz_tables(self) -> Tensor:
+        """The r-dependent rows of the axisymmetric operators, one value per r node, in the mesh dtype,
+        computed with the reference's literal expressions (rows of the 5 x n_r table of pa_coord_set):
+          0  (1 + s) / dr^2,  s = nan_to_num(dr / (2 r))                      Laplacian Ap  (tools.py:86-99)
+          1  (1 - s) / dr^2                                                    Laplacian Am  (tools.py:101-106)
+          2  (2/3 + a) / dr^2, a = nan_to_num(2/3 dr / r)   neumann / symmetry row     (fdc.py:395-417)
+          3  2/3 - nan_to_num(1/3 dr / r)                    rhs adjustment factor       (fdc.py:440-453)
+          4  nan_to_num(2 dr / r)                            Div Ac row (u phi / r term)  (tools.py:64-78)"""
+        assert self.coord_sys == "rz"
+        f = self.dtype.float
+        r = self._gx_host[0]
+        dx = torch.tensor(self._dx, dtype=f)
+        dr = dx[0]
+        ones = torch.ones_like(r)
+
+        def nn(t: Tensor) -> Tensor:
+            return torch.nan_to_num(t, nan=0.0, posinf=0.0, neginf=0.0)
+
+        s = nn(dr / (2 * r))
+        ap = (1 + s) * ones
+        am = (1 - s) * ones
+        ap = ap / dx[0] ** 2
+        am = am / dx[0] ** 2
+        b = 2 / 3 + nn(2 / 3 * dr / r)
+        b = b / dx[0] ** 2
+        r4 = 2 / 3 - nn(1 / 3 * dr / r)
+        s2 = nn(2 * dr / r) * ones
+        return torch.stack([ap, am, b, r4, s2]).contiguous()
 
     def __repr__(self) -> str:
         return f"{self.domain} with dx={self._dx}"

@@ -15,6 +15,7 @@ from torch import Tensor
 from ..backend import require_gpu
 from ..hip import lib as L
 from ..hip.context import context_for
+from ..mesh.tools import boundary_slicer
 from ..variables import Field
 from .fdc import _adv_of, div_kind
 from .tools import FDMSolverConfig
@@ -90,6 +91,9 @@ def _run(method: str, var: Field, rhs: Tensor, eqs: dict[int, OPStype], config: 
     if not var().is_contiguous():
         var.set_var_tensor(var().contiguous())
     tol, max_it = config["tol"], config["max_it"]
+    # linalg.py:104 / 183: the reference resolves the periodic faces through the xyz letter table
+    # (mesh/tools.py:11-13), so a periodic face of an rz mesh raises KeyError / IndexError there too
+    boundary_slicer(mesh.dim, var.bcs)
     ctx = context_for(mesh)
     terms, _ = terms_of(eqs)
     ctx.bind_bcs(var(), var.bcs, 0)          # the BC fill uses the solved field's own list

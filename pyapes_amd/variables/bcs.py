@@ -15,7 +15,7 @@ import torch
 from torch import Tensor
 
 from ..backend import DType, require_gpu
-from ..geometry.basis import DIR_TO_NUM, FDIR
+from ..geometry.basis import FDIR, FDIR_RZ, d2n_coord
 
 BC_val_type = int | float | list | Callable | Tensor | None
 
@@ -50,7 +50,7 @@ class BC:
 
     def __post_init__(self):
         _check_val(self.bc_val)
-        self._bc_face_dim = DIR_TO_NUM[self.bc_face[0]]
+        self._bc_face_dim = d2n_coord(self.bc_coord_sys)[self.bc_face[0]]   # bcs.py:72-75
         self._bc_n_dir = -1 if self.bc_face[-1] == "l" else 1
         self._bc_type = self.__class__.__name__.lower()
         self._bc_n_vec = torch.zeros(3, dtype=self.dtype.float, device=self.device)
@@ -173,6 +173,24 @@ class BoxBoundary(NamedTuple):
     def __call__(self) -> list[BCConfig]:
         cfg: list[BCConfig] = []
         for face in FDIR:
+            d = getattr(self, face)
+            if d is not None:
+                cfg.append({"bc_face": face, "bc_type": d["bc_type"], "bc_val": d["bc_val"],
+                            "bc_val_opt": d.get("bc_val_opt")})
+        return cfg
+
+
+class CylinderBoundary(NamedTuple):
+    """``CylinderBoundary(rl={"bc_type": "neumann", "bc_val": 0.0}, ...)()`` (bcs.py:301-328)."""
+
+    rl: BCContainer | None = None
+    ru: BCContainer | None = None
+    zl: BCContainer | None = None
+    zu: BCContainer | None = None
+
+    def __call__(self) -> list[BCConfig]:
+        cfg: list[BCConfig] = []
+        for face in FDIR_RZ:
             d = getattr(self, face)
             if d is not None:
                 cfg.append({"bc_face": face, "bc_type": d["bc_type"], "bc_val": d["bc_val"],

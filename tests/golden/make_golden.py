@@ -45,7 +45,7 @@ sys.modules["pymytools"] = _m
 sys.modules["pymytools.indices"] = _mi
 sys.path.insert(0, "/root/reference")
 
-from pyapes.geometry import Box  # noqa: E402
+from pyapes.geometry import Box, Cylinder  # noqa: E402
 from pyapes.mesh import Mesh  # noqa: E402
 from pyapes.solver.fdc import FDC  # noqa: E402
 from pyapes.solver.fdm import FDM  # noqa: E402
@@ -60,12 +60,27 @@ FACES = O.FACES
 
 # ---------------------------------------------------------------- helpers
 def ref_mesh(case):
-    dom = Box(case["lower"], case["upper"])
+    geo = Cylinder if case.get("coord", "xyz") == "rz" else Box
+    dom = geo(case["lower"], case["upper"])
     return Mesh(dom, None, case["spacing"], "cpu", case["dtype"])
 
 
 def orc_mesh(case):
-    return O.OMesh(case["lower"], case["upper"], case["spacing"], case["dtype"])
+    return O.OMesh(case["lower"], case["upper"], case["spacing"], case["dtype"], case.get("coord", "xyz"))
+
+
+def _rz_test_bcs():
+    """the BC set of tests/test_solver.py:317-332 (values written out here, same formulas)"""
+    from math import cos, exp
+    return [
+        {"bc_face": "rl", "bc_type": "neumann", "bc_val": 0.0, "bc_val_opt": None},
+        {"bc_face": "ru", "bc_type": "dirichlet", "bc_val_opt": None,
+         "bc_val": lambda grid, mask, *_: torch.exp(-grid[1][mask]) * cos(1)},
+        {"bc_face": "zl", "bc_type": "dirichlet", "bc_val_opt": None,
+         "bc_val": lambda grid, mask, *_: torch.cos(grid[0][mask])},
+        {"bc_face": "zu", "bc_type": "dirichlet", "bc_val_opt": None,
+         "bc_val": lambda grid, mask, *_: torch.cos(grid[0][mask]) * exp(-1)},
+    ]
 
 
 def bc_cfg(case):
@@ -73,10 +88,13 @@ def bc_cfg(case):
     nd = len(case["lower"])
     if case["bcs"] == "poisson":
         return poisson_bcs(nd), O.poisson_cfg(nd)
+    if case["bcs"] == "poisson_rz":
+        return _rz_test_bcs(), O.poisson_rz_cfg()
+    faces = O.FACES_RZ if case.get("coord", "xyz") == "rz" else FACES
     ref, orc = [], []
     for i, (t, v) in enumerate(case["bcs"]):
-        ref.append({"bc_face": FACES[i], "bc_type": t, "bc_val": v, "bc_val_opt": None})
-        orc.append({"bc_face": FACES[i], "bc_type": t, "bc_val": v})
+        ref.append({"bc_face": faces[i], "bc_type": t, "bc_val": v, "bc_val_opt": None})
+        orc.append({"bc_face": faces[i], "bc_type": t, "bc_val": v})
     return ref, orc
 
 
@@ -103,6 +121,11 @@ def rhs_of(case, mesh_r):
         return r.to(mesh_r.dtype.float)
     if kind == "zero":
         return torch.zeros(shape, dtype=mesh_r.dtype.float)
+    if kind == "poisson_rz":   # tests/test_solver.py:347-351
+        r = torch.zeros(shape, dtype=mesh_r.dtype.float)
+        r[0] = -torch.sin(mesh_r.X) / (mesh_r.X * torch.exp(mesh_r.Z))
+        r[0][mesh_r.X.eq(0.0)] = -1.0 / torch.exp(mesh_r.Z[mesh_r.X.eq(0.0)])
+        return r
     if kind == "test_periodic_2d":
         r = torch.zeros(shape, dtype=mesh_r.dtype.float)
         r[0] = mesh_r.X * torch.sin(5.0 * pi * mesh_r.Y) + torch.exp(
@@ -167,7 +190,8 @@ def run_ops(case):
     g = torch.Generator().manual_seed(case.get("seed", 0) + 7)
     ut = torch.randn((1, *mr.nx), generator=g, dtype=torch.float64).to(mr.dtype.float)
     out["u_tensor"] = npy(ut)
-    treat = any(t in ("neumann", "symmetry") for t, _ in case["bcs"]) if case["bcs"] != "poisson" else False
+    treat = any(t in ("neumann", "symmetry") for t, _ in case["bcs"]) if isinstance(case["bcs"], list) else \
+        case["bcs"] == "poisson_rz"
     if not treat:  # the reference raises IndexError for central Div with neumann/symmetry faces
         out["div_none_f"] = npy(FDC({"div": {"limiter": "none", "edge": False}}).div(u, var))
         out["div_none_t"] = npy(FDC({"div": {"limiter": "none", "edge": False}}).div(ut, var))
@@ -246,7 +270,7 @@ def run_spatial(case):
     var.set_var_tensor(x0.clone())
     jac = jacobian(var)
     hess = hessian(var)
-    names = "xyz"
+    names = "rz" if case.get("coord", "xyz") == "rz" else "xyz"
     for i in range(nd):
         out["jac_" + names[i]] = npy(jac[names[i]])
         for j in range(i, nd):
@@ -362,11 +386,40 @@ for dt in ("double", "single"):
     ]
 
 
+# axisymmetric (Cylinder, rz) meshes: SURVEY 8f rank 4 -- tools.py:64-107, fdc.py:395-403, 440-448
+CYL = ([0.0, 0.0], [1.0, 1.0])
+for dt in ("double", "single"):
+    s_ = "f64" if dt == "double" else "f32"
+    CASES += [
+        mk(f"rz_ops_dir_{s_}", "ops", 2, [9, 12], dt, [D(0.1), D(0.2), D(0.3), D(0.4)], coord="rz", box=CYL),
+        mk(f"rz_ops_mix_{s_}", "ops", 2, [11, 8], dt, [N(0.3), D(1.0), SY, N(0.2)], coord="rz",
+           box=([0.0, 0.0], [1.0, 2.0]), coeff=0.7),
+        mk(f"rz_ops_off_axis_{s_}", "ops", 2, [8, 10], dt, [SY, N(-0.4), D(0.0), D(1.0)], coord="rz",
+           box=([0.5, -1.0], [1.5, 1.0]), sign=-1.0),
+        mk(f"rz_ops_zper_{s_}", "ops", 2, [10, 9], dt, [N(0.0), D(0.5), PE, PE], coord="rz", box=CYL),
+        mk(f"rz_spatial_{s_}", "spatial", 2, [7, 9], dt, [D(0.0)] * 4, coord="rz", box=CYL),
+    ]
+CASES += [
+    mk("rz_bicg_poisson21_f64", "solve", 2, [21, 21], "double", "poisson_rz", rhs="poisson_rz", method="bicgstab",
+       tol=1e-5, max_its=[2, 6, 1000], coord="rz", box=CYL, sensitive=True),   # tests/test_solver.py:309-358, small
+    mk("rz_bicg_poisson101_f64", "solve", 2, [101, 101], "double", "poisson_rz", rhs="poisson_rz",
+       method="bicgstab", tol=1e-5, max_its=[1000], coord="rz", box=CYL, sensitive=True),  # the test itself: 321 its
+    mk("rz_cg_mix_f64", "solve", 2, [17, 19], "double", [N(0.0), D(1.0), D(0.0), N(0.5)], rhs="randn", method="cg",
+       tol=1e-30, max_its=[2, 8], coord="rz", box=CYL),
+    mk("rz_bicg_mix_f32", "solve", 2, [17, 19], "single", [SY, D(1.0), D(0.0), N(0.5)], rhs="randn",
+       method="bicgstab", tol=1e-30, max_its=[4], coord="rz", box=CYL),
+]
+
+
 def main():
     torch.set_num_threads(8)
+    only = sys.argv[1] if len(sys.argv) > 1 else None   # name prefix: regenerate just those cases
     index = []
     total = 0
     for case in CASES:
+        if only is not None and not case["name"].startswith(only):
+            index.append(case)
+            continue
         print(f"[golden] {case['name']}")
         out = {"ops": run_ops, "solve": run_solve, "spatial": run_spatial}[case["kind"]](case)
         path = os.path.join(HERE, case["name"] + ".npz")

@@ -6,7 +6,7 @@ import numpy as np
 import torch
 
 import pyapes_oracle as O
-from pyapes_amd.geometry import Box
+from pyapes_amd.geometry import Box, Cylinder
 from pyapes_amd.mesh import Mesh
 from pyapes_amd.solver.fdm import FDM
 from pyapes_amd.solver.ops import Solver
@@ -16,27 +16,39 @@ from pyapes_amd.variables import Field
 FACES = O.FACES
 
 
+def case_faces(case):
+    return O.FACES_RZ if case.get("coord", "xyz") == "rz" else FACES
+
+
 def oracle_cfg(case):
     nd = len(case["lower"])
     if case["bcs"] == "poisson":
         return O.poisson_cfg(nd)
-    return [{"bc_face": FACES[i], "bc_type": t, "bc_val": v} for i, (t, v) in enumerate(case["bcs"])]
+    if case["bcs"] == "poisson_rz":
+        return O.poisson_rz_cfg()
+    faces = case_faces(case)
+    return [{"bc_face": faces[i], "bc_type": t, "bc_val": v} for i, (t, v) in enumerate(case["bcs"])]
 
 
 def product_cfg(case):
     nd = len(case["lower"])
     if case["bcs"] == "poisson":
         return poisson_bcs(nd)
-    return [{"bc_face": FACES[i], "bc_type": t, "bc_val": v, "bc_val_opt": None}
+    if case["bcs"] == "poisson_rz":
+        from pyapes_amd.testing.poisson import poisson_rz_bcs
+        return poisson_rz_bcs()
+    faces = case_faces(case)
+    return [{"bc_face": faces[i], "bc_type": t, "bc_val": v, "bc_val_opt": None}
             for i, (t, v) in enumerate(case["bcs"])]
 
 
 def oracle_mesh(case):
-    return O.OMesh(case["lower"], case["upper"], case["spacing"], case["dtype"])
+    return O.OMesh(case["lower"], case["upper"], case["spacing"], case["dtype"], case.get("coord", "xyz"))
 
 
 def product_mesh(case, device="cuda"):
-    return Mesh(Box(case["lower"], case["upper"]), None, case["spacing"], device, case["dtype"])
+    geo = Cylinder if case.get("coord", "xyz") == "rz" else Box
+    return Mesh(geo(case["lower"], case["upper"]), None, case["spacing"], device, case["dtype"])
 
 
 def product_field(case, mesh, x0=None):

@@ -103,11 +103,12 @@ def test_solve_vs_reference(case):
         err = rel_err(x, g[f"x_K{K}"])
         if case.get("sensitive") and K > 10:
             band, its = summation_band(case, g["rhs0"], K)
-            slack = max(3, max(its) - min(its))
+            # the count at which a summation-order-chaotic iteration crosses tol scatters by a few per cent
+            slack = max(3, max(its) - min(its), -(-max(its) // 20))
             assert min(its) - slack <= rep["itr"] <= max(its) + slack, (case["name"], K, rep, its)
             assert rep["converge"] == ref["converge"]
             assert err <= max(rtol, 5 * band), (case["name"], K, err, band)
-            periodic = any(t == "periodic" for t, _ in case["bcs"])
+            periodic = isinstance(case["bcs"], list) and any(t == "periodic" for t, _ in case["bcs"])
             if rep["converge"] and not periodic:
                 # converged: the true residual of the returned iterate must be at the stop-test level
                 # (not meaningful with periodic faces: their BC fill edits nodes of the interior set, Q5)

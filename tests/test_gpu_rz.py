@@ -1,0 +1,108 @@
+"""-m gpu: axisymmetric (Cylinder, rz) meshes -- SURVEY 8f rank 4.  The golden rz cases run through the
+generic parity tests (test_gpu_parity_golden / test_gpu_spatial); here: the reference's own
+test_poisson_rz at full size, the API surface, Jacobi / Euler on rz against the oracle, the
+periodic-face errors."""
+import warnings
+
+import pytest
+import torch
+
+import pyapes_oracle as O
+from conftest import golden_cases, golden_load
+from helpers import rel_err
+
+pytestmark = pytest.mark.gpu
+
+from pyapes_amd.geometry import Cylinder
+from pyapes_amd.mesh import Mesh
+from pyapes_amd.solver.fdc import FDC
+from pyapes_amd.solver.fdm import FDM
+from pyapes_amd.solver.march import euler_step
+from pyapes_amd.solver.ops import Solver
+from pyapes_amd.testing.poisson import poisson_rz_bcs, poisson_rz_exact, poisson_rz_rhs
+from pyapes_amd.variables import Field
+from pyapes_amd.variables.bcs import CylinderBoundary
+
+
+def test_poisson_rz_reference_test():
+    """tests/test_solver.py:309-358 verbatim in structure: 101 x 101, BiCGSTAB tol 1e-5 -> exp(-z) cos(r)"""
+    mesh = Mesh(Cylinder[0:1, 0:1], None, [101, 101], "cuda", "double")
+    assert mesh.coord_sys == "rz" and mesh.Y.numel() == 0 and mesh.Z is mesh.grid[1] and mesh.R is mesh.grid[0]
+    cfg = poisson_rz_bcs()
+    f_bc = CylinderBoundary(rl={"bc_type": "neumann", "bc_val": 0.0},
+                            ru={"bc_type": "dirichlet", "bc_val": cfg[1]["bc_val"]},
+                            zl={"bc_type": "dirichlet", "bc_val": cfg[2]["bc_val"]},
+                            zu={"bc_type": "dirichlet", "bc_val": cfg[3]["bc_val"]})
+    var = Field("U", 1, mesh, {"domain": f_bc(), "obstacle": None}, init_val=0.0)
+    assert [bc.bc_face for bc in var.bcs] == ["rl", "ru", "zl", "zu"]
+    assert [bc.bc_face_dim for bc in var.bcs] == [0, 0, 1, 1]
+    solver = Solver({"fdm": {"method": "bicgstab", "tol": 1e-5, "max_it": 1000, "report": False}})
+    rhs = poisson_rz_rhs(mesh, var)
+    torch.testing.assert_close(rhs.cpu(), torch.as_tensor(golden_load("rz_bicg_poisson101_f64")["rhs0"]),
+                               rtol=1e-14, atol=1e-15)   # sin / exp evaluated on the GPU: last-ulp differences
+    solver.set_eq(FDM().laplacian(1.0, var) == rhs)
+    rep = solver.solve()
+    assert rep["converge"]
+    torch.testing.assert_close(var()[0], poisson_rz_exact(mesh), atol=1e-3, rtol=1e-3)
+    # the reference needs 321 iterations; BiCGSTAB is summation-order sensitive, so a band, not equality
+    assert abs(rep["itr"] - 321) <= 40, rep
+
+
+@pytest.mark.parametrize("dtype", ["double", "single"])
+def test_rz_jacobi_and_euler_vs_oracle(dtype):
+    n = (19, 23)
+    mo = O.OMesh([0.0, 0.0], [1.0, 1.5], list(n), dtype, "rz")
+    cfg = O.mixed_cfg([0.0, 1.0, 0.0, 0.5], ["neumann", "dirichlet", "dirichlet", "neumann"], O.FACES_RZ)
+    pcfg = [dict(c, bc_val_opt=None) for c in cfg]
+    mesh = Mesh(Cylinder([0.0, 0.0], [1.0, 1.5]), None, list(n), "cuda", dtype)
+    g = torch.Generator().manual_seed(2)
+    rhs = torch.randn((1, *n), generator=g, dtype=torch.float64).to(mo.dtype)
+    tol = 1e-10 if dtype == "double" else 2e-5
+    # Jacobi, fixed iteration count
+    xo, ro = O.solve_poisson(mo, cfg, rhs.clone(), method="jacobi", tol=-1.0, max_it=30)
+    var = Field("p", 1, mesh, {"domain": pcfg, "obstacle": None})
+    s = Solver({"fdm": {"method": "jacobi", "tol": -1.0, "max_it": 30, "report": False}})
+    s.set_eq(FDM().laplacian(1.0, var) == rhs.cuda().clone())
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        rep = s.solve()
+    assert rep["itr"] == ro["itr"]
+    assert rel_err(var().cpu(), xo) < tol
+    # explicit Euler step, upwind (intended) and central-free config: lap + div with the u phi / r term
+    bcs = O.make_bcs(mo, cfg)
+    phi0 = torch.exp(-((mo.grid[0] - 0.4) ** 2 + (mo.grid[1] - 0.7) ** 2) / 0.05).unsqueeze(0).to(mo.dtype)
+    O.bc_fill(phi0, bcs)
+    ut = (0.3 + 0.2 * torch.randn((1, *n), generator=g, dtype=torch.float64)).to(mo.dtype)
+    for u in (0.8, ut):
+        po = O.euler_step(phi0.clone(), u, 1e-2, 1e-3, mo, bcs, "upwind")
+        v = Field("phi", 1, mesh, {"domain": pcfg, "obstacle": None})
+        v.set_var_tensor(phi0.cuda().clone())
+        euler_step(v, u.cuda() if isinstance(u, torch.Tensor) else u, 1e-2, 1e-3, {"div": {"limiter": "upwind"}})
+        assert rel_err(v().cpu(), po) < (1e-13 if dtype == "double" else 1e-6)
+
+
+def test_rz_periodic_faces_raise_like_the_reference():
+    mesh = Mesh(Cylinder[0:1, 0:1], None, [8, 8], "cuda", "double")
+    names = ["rl", "ru", "zl", "zu"]
+    for tv, exc in (([("neumann", 0.0), ("dirichlet", 0.0), ("periodic", None), ("periodic", None)], IndexError),
+                    ([("periodic", None), ("periodic", None), ("dirichlet", 0.0), ("dirichlet", 0.0)], KeyError)):
+        cfg = [{"bc_face": f, "bc_type": t, "bc_val": v, "bc_val_opt": None} for f, (t, v) in zip(names, tv)]
+        var = Field("U", 1, mesh, {"domain": cfg, "obstacle": None})
+        s = Solver({"fdm": {"method": "bicgstab", "tol": 1e-5, "max_it": 10, "report": False}})
+        s.set_eq(FDM().laplacian(1.0, var) == torch.zeros_like(var()))
+        with pytest.raises(exc):
+            s.solve()
+
+
+def test_rz_mesh_rules():
+    with pytest.raises(AssertionError):
+        Cylinder([0.0, 0.0, 0.0], [1.0, 1.0, 1.0])
+    with pytest.raises(AssertionError):
+        Cylinder([-0.1, 0.0], [1.0, 1.0])
+    c = Cylinder[0:2, 0:3]
+    assert c.type == "cylinder" and c.dim == 2 and abs(c.size - 3.141592653589793 * 4 * 3) < 1e-12
+    assert [f["face"] for f in c.config.values()] == ["zl", "zu", "rl", "ru"]
+    mesh = Mesh(c, None, [5, 7], "cuda", "single")
+    with pytest.raises(IndexError):   # edge=True Div of a scalar field: 1-D only, like the reference
+        v = Field("q", 1, mesh, {"domain": None, "obstacle": None})
+        FDC({"div": {"limiter": "none", "edge": True}}).div(1.0, v)

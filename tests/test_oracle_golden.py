@@ -19,11 +19,14 @@ def _cfg(case):
     nd = len(case["lower"])
     if case["bcs"] == "poisson":
         return O.poisson_cfg(nd)
-    return [{"bc_face": O.FACES[i], "bc_type": t, "bc_val": v} for i, (t, v) in enumerate(case["bcs"])]
+    if case["bcs"] == "poisson_rz":
+        return O.poisson_rz_cfg()
+    faces = O.FACES_RZ if case.get("coord", "xyz") == "rz" else O.FACES
+    return [{"bc_face": faces[i], "bc_type": t, "bc_val": v} for i, (t, v) in enumerate(case["bcs"])]
 
 
 def _mesh(case):
-    return O.OMesh(case["lower"], case["upper"], case["spacing"], case["dtype"])
+    return O.OMesh(case["lower"], case["upper"], case["spacing"], case["dtype"], case.get("coord", "xyz"))
 
 
 def _eq(a, b, what):
@@ -88,6 +91,26 @@ def test_known_answers():
     assert golden_load("cg3d_mix33_f64")["_reports"]["1000"]["itr"] == 402
     r = golden_load("cg3d_poisson_dx01_f64")["_reports"]["1000"]
     assert r["itr"] == 2 and abs(r["tol"] - 2.5114204125896697e-17) < 1e-25
+    # the reference's own axisymmetric test (tests/test_solver.py:309-358) at its size, run here: 321 its
+    r = golden_load("rz_bicg_poisson101_f64")["_reports"]["1000"]
+    assert r["itr"] == 321 and r["converge"] and abs(r["tol"] - 5.595559978087123e-06) < 1e-16
+
+
+def test_rz_reference_test_assertion():
+    """tests/test_solver.py:355-358: the axisymmetric solution matches exp(-z) cos(r) to 1e-3"""
+    case = [c for c in golden_cases("solve") if c["name"] == "rz_bicg_poisson101_f64"][0]
+    g = golden_load(case["name"])
+    mesh = _mesh(case)
+    torch.testing.assert_close(torch.from_numpy(g["x_K1000"])[0], O.poisson_rz_exact(mesh), atol=1e-3, rtol=1e-3)
+    assert torch.equal(torch.from_numpy(g["rhs0"]), O.poisson_rz_rhs(mesh))
+
+
+def test_rz_periodic_faces_raise_in_the_solver():
+    """mesh/tools.py:11-13 looks the face letter up in the xyz table: rz + periodic cannot be solved"""
+    mesh = O.OMesh([0.0, 0.0], [1.0, 1.0], [8, 8], "double", "rz")
+    cfg = O.mixed_cfg([0.0, 0.0, None, None], ["neumann", "dirichlet", "periodic", "periodic"], O.FACES_RZ)
+    with pytest.raises(IndexError):
+        O.solve_poisson(mesh, cfg, torch.zeros(1, 8, 8, dtype=torch.float64), method="bicgstab")
 
 
 def test_reference_csv_fixture():
