@@ -206,6 +206,35 @@ int pa_cg_iterate(pa_ctx* ctx, int64_t n);
 int pa_cg_end(pa_ctx* ctx, pa_report* out);       /* synchronises */
 int pa_report_read(pa_ctx* ctx, pa_report* out);  /* synchronises */
 
+/* ---- RCCL inside the library (slab mode, SURVEY 8e: "pa_comm_init(ctx, rank, nranks, rccl_unique_id)") --
+ * The stepwise calls above let a host driver run the exchange; these entry points put the whole
+ * iteration -- kernels, the two scalar all-reduces (ncclAllReduce on the PA_NSUM buffer) and the
+ * one packed plane exchange per neighbour (grouped ncclSend / ncclRecv) -- on the ctx stream, so
+ * that n iterations are enqueued by ONE call with no host work in between.  librccl is resolved at
+ * run time (dlopen of the copy already in the process, e.g. PyTorch's); without it these return
+ * PA_E_STATE and the stepwise path remains.
+ *   pa_comm_unique_id   rank 0: 128-byte ncclUniqueId to hand to the other ranks (any transport)
+ *   pa_comm_init        collective: ncclCommInitRank on the ctx device
+ *   pa_comm_selftest    collective: a sum all-reduce and a ring exchange with known answers, the
+ *                       stream polled against timeout_s; on timeout the communicator is aborted
+ *                       and an error returned (callers then fall back to the stepwise path)
+ *   pa_comm_plan        neighbours (-1 = none) and the packed send / receive buffers of one
+ *                       iteration, counts in elements of the grid dtype; lower neighbour first
+ *   pa_cg_iterate_comm  n x { phase_a, all-reduce sums[0], phase_b, exchange, bc,
+ *                             all-reduce sums[1..2], finish_iter } */
+typedef struct {
+  int nb_lo, nb_hi;
+  const void* send_lo; const void* send_hi;
+  void* recv_lo; void* recv_hi;
+  int64_t n_send_lo, n_send_hi, n_recv_lo, n_recv_hi;
+} pa_exchange;
+int pa_comm_unique_id(void* id128);
+int pa_comm_init(pa_ctx* ctx, int rank, int nranks, const void* id128);
+int pa_comm_selftest(pa_ctx* ctx, double timeout_s);
+int pa_comm_plan(pa_ctx* ctx, const pa_exchange* plan);
+int pa_cg_iterate_comm(pa_ctx* ctx, int64_t n);
+int pa_comm_destroy(pa_ctx* ctx);
+
 /* ---- measurement (bench.py roofline leg) ---------------------------------
  * on: bracket each launch of the two dominant CG kernels (phase A stencil+dot,
  * phase B update+stencil+dots) with HIP events on the ctx stream and accumulate

@@ -88,6 +88,11 @@ struct pa_ctx {
   int64_t prof_n[2] = {0, 0};
   // 3-D fast path switch (PYAPES_HIP_FASTPATH=0 disables; tests compare both)
   int fastpath = 1;
+  // RCCL communicator owned by the library (pa_comm_*): slab iterations without host work
+  void* comm = nullptr;          // ncclComm_t
+  int comm_rank = 0, comm_n = 0;
+  pa_exchange plan;
+  int plan_set = 0;
   int coord = 0;                 // PA_COORD_*
   const void* rz_tab = nullptr;  // 5 x n_r table of pa_coord_set (device, caller-owned)
 };

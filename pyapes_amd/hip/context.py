@@ -269,6 +269,42 @@ class HipContext:
         return {"phase_a_ms": ma.value / max(na.value, 1), "phase_a_n": na.value,
                 "phase_b_ms": mb.value / max(nb.value, 1), "phase_b_n": nb.value}
 
+    # -- RCCL inside the library (slab iterations without host work between the phases) -------------
+    def comm_unique_id(self) -> bytes:
+        buf = C.create_string_buffer(128)
+        rc = self.lib.pa_comm_unique_id(C.cast(buf, C.c_void_p))
+        if rc != L.PA_OK:
+            raise L.PaError(rc, "pa_comm_unique_id: librccl not available")
+        return buf.raw
+
+    def comm_init(self, rank: int, world: int, uid: bytes) -> None:
+        buf = C.create_string_buffer(uid, 128)
+        self._rc(self.lib.pa_comm_init(self.h, int(rank), int(world), C.cast(buf, C.c_void_p)))
+
+    def comm_selftest(self, timeout_s: float = 20.0) -> None:
+        self._rc(self.lib.pa_comm_selftest(self.h, float(timeout_s)))
+
+    def comm_plan(self, nb_lo: int | None, nb_hi: int | None, send_lo: Tensor | None, send_hi: Tensor | None,
+                  recv_lo: Tensor | None, recv_hi: Tensor | None) -> None:
+        p = L.PaExchange()
+        p.nb_lo = -1 if nb_lo is None else int(nb_lo)
+        p.nb_hi = -1 if nb_hi is None else int(nb_hi)
+        for name, t in (("send_lo", send_lo), ("send_hi", send_hi), ("recv_lo", recv_lo), ("recv_hi", recv_hi)):
+            if t is not None:
+                require_gpu(t, "exchange buffer")
+                assert t.is_contiguous() and t.dtype == self.dtype
+            setattr(p, name, None if t is None else t.data_ptr())
+            setattr(p, "n_" + name, 0 if t is None else t.numel())
+        self._keep["plan"] = (p, send_lo, send_hi, recv_lo, recv_hi)
+        self._rc(self.lib.pa_comm_plan(self.h, C.byref(p)))
+
+    def cg_iterate_comm(self, n: int) -> None:
+        self._rc(self.lib.pa_cg_iterate_comm(self.h, int(n)))
+
+    def comm_destroy(self) -> None:
+        self._rc(self.lib.pa_comm_destroy(self.h))
+        self._keep.pop("plan", None)
+
     def slab_set(self, bufs: dict[str, Tensor | None] | None) -> None:
         if bufs is None:
             self._rc(self.lib.pa_slab_set(self.h, None))

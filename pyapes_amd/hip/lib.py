@@ -48,6 +48,12 @@ class PaSlab(C.Structure):
         "bc_far_lo0", "bc_far_lo1", "bc_far_hi0", "x_pack_lo1", "x_pack_hi0", "x_pack_hi1")]
 
 
+class PaExchange(C.Structure):
+    _fields_ = [("nb_lo", C.c_int), ("nb_hi", C.c_int), ("send_lo", C.c_void_p), ("send_hi", C.c_void_p),
+                ("recv_lo", C.c_void_p), ("recv_hi", C.c_void_p), ("n_send_lo", C.c_int64),
+                ("n_send_hi", C.c_int64), ("n_recv_lo", C.c_int64), ("n_recv_hi", C.c_int64)]
+
+
 # name -> (restype, argtypes); every symbol include/pyapes_hip.h declares
 _I64P = C.POINTER(C.c_int64)
 _F64P = C.POINTER(C.c_double)
@@ -82,6 +88,12 @@ SIGNATURES: dict[str, tuple[Any, list[Any]]] = {
     "pa_cg_iterate": (C.c_int, [_VP, C.c_int64]),
     "pa_cg_end": (C.c_int, [_VP, C.POINTER(PaReport)]),
     "pa_slab_set": (C.c_int, [_VP, C.POINTER(PaSlab)]),
+    "pa_comm_unique_id": (C.c_int, [_VP]),
+    "pa_comm_init": (C.c_int, [_VP, C.c_int, C.c_int, _VP]),
+    "pa_comm_selftest": (C.c_int, [_VP, C.c_double]),
+    "pa_comm_plan": (C.c_int, [_VP, C.POINTER(PaExchange)]),
+    "pa_cg_iterate_comm": (C.c_int, [_VP, C.c_int64]),
+    "pa_comm_destroy": (C.c_int, [_VP]),
     "pa_report_read": (C.c_int, [_VP, C.POINTER(PaReport)]),
     "pa_profile_set": (C.c_int, [_VP, C.c_int]),
     "pa_profile_read": (C.c_int, [_VP, _F64P, _I64P, _F64P, _I64P]),

@@ -97,6 +97,49 @@ class SlabCG:
         self._iter_ops = None
         self.terms = list(terms)
         self._stage = None  # pinned CPU staging when the process group cannot move GPU tensors
+        self.lib_comm = self._setup_lib_comm()
+
+    # -- RCCL inside the library ---------------------------------------------------
+    def _setup_lib_comm(self) -> bool:
+        """Give the library its own RCCL communicator so that ``iterate(n)`` is ONE C call (kernels,
+        all-reduces and the plane exchange on one stream, no Python between the phases).  Used when the
+        process group is RCCL and every rank passes the library's collective self-test; otherwise the
+        stepwise torch.distributed path below stays (PYAPES_HIP_COMM=0 forces that)."""
+        import os
+        be, d = self.be, self.dist
+        if os.environ.get("PYAPES_HIP_COMM", "1") == "0" or not hasattr(be, "comm_init"):
+            return False
+        if not self.x.is_cuda or d.get_backend(self.group) != "nccl":
+            return False
+        dev = self.x.device
+        ok = 1
+        uid = torch.zeros(128, dtype=torch.uint8, device=dev)
+        try:
+            if self.rank == 0:
+                uid.copy_(torch.frombuffer(bytearray(be.comm_unique_id()), dtype=torch.uint8))
+        except Exception:
+            ok = 0
+        flag = torch.tensor([ok], dtype=torch.int32, device=dev)
+        src = d.get_global_rank(self.group, 0) if self.group is not None else 0
+        d.broadcast(flag, src=src, group=self.group)          # rank 0 could not even make an id: all skip
+        if int(flag.item()) == 0:
+            return False
+        d.broadcast(uid, src=src, group=self.group)
+        try:
+            be.comm_init(self.rank, self.world, bytes(uid.cpu().numpy().tobytes()))
+            be.comm_selftest(float(os.environ.get("PYAPES_HIP_COMM_TIMEOUT", "30")))
+        except Exception:
+            ok = 0
+        flag.fill_(ok)
+        d.all_reduce(flag, op=d.ReduceOp.MIN, group=self.group)
+        if int(flag.item()) == 0:
+            try:
+                be.comm_destroy()
+            except Exception:
+                pass
+            return False
+        be.comm_plan(self.nb_lo, self.nb_hi, self.send_lo, self.send_hi, self.recv_lo, self.recv_hi)
+        return True
 
     # -- communication -----------------------------------------------------------
     def _p2p(self, sends: list[tuple[Tensor, int, int]], recvs: list[tuple[Tensor, int, int]]) -> None:
@@ -182,6 +225,9 @@ class SlabCG:
 
     def iterate(self, n: int) -> None:
         be = self.be
+        if self.lib_comm:
+            be.cg_iterate_comm(n)
+            return
         for _ in range(n):
             be.cg_phase_a()                              # d' = r + beta d ; local sum d'.Ad'
             self._allreduce(0, 1)

@@ -84,3 +84,64 @@ def test_two_slabs_pair_bc_kernels(name, tmp_path, monkeypatch):
     plain = torch.load(str(tmp_path / "x.pt"))
     assert torch.equal(paired["x"], plain["x"])
     assert abs(paired["tol"] - plain["tol"]) <= 1e-12 * abs(plain["tol"])
+
+
+def _worker_rccl(rank, world, port, name, n, K, out, lib_comm):
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    sys.path.insert(0, here)
+    sys.path.insert(0, os.path.dirname(here))
+    warnings.filterwarnings("ignore")
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ["PYAPES_HIP_COMM"] = "1" if lib_comm else "0"
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", 0))
+    try:
+        from pyapes_amd.geometry import Box
+        from pyapes_amd.mesh import Mesh
+        from pyapes_amd.slab import SlabCG
+        from pyapes_amd.variables import Field
+        bcs = [{"bc_face": O.FACES[i], "bc_type": t, "bc_val": v, "bc_val_opt": None}
+               for i, (t, v) in enumerate(CASES[name])]
+        mesh = Mesh(Box[0:1, 0:1, 0:0.5], None, list(n), "cuda", "double", slab=(rank, world))
+        var = Field("p", 1, mesh, {"domain": bcs, "obstacle": None})
+        g = torch.Generator().manual_seed(7)
+        rhs_g = torch.randn((1, *n), generator=g, dtype=torch.float64)
+        if name == "per":
+            rhs_g -= rhs_g.mean()
+        drv = SlabCG(mesh, var, rhs_g.cuda(), [{"kind": 0, "sign": -1.0, "coeff": 0.7}], dist)
+        assert drv.lib_comm == lib_comm, "library-side RCCL communicator not in use"
+        rep = drv.solve(1e-30, K, poll=3)
+        torch.save({"x": var().cpu(), "itr": int(rep.itr), "tol": float(rep.tol)}, out)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("name", ["per", "xper", "mix"])
+def test_library_side_rccl_one_rank(name, tmp_path):
+    """The C-side iteration loop (pa_cg_iterate_comm: kernels + ncclAllReduce + grouped ncclSend/Recv on
+    one stream) with a 1-rank RCCL communicator -- on a periodic axis 0 the rank is its own ring
+    neighbour, so the packed plane exchange really runs -- against the stepwise torch.distributed
+    driver (bit for bit) and the single-domain oracle."""
+    if name not in CASES:
+        pytest.skip(name)
+    n, K = (24, 20, 132), 6
+    res = {}
+    for lib_comm in (True, False):
+        out = str(tmp_path / f"x{int(lib_comm)}.pt")
+        mp.spawn(_worker_rccl, args=(1, _free_port(), name, n, K, out, lib_comm), nprocs=1, join=True)
+        res[lib_comm] = torch.load(out)
+    assert torch.equal(res[True]["x"], res[False]["x"]) and res[True]["itr"] == res[False]["itr"] == K + 1
+    assert res[True]["tol"] == res[False]["tol"]
+    mesh = O.OMesh([0, 0, 0], [1, 1, 0.5], list(n), "double")
+    cfg = [{"bc_face": O.FACES[i], "bc_type": t, "bc_val": v} for i, (t, v) in enumerate(CASES[name])]
+    g = torch.Generator().manual_seed(7)
+    rhs = torch.randn((1, *n), generator=g, dtype=torch.float64)
+    if name == "per":
+        rhs -= rhs.mean()
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        xo, ro = O.solve_poisson(mesh, cfg, rhs, method="cg", tol=1e-30, max_it=K, coeff=0.7, sign=-1.0)
+    err = float(torch.linalg.norm(res[True]["x"] - xo) / torch.linalg.norm(xo))
+    assert err < 1e-10, err
