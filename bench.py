@@ -258,6 +258,7 @@ def main():
                     "phase_a_ms": pr["phase_a_ms"], "phase_b_ms": pr["phase_b_ms"],
                     "alg_bytes_per_launch": alg_bytes, "scope": "rank 0, per GPU"}
         drv.end()
+        comm_kind = "rccl-in-library" if drv.lib_comm else "torch.distributed-stepwise"
 
     if rank == 0:
         value = cells_global * K / secs
@@ -275,7 +276,7 @@ def main():
             "dtype": "f64" if dtype == "double" else "f32",
             "data": "synthetic",
             "config": {"workload": f"3-D Poisson {gn[0]}x{gn[1]}x{gn[2]} {dtype}, {kind} BCs, CG (BASELINE config {args.workload})",
-                       "global_cells": cells_global, "parallelism": f"slab{world}" if world > 1 else "single"},
+                       "global_cells": cells_global, "parallelism": (f"slab{world} ({comm_kind})" if (world > 1 or force_slab) else "single")},
             "hbm_alg_GBs": ALG_PASSES_CG * esize * cells_global * K / secs / 1e9,
             "hbm_alg_frac_of_peak": ALG_PASSES_CG * esize * cells_global * K / secs / 1e9 / (HBM_PEAK_GBS * world),
             "stream_ms_per_step": ev_ms / K,
