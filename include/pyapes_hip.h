@@ -94,7 +94,7 @@ int pa_grid_set(pa_ctx* ctx, int ndim, const int64_t* n, const double* dx, int d
 /* ---- coordinate system ------------------------------------------------
  * replaces: the axisymmetric (Cylinder, "rz") rows of default_A_ops (pyapes/solver/tools.py:64-107),
  * Laplacian.build_A_coeffs / adjust_rhs (fdc.py:395-417, 440-453).  2-D grids only (axis 0 = r,
- * axis 1 = z; _mesh.py:48-49).  r_tables: device pointer the caller keeps alive, 5 rows x n[0]
+ * axis 1 = z; _mesh.py:48-49).  r_tables: device pointer the caller keeps alive, 6 rows x n[0]
  * values of the grid dtype, one value per r node, evaluated by the host with the reference's
  * literal expressions (dr = dx[0]; nn = nan_to_num(., 0, 0, 0)):
  *   row 0  (1 + nn(dr / (2 r))) / dr^2          Laplacian Ap along r
@@ -102,6 +102,7 @@ int pa_grid_set(pa_ctx* ctx, int ndim, const int64_t* n, const double* dx, int d
  *   row 2  (2/3 + nn(2/3 dr / r)) / dr^2        neumann / symmetry row along r (Ap = -Ac or Am = -Ac)
  *   row 3  2/3 - nn(1/3 dr / r)                 factor of the Laplacian rhs adjustment along r
  *   row 4  nn(2 dr / r)                         Ac of Div along r (the u phi / r term)
+ *   row 5  r                                    the node radii (edge rz terms fdc.py:330-357, DiffFlux, rfp.py)
  * PA_COORD_XYZ (tables ignored) restores the Cartesian operators; pa_grid_set resets to it. */
 enum { PA_COORD_XYZ = 0, PA_COORD_RZ = 1 };
 int pa_coord_set(pa_ctx* ctx, int coord_sys, const void* r_tables);
@@ -140,6 +141,32 @@ int pa_div(pa_ctx* ctx, int kind, double u, const void* u_field, const void* x, 
 /* edge=True post-pass of Div (fdc.py:290-361): overwrites the two end nodes of y with the one-sided
  * 2nd-order formula times the advection value.  1-D only, like the reference for scalar fields. */
 int pa_div_edge(pa_ctx* ctx, double u, const void* u_field, const void* x, void* y);
+
+/* ---- general Div, DiffFlux and the Fokker-Planck operators ------------------
+ * pa_div_general replaces Div.build_A_coeffs + Discretizer.apply + _treat_edge in full generality
+ * (fdc.py:93-102, 290-361, 623-664, 708-772): y = sum over mesh axes a of the stencil along a applied
+ * to x[a] (scalar field: the same pointer for every a; vector field: component a) with the advection
+ * u_int[a] (field or NULL = the scalar u; the reference uses component 0 / Jac[n2d[0]] on every axis
+ * for a scalar target and component a for a vector target -- the binding resolves that); with
+ * edge != 0 the two end planes of axis a of that contribution are replaced by the one-sided formula
+ * times u_edge[a] (or u), plus the literal rz terms on the r axis.  Single GPU.
+ * pa_diff_flux replaces DiffFlux.__call__ (fdc.py:818-856): out[i] = sum_j w_i D[i*ndim+j] J[j],
+ * w = r on the r row of an rz mesh, out shaped (ndim, *n).
+ * pa_rfp_friction / pa_rfp_diffusion replace Friction / Diffusion.__call__ (solver/rfp.py:19-82,
+ * 85-218), rz grids only.  pa_limiter: minmod (0) / mc_limiter (1), rfp.py:262-286, n elements. */
+typedef struct {
+  const void* x[3];
+  const void* u_int[3];
+  const void* u_edge[3];
+  double u;
+  int kind;  /* PA_OP_DIV_CENTRAL | PA_OP_DIV_UPWIND_COMPAT | PA_OP_DIV_UPWIND */
+  int edge;
+} pa_div_spec;
+int pa_div_general(pa_ctx* ctx, const pa_div_spec* spec, void* y);
+int pa_diff_flux(pa_ctx* ctx, const void* const* D, const void* const* J, void* out);
+int pa_rfp_friction(pa_ctx* ctx, const void* Hr, const void* Hz, const void* pdf, void* out);
+int pa_rfp_diffusion(pa_ctx* ctx, const void* Drr, const void* Drz, const void* Dzz, const void* pdf, void* out);
+int pa_limiter(pa_ctx* ctx, int which, const void* a, const void* b, void* out, int64_t n);
 
 /* ---- solvers (linalg.solve -> cg | bicgstab, linalg.py:33-279) --------- */
 int pa_cg(pa_ctx* ctx, void* x, const void* rhs, double tol, int64_t max_it, pa_report* out);

@@ -93,6 +93,11 @@ class OMesh:
         return torch.tensor(self.dx_list, dtype=self.dtype)
 
     @property
+    def letters(self) -> str:
+        """axis letters (geometry/basis.py:8,13)"""
+        return "rz" if self.coord == "rz" else "xyz"
+
+    @property
     def faces(self) -> list[str]:
         return FACES_RZ if self.coord == "rz" else FACES[:2 * self.dim]
 
@@ -372,12 +377,23 @@ def grad_rhs_adjust(var: Tensor, mesh: OMesh, bcs: Sequence[OBC] | None) -> Tens
     return adj
 
 
-def adv_tensor(u: float | Tensor, var: Tensor) -> Tensor:
-    """fdc.py:775-792 (float | Tensor only)."""
+def adv_tensor(u: Any, var: Tensor) -> Any:
+    """fdc.py:775-792.  float | Tensor -> Tensor shaped like var; a Jac (dict axis letter -> Tensor,
+    variables/container.py) is passed through, as Div.build_A_coeffs does (fdc.py:640-643)."""
+    if isinstance(u, dict):
+        return u
     if isinstance(u, float):
         return torch.ones_like(var) * u
     assert u.shape == var.shape, "oracle: adv shape must match var shape"
     return u
+
+
+def _adv_comp(adv: Any, i: int, mesh: "OMesh") -> Tensor:
+    """fdc.py:726-733 / 758-765: component of the advection term that multiplies var component i --
+    adv[i] for tensors, adv[n2d[i]] for a Jac (n2d = axis letters of the coordinate system)."""
+    if isinstance(adv, dict):
+        return adv[mesh.letters[i]]
+    return adv[i]
 
 
 def div_tables(u: float | Tensor, var: Tensor, mesh: OMesh, bcs: Sequence[OBC] | None,
@@ -392,7 +408,7 @@ def div_tables(u: float | Tensor, var: Tensor, mesh: OMesh, bcs: Sequence[OBC] |
         advection = torch.zeros_like(var[0])
         for i in range(var.shape[0]):
             for j in range(mesh.dim):
-                advection = adv[i]
+                advection = _adv_comp(adv, i, mesh)
                 Ap[j][i] *= torch.roll(advection, -1, dims=j)
                 Ac[j][i] *= advection
                 Am[j][i] *= torch.roll(advection, 1, dims=j)
@@ -401,7 +417,7 @@ def div_tables(u: float | Tensor, var: Tensor, mesh: OMesh, bcs: Sequence[OBC] |
         zeros = torch.zeros_like(var[0])
         for i in range(var.shape[0]):
             for j in range(mesh.dim):
-                advection = adv[i]
+                advection = _adv_comp(adv, i, mesh)
                 Ap[j][i] = 2.0 * torch.min(advection, zeros)
                 Ac[j][i] *= 2.0 * advection
                 Am[j][i] = 2.0 * torch.max(advection, zeros)
@@ -455,11 +471,179 @@ def apply_grad(tabs, var: Tensor, ndim: int) -> Tensor:
     return torch.stack(comps)
 
 
-def apply_div(tabs, var: Tensor, ndim: int) -> Tensor:
+def apply_div(tabs, var: Tensor, ndim: int, edge: tuple | None = None) -> Tensor:
+    """fdc.py:93-102.  edge = (mesh, var_add): the per-axis edge treatment of edge=True."""
     out = torch.zeros_like(var[0]).unsqueeze(0)
     for a in range(ndim):
-        out[0] += _axis_sum(tabs, var, a, a)
+        disc = _axis_sum(tabs, var, a, a)
+        if edge is not None:
+            edge_div(disc, var, edge[0], a, edge[1])
+        out[0] += disc
     return out
+
+
+def edge_div(disc: Tensor, var: Tensor, mesh: "OMesh", dim: int, var_add: Any) -> None:
+    """fdc.py:290-361: the two end planes of axis ``dim`` of this axis' contribution get the one-sided
+    2nd-order derivative times the advection value (+ the rz terms, literal: the lower one without
+    the advection factor).  Raises IndexError exactly where the reference's indexing does (scalar
+    field with float / same-shaped tensor advection on an axis > 0)."""
+    nd = mesh.dim
+    if isinstance(var_add, Tensor):
+        adv = var_add[dim] if var_add.shape == var.shape else var_add
+    elif isinstance(var_add, float):
+        adv = torch.ones_like(var[dim]) * var_add
+    elif isinstance(var_add, dict):
+        adv = var_add[mesh.letters[dim]]
+    elif var_add is None:
+        adv = torch.ones_like(var[dim])
+    else:
+        raise NotImplementedError
+    target = var[0] if var.shape[0] == 1 else var[dim]
+    for side in (0, 1):
+        s = [[slice(None)] * nd for _ in range(3)]
+        for q in range(3):
+            s[q][dim] = q if side == 0 else -1 - q
+        s1 = tuple(s[0])
+        t0, t1, t2 = (target[tuple(s[q])] for q in range(3))
+        if side == 0:
+            disc[s1] = -(3 / 2 * t0 - 2.0 * t1 + 1 / 2 * t2) / (mesh.dx[dim]) * adv[s1]
+            if mesh.coord == "rz" and dim == 0:
+                disc[s1] += _nn(t0 / mesh.R[s1])
+        else:
+            disc[s1] = (3 / 2 * t0 - 2.0 * t1 + 1 / 2 * t2) / (mesh.dx[dim]) * adv[s1]
+            if mesh.coord == "rz" and dim == 0:
+                disc[s1] += _nn(t0 * adv[s1] / mesh.R[s1])
+
+
+# fdc.py:896-944: first / second derivatives of a scalar array as edge=True gradients of a BC-free field
+def jacobian(field: Tensor, mesh: "OMesh") -> dict:
+    v = field.unsqueeze(0)
+    g = apply_grad(grad_tables(v, mesh, []), v, mesh.dim)
+    edge_grad(g, v, mesh)
+    return {mesh.letters[i]: g[0][i] for i in range(mesh.dim)}
+
+
+def hessian(field: Tensor, mesh: "OMesh") -> dict:
+    jac = jacobian(field, mesh)
+    out = {}
+    for i in range(mesh.dim):
+        gi = jacobian(jac[mesh.letters[i]], mesh)
+        for j in range(i, mesh.dim):
+            out[mesh.letters[i] + mesh.letters[j]] = gi[mesh.letters[j]]
+    return out
+
+
+def _hkey(h: dict, key: str) -> Tensor:
+    return h["".join(sorted(key))]      # variables/container.py:43-58
+
+
+def diff_flux(hess: dict, field: Tensor, mesh: "OMesh") -> Tensor:
+    """fdc.py:818-856: D_ij d(phi)/dx_j as a vector field (mesh.dim, *nx); the r row carries a factor r."""
+    jac = jacobian(field, mesh)
+    L = mesh.letters
+    out = torch.zeros(mesh.dim, *mesh.nx, dtype=mesh.dtype)
+    for i in range(mesh.dim):
+        acc = torch.zeros_like(field)
+        for j in range(mesh.dim):
+            d = _hkey(hess, L[i] + L[j])
+            if L[i] == "r":
+                d = mesh.grid[0] * d
+            acc += d * jac[L[j]]
+        out[i] = acc
+    return out
+
+
+# --------------------------------------------------------------------------
+# Rosenbluth-Fokker-Planck explicit operators, rz only (solver/rfp.py)
+# --------------------------------------------------------------------------
+def rfp_friction(jacH: dict, pdf: Tensor, mesh: "OMesh") -> Tensor:
+    """rfp.py:19-82: div(grad(H) f) in conservative form on face-averaged values, zero normal flux
+    rows written afterwards in the order r=0, r=R, z=0, z=Z."""
+    assert mesh.coord == "rz"
+    Hr, Hz = jacH["r"], jacH["z"]
+    dx = mesh.dx
+    R = mesh.R
+    up = lambda t, a: torch.roll(t, -1, a)   # noqa: E731  value at index + 1
+    dn = lambda t, a: torch.roll(t, 1, a)    # noqa: E731  value at index - 1
+    Arp, Arm = (up(Hr, 0) + Hr) / 2.0, (Hr + dn(Hr, 0)) / 2.0
+    Azp, Azm = (up(Hz, 1) + Hz) / 2.0, (Hz + dn(Hz, 1)) / 2.0
+    Prp, Prm = (up(pdf, 0) + pdf) / 2.0, (pdf + dn(pdf, 0)) / 2.0
+    Pzp, Pzm = (up(pdf, 1) + pdf) / 2.0, (pdf + dn(pdf, 1)) / 2.0
+    r_p, r_m = (up(R, 0) + R) / 2, (R + dn(R, 0)) / 2
+    zflux = Azp * Pzp - Azm * Pzm
+    rflux = (r_p * Arp * Prp - r_m * Arm * Prm) / (R * dx[0])
+    out = zflux / dx[1] + rflux
+    out[0, :] = zflux[0, :] / (dx[1])
+    out[-1, :] = zflux[-1, :] / (dx[1]) + 2.0 * ((-r_m * Arm * Prm) / (R * dx[0]))[-1, :]
+    out[:, 0] = 2.0 * (Azp * Pzp)[:, 0] / (dx[1]) + _nn(rflux)[:, 0]
+    out[:, -1] = 2.0 * (-Azm * Pzm)[:, -1] / (dx[1]) + _nn(rflux)[:, -1]
+    return out
+
+
+def _sh(t: Tensor, di: int, dj: int) -> Tensor:
+    """value at (i + di, j + dj), wrap-around"""
+    return torch.roll(t, (-di, -dj), (0, 1))
+
+
+def _face_grad(t: Tensor, p: tuple[int, int], m: tuple[int, int], h: Tensor) -> Tensor:
+    """rfp.py:221-230"""
+    return (_sh(t, *p) - _sh(t, *m)) / h
+
+
+def _cell_avg(t: Tensor, ui: int, uj: int) -> Tensor:
+    """rfp.py:233-251: mean over the cell whose upper corner is (i + ui, j + uj)"""
+    return (_sh(t, ui, uj) + _sh(t, ui, uj - 1) + _sh(t, ui - 1, uj) + _sh(t, ui - 1, uj - 1)) / 4
+
+
+def rfp_diffusion(hessG: dict, pdf: Tensor, mesh: "OMesh") -> Tensor:
+    """rfp.py:85-218: div(D grad f), D = hess(G), symmetric differences; the mixed term uses cell-centre
+    averages of D_rz; boundary rows written afterwards in the order r=0, r=R, z=0, z=Z."""
+    assert mesh.coord == "rz"
+    Drr, Dzz, Drz = _hkey(hessG, "rr"), _hkey(hessG, "zz"), _hkey(hessG, "rz")
+    dx = mesh.dx
+    R = mesh.grid[0]
+    f = pdf
+    rr_p = (_sh(Drr, 1, 0) + Drr) * (_sh(f, 1, 0) - f) / (2.0 * dx[0])
+    rr_m = (_sh(Drr, -1, 0) + Drr) * (f - _sh(f, -1, 0)) / (2.0 * dx[0])
+    zz_p = (_sh(Dzz, 0, 1) + Dzz) * (_sh(f, 0, 1) - f) / (2.0 * dx[1])
+    zz_m = (_sh(Dzz, 0, -1) + Dzz) * (f - _sh(f, 0, -1)) / (2.0 * dx[1])
+    c_pp, c_pm, c_mp, c_mm = _cell_avg(Drz, 1, 1), _cell_avg(Drz, 1, 0), _cell_avg(Drz, 0, 1), _cell_avg(Drz, 0, 0)
+    G = _face_grad
+    rz_r_zp = 0.25 * c_pp * (G(f, (1, 0), (0, 0), dx[0]) + G(f, (1, 1), (0, 1), dx[0])) \
+        + 0.25 * c_mp * (G(f, (0, 0), (-1, 0), dx[0]) + G(f, (0, 1), (-1, 1), dx[0]))
+    rz_r_zm = 0.25 * c_pm * (G(f, (1, -1), (0, -1), dx[0]) + G(f, (1, 0), (0, 0), dx[0])) \
+        + 0.25 * c_mm * (G(f, (0, -1), (-1, -1), dx[0]) + G(f, (0, 0), (-1, 0), dx[0]))
+    rz_z_rp = 0.25 * c_pp * (G(f, (0, 1), (0, 0), dx[1]) + G(f, (1, 1), (1, 0), dx[1])) \
+        + 0.25 * c_mp * (G(f, (0, 0), (0, -1), dx[1]) + G(f, (1, 0), (1, -1), dx[1]))
+    rz_z_rm = 0.25 * c_pm * (G(f, (-1, 1), (-1, 0), dx[1]) + G(f, (0, 1), (0, 0), dx[1])) \
+        + 0.25 * c_mm * (G(f, (-1, 0), (-1, -1), dx[1]) + G(f, (0, 0), (0, -1), dx[1]))
+    r_p, r_m = (_sh(R, 1, 0) + R) / 2, (R + _sh(R, -1, 0)) / 2
+    rad_mixed = (r_p * rz_z_rp - r_m * rz_z_rm) / (R * dx[0])
+    rad_rr = (r_p * rr_p - r_m * rr_m) / (R * dx[0])
+    out = (zz_p - zz_m) / dx[1] + (rz_r_zp - rz_r_zm) / dx[1] + rad_mixed + rad_rr
+    out[0, :] = (zz_p - zz_m)[0, :] / dx[1] + 2.0 * (rz_r_zp - rz_r_zm)[0, :] / dx[1]
+    out[-1, :] = (((zz_p - zz_m) / dx[1] + (rz_r_zp - rz_r_zm) / dx[1])[-1, :]
+                  + 2.0 * ((-r_m * rz_z_rm) / (R * dx[0]))[-1, :]
+                  + 2.0 * ((-r_m * rr_m) / (R * dx[0]))[-1, :])
+    out[:, 0] = 2.0 * ((zz_p) / dx[1] + (rz_r_zp) / dx[1])[:, 0] + _nn(rad_mixed + rad_rr)[:, 0]
+    out[:, -1] = 2.0 * ((-zz_m) / dx[1] + (-rz_r_zm) / dx[1])[:, -1] + _nn(rad_mixed + rad_rr)[:, -1]
+    return out
+
+
+def minmod(a: Tensor, b: Tensor) -> Tensor:
+    """rfp.py:268-286"""
+    val = torch.zeros_like(a)
+    m = torch.logical_and(a.ge(0.0), b.ge(0.0))
+    val[m] = torch.min(a[m], b[m])
+    m = torch.logical_and(a.lt(0.0), b.lt(0.0))
+    val[m] = torch.max(a[m], b[m])
+    val[(a * b).le(0.0)] = 0.0
+    return val
+
+
+def mc_limiter(a: Tensor, b: Tensor) -> Tensor:
+    """rfp.py:262-265"""
+    return minmod(2.0 * minmod(a, b), (a + b) / 2.0)
 
 
 # fdc.py:203-366 (explicit one-sided boundary formulas, edge=True)

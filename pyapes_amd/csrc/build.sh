@@ -10,5 +10,5 @@ HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
 "$HIPCC" --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -ffp-contract=off \
   -Wall -Wno-unused-function -Wno-unused-variable \
   ${PA_EXTRA_FLAGS:-} \
-  -o "$OUT/libpyapes_hip.so" "$HERE/pa_core.hip" "$HERE/pa_cg3d.hip" "$HERE/pa_comm.hip" -ldl
+  -o "$OUT/libpyapes_hip.so" "$HERE/pa_core.hip" "$HERE/pa_cg3d.hip" "$HERE/pa_comm.hip" "$HERE/pa_rfp.hip" -ldl
 echo "built $OUT/libpyapes_hip.so"

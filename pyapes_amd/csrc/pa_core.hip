@@ -17,13 +17,6 @@
 //  kernels
 // ============================================================================
 
-__device__ __forceinline__ void pa_decode(const DevGeom& G, int64_t idx, int64_t& i, int64_t& j, int64_t& k) {
-  i = idx / G.s0;
-  int64_t rem = idx - i * G.s0;
-  j = rem / G.s1;
-  k = rem - j * G.s1;
-}
-
 // ---- BC fill of one face (pyapes/variables/bcs.py:200-280) --------------------------
 template <typename T>
 struct BCArgs {

@@ -84,6 +84,13 @@ struct Vec {
   const T* ghi;  // plane "n0"
 };
 
+__device__ __forceinline__ void pa_decode(const DevGeom& G, int64_t idx, int64_t& i, int64_t& j, int64_t& k) {
+  i = idx / G.s0;
+  int64_t rem = idx - i * G.s0;
+  j = rem / G.s1;
+  k = rem - j * G.s1;
+}
+
 __device__ __forceinline__ int64_t pa_wrap(int64_t v, int64_t n) {
   return v < 0 ? v + n : (v >= n ? v - n : v);
 }

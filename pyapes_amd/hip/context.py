@@ -177,6 +177,54 @@ class HipContext:
         self._rc(self.lib.pa_div_edge(self.h, us, self._ptr(uf), self._ptr(self._field(x, "div edge")),
                                       self._ptr(self._field(y, "div edge out"))))
 
+    def div_general(self, kind: int, edge: bool, x: Sequence[Tensor], u: float, u_int: Sequence[Tensor | None],
+                    u_edge: Sequence[Tensor | None], out: Tensor) -> Tensor:
+        """General Div (one entry per mesh axis in x / u_int / u_edge; None = the scalar u)."""
+        sp = L.PaDivSpec()
+        keep = []
+        for a in range(self.mesh.dim):
+            sp.x[a] = self._field(x[a], "div target").data_ptr()
+            for name, lst in (("u_int", u_int), ("u_edge", u_edge)):
+                t = lst[a]
+                if t is not None:
+                    t = self._field(t, "advection tensor")
+                    keep.append(t)
+                    getattr(sp, name)[a] = t.data_ptr()
+        sp.u, sp.kind, sp.edge = float(u), int(kind), int(bool(edge))
+        self._rc(self.lib.pa_div_general(self.h, C.byref(sp), self._ptr(self._field(out, "div out"))))
+        return out
+
+    def diff_flux(self, D: Sequence[Tensor], J: Sequence[Tensor], out: Tensor) -> Tensor:
+        nd = self.mesh.dim
+        Dp = (C.c_void_p * (nd * nd))(*[self._field(t, "diffusion tensor").data_ptr() for t in D])
+        Jp = (C.c_void_p * nd)(*[self._field(t, "jacobian").data_ptr() for t in J])
+        require_gpu(out, "DiffFlux out")
+        assert out.is_contiguous() and out.numel() == nd * self.mesh.N and out.dtype == self.dtype
+        self._rc(self.lib.pa_diff_flux(self.h, Dp, Jp, self._ptr(out)))
+        return out
+
+    def rfp_friction(self, Hr: Tensor, Hz: Tensor, pdf: Tensor) -> Tensor:
+        out = torch.empty(tuple(self.mesh.nx), dtype=self.dtype, device=self.device)
+        self._rc(self.lib.pa_rfp_friction(self.h, self._ptr(self._field(Hr, "H_r")), self._ptr(self._field(Hz, "H_z")),
+                                          self._ptr(self._field(pdf, "pdf")), self._ptr(out)))
+        return out
+
+    def rfp_diffusion(self, Drr: Tensor, Drz: Tensor, Dzz: Tensor, pdf: Tensor) -> Tensor:
+        out = torch.empty(tuple(self.mesh.nx), dtype=self.dtype, device=self.device)
+        self._rc(self.lib.pa_rfp_diffusion(self.h, self._ptr(self._field(Drr, "D_rr")),
+                                           self._ptr(self._field(Drz, "D_rz")), self._ptr(self._field(Dzz, "D_zz")),
+                                           self._ptr(self._field(pdf, "pdf")), self._ptr(out)))
+        return out
+
+    def limiter(self, which: int, a: Tensor, b: Tensor) -> Tensor:
+        require_gpu(a, "limiter")
+        require_gpu(b, "limiter")
+        assert a.shape == b.shape and a.dtype == b.dtype == self.dtype
+        a, b = a.contiguous(), b.contiguous()
+        out = torch.empty_like(a)
+        self._rc(self.lib.pa_limiter(self.h, int(which), self._ptr(a), self._ptr(b), self._ptr(out), a.numel()))
+        return out
+
     def euler_march(self, phi: Tensor, tmp: Tensor, kind: int, u: float | Tensor, nu: float, dt: float,
                     nsteps: int) -> Tensor:
         """``nsteps`` explicit Euler steps enqueued back to back, ping-ponging phi <-> tmp; returns the

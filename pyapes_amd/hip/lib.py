@@ -48,6 +48,11 @@ class PaSlab(C.Structure):
         "bc_far_lo0", "bc_far_lo1", "bc_far_hi0", "x_pack_lo1", "x_pack_hi0", "x_pack_hi1")]
 
 
+class PaDivSpec(C.Structure):
+    _fields_ = [("x", C.c_void_p * 3), ("u_int", C.c_void_p * 3), ("u_edge", C.c_void_p * 3),
+                ("u", C.c_double), ("kind", C.c_int), ("edge", C.c_int)]
+
+
 class PaExchange(C.Structure):
     _fields_ = [("nb_lo", C.c_int), ("nb_hi", C.c_int), ("send_lo", C.c_void_p), ("send_hi", C.c_void_p),
                 ("recv_lo", C.c_void_p), ("recv_hi", C.c_void_p), ("n_send_lo", C.c_int64),
@@ -75,6 +80,11 @@ SIGNATURES: dict[str, tuple[Any, list[Any]]] = {
     "pa_div": (C.c_int, [_VP, C.c_int, C.c_double, _VP, _VP, _VP]),
     "pa_div_edge": (C.c_int, [_VP, C.c_double, _VP, _VP, _VP]),
     "pa_coord_set": (C.c_int, [_VP, C.c_int, _VP]),
+    "pa_div_general": (C.c_int, [_VP, C.POINTER(PaDivSpec), _VP]),
+    "pa_diff_flux": (C.c_int, [_VP, C.POINTER(_VP), C.POINTER(_VP), _VP]),
+    "pa_rfp_friction": (C.c_int, [_VP, _VP, _VP, _VP, _VP]),
+    "pa_rfp_diffusion": (C.c_int, [_VP, _VP, _VP, _VP, _VP, _VP]),
+    "pa_limiter": (C.c_int, [_VP, C.c_int, _VP, _VP, _VP, C.c_int64]),
     "pa_cg": (C.c_int, [_VP, _VP, _VP, C.c_double, C.c_int64, C.POINTER(PaReport)]),
     "pa_bicgstab": (C.c_int, [_VP, _VP, _VP, C.c_double, C.c_int64, C.POINTER(PaReport)]),
     "pa_jacobi": (C.c_int, [_VP, _VP, _VP, C.c_double, C.c_int64, C.c_double, C.POINTER(PaReport)]),

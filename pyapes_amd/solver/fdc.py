@@ -3,8 +3,8 @@
 ``FDC(config).laplacian(var)``, ``.grad(var)``, ``.div(var_j, var_i)`` evaluate the
 2nd-order stencils on the current field and return a tensor; ``build_A_coeffs`` /
 ``adjust_rhs`` / ``apply`` keep their meaning.  All arithmetic is done by
-``k_aop`` / ``k_grad`` / ``k_edge`` / ``k_rhs_adjust`` in ``csrc/pa_core.hip``.
-Out of scope: DiffFlux, jacobian, hessian, rz terms.
+``k_aop`` / ``k_grad`` / ``k_edge`` / ``k_rhs_adjust`` in ``csrc/pa_core.hip`` and, for the general
+Div (Jac advection, vector targets, edge=True in n-D) and ``DiffFlux``, ``csrc/pa_rfp.hip``.
 """
 from __future__ import annotations
 
@@ -52,7 +52,55 @@ def _adv_of(var_j: Any, var_i: Field) -> float | Tensor:
         return var_j
     if isinstance(var_j, (float, int)):
         return float(var_j)
-    raise NotImplementedError("FDC Div: Jac / Hess advection is out of scope")
+    if isinstance(var_j, Jac):
+        # fdc.py:726-733: a scalar target takes Jac[n2d[0]] on every axis (like adv[0])
+        return var_j[n2d_coord(var_i.mesh.coord_sys)[0]].unsqueeze(0)
+    raise NotImplementedError("FDC: var_j Hess is not implemented yet!")
+
+
+def _div_plan(var_j: Any, var_i: Field, edge: bool) -> tuple[list, float, list, list]:
+    """Resolve the reference's indexing of target and advection per mesh axis (fdc.py:93-102, 292-311,
+    708-792) -> (x, u, u_int, u_edge): one entry per axis, ``None`` = the scalar ``u``.  Raises
+    IndexError where the reference's own indexing does (edge=True with a scalar target and a float /
+    same-shaped tensor / scalar-Field advection on a mesh with more than one axis)."""
+    mesh = var_i.mesh
+    nd, vd = mesh.dim, var_i.dim
+    n2d = n2d_coord(mesh.coord_sys)
+    if vd != 1 and vd < nd:
+        raise IndexError(f"index {vd} is out of bounds for dimension 0 with size {vd}")   # var[idx], fdc.py:99
+    if isinstance(var_j, Hess):
+        raise NotImplementedError("FDC: var_j Hess is not implemented yet!")
+    u = 0.0
+    full: Tensor | None = None
+    if isinstance(var_j, Field):
+        full = var_j()
+    elif isinstance(var_j, Tensor):
+        assert var_j.shape == var_i().shape, "FDC Div: adv shape must match var_i shape"
+        full = var_j
+    elif isinstance(var_j, (float, int)):
+        u = float(var_j)
+    elif not isinstance(var_j, Jac):
+        raise NotImplementedError("FDC: var_j Hess is not implemented yet!")
+
+    def interior(i: int) -> Tensor | None:          # advection multiplying var component i
+        if isinstance(var_j, Jac):
+            return var_j[n2d[i]]
+        return None if full is None else full[i]
+
+    def at_edge(a: int) -> Tensor | None:           # _treat_edge's own choice, fdc.py:294-309
+        if isinstance(var_j, Jac):
+            return var_j[n2d[a]]
+        if isinstance(var_j, Field):
+            return var_j[a]
+        if isinstance(var_j, Tensor):
+            return var_j[a] if var_j.shape == var_i().shape else var_j
+        var_i[a]                                      # torch.ones_like(var[dim]) * var_add
+        return None
+
+    x = [var_i()[0] if vd == 1 else var_i()[a] for a in range(nd)]
+    u_int = [interior(0 if vd == 1 else a) for a in range(nd)]
+    u_edge = [at_edge(a) if edge else None for a in range(nd)]
+    return x, u, u_int, u_edge
 
 
 class Discretizer:
@@ -194,20 +242,39 @@ class Div(Discretizer):
     def apply(self, A_coeffs: StencilSpec, var: Field) -> Tensor:
         assert A_coeffs is not None, "FDC: A_A_coeffs is not defined!"
         require_gpu(var(), "FDC.div")
-        if var.dim != 1:
-            raise NotImplementedError("pyapes_amd: Div of a vector field is not covered (scalar fields only)")
         edge = self._edge()
-        if edge and var.mesh.dim != 1:
-            raise IndexError("pyapes_amd: edge=True Div of a scalar field works in 1-D only "
-                             "(the reference indexes var[dim] / adv[dim] and raises IndexError, fdc.py:296-303)")
+        kind = div_kind(A_coeffs.limiter, A_coeffs.compat)
         ctx = context_for(var.mesh)
         ctx.bind_bcs(var(), A_coeffs.bcs, 0)
-        u = _adv_of(A_coeffs.var_j, var)
-        out = torch.empty_like(var())
-        ctx.div(div_kind(A_coeffs.limiter, A_coeffs.compat), u, var()[0], out=out[0])
-        if edge:
-            ctx.div_edge(u, var()[0], out[0])
+        out = torch.empty((1, *var.mesh.nx), dtype=var().dtype, device=var().device)
+        var_j = A_coeffs.var_j
+        if var.dim == 1 and not edge and not isinstance(var_j, (Jac, Hess)):
+            ctx.div(kind, _adv_of(var_j, var), var()[0], out=out[0])      # the solver's operator, tiled
+            return out
+        if not var().is_contiguous():
+            var.set_var_tensor(var().contiguous())
+        x, u, u_int, u_edge = _div_plan(var_j, var, edge)
+        ctx.div_general(kind, edge, x, u, u_int, u_edge, out[0])
         return out
+
+
+class DiffFlux:
+    """``D_ij d(phi)/dx_j`` of a scalar field as a vector ``Field`` (fdc.py:818-856); the r row of an
+    rz mesh carries a factor r.  No boundary treatment beyond the edge=True gradient."""
+
+    @staticmethod
+    def __call__(diff: Hess, var: Field) -> Field:
+        mesh = var.mesh
+        n2d = n2d_coord(mesh.coord_sys)
+        jac = jacobian(var)
+        nd = mesh.dim
+        flux = Field("DiffFlux", len(jac), mesh, None)
+        D = [diff[n2d[i] + n2d[j]].contiguous() for i in range(nd) for j in range(nd)]
+        J = [jac[n2d[j]].contiguous() for j in range(nd)]
+        out = torch.empty((nd, *mesh.nx), dtype=var().dtype, device=var().device)
+        context_for(mesh).diff_flux(D, J, out)
+        flux.set_var_tensor(out)
+        return flux
 
 
 class FDC:
@@ -218,6 +285,7 @@ class FDC:
         self.div = Div()
         self.laplacian = Laplacian()
         self.grad = Grad()
+        self.diffFlux = DiffFlux()
         self.config = config
         if config is not None:
             for c in config:

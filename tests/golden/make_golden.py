@@ -288,6 +288,61 @@ def run_spatial(case):
     return out
 
 
+def run_rfp(case):
+    """General Div (Jac advection, vector target, edge=True in n-D: fdc.py:93-102, 290-361, 708-772),
+    DiffFlux (fdc.py:818-856) and -- on rz meshes -- the Fokker-Planck operators of solver/rfp.py."""
+    from pyapes.solver.fdc import hessian, jacobian
+    from pyapes.solver.rfp import RFP, mc_limiter
+    mr, mo = ref_mesh(case), orc_mesh(case)
+    nd = mr.dim
+    rz = case.get("coord", "xyz") == "rz"
+    L = "rz" if rz else "xyz"
+    f = mr.dtype.float
+    g = torch.Generator().manual_seed(case.get("seed", 0) + 31)
+
+    def noise(scale=0.05):
+        return scale * torch.randn(tuple(mr.nx), generator=g, dtype=torch.float64).to(f)
+
+    r2 = sum(gi ** 2 for gi in mr.grid)
+    pdf_t = (torch.exp(-r2 / 2) + noise()).unsqueeze(0)
+    H_t = (1.0 / (1.0 + r2) + noise()).unsqueeze(0)
+    G_t = (torch.sqrt(1.0 + r2) + noise()).unsqueeze(0)
+    ut = torch.stack([(0.5 + noise()) * (1.0 if a % 2 == 0 else -0.7) for a in range(nd)])
+    out = {"pdf": npy(pdf_t), "H": npy(H_t), "G": npy(G_t), "ut": npy(ut)}
+
+    def mk_field(name, t):
+        return Field(name, t.shape[0], mr, {"domain": None, "obstacle": None}).set_var_tensor(t.clone())
+
+    pdf, H, G = mk_field("pdf", pdf_t), mk_field("H", H_t), mk_field("G", G_t)
+    jacH, hessG = jacobian(H), hessian(G)
+    jo, ho = O.jacobian(H_t[0], mo), O.hessian(G_t[0], mo)
+    flux = FDC().diffFlux(hessG, pdf)
+    out["flux"] = npy(flux())
+    fo = O.diff_flux(ho, pdf_t[0], mo)
+    same(fo, out["flux"], "diffFlux")
+    for lim in ("none", "upwind"):
+        for edge in (True, False):
+            tag = f"{lim}_{'edge' if edge else 'noedge'}"
+            fdc = FDC({"div": {"limiter": lim, "edge": edge}})
+            e = lambda va: (mo, va) if edge else None   # noqa: E731
+            out[f"div_jac_{tag}"] = npy(fdc.div(jacH, pdf))
+            same(O.apply_div(O.div_tables(jo, pdf_t, mo, [], lim), pdf_t, nd, e(jo)), out[f"div_jac_{tag}"], "div_jac_" + tag)
+            out[f"div_vec_f_{tag}"] = npy(fdc.div(1.0, flux))
+            same(O.apply_div(O.div_tables(1.0, fo, mo, [], lim), fo, nd, e(1.0)), out[f"div_vec_f_{tag}"], "div_vec_f_" + tag)
+            out[f"div_vec_t_{tag}"] = npy(fdc.div(ut, flux))
+            same(O.apply_div(O.div_tables(ut, fo, mo, [], lim), fo, nd, e(ut)), out[f"div_vec_t_{tag}"], "div_vec_t_" + tag)
+    if rz:
+        rfp = RFP()
+        out["friction"] = npy(rfp.friction(jacH, pdf))
+        out["diffusion"] = npy(rfp.diffusion(hessG, pdf))
+        same(O.rfp_friction(jo, pdf_t[0], mo), out["friction"], "friction")
+        same(O.rfp_diffusion(ho, pdf_t[0], mo), out["diffusion"], "diffusion")
+        a, b = noise(1.0), noise(1.0)
+        out["mc_a"], out["mc_b"], out["mc"] = npy(a), npy(b), npy(mc_limiter(a, b))
+        same(O.mc_limiter(a, b), out["mc"], "mc_limiter")
+    return out
+
+
 # ---------------------------------------------------------------- case list
 def D(v=0.0):
     return ["dirichlet", v]
@@ -411,6 +466,18 @@ CASES += [
 ]
 
 
+for dt in ("double", "single"):
+    s_ = "f64" if dt == "double" else "f32"
+    CASES += [
+        mk(f"rfp_rz_{s_}", "rfp", 2, [16, 24], dt, [], coord="rz", box=([0.0, -5.0], [5.0, 5.0])),
+        mk(f"rfp_rz_off_axis_{s_}", "rfp", 2, [9, 7], dt, [], coord="rz", box=([0.5, 0.0], [2.0, 1.0])),
+        mk(f"divgen_xy_{s_}", "rfp", 2, [8, 11], dt, [], box=([0.0, 0.0], [1.0, 2.0])),
+        mk(f"divgen_xyz_{s_}", "rfp", 3, [5, 6, 7], dt, []),
+    ]
+CASES += [mk("rfp_rz_32x64_f64", "rfp", 2, [32, 64], "double", [], coord="rz",
+             box=([0.0, -5.0], [5.0, 5.0]))]    # mesh of the reference's tests/test_ops.py::test_fp
+
+
 def main():
     torch.set_num_threads(8)
     only = sys.argv[1] if len(sys.argv) > 1 else None   # name prefix: regenerate just those cases
@@ -421,7 +488,7 @@ def main():
             index.append(case)
             continue
         print(f"[golden] {case['name']}")
-        out = {"ops": run_ops, "solve": run_solve, "spatial": run_spatial}[case["kind"]](case)
+        out = {"ops": run_ops, "solve": run_solve, "spatial": run_spatial, "rfp": run_rfp}[case["kind"]](case)
         path = os.path.join(HERE, case["name"] + ".npz")
         np.savez_compressed(path, **out)
         total += os.path.getsize(path)

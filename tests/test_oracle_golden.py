@@ -157,3 +157,40 @@ def test_reference_algorithm_is_summation_order_sensitive():
     assert b_bicg > 1e-6 and len(set(its_bicg)) > 1
     assert b_pcg > 1e-6
     assert b_cg < 1e-13 and len(set(its_cg)) == 1
+
+
+def _rfp_inputs(case, g):
+    mesh = _mesh(case)
+    t = lambda k: torch.from_numpy(g[k])   # noqa: E731
+    return mesh, t("pdf"), t("H"), t("G"), t("ut")
+
+
+@pytest.mark.parametrize("case", golden_cases("rfp"), ids=lambda c: c["name"])
+def test_oracle_general_div_diffflux_rfp_bit_exact(case):
+    """general Div (Jac advection / vector target / edge in n-D), DiffFlux and the rz Fokker-Planck
+    operators: oracle == reference outputs, bit for bit"""
+    g = golden_load(case["name"])
+    mesh, pdf, H, G, ut = _rfp_inputs(case, g)
+    nd = mesh.dim
+    jo, ho = O.jacobian(H[0], mesh), O.hessian(G[0], mesh)
+    fo = O.diff_flux(ho, pdf[0], mesh)
+    _eq(fo, g["flux"], "diffFlux")
+    for lim in ("none", "upwind"):
+        for edge in (True, False):
+            tag = f"{lim}_{'edge' if edge else 'noedge'}"
+            e = lambda va: (mesh, va) if edge else None   # noqa: E731
+            _eq(O.apply_div(O.div_tables(jo, pdf, mesh, [], lim), pdf, nd, e(jo)), g[f"div_jac_{tag}"], "div_jac_" + tag)
+            _eq(O.apply_div(O.div_tables(1.0, fo, mesh, [], lim), fo, nd, e(1.0)), g[f"div_vec_f_{tag}"], "div_vec_f_" + tag)
+            _eq(O.apply_div(O.div_tables(ut, fo, mesh, [], lim), fo, nd, e(ut)), g[f"div_vec_t_{tag}"], "div_vec_t_" + tag)
+    if case.get("coord") == "rz":
+        _eq(O.rfp_friction(jo, pdf[0], mesh), g["friction"], "friction")
+        _eq(O.rfp_diffusion(ho, pdf[0], mesh), g["diffusion"], "diffusion")
+        _eq(O.mc_limiter(torch.from_numpy(g["mc_a"]), torch.from_numpy(g["mc_b"])), g["mc"], "mc_limiter")
+
+
+def test_edge_div_scalar_target_raises_like_the_reference():
+    mesh = O.OMesh([0.0, 0.0], [1.0, 1.0], [6, 7], "double")
+    v = torch.rand(1, 6, 7, dtype=torch.float64)
+    for adv in (1.5, torch.rand(1, 6, 7, dtype=torch.float64)):
+        with pytest.raises(IndexError):
+            O.apply_div(O.div_tables(adv, v, mesh, [], "none"), v, 2, (mesh, adv))
