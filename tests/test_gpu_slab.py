@@ -54,10 +54,10 @@ def _worker(rank, world, port, name, n, K, dtype, out):
 @pytest.mark.parametrize("shape", [((24, 20, 132), "double"), ((12, 9, 11), "double"), ((16, 12, 136), "single")],
                          ids=["fast_f64", "generic_f64", "fast_f32"])
 @pytest.mark.parametrize("name", list(CASES), ids=list(CASES))
-def test_two_slabs_on_one_gpu(name, shape, tmp_path):
+def test_two_slabs_on_one_gpu(name, shape, tmp_path, world=2):
     (n, dtype), K = shape, 6
     out = str(tmp_path / "x.pt")
-    mp.spawn(_worker, args=(2, _free_port(), name, n, K, dtype, out), nprocs=2, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), name, n, K, dtype, out), nprocs=world, join=True)
     res = torch.load(out)
     mesh = O.OMesh([0, 0, 0], [1, 1, 0.5], list(n), dtype)
     cfg = [{"bc_face": O.FACES[i], "bc_type": t, "bc_val": v} for i, (t, v) in enumerate(CASES[name])]
@@ -145,3 +145,13 @@ def test_library_side_rccl_one_rank(name, tmp_path):
         xo, ro = O.solve_poisson(mesh, cfg, rhs, method="cg", tol=1e-30, max_it=K, coeff=0.7, sign=-1.0)
     err = float(torch.linalg.norm(res[True]["x"] - xo) / torch.linalg.norm(xo))
     assert err < 1e-10, err
+
+
+@pytest.mark.parametrize("bc_path", ["fused", "pair"])
+@pytest.mark.parametrize("name", ["per", "xper", "mix"])
+def test_four_slabs_on_one_gpu(name, bc_path, tmp_path, monkeypatch):
+    """P = 4: two interior ranks that own no global x face (no x BC fill, both neighbours real), the
+    uneven split 26 = 7 + 7 + 6 + 6, a periodic ring longer than its two end ranks"""
+    if bc_path == "pair":
+        monkeypatch.setenv("PYAPES_HIP_BC_UNFUSED", "1")
+    test_two_slabs_on_one_gpu(name, ((26, 20, 132), "double"), tmp_path, world=4)
