@@ -26,6 +26,7 @@
 // The grid is exactly one resident wave of workgroups: chunks = capacity / tiles, so every
 // CU carries the same number of identical work items and nothing queues behind a tail.
 #include "pa_host.h"
+#include "pa_epilogue.h"
 
 #include <stdio.h>
 #include <stdlib.h>
@@ -61,6 +62,7 @@ struct Cg3dArgs {
   T hh[3], h2[3], ih[3];  // h, fl(2h), fl(1/h) per axis
   int kind;             // Euler: PA_OP_DIV_*
   int interior_only;    // A x: zero outside the interior set
+  CgEpi epi;            // phases 0 / 1: the last block finishes the reduction (pa_epilogue.h)
 };
 
 __device__ __forceinline__ int pa_xcd_remap(int b, int nb) {
@@ -519,9 +521,11 @@ __global__ void __launch_bounds__(256) k_cg3d(Cg3dArgs<T> A) {
   if (PHASE == 0) {
     double s[1] = {s0};
     pa_block_reduce_store<1>(s, A.partials);
+    pa_cg_epilogue<T>(A.epi);
   } else if (PHASE == 1 || PHASE == 4) {
     double s[2] = {s0, s1};
     pa_block_reduce_store<2>(s, A.partials);
+    if (PHASE == 1) pa_cg_epilogue<T>(A.epi);
   } else if (PHASE == 5) {
     double s[1] = {s0};
     pa_block_reduce_store<1>(s, A.partials);
@@ -651,13 +655,14 @@ static void fill_common(pa_ctx* c, const DevEq<T>& E, Cg3dArgs<T>& A) {
 }
 
 template <typename T>
-int pa_cg3d_phase_a(pa_ctx* c, const DevEq<T>& E, Vec<T> r, Vec<T> d, T* dnew, double* partials) {
+int pa_cg3d_phase_a(pa_ctx* c, const DevEq<T>& E, Vec<T> r, Vec<T> d, T* dnew, double* partials, const CgEpi& epi) {
   if (!cg3d_covered<T>(c, E, r.p, d.p, dnew)) return 0;
   if (((uintptr_t)r.glo | (uintptr_t)r.ghi | (uintptr_t)d.glo | (uintptr_t)d.ghi) & 15) return 0;
   Cg3dArgs<T> A;
   memset(&A, 0, sizeof(A));
   fill_common<T>(c, E, A);
   A.r = r; A.d = d; A.dnew = dnew; A.partials = partials;
+  A.epi = epi;
   A.reverse = 0;
   int n = launch_any<T, 0>(c, A);
   if (n > 0 && hipGetLastError() != hipSuccess) { pa_set_err(c, "k_cg3d phase A launch failed"); return PA_E_HIP; }
@@ -665,7 +670,7 @@ int pa_cg3d_phase_a(pa_ctx* c, const DevEq<T>& E, Vec<T> r, Vec<T> d, T* dnew, d
 }
 
 template <typename T>
-int pa_cg3d_phase_b(pa_ctx* c, const DevEq<T>& E, Vec<T> d, T* x, T* r, double* partials) {
+int pa_cg3d_phase_b(pa_ctx* c, const DevEq<T>& E, Vec<T> d, T* x, T* r, double* partials, const CgEpi& epi) {
   if (!cg3d_covered<T>(c, E, d.p, x, r)) return 0;
   if (((uintptr_t)d.glo | (uintptr_t)d.ghi) & 15) return 0;
   if (((uintptr_t)c->r_send_lo | (uintptr_t)c->r_send_hi) & 15) return 0;
@@ -673,6 +678,7 @@ int pa_cg3d_phase_b(pa_ctx* c, const DevEq<T>& E, Vec<T> d, T* x, T* r, double* 
   memset(&A, 0, sizeof(A));
   fill_common<T>(c, E, A);
   A.d = d; A.x = x; A.rw = r; A.partials = partials;
+  A.epi = epi;
   A.send_lo = (T*)c->r_send_lo; A.send_hi = (T*)c->r_send_hi;
   A.reverse = 1;
   int n = launch_any<T, 1>(c, A);
@@ -775,7 +781,7 @@ template int pa_tile3d_euler<double>(pa_ctx*, Vec<double>, double*, int, double,
 template int pa_tile3d_jacobi<float>(pa_ctx*, const DevEq<float>&, Vec<float>, const float*, float*, double, double*);
 template int pa_tile3d_jacobi<double>(pa_ctx*, const DevEq<double>&, Vec<double>, const double*, double*, double, double*);
 
-template int pa_cg3d_phase_a<float>(pa_ctx*, const DevEq<float>&, Vec<float>, Vec<float>, float*, double*);
-template int pa_cg3d_phase_a<double>(pa_ctx*, const DevEq<double>&, Vec<double>, Vec<double>, double*, double*);
-template int pa_cg3d_phase_b<float>(pa_ctx*, const DevEq<float>&, Vec<float>, float*, float*, double*);
-template int pa_cg3d_phase_b<double>(pa_ctx*, const DevEq<double>&, Vec<double>, double*, double*, double*);
+template int pa_cg3d_phase_a<float>(pa_ctx*, const DevEq<float>&, Vec<float>, Vec<float>, float*, double*, const CgEpi&);
+template int pa_cg3d_phase_a<double>(pa_ctx*, const DevEq<double>&, Vec<double>, Vec<double>, double*, double*, const CgEpi&);
+template int pa_cg3d_phase_b<float>(pa_ctx*, const DevEq<float>&, Vec<float>, float*, float*, double*, const CgEpi&);
+template int pa_cg3d_phase_b<double>(pa_ctx*, const DevEq<double>&, Vec<double>, double*, double*, double*, const CgEpi&);

@@ -4,6 +4,7 @@
 // Reference seams (paths relative to the reference repo) are cited per function.
 // The 3-D fast-path kernels for the CG phases live in pa_cg3d.hip.
 #include "pa_host.h"
+#include "pa_epilogue.h"
 
 #include <math.h>
 #include <stdlib.h>
@@ -320,7 +321,7 @@ __global__ void __launch_bounds__(PA_BLOCK) k_cg_init(DevGeom G, DevEq<T> E, Vec
 template <typename T>
 __global__ void __launch_bounds__(PA_BLOCK) k_cg_a(DevGeom G, DevEq<T> E, const SolverScalars* __restrict__ sc,
                                                     Vec<T> rv, Vec<T> dv, T* __restrict__ dnew,
-                                                    double* __restrict__ partials) {
+                                                    double* __restrict__ partials, CgEpi epi) {
   if (sc->done) return;
   DirAcc<T> acc{rv, dv, (T)sc->beta};
   double s[1] = {0.0};
@@ -338,6 +339,7 @@ __global__ void __launch_bounds__(PA_BLOCK) k_cg_a(DevGeom G, DevEq<T> E, const 
     dnew[idx] = e;
   }
   pa_block_reduce_store<1>(s, partials);
+  pa_cg_epilogue<T>(epi);
 }
 
 // ---- CG phase B: x += alpha d ; r -= alpha A d ; partial sums r.r and |dx|^2 off-shell
@@ -346,7 +348,7 @@ template <typename T>
 __global__ void __launch_bounds__(PA_BLOCK) k_cg_b(DevGeom G, DevEq<T> E, const SolverScalars* __restrict__ sc,
                                                     Vec<T> dv, T* __restrict__ x, T* __restrict__ r,
                                                     T* __restrict__ send_lo, T* __restrict__ send_hi,
-                                                    double* __restrict__ partials) {
+                                                    double* __restrict__ partials, CgEpi epi) {
   if (sc->done) return;
   FieldAcc<T> acc{dv};
   const T alpha = (T)sc->alpha;
@@ -378,6 +380,7 @@ __global__ void __launch_bounds__(PA_BLOCK) k_cg_b(DevGeom G, DevEq<T> E, const 
     if (send_hi && i == G.n0 - 1) send_hi[j * G.s1 + k] = rn;
   }
   pa_block_reduce_store<2>(s, partials);
+  pa_cg_epilogue<T>(epi);
 }
 
 // ---- boundary shell: sum (x_new - x_old)^2 over shell nodes after the BC fill, and keep
@@ -703,7 +706,7 @@ __device__ __forceinline__ T pa_bc_face_value(const BCArgs<T>& B, const T* __res
 template <typename T>
 __global__ void __launch_bounds__(PA_BLOCK) k_bc_pair(DevGeom G, T* __restrict__ x, BCPairArgs<T> P,
                                                        const int* __restrict__ done, T* __restrict__ shell_old,
-                                                       double* __restrict__ partials, int mode) {
+                                                       double* __restrict__ partials, int mode, CgEpi epi) {
   if (done && *done) return;
   const int a = P.axis;
   const int64_t nu = (a == 0) ? G.n1 : G.n0;
@@ -768,7 +771,10 @@ __global__ void __launch_bounds__(PA_BLOCK) k_bc_pair(DevGeom G, T* __restrict__
       }
     }
   }
-  if (mode == 1) pa_block_reduce_store<1>(s, partials);
+  if (mode == 1) {
+    pa_block_reduce_store<1>(s, partials);
+    pa_cg_epilogue<T>(epi);
+  }
 }
 
 // ---- reductions of per-block partials + scalar logic ------------------------------------
@@ -802,12 +808,7 @@ __global__ void __launch_bounds__(PA_BLOCK) k_cg_post_a(SolverScalars* sc, const
     double v = pa_reduce_partials(partials, nblk, 1, 0, sm);
     if (threadIdx.x == 0) sums[0] = v;
   }
-  if (stage != 0 && threadIdx.x == 0) {
-    T dAd = (T)sums[0];
-    T rr = (T)sc->rr;
-    sc->dAd = (double)dAd;
-    sc->alpha = pa_nan_to_num<T>(rr / dAd);
-  }
+  if (stage != 0 && threadIdx.x == 0) pa_logic_a<T>(sc, sums);
 }
 
 template <typename T>
@@ -825,22 +826,7 @@ __global__ void __launch_bounds__(PA_BLOCK) k_cg_post_b(SolverScalars* sc, const
       sums[2] = dx2 + sh;
     }
   }
-  if (stage != 0 && threadIdx.x == 0) {
-    T rr_new = (T)sums[1];
-    T tol = (T)sqrt(sums[2]);
-    sc->tol = (double)tol;
-    if (isnan(tol) || isinf(tol)) {  // linalg.py:334-336 raises before beta / itr
-      sc->err = 1;
-      sc->done = 1;
-      return;
-    }
-    T rr_old = (T)sc->rr;
-    sc->rr_old = (double)rr_old;
-    sc->beta = (double)(rr_new / rr_old);
-    sc->rr = (double)rr_new;
-    sc->itr += 1;
-    if (sc->itr > sc->max_it || !(sc->tol > sc->tolerance)) sc->done = 1;
-  }
+  if (stage != 0 && threadIdx.x == 0) pa_logic_b<T>(sc, sums);
 }
 
 // overlap mode: the part of post_b the next phase A needs (sum r.r -> beta) ...
@@ -1425,6 +1411,7 @@ int pa_ctx_create(int device, void* hip_stream, pa_ctx** out) {
   if (const char* fp = getenv("PYAPES_HIP_FASTPATH")) c->fastpath = atoi(fp) != 0;
   if (hipMalloc((void**)&c->sc, sizeof(SolverScalars)) != hipSuccess ||
       hipMalloc((void**)&c->sums, PA_NSUM * sizeof(double)) != hipSuccess ||
+      hipMalloc((void**)&c->tickets, 4 * sizeof(unsigned int)) != hipSuccess ||
       hipHostMalloc((void**)&c->h_sc, sizeof(SolverScalars)) != hipSuccess ||
       hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess) {
     pa_set_err(nullptr, "pa_ctx_create: allocation failed");
@@ -1433,6 +1420,8 @@ int pa_ctx_create(int device, void* hip_stream, pa_ctx** out) {
   }
   (void)hipMemsetAsync(c->sc, 0, sizeof(SolverScalars), c->stream);
   (void)hipMemsetAsync(c->sums, 0, PA_NSUM * sizeof(double), c->stream);
+  (void)hipMemsetAsync(c->tickets, 0, 4 * sizeof(unsigned int), c->stream);
+  if (const char* ep = getenv("PYAPES_HIP_EPILOGUE")) c->epilogue = atoi(ep) != 0;
   *out = c;
   return PA_OK;
 }
@@ -1445,6 +1434,7 @@ int pa_ctx_destroy(pa_ctx* c) {
     if (c->scr[q]) (void)hipFree(c->scr[q]);
   if (c->sc) (void)hipFree(c->sc);
   if (c->sums) (void)hipFree(c->sums);
+  if (c->tickets) (void)hipFree(c->tickets);
   if (c->h_sc) (void)hipHostFree(c->h_sc);
   if (c->ev0) (void)hipEventDestroy(c->ev0);
   if (c->ev1) (void)hipEventDestroy(c->ev1);
@@ -1947,6 +1937,27 @@ static int bc_shell_fused(pa_ctx* c, T* x, double* part2, int with_delta, bool g
   return PA_OK;
 }
 
+// epilogue descriptors (pa_epilogue.h); kind 0 = "keep the separate k_cg_post_* launch"
+static CgEpi epi_none() {
+  CgEpi e;
+  memset(&e, 0, sizeof(e));
+  return e;
+}
+static CgEpi epi_a(pa_ctx* c, const double* part, int logic) {
+  CgEpi e = epi_none();
+  if (!c->epilogue || c->profile) return e;
+  e.kind = 1; e.logic = logic; e.ticket = c->tickets + 0; e.sc = c->sc; e.sums = pa_sums(c);
+  e.part = part; e.npart = -1;
+  return e;
+}
+static CgEpi epi_b(pa_ctx* c, int slot, const double* part, int npart, const double* part_shell, int nshell, int logic) {
+  CgEpi e = epi_none();
+  if (!c->epilogue || c->profile) return e;
+  e.kind = 2; e.logic = logic; e.ticket = c->tickets + slot; e.sc = c->sc; e.sums = pa_sums(c);
+  e.part = part; e.npart = npart; e.part_shell = part_shell; e.nshell = nshell;
+  return e;
+}
+
 // BC list in factory order with both faces of every mesh axis present (what the BC factories emit),
 // >= 5 nodes per axis: the per-axis pair kernels apply
 static bool bc_pairable(const pa_ctx* c) {
@@ -2005,13 +2016,24 @@ static void bc_face_args(pa_ctx* c, int f, BCArgs<T>& B, bool guarded) {
 // mode 0: fill only; 1: fill + shell delta (partials -> part2, rows returned in *nsh) + save; 2: fill + save;
 // 3: save only (slab: the driver has filled the BCs itself)
 template <typename T>
-static int bc_pair_apply(pa_ctx* c, T* x, double* part2, int mode, bool guarded, int* nsh) {
+static int bc_pair_apply(pa_ctx* c, T* x, double* part2, int mode, bool guarded, int* nsh,
+                         const double* partB = nullptr, int nB = 0, int tail_logic = -1) {
   const DevGeom& G = c->G;
   const int64_t sz[3] = {G.n1 * G.n2, G.n0 * G.n2, G.n0 * G.n1};
   int64_t start[6], total = 0;
   for (int f = 0; f < 6; ++f) { start[f] = total; total += G.act[f >> 1] ? sz[f >> 1] : 0; }
   T* shell = (T*)c->scr[SCR_SHELL];
   int rows = 0;
+  int last_axis = -1;  // the launch whose last block finishes the B-chain reduction (tail_logic >= 0)
+  if (tail_logic >= 0 && mode == 1)
+    for (int a = 0; a < 3; ++a) {
+      if (!G.act[a]) continue;
+      BCArgs<T> lo, hi;
+      bc_face_args<T>(c, 2 * a, lo, guarded);
+      bc_face_args<T>(c, 2 * a + 1, hi, guarded);
+      if (lo.type || hi.type) last_axis = a;
+    }
+  c->b_tail_done = 0;
   for (int a = 0; a < 3; ++a) {
     if (!G.act[a]) continue;
     BCPairArgs<T> P;
@@ -2027,9 +2049,14 @@ static int bc_pair_apply(pa_ctx* c, T* x, double* part2, int mode, bool guarded,
     P.pos_lo = start[2 * a];
     P.pos_hi = start[2 * a + 1];
     const int nb = pa_grid_blocks(sz[a]);
+    CgEpi epi = epi_none();
+    if (a == last_axis) {
+      epi = epi_b(c, 2, partB, nB, part2, rows + nb, tail_logic);
+      if (epi.kind) c->b_tail_done = 1;
+    }
     hipLaunchKernelGGL(k_bc_pair<T>, dim3(nb), dim3(PA_BLOCK), 0, pa_ls(c), G, x, P,
                        guarded ? pa_done_flag(c) : (const int*)nullptr, shell, part2 ? part2 + rows : nullptr,
-                       mode);
+                       mode, epi);
     if (mode == 1) rows += nb;
   }
   if (nsh) *nsh = rows;
@@ -2217,17 +2244,19 @@ int pa_cg_phase_a_t(pa_ctx* c, int stage_post) {
                        (const T*)c->d_ghi[c->cur], (T*)c->d_glo[c->cur ^ 1], (T*)c->d_ghi[c->cur ^ 1]);
   }
   if (c->profile) (void)hipEventRecord(c->pev[0], c->stream);
-  int rc = pa_cg3d_phase_a<T>(c, E, rv, dv, dnew, part);
+  const CgEpi epa = epi_a(c, part, stage_post == 2);
+  int rc = pa_cg3d_phase_a<T>(c, E, rv, dv, dnew, part, epa);
   if (rc < 0) return rc;
   int used_blocks = rc;
   if (rc == 0) {
-    hipLaunchKernelGGL(k_cg_a<T>, dim3(nblk), dim3(PA_BLOCK), 0, c->stream, G, E, c->sc, rv, dv, dnew, part);
+    hipLaunchKernelGGL(k_cg_a<T>, dim3(nblk), dim3(PA_BLOCK), 0, c->stream, G, E, c->sc, rv, dv, dnew, part, epa);
     used_blocks = nblk;
   }
   if (c->profile) pa_profile_stop(c, 0);
   c->cur ^= 1;
-  hipLaunchKernelGGL(k_cg_post_a<T>, dim3(1), dim3(PA_BLOCK), 0, c->stream, c->sc, part, used_blocks, pa_sums(c),
-                     stage_post);
+  if (!epa.kind)
+    hipLaunchKernelGGL(k_cg_post_a<T>, dim3(1), dim3(PA_BLOCK), 0, c->stream, c->sc, part, used_blocks, pa_sums(c),
+                       stage_post);
   PA_HIP(c, hipGetLastError());
   return PA_OK;
 }
@@ -2246,12 +2275,16 @@ int pa_cg_phase_b_t(pa_ctx* c, int stage_post) {
   Vec<T> dv = cg_vec<T>(c, d, 1);
   if (int rcj = pa_join_side(c)) return rcj;  // x and the done flag of the previous iteration are final
   if (c->profile) (void)hipEventRecord(c->pev[2], c->stream);
-  int rc = pa_cg3d_phase_b<T>(c, E, dv, x, r, part);
+  // with frozen (all-dirichlet) BCs nothing follows phase B: its last block finishes the iteration
+  CgEpi epb = epi_none();
+  if (c->bc_static && !(c->overlap && stage_post == 2)) epb = epi_b(c, 1, part, -1, nullptr, 0, stage_post == 2);
+  c->b_tail_done = epb.kind ? 1 : 0;
+  int rc = pa_cg3d_phase_b<T>(c, E, dv, x, r, part, epb);
   if (rc < 0) return rc;
   int used_blocks = rc;
   if (rc == 0) {
     hipLaunchKernelGGL(k_cg_b<T>, dim3(nblk), dim3(PA_BLOCK), 0, c->stream, G, E, c->sc, dv, x, r,
-                       (T*)c->r_send_lo, (T*)c->r_send_hi, part);
+                       (T*)c->r_send_lo, (T*)c->r_send_hi, part, epb);
     used_blocks = nblk;
   }
   if (c->profile) pa_profile_stop(c, 1);
@@ -2297,7 +2330,7 @@ int pa_cg_phase_b_t(pa_ctx* c, int stage_post) {
     if (c->bc_fused) {
       if ((rc = bc_shell_fused<T>(c, x, part2, 1, true, &nsh, false))) return rc;
     } else if (c->bc_pair) {
-      if ((rc = bc_pair_apply<T>(c, x, part2, 1, true, &nsh))) return rc;
+      if ((rc = bc_pair_apply<T>(c, x, part2, 1, true, &nsh, part, used_blocks, stage_post == 2))) return rc;
     } else {
       if ((rc = bc_apply_t<T>(c, x, true))) return rc;
       nsh = shell_blocks(c);
@@ -2305,8 +2338,9 @@ int pa_cg_phase_b_t(pa_ctx* c, int stage_post) {
                          (T*)c->scr[SCR_SHELL], part2, 1);
     }
   }
-  hipLaunchKernelGGL(k_cg_post_b<T>, dim3(1), dim3(PA_BLOCK), 0, c->stream, c->sc, part, used_blocks, part2, nsh,
-                     pa_sums(c), stage_post);
+  if (!c->b_tail_done)
+    hipLaunchKernelGGL(k_cg_post_b<T>, dim3(1), dim3(PA_BLOCK), 0, c->stream, c->sc, part, used_blocks, part2, nsh,
+                       pa_sums(c), stage_post);
   PA_HIP(c, hipGetLastError());
   return PA_OK;
 }
@@ -2324,7 +2358,7 @@ int pa_cg_bc_t(pa_ctx* c) {
     if (c->bc_fused) {
       if ((rc = bc_shell_fused<T>(c, x, part2, 1, true, &nsh, false))) return rc;
     } else if (c->bc_pair) {
-      if ((rc = bc_pair_apply<T>(c, x, part2, 1, true, &nsh))) return rc;
+      if ((rc = bc_pair_apply<T>(c, x, part2, 1, true, &nsh, part, c->b_blocks, 0))) return rc;
     } else {
       if ((rc = bc_apply_t<T>(c, x, true))) return rc;
       nsh = shell_blocks(c);
@@ -2332,8 +2366,9 @@ int pa_cg_bc_t(pa_ctx* c) {
                          (T*)c->scr[SCR_SHELL], part2, 1);
     }
   }
-  hipLaunchKernelGGL(k_cg_post_b<T>, dim3(1), dim3(PA_BLOCK), 0, c->stream, c->sc, part, c->b_blocks, part2, nsh,
-                     pa_sums(c), 0);
+  if (!c->b_tail_done)   // (frozen BCs: phase B's own epilogue has reduced already)
+    hipLaunchKernelGGL(k_cg_post_b<T>, dim3(1), dim3(PA_BLOCK), 0, c->stream, c->sc, part, c->b_blocks, part2, nsh,
+                       pa_sums(c), 0);
   PA_HIP(c, hipGetLastError());
   return PA_OK;
 }

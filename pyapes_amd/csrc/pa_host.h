@@ -19,6 +19,19 @@ struct SolverScalars {
   int done, err, finished_early;
 };
 
+// last-block epilogue of a CG kernel (pa_epilogue.h)
+struct CgEpi {
+  int kind;              // 0 none; 1 tail of phase A: sums[0] (+ alpha); 2 tail of phase B / BC chain: sums[1..2] (+ beta, stop)
+  int logic;             // run the scalar logic too (single GPU); 0 on a slab (the all-reduce comes first)
+  unsigned int* ticket;  // zero before the launch; the last block resets it
+  SolverScalars* sc;
+  double* sums;
+  const double* part;    // kind 1: d.Ad partials (1 column); kind 2: phase-B partials (2 columns)
+  int npart;             // rows of `part`; < 0: one per block of THIS launch
+  const double* part_shell;  // kind 2: boundary-shell partials of the stop test (1 column) or null
+  int nshell;
+};
+
 struct HostBC {
   int type = PA_BC_NONE;
   double value = 0.0;
@@ -88,6 +101,10 @@ struct pa_ctx {
   int64_t prof_n[2] = {0, 0};
   // 3-D fast path switch (PYAPES_HIP_FASTPATH=0 disables; tests compare both)
   int fastpath = 1;
+  // last-block epilogues (pa_epilogue.h): tickets[0] phase A, [1] phase B, [2] BC pair chain
+  unsigned int* tickets = nullptr;
+  int epilogue = 0;              // opt-in (PYAPES_HIP_EPILOGUE=1); default: separate k_cg_post_* launches
+  int b_tail_done = 0;           // the B-chain reduction of this iteration already ran in an epilogue
   // RCCL communicator owned by the library (pa_comm_*): slab iterations without host work
   void* comm = nullptr;          // ncclComm_t
   int comm_rank = 0, comm_n = 0;
@@ -121,9 +138,9 @@ Vec<T> pa_vec_self(const pa_ctx* c, const T* p);
 // kernel ran, 0 when the configuration is not covered (caller falls back to the generic
 // kernel, which is still HIP), < 0 on error.
 template <typename T>
-int pa_cg3d_phase_a(pa_ctx* c, const DevEq<T>& E, Vec<T> r, Vec<T> d, T* dnew, double* partials);
+int pa_cg3d_phase_a(pa_ctx* c, const DevEq<T>& E, Vec<T> r, Vec<T> d, T* dnew, double* partials, const CgEpi& epi);
 template <typename T>
-int pa_cg3d_phase_b(pa_ctx* c, const DevEq<T>& E, Vec<T> d, T* x, T* r, double* partials);
+int pa_cg3d_phase_b(pa_ctx* c, const DevEq<T>& E, Vec<T> d, T* x, T* r, double* partials, const CgEpi& epi);
 
 // single-field tiled kernels (pa_cg3d.hip); same return convention as the CG phases
 template <typename T>
