@@ -204,3 +204,34 @@ def test_mesh_masks_and_geometry():
     for i, box in enumerate([Box[0:2], Box[0:2, 0:2], Box[0:2, 0:2, 0:2]]):
         assert box.type == "box" and box.dim == i + 1 and box.size == pytest.approx(2 ** (i + 1))
         assert box.lower == [0] * (i + 1) and box.upper == [2] * (i + 1)
+
+
+def test_install_as_pyapes_aliases_are_the_same_modules():
+    """unmodified pyapes imports (current layout and the notebooks' pyapes.core.* layout) resolve to
+    this package's own module objects"""
+    import subprocess
+    import sys
+    code = r"""
+import sys
+sys.path.insert(0, %r)
+import pyapes_amd
+pyapes_amd.install_as_pyapes()
+from pyapes.geometry import Box, Cylinder
+from pyapes.mesh import Mesh
+from pyapes.solver.fdm import FDM
+from pyapes.solver.ops import Solver
+from pyapes.variables import Field
+from pyapes.variables.bcs import CylinderBoundary, homogeneous_bcs
+from pyapes.core.solver.fdm import FDM as FDM2
+from pyapes.core.variables.bcs import homogeneous_bcs as hb2
+from pyapes.testing.poisson import poisson_bcs
+import pyapes_amd.solver.fdm as real
+assert FDM is real.FDM and FDM2 is real.FDM and hb2 is homogeneous_bcs
+assert sys.modules["pyapes.solver.fdm"] is real
+m = Mesh(Box[0:1, 0:1], None, [5, 5])            # host logic works without a GPU
+f = Field("p", 1, m, {"domain": poisson_bcs(2), "obstacle": None})
+assert f().shape == (1, 5, 5)
+print("ok")
+""" % ROOT
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and out.stdout.strip().endswith("ok"), out.stderr[-2000:]
