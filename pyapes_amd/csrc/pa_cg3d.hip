@@ -272,6 +272,19 @@ __global__ void __launch_bounds__(256) k_cg3d(Cg3dArgs<T> A) {
   double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
   const T sgn = A.sign, cf = A.coeff;
   const int hasc = A.has_coeff;
+  // the stencil works on whole V rows (packed fp32 multiplies / adds; the explicit Euler step moves only
+  // 8 B / cell and is VALU-bound when written per component): per-component k-axis coefficients
+  constexpr bool VROW = (PHASE == 2 || PHASE == 3 || PHASE == 4);   // CG / BiCGSTAB phases: per component (A/B: -9 % on fp32 CG as V rows)
+  V cPkV, cCkV, cMkV;
+  if (VROW) {
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) {
+      T p = A.lap.inv[2], c0 = A.lap.m2inv[2], mq = A.lap.inv[2];
+      if (colLo >> v & 1) { p = A.lap.c23[2]; c0 = -A.lap.c23[2]; mq = (T)0; }
+      if (colHi >> v & 1) { p = (T)0; c0 = -A.lap.c23[2]; mq = A.lap.c23[2]; }
+      cPkV[v] = p; cCkV[v] = c0; cMkV[v] = mq;
+    }
+  }
 
   for (int m = 0; m < CI; ++m) {
     const int buf = m & 1;
@@ -332,97 +345,176 @@ __global__ void __launch_bounds__(256) k_cg3d(Cg3dArgs<T> A) {
       if (jj < RJ - 1) dn = ec[jj + 1]; else dn = *reinterpret_cast<const V*>(&tile[buf][R + 1][VEC + lane * VEC]);
       const T left = tile[buf][R][VEC + lane * VEC - 1];
       const T right = tile[buf][R][VEC + lane * VEC + VEC];
-#pragma unroll
-      for (int v = 0; v < VEC; ++v) {
-        const T xc = ec[jj][v];
-        const T xpi = rev ? ea[jj][v] : eb[jj][v];
-        const T xmi = rev ? eb[jj][v] : ea[jj][v];
-        T s = cPi * xpi;
-        T mm = cCi * xc;
-        s = s + mm;
-        mm = cMi * xmi;
-        s = s + mm;
-        T ax = act0 ? s : (T)0;
-        s = cPj * dn[v];
-        mm = cCj * xc;
-        s = s + mm;
-        mm = cMj * up[v];
-        s = s + mm;
-        ax = ax + s;
-        T cPk = A.lap.inv[2], cCk = A.lap.m2inv[2], cMk = A.lap.inv[2];
-        if (colLo >> v & 1) { cPk = A.lap.c23[2]; cCk = -A.lap.c23[2]; cMk = (T)0; }
-        if (colHi >> v & 1) { cPk = (T)0; cCk = -A.lap.c23[2]; cMk = A.lap.c23[2]; }
-        const T xpk = (v < VEC - 1) ? ec[jj][v + 1 < VEC ? v + 1 : v] : right;
-        const T xmk = (v > 0) ? ec[jj][v > 0 ? v - 1 : 0] : left;
-        s = cPk * xpk;
-        mm = cCk * xc;
-        s = s + mm;
-        mm = cMk * xmk;
-        s = s + mm;
-        ax = ax + s;
-        if (hasc) ax = ax * (CF ? cv[jj][v] : cf);
-        ax = ax * sgn;
-        if (PHASE == 3) {
-          // explicit Euler:  phi + dt (nu lap - adv)   (k_euler, pa_core.hip; ax = plain Laplacian)
-          const T uc = A.aux ? xv[jj][v] : A.u;
-          const T xp3[3] = {xpi, dn[v], xpk}, xm3[3] = {xmi, up[v], xmk};
-          const bool plo[3] = {iPLo, (bool)(rowPLo >> jj & 1), (bool)(colPLo >> v & 1)};
-          const bool phi_[3] = {iPHi, (bool)(rowPHi >> jj & 1), (bool)(colPHi >> v & 1)};
-          T adv = (T)0;
-#pragma unroll
-          for (int a = 0; a < 3; ++a) {
-            if (a == 0 && !act0) continue;
-            T t;
-            if (A.kind == 4) {  // upwind as the reference's test states it
-              const T upl = uc > (T)0 ? uc : (T)0, umi = uc < (T)0 ? uc : (T)0;
-              T bwd = xc - xm3[a];
-              T fwd = xp3[a] - xc;
-              t = upl * bwd;
-              T m2 = umi * fwd;
+      if constexpr (VROW) {
+        // A x of this row, one V at a time: the same operations in the same order as a per-component loop
+        const V xc = ec[jj];
+        const V xpi = rev ? ea[jj] : eb[jj];
+        const V xmi = rev ? eb[jj] : ea[jj];
+        V xpk, xmk;
+  #pragma unroll
+        for (int v = 0; v < VEC; ++v) {
+          xpk[v] = (v < VEC - 1) ? xc[v + 1 < VEC ? v + 1 : v] : right;
+          xmk[v] = (v > 0) ? xc[v > 0 ? v - 1 : 0] : left;
+        }
+        V axv;
+        {
+          V s = cPi * xpi;
+          V mm = cCi * xc;
+          s = s + mm;
+          mm = cMi * xmi;
+          s = s + mm;
+          if (act0) axv = s; else axv = (V)(T)0;
+          s = cPj * dn;
+          mm = cCj * xc;
+          s = s + mm;
+          mm = cMj * up;
+          s = s + mm;
+          axv = axv + s;
+          s = cPkV * xpk;
+          mm = cCkV * xc;
+          s = s + mm;
+          mm = cMkV * xmk;
+          s = s + mm;
+          axv = axv + s;
+          if (hasc) {
+            if (CF) axv = axv * cv[jj]; else axv = axv * cf;
+          }
+          axv = axv * sgn;
+        }
+        if constexpr (PHASE == 3) {
+          const V ax = axv;
+          V uc;
+          if (A.aux) uc = xv[jj]; else uc = (V)A.u;
+          const V xp3[3] = {xpi, dn, xpk}, xm3[3] = {xmi, up, xmk};
+          V adv = (V)(T)0;
+          if (A.kind == 4) {  // upwind as the reference's test states it
+            V upl, umi;
+  #pragma unroll
+            for (int v = 0; v < VEC; ++v) {
+              upl[v] = uc[v] > (T)0 ? uc[v] : (T)0;
+              umi[v] = uc[v] < (T)0 ? uc[v] : (T)0;
+            }
+  #pragma unroll
+            for (int a = 0; a < 3; ++a) {
+              if (a == 0 && !act0) continue;
+              V bwd = xc - xm3[a];
+              V fwd = xp3[a] - xc;
+              V t = upl * bwd;
+              V m2 = umi * fwd;
               t = t + m2;
               t = t * A.ih[a];
-            } else if (A.kind == 3) {  // literal reference upwind
-              const T cP = (T)2 * (uc < (T)0 ? uc : (T)0);
-              const T cC = (T)0 * ((T)2 * uc);
-              const T cM = (T)2 * (uc > (T)0 ? uc : (T)0);
-              t = cP * xp3[a];
-              T m2 = cC * xc;
+              adv = adv + t;
+            }
+          } else if (A.kind == 3) {  // literal reference upwind
+            V cP, cC, cM;
+  #pragma unroll
+            for (int v = 0; v < VEC; ++v) {
+              cP[v] = (T)2 * (uc[v] < (T)0 ? uc[v] : (T)0);
+              cC[v] = (T)0 * ((T)2 * uc[v]);
+              cM[v] = (T)2 * (uc[v] > (T)0 ? uc[v] : (T)0);
+            }
+  #pragma unroll
+            for (int a = 0; a < 3; ++a) {
+              if (a == 0 && !act0) continue;
+              V t = cP * xp3[a];
+              V m2 = cC * xc;
               t = t + m2;
               m2 = cM * xm3[a];
               t = t + m2;
-            } else {  // central, scalar u
-              T cP = uc, cC = (T)0 * uc, cM = -uc;
-              if (plo[a]) cM = (T)0;
-              if (phi_[a]) cP = (T)0;
+              adv = adv + t;
+            }
+          } else {  // central, scalar u
+  #pragma unroll
+            for (int a = 0; a < 3; ++a) {
+              if (a == 0 && !act0) continue;
+              V cP = uc, cC = (T)0 * uc, cM = -uc;
+  #pragma unroll
+              for (int v = 0; v < VEC; ++v) {
+                const bool lo = a == 0 ? iPLo : (a == 1 ? (bool)(rowPLo >> jj & 1) : (bool)(colPLo >> v & 1));
+                const bool hi = a == 0 ? iPHi : (a == 1 ? (bool)(rowPHi >> jj & 1) : (bool)(colPHi >> v & 1));
+                if (lo) cM[v] = (T)0;
+                if (hi) cP[v] = (T)0;
+              }
               cP = cP / A.h2[a];
               cC = cC / A.h2[a];
               cM = cM / A.h2[a];
-              t = cP * xp3[a];
-              T m2 = cC * xc;
+              V t = cP * xp3[a];
+              V m2 = cC * xc;
               t = t + m2;
               m2 = cM * xm3[a];
               t = t + m2;
+              adv = adv + t;
             }
-            adv = adv + t;
           }
-          T q = A.p0 * ax;
+          V q = A.p0 * ax;
           q = q - adv;
           q = A.p1 * q;
-          ax = xc + q;
+          res[jj] = xc + q;
+          continue;
         }
-        if (PHASE == 4) {
-          // Jacobi:  x + omega (b - A x) / diag(A)   (k_jacobi, pa_core.hip)
-          T dg = act0 ? cCi : (T)0;
-          dg = dg + cCj;
-          dg = dg + cCk;
-          if (hasc) dg = dg * (CF ? cv[jj][v] : cf);
-          dg = dg * sgn;
-          T q = xv[jj][v] - ax;
-          q = q / dg;
-          q = A.p0 * q;
-          ax = xc + q;
+  #pragma unroll
+        for (int v = 0; v < VEC; ++v) {
+          T ax = axv[v];
+          T cCk = cCkV[v];
+          if (PHASE == 4) {
+            // Jacobi:  x + omega (b - A x) / diag(A)   (k_jacobi, pa_core.hip)
+            T dg = act0 ? cCi : (T)0;
+            dg = dg + cCj;
+            dg = dg + cCk;
+            if (hasc) dg = dg * (CF ? cv[jj][v] : cf);
+            dg = dg * sgn;
+            T q = xv[jj][v] - ax;
+            q = q / dg;
+            q = A.p0 * q;
+            ax = xc[v] + q;
+          }
+          res[jj][v] = ax;
         }
-        res[jj][v] = ax;
+      } else {
+  #pragma unroll
+        for (int v = 0; v < VEC; ++v) {
+          const T xc = ec[jj][v];
+          const T xpi = rev ? ea[jj][v] : eb[jj][v];
+          const T xmi = rev ? eb[jj][v] : ea[jj][v];
+          T s = cPi * xpi;
+          T mm = cCi * xc;
+          s = s + mm;
+          mm = cMi * xmi;
+          s = s + mm;
+          T ax = act0 ? s : (T)0;
+          s = cPj * dn[v];
+          mm = cCj * xc;
+          s = s + mm;
+          mm = cMj * up[v];
+          s = s + mm;
+          ax = ax + s;
+          T cPk = A.lap.inv[2], cCk = A.lap.m2inv[2], cMk = A.lap.inv[2];
+          if (colLo >> v & 1) { cPk = A.lap.c23[2]; cCk = -A.lap.c23[2]; cMk = (T)0; }
+          if (colHi >> v & 1) { cPk = (T)0; cCk = -A.lap.c23[2]; cMk = A.lap.c23[2]; }
+          const T xpk = (v < VEC - 1) ? ec[jj][v + 1 < VEC ? v + 1 : v] : right;
+          const T xmk = (v > 0) ? ec[jj][v > 0 ? v - 1 : 0] : left;
+          s = cPk * xpk;
+          mm = cCk * xc;
+          s = s + mm;
+          mm = cMk * xmk;
+          s = s + mm;
+          ax = ax + s;
+          if (hasc) ax = ax * (CF ? cv[jj][v] : cf);
+          ax = ax * sgn;
+          if (PHASE == 4) {
+            // Jacobi:  x + omega (b - A x) / diag(A)   (k_jacobi, pa_core.hip)
+            T dg = act0 ? cCi : (T)0;
+            dg = dg + cCj;
+            dg = dg + cCk;
+            if (hasc) dg = dg * (CF ? cv[jj][v] : cf);
+            dg = dg * sgn;
+            T q = xv[jj][v] - ax;
+            q = q / dg;
+            q = A.p0 * q;
+            ax = xc + q;
+          }
+          res[jj][v] = ax;
+        }
       }
     }
 

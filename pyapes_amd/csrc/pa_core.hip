@@ -1430,6 +1430,7 @@ int pa_ctx_destroy(pa_ctx* c) {
   if (!c) return PA_OK;
   (void)hipSetDevice(c->device);
   (void)hipStreamSynchronize(c->stream);
+  if (c->comm) (void)pa_comm_destroy(c);
   for (int q = 0; q < PA_NSCRATCH; ++q)
     if (c->scr[q]) (void)hipFree(c->scr[q]);
   if (c->sc) (void)hipFree(c->sc);
