@@ -76,7 +76,10 @@ __device__ __forceinline__ int64_t pa_wrapmod(int64_t v, int64_t n) {
   return v < 0 ? v + n : v;
 }
 
-template <typename T, int RJ, int PHASE, bool CF = false>
+// KIND: the Div scheme of the explicit Euler step (PHASE 3) as a compile-time constant -- with all three
+// schemes in one body the uniform operands no longer fit the scalar registers and get spilled into
+// vector lanes (v_readlane / v_writelane were a third of the VALU instructions of that kernel)
+template <typename T, int RJ, int PHASE, bool CF = false, int KIND = 0>
 __global__ void __launch_bounds__(256) k_cg3d(Cg3dArgs<T> A) {
   typedef typename VecOf<T>::type V;
   constexpr int VEC = VecOf<T>::N;
@@ -387,7 +390,7 @@ __global__ void __launch_bounds__(256) k_cg3d(Cg3dArgs<T> A) {
           if (A.aux) uc = xv[jj]; else uc = (V)A.u;
           const V xp3[3] = {xpi, dn, xpk}, xm3[3] = {xmi, up, xmk};
           V adv = (V)(T)0;
-          if (A.kind == 4) {  // upwind as the reference's test states it
+          if (KIND == 4) {  // upwind as the reference's test states it
             V upl, umi;
   #pragma unroll
             for (int v = 0; v < VEC; ++v) {
@@ -405,7 +408,7 @@ __global__ void __launch_bounds__(256) k_cg3d(Cg3dArgs<T> A) {
               t = t * A.ih[a];
               adv = adv + t;
             }
-          } else if (A.kind == 3) {  // literal reference upwind
+          } else if (KIND == 3) {  // literal reference upwind
             V cP, cC, cM;
   #pragma unroll
             for (int v = 0; v < VEC; ++v) {
@@ -653,21 +656,21 @@ static int cus_of(pa_ctx* c) {
   return cus;
 }
 
-template <typename T, int RJ, int PHASE, bool CF>
+template <typename T, int RJ, int PHASE, bool CF, int KIND = 0>
 static int blocks_per_cu() {
   static int cached = 0;
   if (!cached) {
     const char* e = getenv(PHASE == 0 ? "PYAPES_HIP_BPC_A" : (PHASE == 1 ? "PYAPES_HIP_BPC_B" : "PYAPES_HIP_BPC_X"));
     int n = e ? atoi(e) : 0;
     if (n <= 0) {
-      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_cg3d<T, RJ, PHASE, CF>, 256, 0) != hipSuccess || n <= 0) n = 2;
+      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_cg3d<T, RJ, PHASE, CF, KIND>, 256, 0) != hipSuccess || n <= 0) n = 2;
     }
     cached = n;
   }
   return cached;
 }
 
-template <typename T, int RJ, int PHASE, bool CF = false>
+template <typename T, int RJ, int PHASE, bool CF = false, int KIND = 0>
 static int launch_cg3d(pa_ctx* c, Cg3dArgs<T>& A) {
   constexpr int VEC = VecOf<T>::N;
   constexpr int TJ = 4 * RJ, TK = 64 * VEC;
@@ -675,7 +678,7 @@ static int launch_cg3d(pa_ctx* c, Cg3dArgs<T>& A) {
   A.tiles_j = (int)((G.n1 + TJ - 1) / TJ);
   A.tiles_k = (int)((G.n2 + TK - 1) / TK);
   const int tiles = A.tiles_j * A.tiles_k;
-  const int capacity = cus_of(c) * blocks_per_cu<T, RJ, PHASE, CF>();
+  const int capacity = cus_of(c) * blocks_per_cu<T, RJ, PHASE, CF, KIND>();
   int chunks = capacity / tiles;
   if (chunks < 1) chunks = 1;
   if (chunks > G.n0) chunks = (int)G.n0;
@@ -688,9 +691,9 @@ static int launch_cg3d(pa_ctx* c, Cg3dArgs<T>& A) {
     --dbg;
     fprintf(stderr, "[pyapes_hip] k_cg3d phase %c: tiles %dx%d chunks %d (CI ~%lld) blocks %d, %d blocks/CU x %d CUs\n",
             (char)('A' + PHASE), A.tiles_j, A.tiles_k, chunks, (long long)(G.n0 / chunks), nblk,
-            blocks_per_cu<T, RJ, PHASE, CF>(), cus_of(c));
+            blocks_per_cu<T, RJ, PHASE, CF, KIND>(), cus_of(c));
   }
-  hipLaunchKernelGGL((k_cg3d<T, RJ, PHASE, CF>), dim3(nblk), dim3(256), 0, c->stream, A);
+  hipLaunchKernelGGL((k_cg3d<T, RJ, PHASE, CF, KIND>), dim3(nblk), dim3(256), 0, c->stream, A);
   return nblk;
 }
 
@@ -727,6 +730,23 @@ static int launch_any(pa_ctx* c, Cg3dArgs<T>& A) {
         default: return launch_cg3d<T, 4, PHASE, true>(c, A);
       }
     }
+  }
+  if constexpr (PHASE == 3) {  // one instantiation per Div scheme
+    const int rj = pick_rj<T>(c);
+#define PA_EULER_CASE(K)                                                   \
+    case K:                                                                \
+      switch (rj) {                                                        \
+        case 1: return launch_cg3d<T, 1, 3, false, K>(c, A);               \
+        case 2: return launch_cg3d<T, 2, 3, false, K>(c, A);               \
+        default: return launch_cg3d<T, 4, 3, false, K>(c, A);              \
+      }
+    switch (A.kind) {
+      PA_EULER_CASE(PA_OP_DIV_CENTRAL)
+      PA_EULER_CASE(PA_OP_DIV_UPWIND_COMPAT)
+      PA_EULER_CASE(PA_OP_DIV_UPWIND)
+      default: return 0;
+    }
+#undef PA_EULER_CASE
   }
   switch (pick_rj<T>(c)) {
     case 1: return launch_cg3d<T, 1, PHASE>(c, A);

@@ -1370,18 +1370,22 @@ static bool bc_fusable(const pa_ctx* c);
 template <typename T>
 static int bc_shell_fused(pa_ctx* c, T* x, double* part2, int with_delta, bool guarded, int* nsh, bool standalone);
 
-// ordered BC fill of one field: fused (2 launches) when the list allows it, else face by face
+static bool bc_pairable(const pa_ctx* c);
+template <typename T>
+static int bc_pair_apply(pa_ctx* c, T* x, double* part2, int mode, bool guarded, int* nsh,
+                         const double* partB = nullptr, int nB = 0, int tail_logic = -1);
+
+// fewest launches that keep the sequential semantics: closed form (2) for small shells, one launch per
+// axis (<= 3) for the factory order, else one per face in list order
 template <typename T>
 static int bc_apply_auto(pa_ctx* c, T* x, bool guarded) {
   if (bc_fusable(c)) return bc_shell_fused<T>(c, x, nullptr, 0, guarded, nullptr, true);
+  if (bc_pairable(c)) return bc_pair_apply<T>(c, x, nullptr, 0, guarded, nullptr);
   return bc_apply_t<T>(c, x, guarded);
 }
 
 int pa_bc_apply_any(pa_ctx* c, void* x) {
-  if (bc_fusable(c))
-    return c->dtype == PA_F64 ? bc_shell_fused<double>(c, (double*)x, nullptr, 0, false, nullptr, true)
-                              : bc_shell_fused<float>(c, (float*)x, nullptr, 0, false, nullptr, true);
-  return c->dtype == PA_F64 ? bc_apply_t<double>(c, (double*)x) : bc_apply_t<float>(c, (float*)x);
+  return c->dtype == PA_F64 ? bc_apply_auto<double>(c, (double*)x, false) : bc_apply_auto<float>(c, (float*)x, false);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -1849,9 +1853,12 @@ static bool bc_fusable(const pa_ctx* c) {
   if (getenv("PYAPES_HIP_BC_UNFUSED")) return false;
   // Measured on MI355X (512^3 fp64 periodic): the closed form costs 86 + 40 us against 62 + 19 us for
   // six face launches + the shell pass, so it only wins where launches, not bytes, set the time.
-  // PYAPES_HIP_BC_FUSED=1 forces it (tests do).
+  // Against the per-axis pair kernels (explicit Euler step, fp32, us / step fused : pair : faces):
+  // 64^3 17 : 20 : 25, 128^3 27.9 : 28.5 : 33, 192^3 44 : 40 : 45, 256^3 65 : 55 : 59 -- the crossover
+  // sits between 98 k and 221 k shell nodes.  PYAPES_HIP_BC_FUSED=1 forces the closed form (tests do).
+  const int64_t limit = bc_pairable(c) ? 150000 : 400000;
   if (!getenv("PYAPES_HIP_BC_FUSED") &&
-      2 * (c->G.n1 * c->G.n2 + c->G.n0 * c->G.n2 + c->G.n0 * c->G.n1) > 400000)
+      2 * (c->G.n1 * c->G.n2 + c->G.n0 * c->G.n2 + c->G.n0 * c->G.n1) > limit)
     return false;
   int last = -1;
   for (int w = 0; w < c->nbc; ++w) {
@@ -2018,7 +2025,7 @@ static void bc_face_args(pa_ctx* c, int f, BCArgs<T>& B, bool guarded) {
 // 3: save only (slab: the driver has filled the BCs itself)
 template <typename T>
 static int bc_pair_apply(pa_ctx* c, T* x, double* part2, int mode, bool guarded, int* nsh,
-                         const double* partB = nullptr, int nB = 0, int tail_logic = -1) {
+                         const double* partB, int nB, int tail_logic) {
   const DevGeom& G = c->G;
   const int64_t sz[3] = {G.n1 * G.n2, G.n0 * G.n2, G.n0 * G.n1};
   int64_t start[6], total = 0;
