@@ -94,18 +94,16 @@ int pa_grid_set(pa_ctx* ctx, int ndim, const int64_t* n, const double* dx, int d
 /* ---- coordinate system ------------------------------------------------
  * replaces: the axisymmetric (Cylinder, "rz") rows of default_A_ops (pyapes/solver/tools.py:64-107),
  * Laplacian.build_A_coeffs / adjust_rhs (fdc.py:395-417, 440-453).  2-D grids only (axis 0 = r,
- * axis 1 = z; _mesh.py:48-49).  r_tables: device pointer the caller keeps alive, 6 rows x n[0]
- * values of the grid dtype, one value per r node, evaluated by the host with the reference's
- * literal expressions (dr = dx[0]; nn = nan_to_num(., 0, 0, 0)):
- *   row 0  (1 + nn(dr / (2 r))) / dr^2          Laplacian Ap along r
- *   row 1  (1 - nn(dr / (2 r))) / dr^2          Laplacian Am along r
- *   row 2  (2/3 + nn(2/3 dr / r)) / dr^2        neumann / symmetry row along r (Ap = -Ac or Am = -Ac)
- *   row 3  2/3 - nn(1/3 dr / r)                 factor of the Laplacian rhs adjustment along r
- *   row 4  nn(2 dr / r)                         Ac of Div along r (the u phi / r term)
- *   row 5  r                                    the node radii (edge rz terms fdc.py:330-357, DiffFlux, rfp.py)
- * PA_COORD_XYZ (tables ignored) restores the Cartesian operators; pa_grid_set resets to it. */
+ * axis 1 = z; _mesh.py:48-49).  r_nodes: device pointer to the n[0] node radii (Mesh.x[0]) in the grid
+ * dtype; only read during the call.  The library evaluates, once, the r-dependent coefficient rows
+ * with the reference's literal expressions (dr = dx[0]; nn = nan_to_num(., 0, 0, 0)):
+ *   (1 +- nn(dr / (2 r))) / dr^2     Laplacian Ap / Am along r
+ *   (2/3 + nn(2/3 dr / r)) / dr^2    neumann / symmetry row along r (Ap = -Ac or Am = -Ac)
+ *   2/3 - nn(1/3 dr / r)             factor of the Laplacian rhs adjustment along r
+ *   nn(2 dr / r)                     Ac of Div along r (the u phi / r term)
+ * PA_COORD_XYZ (r_nodes ignored) restores the Cartesian operators; pa_grid_set resets to it. */
 enum { PA_COORD_XYZ = 0, PA_COORD_RZ = 1 };
-int pa_coord_set(pa_ctx* ctx, int coord_sys, const void* r_tables);
+int pa_coord_set(pa_ctx* ctx, int coord_sys, const void* r_nodes);
 
 /* ---- boundary conditions ---------------------------------------------
  * replaces: BC objects + BC.apply (pyapes/variables/bcs.py:70-95, 200-280) and the

@@ -777,6 +777,41 @@ __global__ void __launch_bounds__(PA_BLOCK) k_bc_pair(DevGeom G, T* __restrict__
   }
 }
 
+// ---- axisymmetric meshes: the r-dependent coefficient rows, once per mesh -------------------------
+// Row q of the 6 x n_r table (literal expressions of the reference, evaluated in the grid dtype):
+//   0  (1 + s) / dr^2, s = nan_to_num(dr / (2 r))       Laplacian Ap along r   (tools.py:86-99)
+//   1  (1 - s) / dr^2                                    Laplacian Am along r   (tools.py:101-106)
+//   2  (2/3 + nan_to_num(2/3 dr / r)) / dr^2            neumann / symmetry row (fdc.py:395-417)
+//   3  2/3 - nan_to_num(1/3 dr / r)                      rhs adjustment factor  (fdc.py:440-453)
+//   4  nan_to_num(2 dr / r)                              Ac of Div along r      (tools.py:64-78)
+//   5  r
+template <typename T>
+__global__ void __launch_bounds__(PA_BLOCK) k_rz_tables(int64_t nr, const T* __restrict__ r_nodes, T dr,
+                                                         T* __restrict__ tab) {
+  auto nn = [](T v) -> T { return (isnan(v) || isinf(v)) ? (T)0 : v; };
+  const T h2 = dr * dr;                       // dx[0] ** 2
+  const T c23 = (T)(2.0 / 3.0), c13 = (T)(1.0 / 3.0);
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nr; i += (int64_t)gridDim.x * blockDim.x) {
+    const T r = r_nodes[i];
+    T t = (T)2 * r;
+    const T s = nn(dr / t);
+    T ap = (T)1 + s;
+    T am = (T)1 - s;
+    tab[i] = ap / h2;
+    tab[nr + i] = am / h2;
+    t = c23 * dr;
+    T a = nn(t / r);
+    a = c23 + a;
+    tab[2 * nr + i] = a / h2;
+    t = c13 * dr;
+    a = nn(t / r);
+    tab[3 * nr + i] = c23 - a;
+    t = (T)2 * dr;
+    tab[4 * nr + i] = nn(t / r);
+    tab[5 * nr + i] = r;
+  }
+}
+
 // ---- reductions of per-block partials + scalar logic ------------------------------------
 // sums[slot[s]] (+)= sum over blocks of partials[b*ns + s]
 __device__ __forceinline__ double pa_reduce_partials(const double* __restrict__ partials, int nblk, int ns,
@@ -1493,14 +1528,25 @@ int pa_grid_set(pa_ctx* c, int ndim, const int64_t* n, const double* dx, int dty
   return PA_OK;
 }
 
-int pa_coord_set(pa_ctx* c, int coord_sys, const void* r_tables) {
+int pa_coord_set(pa_ctx* c, int coord_sys, const void* r_nodes) {
   if (!c || !c->grid_set) { if (c) pa_set_err(c, "pa_coord_set before pa_grid_set"); return PA_E_STATE; }
   if (coord_sys == PA_COORD_XYZ) { c->coord = PA_COORD_XYZ; c->rz_tab = nullptr; return PA_OK; }
   if (coord_sys != PA_COORD_RZ) { pa_set_err(c, "pa_coord_set: unknown coordinate system %d", coord_sys); return PA_E_ARG; }
   if (c->ndim != 2) { pa_set_err(c, "pa_coord_set: rz coordinate system only accepts 2-D grids (_mesh.py:48-49)"); return PA_E_ARG; }
-  if (!r_tables) { pa_set_err(c, "pa_coord_set: rz needs the r tables"); return PA_E_ARG; }
+  if (!r_nodes) { pa_set_err(c, "pa_coord_set: rz needs the r coordinates of the nodes"); return PA_E_ARG; }
+  PA_HIP(c, hipSetDevice(c->device));
+  const int64_t nr = c->G.n1;
+  int rc = pa_scratch(c, &c->scr[SCR_RZ], &c->cap[SCR_RZ], (size_t)6 * nr * c->esize);
+  if (rc) return rc;
+  if (c->dtype == PA_F64)
+    hipLaunchKernelGGL(k_rz_tables<double>, dim3(pa_grid_blocks(nr)), dim3(PA_BLOCK), 0, c->stream, nr,
+                       (const double*)r_nodes, (double)c->dx[1], (double*)c->scr[SCR_RZ]);
+  else
+    hipLaunchKernelGGL(k_rz_tables<float>, dim3(pa_grid_blocks(nr)), dim3(PA_BLOCK), 0, c->stream, nr,
+                       (const float*)r_nodes, (float)c->dx[1], (float*)c->scr[SCR_RZ]);
+  PA_HIP(c, hipGetLastError());
   c->coord = PA_COORD_RZ;
-  c->rz_tab = r_tables;
+  c->rz_tab = c->scr[SCR_RZ];
   c->solver_live = 0;
   return PA_OK;
 }

@@ -41,7 +41,7 @@ struct HostBC {
 
 enum {
   SCR_R = 0, SCR_D0, SCR_D1, SCR_PART, SCR_PART2, SCR_SHELL, SCR_R0, SCR_V0, SCR_V1, SCR_S, SCR_TT,
-  SCR_GHOST, SCR_SHELL2, PA_NSCRATCH
+  SCR_GHOST, SCR_SHELL2, SCR_RZ, PA_NSCRATCH
 };
 
 struct pa_ctx {
@@ -111,7 +111,7 @@ struct pa_ctx {
   pa_exchange plan;
   int plan_set = 0;
   int coord = 0;                 // PA_COORD_*
-  const void* rz_tab = nullptr;  // 5 x n_r table of pa_coord_set (device, caller-owned)
+  const void* rz_tab = nullptr;  // 6 x n_r table built by pa_coord_set (ctx scratch)
 };
 
 static inline double* pa_sums(const pa_ctx* c) { return (c->slab && c->ext_sums) ? c->ext_sums : c->sums; }

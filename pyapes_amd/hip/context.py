@@ -48,9 +48,7 @@ class HipContext:
         self._keep: dict[str, Any] = {}
         self._bc_sig: Any = None
         if mesh.coord_sys == "rz":
-            tab = mesh.rz_tables().to(self.device)
-            self._keep["rz"] = tab
-            self._rc(self.lib.pa_coord_set(self.h, L.PA_COORD_RZ, self._ptr(tab)))
+            self._rc(self.lib.pa_coord_set(self.h, L.PA_COORD_RZ, self._ptr(mesh.x[0].contiguous())))
 
     def __del__(self):
         try:

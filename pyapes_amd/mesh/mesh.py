@@ -243,35 +243,6 @@ class Mesh:
         """0..5 = lower / upper face of mesh axis 0, 1, 2 (the C ABI's face id)"""
         return 2 * self.d_mask_dim(face) + (0 if face[1] == "l" else 1)
 
-    def rz_tables(self) -> Tensor:
-        """The r-dependent rows of the axisymmetric operators, one value per r node, in the mesh dtype,
-        computed with the reference's literal expressions (rows of the 6 x n_r table of pa_coord_set):
-          0  (1 + s) / dr^2,  s = nan_to_num(dr / (2 r))                      Laplacian Ap  (tools.py:86-99)
-          1  (1 - s) / dr^2                                                    Laplacian Am  (tools.py:101-106)
-          2  (2/3 + a) / dr^2, a = nan_to_num(2/3 dr / r)   neumann / symmetry row     (fdc.py:395-417)
-          3  2/3 - nan_to_num(1/3 dr / r)                    rhs adjustment factor       (fdc.py:440-453)
-          4  nan_to_num(2 dr / r)                            Div Ac row (u phi / r term)  (tools.py:64-78)
-          5  r                                               node radii (edge rz terms, DiffFlux, rfp.py)"""
-        assert self.coord_sys == "rz"
-        f = self.dtype.float
-        r = self._gx_host[0]
-        dx = torch.tensor(self._dx, dtype=f)
-        dr = dx[0]
-        ones = torch.ones_like(r)
-
-        def nn(t: Tensor) -> Tensor:
-            return torch.nan_to_num(t, nan=0.0, posinf=0.0, neginf=0.0)
-
-        s = nn(dr / (2 * r))
-        ap = (1 + s) * ones
-        am = (1 - s) * ones
-        ap = ap / dx[0] ** 2
-        am = am / dx[0] ** 2
-        b = 2 / 3 + nn(2 / 3 * dr / r)
-        b = b / dx[0] ** 2
-        r4 = 2 / 3 - nn(1 / 3 * dr / r)
-        s2 = nn(2 * dr / r) * ones
-        return torch.stack([ap, am, b, r4, s2, r.clone()]).contiguous()
 
     def __repr__(self) -> str:
         return f"{self.domain} with dx={self._dx}"
