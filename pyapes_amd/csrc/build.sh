@@ -2,13 +2,19 @@
 # Build libpyapes_hip.so for gfx950 (MI355X).  hipcc cross-compiles without a GPU.
 #   -ffp-contract=off : the stencil arithmetic must round every product and sum
 #                       separately to reproduce the reference bit for bit (pa_device.h)
+# The translation units are compiled in parallel (objects under build/, git-ignored), then linked.
 set -euo pipefail
 HERE="$(cd "$(dirname "${BASH_SOURCE[0]}")" && pwd)"
 OUT="$HERE/../lib"
-mkdir -p "$OUT"
+OBJ="$HERE/build"
+mkdir -p "$OUT" "$OBJ"
 HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
-"$HIPCC" --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -ffp-contract=off \
-  -Wall -Wno-unused-function -Wno-unused-variable \
-  ${PA_EXTRA_FLAGS:-} \
-  -o "$OUT/libpyapes_hip.so" "$HERE/pa_core.hip" "$HERE/pa_cg3d.hip" "$HERE/pa_comm.hip" "$HERE/pa_rfp.hip" -ldl
+FLAGS=(--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Wall -Wno-unused-function -Wno-unused-variable ${PA_EXTRA_FLAGS:-})
+pids=()
+for tu in pa_core pa_cg3d pa_comm pa_rfp; do
+  "$HIPCC" "${FLAGS[@]}" -c "$HERE/$tu.hip" -o "$OBJ/$tu.o" &
+  pids+=($!)
+done
+for p in "${pids[@]}"; do wait "$p"; done
+"$HIPCC" --offload-arch=gfx950 -shared -fPIC -o "$OUT/libpyapes_hip.so" "$OBJ/pa_core.o" "$OBJ/pa_cg3d.o" "$OBJ/pa_comm.o" "$OBJ/pa_rfp.o" -ldl
 echo "built $OUT/libpyapes_hip.so"
