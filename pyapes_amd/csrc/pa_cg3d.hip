@@ -699,7 +699,7 @@ static int launch_cg3d(pa_ctx* c, Cg3dArgs<T>& A) {
 
 // rows per thread: 4 (16-row tiles) for big planes; fewer rows = more tiles = longer marching chunks
 // when a plane has too few 16-row tiles to give every resident workgroup >= 32 planes
-template <typename T>
+template <typename T, int PHASE = 0>
 static int pick_rj(pa_ctx* c) {
   if (const char* e = getenv("PYAPES_HIP_RJ")) {
     int v = atoi(e);
@@ -713,7 +713,9 @@ static int pick_rj(pa_ctx* c) {
   for (int rj = 4; rj >= 2; rj >>= 1) {
     const int64_t tiles = ((G.n1 + 4 * rj - 1) / (4 * rj)) * tk;
     const int64_t chunks = cap / tiles > 0 ? cap / tiles : 1;
-    if (G.n0 / chunks >= 24) return rj;
+    // the explicit Euler step is instruction-bound: more rows per thread amortise the per-plane
+    // bookkeeping, and it tolerates shorter chunks (256^3 fp32: RJ 2 48 us / step, RJ 1 52)
+    if (G.n0 / chunks >= (PHASE == 3 ? 12 : 24)) return rj;
   }
   return 1;
 }
@@ -732,7 +734,7 @@ static int launch_any(pa_ctx* c, Cg3dArgs<T>& A) {
     }
   }
   if constexpr (PHASE == 3) {  // one instantiation per Div scheme
-    const int rj = pick_rj<T>(c);
+    const int rj = pick_rj<T, 3>(c);
 #define PA_EULER_CASE(K)                                                   \
     case K:                                                                \
       switch (rj) {                                                        \
