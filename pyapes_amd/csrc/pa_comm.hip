@@ -150,7 +150,10 @@ int pa_comm_selftest(pa_ctx* c, double timeout_s) {
   PA_HIP(c, hipMalloc(&dev, 4 * sizeof(double)));
   const int n = c->comm_n, rk = c->comm_rank;
   double h[4] = {1.0, (double)(rk + 1), (double)rk, -1.0};
-  PA_HIP(c, hipMemcpyAsync(dev, h, sizeof(h), hipMemcpyHostToDevice, c->stream));
+  if (hipError_t he = hipMemcpyAsync(dev, h, sizeof(h), hipMemcpyHostToDevice, c->stream); he != hipSuccess) {
+    (void)hipFree(dev);
+    return pa_hip_fail(c, he, "pa_comm_selftest: hipMemcpyAsync");
+  }
   ncclResult_t e = R->AllReduce(dev, dev, 2, ncclDouble, ncclSum, comm, c->stream);
   if (e == ncclSuccess) e = R->GroupStart();
   if (e == ncclSuccess) e = R->Send(dev + 2, 1, ncclDouble, (rk + 1) % n, comm, c->stream);
@@ -165,8 +168,9 @@ int pa_comm_selftest(pa_ctx* c, double timeout_s) {
     pa_set_err(c, "pa_comm_selftest: no completion within %.1f s, communicator aborted", timeout_s);
     return PA_E_STATE;
   }
-  PA_HIP(c, hipMemcpy(h, dev, sizeof(h), hipMemcpyDeviceToHost));
+  const hipError_t back = hipMemcpy(h, dev, sizeof(h), hipMemcpyDeviceToHost);
   (void)hipFree(dev);
+  if (back != hipSuccess) return pa_hip_fail(c, back, "pa_comm_selftest: hipMemcpy");
   const double want1 = 0.5 * n * (n + 1.0), want3 = (double)((rk + n - 1) % n);
   if (h[0] != (double)n || h[1] != want1 || h[3] != want3) {
     pa_set_err(c, "pa_comm_selftest: wrong answers (%g %g %g, expected %d %g %g)", h[0], h[1], h[3], n, want1, want3);

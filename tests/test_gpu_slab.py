@@ -113,6 +113,13 @@ def _worker_rccl(rank, world, port, name, n, K, out, lib_comm):
         drv = SlabCG(mesh, var, rhs_g.cuda(), [{"kind": 0, "sign": -1.0, "coeff": 0.7}], dist)
         assert drv.lib_comm == lib_comm, "library-side RCCL communicator not in use"
         rep = drv.solve(1e-30, K, poll=3)
+        if lib_comm:   # a second solve on the same mesh reuses the communicator (no silent fallback)
+            first = var().clone()
+            var2 = Field("p", 1, mesh, {"domain": bcs, "obstacle": None})
+            drv2 = SlabCG(mesh, var2, rhs_g.cuda(), [{"kind": 0, "sign": -1.0, "coeff": 0.7}], dist)
+            assert drv2.lib_comm, "second solve fell back to the stepwise driver"
+            rep2 = drv2.solve(1e-30, K, poll=3)
+            assert torch.equal(var2(), first) and rep2.itr == rep.itr
         torch.save({"x": var().cpu(), "itr": int(rep.itr), "tol": float(rep.tol)}, out)
     finally:
         dist.destroy_process_group()
