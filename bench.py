@@ -138,6 +138,13 @@ def main():
     ap.add_argument("--no-roofline-probe", action="store_true")
     args = ap.parse_args()
 
+    # stdout carries exactly ONE line, the JSON record: anything native libraries print on file
+    # descriptor 1 in the meantime (RCCL prints a version banner when a communicator comes up) goes
+    # to stderr instead
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
+
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -259,6 +266,10 @@ def main():
                     "alg_bytes_per_launch": alg_bytes, "scope": "rank 0, per GPU"}
         drv.end()
         comm_kind = "rccl-in-library" if drv.lib_comm else "torch.distributed-stepwise"
+        if drv.lib_comm:            # release the library's communicator while every rank is still alive
+            torch.cuda.synchronize()
+            drv.be.comm_destroy()
+            drv.be.comm_ready = None
 
     if rank == 0:
         value = cells_global * K / secs
@@ -296,7 +307,10 @@ def main():
             out["roofline"] = roof
         if not args.no_cpu_baseline and world == 1:   # reported baseline: rank 0 at N = 1 only
             out["cpu_baseline"] = cpu_baseline(kind, dtype)
-        print(json.dumps(out))
+        sys.stdout.flush()
+        os.dup2(real_stdout, 1)
+        print(json.dumps(out), flush=True)
+        os.dup2(2, 1)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
