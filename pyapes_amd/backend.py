@@ -1,4 +1,4 @@
-"""Device / dtype gate (mirrors ``pyapes/backend.py:7-94``).
+"""Device / dtype gate (the roles of ``pyapes/backend.py:7-94``).
 
 ``Mesh(..., device, dtype)`` builds these.  On PyTorch-ROCm the GPU device string is
 still ``"cuda"``.  A mesh on ``"cpu"`` can be constructed (containers, BC tables and
@@ -7,67 +7,54 @@ raise, they never fall back to torch arithmetic.
 """
 from __future__ import annotations
 
-from dataclasses import dataclass
-
 import torch
 
 TORCH_DEVICE = ["cpu", "cuda", "mps"]
 DTYPE_SINGLE = ["single", "s", 32]
 DTYPE_DOUBLE = ["double", "d", 64]
 
+# precision -> (float, complex, int) torch dtypes
+_DTYPES = {
+    32: (torch.float32, torch.complex64, torch.int32),
+    64: (torch.float64, torch.complex128, torch.int64),
+}
 
-@dataclass
+
 class DType:
-    """``DType("single"|"double")`` -> ``.float/.int/.complex/.bool`` torch dtypes.
+    """``DType("single" | "double" | "s" | "d" | 32 | 64)`` carries the torch dtypes of a mesh as
+    ``.float / .complex / .int / .bool``.  As in the reference (backend.py:28-41), making one also
+    makes its float type torch's process-wide default dtype."""
 
-    Like the reference (backend.py:28-41) constructing it also makes that
-    precision torch's process-wide default dtype.
-    """
+    __slots__ = ("precision", "float", "complex", "int", "bool")
 
-    precision: str | int = "double"
-
-    def __post_init__(self):
-        if self.precision in DTYPE_SINGLE:
-            torch.set_default_dtype(torch.float32)
-            self._float, self._complex, self._int = torch.float32, torch.complex64, torch.int32
-        elif self.precision in DTYPE_DOUBLE:
-            torch.set_default_dtype(torch.float64)
-            self._float, self._complex, self._int = torch.float64, torch.complex128, torch.int64
-        else:
+    def __init__(self, precision: str | int = "double"):
+        bits = 32 if precision in DTYPE_SINGLE else (64 if precision in DTYPE_DOUBLE else None)
+        if bits is None:
             raise ValueError("Invalid precision type!")
-        self._bool = torch.bool
+        self.precision = precision
+        self.float, self.complex, self.int = _DTYPES[bits]
+        self.bool = torch.bool
+        torch.set_default_dtype(self.float)
 
-    @property
-    def float(self) -> torch.dtype:
-        return self._float
+    def __eq__(self, other: object) -> bool:
+        return isinstance(other, DType) and other.float == self.float
 
-    @property
-    def int(self) -> torch.dtype:
-        return self._int
-
-    @property
-    def complex(self) -> torch.dtype:
-        return self._complex
-
-    @property
-    def bool(self) -> torch.dtype:
-        return self._bool
+    def __hash__(self) -> int:
+        return hash(self.float)
 
     def __repr__(self) -> str:
         return f"(torch.dtype){self.precision}"
 
 
 class TorchDevice:
-    """``TorchDevice("cuda").device`` -> ``torch.device`` (backend.py:71-94)."""
+    """``TorchDevice("cuda").device`` is the ``torch.device`` (backend.py:71-94)."""
+
+    __slots__ = ("device_type", "device")
 
     def __init__(self, device_type: str = "cpu"):
         assert device_type in TORCH_DEVICE
         self.device_type = device_type
-        self._device = torch.device(device_type.lower())
-
-    @property
-    def device(self) -> torch.device:
-        return self._device
+        self.device = torch.device(device_type.lower())
 
     def __repr__(self) -> str:
         return f"Device on {self.device}"

@@ -10,9 +10,10 @@ from torch import Tensor
 
 from ..mesh import Mesh
 from .bcs import BC_FACTORY, BC, BCConfig
+from .fieldops import FieldArithmetic
 
 
-class Field:
+class Field(FieldArithmetic):
     """``Field("p", 1, mesh, {"domain": bcs, "obstacle": None}, init_val=0.0)``."""
 
     def __init__(self, name: str, dim: int, mesh: Mesh,
@@ -142,64 +143,6 @@ class Field:
 
     def __call__(self) -> Tensor:
         return self._VAR
-
-    # -- arithmetic sugar (fields.py:256-337): in place, returns self -------------
-    def __add__(self, other: Any) -> "Field":
-        if isinstance(other, Field):
-            self._VAR += other()
-        elif isinstance(other, float):
-            self._VAR += other
-        elif isinstance(other, list):
-            assert len(other) == self.dim, "Field: input vector should match with Field dimension!"
-            for i in range(self.dim):
-                self._VAR[i] += other[i]
-        elif isinstance(other, Tensor):
-            if other.size(0) == self.dim:
-                self._VAR = other
-            else:
-                for i in range(other.size(0)):
-                    self._VAR[i] += other[i]
-        else:
-            raise TypeError("Field: you can only add Field, float, Tensor, list[int], or list[float]!")
-        return self
-
-    def __sub__(self, other: Any) -> "Field":
-        if not isinstance(other, Field):
-            raise TypeError("Field: you can only subtract Field!")
-        self._VAR -= other()
-        return self
-
-    def __mul__(self, other: Any) -> "Field":
-        if isinstance(other, Field):
-            self._VAR *= other()
-        elif isinstance(other, (float, int)):
-            self._VAR *= other
-        else:
-            raise TypeError("Field: you can only multiply Field, int, or float!")
-        return self
-
-    def __truediv__(self, other: Any) -> "Field":
-        if not isinstance(other, Field):
-            raise TypeError("Field: you can only divide by Field!")
-        mask = other().gt(0.0)
-        self._VAR[mask] /= other()[mask]
-        return self
-
-    def __ilshift__(self, other: Any) -> "Field":
-        if isinstance(other, Field):
-            self._VAR = other()
-        elif isinstance(other, Tensor):
-            self.set_var_tensor(other)
-        elif isinstance(other, (float, int)):
-            self._VAR = torch.zeros_like(self._VAR) + other
-        elif isinstance(other, list):
-            assert self.dim == len(other), "Field: dimension mismatch!"
-            self._VAR = torch.zeros_like(self._VAR)
-            for i in range(self.dim):
-                self._VAR[i] += other[i]
-        else:
-            raise TypeError("Field: you can only assign Field, Tensor, float, int, or list!")
-        return self
 
     def volume_integral(self, target: Tensor | None = None) -> Tensor:
         if target is None:
