@@ -79,10 +79,13 @@ __device__ __forceinline__ int64_t pa_wrapmod(int64_t v, int64_t n) {
 // KIND: the Div scheme of the explicit Euler step (PHASE 3) as a compile-time constant -- with all three
 // schemes in one body the uniform operands no longer fit the scalar registers and get spilled into
 // vector lanes (v_readlane / v_writelane were a third of the VALU instructions of that kernel)
-template <typename T, int RJ, int PHASE, bool CF = false, int KIND = 0>
+// NARROW: one cell per lane instead of a 16-byte vector.  For rows whose length is not a multiple of
+// the vector width (node-based meshes love 2^k + 1) or operands that are not 16-byte aligned: no
+// partial vectors, no alignment demand beyond sizeof(T); everything else is the same code.
+template <typename T, int RJ, int PHASE, bool CF = false, int KIND = 0, bool NARROW = false>
 __global__ void __launch_bounds__(256) k_cg3d(Cg3dArgs<T> A) {
-  typedef typename VecOf<T>::type V;
-  constexpr int VEC = VecOf<T>::N;
+  constexpr int VEC = NARROW ? 1 : VecOf<T>::N;
+  typedef T V __attribute__((ext_vector_type(VEC)));
   constexpr int TJ = 4 * RJ, TK = 64 * VEC, TKP = TK + 2 * VEC;
   __shared__ __attribute__((aligned(16))) T tile[2][TJ + 2][TKP];
 
@@ -631,19 +634,21 @@ __global__ void __launch_bounds__(256) k_cg3d(Cg3dArgs<T> A) {
 }
 
 // ---- host side -------------------------------------------------------------------------------
+// 0: not for the tiled kernels; 1: 16-byte vector lanes; 2: one cell per lane (NARROW)
 template <typename T>
-static bool cg3d_covered(const pa_ctx* c, const DevEq<T>& E, const void* p0, const void* p1, const void* p2) {
-  if (!c->fastpath) return false;
-  if (c->coord != PA_COORD_XYZ) return false;  // r-dependent rows: generic kernels
-  if (c->ndim != 3 && c->ndim != 2) return false;
-  if (E.nterms != 1 || E.t[0].kind != PA_OP_LAPLACIAN) return false;
-  if (E.t[0].coeff_f && ((uintptr_t)E.t[0].coeff_f & 15)) return false;
+static int cg3d_mode(const pa_ctx* c, const DevEq<T>& E, std::initializer_list<const void*> ptrs) {
+  if (!c->fastpath) return 0;
+  if (c->coord != PA_COORD_XYZ) return 0;  // r-dependent rows: generic kernels
+  if (c->ndim != 3 && c->ndim != 2) return 0;
+  if (E.nterms != 1 || E.t[0].kind != PA_OP_LAPLACIAN) return 0;
+  if ((c->ndim == 3 && c->G.n0 < 3) || c->G.n1 < 3 || c->G.n2 < 3) return 0;
+  uintptr_t bits = (uintptr_t)E.t[0].coeff_f;
+  for (const void* q : ptrs) bits |= (uintptr_t)q;
+  if (bits & (sizeof(T) - 1)) return 0;
   constexpr int VEC = VecOf<T>::N;
-  if (c->G.n2 % VEC != 0) return false;
-  if ((c->ndim == 3 && c->G.n0 < 3) || c->G.n1 < 3 || c->G.n2 < 2 * VEC) return false;
-  const uintptr_t m = 15;
-  if (((uintptr_t)p0 & m) || ((uintptr_t)p1 & m) || ((uintptr_t)p2 & m)) return false;
-  return true;
+  const char* force = getenv("PYAPES_HIP_NARROW");
+  if ((bits & 15) || c->G.n2 % VEC != 0 || c->G.n2 < 2 * VEC || (force && atoi(force) != 0)) return 2;
+  return 1;
 }
 
 static int cus_of(pa_ctx* c) {
@@ -656,29 +661,29 @@ static int cus_of(pa_ctx* c) {
   return cus;
 }
 
-template <typename T, int RJ, int PHASE, bool CF, int KIND = 0>
+template <typename T, int RJ, int PHASE, bool CF, int KIND = 0, bool NARROW = false>
 static int blocks_per_cu() {
   static int cached = 0;
   if (!cached) {
     const char* e = getenv(PHASE == 0 ? "PYAPES_HIP_BPC_A" : (PHASE == 1 ? "PYAPES_HIP_BPC_B" : "PYAPES_HIP_BPC_X"));
     int n = e ? atoi(e) : 0;
     if (n <= 0) {
-      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_cg3d<T, RJ, PHASE, CF, KIND>, 256, 0) != hipSuccess || n <= 0) n = 2;
+      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_cg3d<T, RJ, PHASE, CF, KIND, NARROW>, 256, 0) != hipSuccess || n <= 0) n = 2;
     }
     cached = n;
   }
   return cached;
 }
 
-template <typename T, int RJ, int PHASE, bool CF = false, int KIND = 0>
+template <typename T, int RJ, int PHASE, bool CF = false, int KIND = 0, bool NARROW = false>
 static int launch_cg3d(pa_ctx* c, Cg3dArgs<T>& A) {
-  constexpr int VEC = VecOf<T>::N;
+  constexpr int VEC = NARROW ? 1 : VecOf<T>::N;
   constexpr int TJ = 4 * RJ, TK = 64 * VEC;
   const DevGeom& G = c->G;
   A.tiles_j = (int)((G.n1 + TJ - 1) / TJ);
   A.tiles_k = (int)((G.n2 + TK - 1) / TK);
   const int tiles = A.tiles_j * A.tiles_k;
-  const int capacity = cus_of(c) * blocks_per_cu<T, RJ, PHASE, CF, KIND>();
+  const int capacity = cus_of(c) * blocks_per_cu<T, RJ, PHASE, CF, KIND, NARROW>();
   int chunks = capacity / tiles;
   if (chunks < 1) chunks = 1;
   if (chunks > G.n0) chunks = (int)G.n0;
@@ -689,23 +694,23 @@ static int launch_cg3d(pa_ctx* c, Cg3dArgs<T>& A) {
   if (dbg < 0) dbg = getenv("PYAPES_HIP_DEBUG") ? 8 : 0;
   if (dbg > 0) {
     --dbg;
-    fprintf(stderr, "[pyapes_hip] k_cg3d phase %c: tiles %dx%d chunks %d (CI ~%lld) blocks %d, %d blocks/CU x %d CUs\n",
-            (char)('A' + PHASE), A.tiles_j, A.tiles_k, chunks, (long long)(G.n0 / chunks), nblk,
-            blocks_per_cu<T, RJ, PHASE, CF, KIND>(), cus_of(c));
+    fprintf(stderr, "[pyapes_hip] k_cg3d phase %c%s: tiles %dx%d chunks %d (CI ~%lld) blocks %d, %d blocks/CU x %d CUs\n",
+            (char)('A' + PHASE), NARROW ? " (narrow)" : "", A.tiles_j, A.tiles_k, chunks, (long long)(G.n0 / chunks), nblk,
+            blocks_per_cu<T, RJ, PHASE, CF, KIND, NARROW>(), cus_of(c));
   }
-  hipLaunchKernelGGL((k_cg3d<T, RJ, PHASE, CF, KIND>), dim3(nblk), dim3(256), 0, c->stream, A);
+  hipLaunchKernelGGL((k_cg3d<T, RJ, PHASE, CF, KIND, NARROW>), dim3(nblk), dim3(256), 0, c->stream, A);
   return nblk;
 }
 
 // rows per thread: 4 (16-row tiles) for big planes; fewer rows = more tiles = longer marching chunks
 // when a plane has too few 16-row tiles to give every resident workgroup >= 32 planes
 template <typename T, int PHASE = 0>
-static int pick_rj(pa_ctx* c) {
+static int pick_rj(pa_ctx* c, bool narrow = false) {
   if (const char* e = getenv("PYAPES_HIP_RJ")) {
     int v = atoi(e);
     if (v == 1 || v == 2 || v == 4) return v;
   }
-  constexpr int VEC = VecOf<T>::N;
+  const int VEC = narrow ? 1 : VecOf<T>::N;
   const DevGeom& G = c->G;
   if (!G.act[0]) return 4;  // 2-D: one plane, nothing to march; the biggest tile has the least halo
   const int64_t tk = (G.n2 + 64 * VEC - 1) / (64 * VEC);
@@ -720,27 +725,27 @@ static int pick_rj(pa_ctx* c) {
   return 1;
 }
 
-template <typename T, int PHASE>
-static int launch_any(pa_ctx* c, Cg3dArgs<T>& A) {
+template <typename T, int PHASE, bool NARROW>
+static int launch_any_w(pa_ctx* c, Cg3dArgs<T>& A) {
   constexpr bool CF_OK = (PHASE == 0 || PHASE == 1 || PHASE == 2 || PHASE == 4);
   if (A.coeff_f) {  // tensor coefficient: separate instantiation, so the scalar-coefficient kernels stay lean
     if (!CF_OK) return 0;
     if constexpr (CF_OK) {
-      switch (pick_rj<T>(c)) {
-        case 1: return launch_cg3d<T, 1, PHASE, true>(c, A);
-        case 2: return launch_cg3d<T, 2, PHASE, true>(c, A);
-        default: return launch_cg3d<T, 4, PHASE, true>(c, A);
+      switch (pick_rj<T>(c, NARROW)) {
+        case 1: return launch_cg3d<T, 1, PHASE, true, 0, NARROW>(c, A);
+        case 2: return launch_cg3d<T, 2, PHASE, true, 0, NARROW>(c, A);
+        default: return launch_cg3d<T, 4, PHASE, true, 0, NARROW>(c, A);
       }
     }
   }
   if constexpr (PHASE == 3) {  // one instantiation per Div scheme
-    const int rj = pick_rj<T, 3>(c);
+    const int rj = pick_rj<T, 3>(c, NARROW);
 #define PA_EULER_CASE(K)                                                   \
     case K:                                                                \
       switch (rj) {                                                        \
-        case 1: return launch_cg3d<T, 1, 3, false, K>(c, A);               \
-        case 2: return launch_cg3d<T, 2, 3, false, K>(c, A);               \
-        default: return launch_cg3d<T, 4, 3, false, K>(c, A);              \
+        case 1: return launch_cg3d<T, 1, 3, false, K, NARROW>(c, A);       \
+        case 2: return launch_cg3d<T, 2, 3, false, K, NARROW>(c, A);       \
+        default: return launch_cg3d<T, 4, 3, false, K, NARROW>(c, A);      \
       }
     switch (A.kind) {
       PA_EULER_CASE(PA_OP_DIV_CENTRAL)
@@ -750,11 +755,16 @@ static int launch_any(pa_ctx* c, Cg3dArgs<T>& A) {
     }
 #undef PA_EULER_CASE
   }
-  switch (pick_rj<T>(c)) {
-    case 1: return launch_cg3d<T, 1, PHASE>(c, A);
-    case 2: return launch_cg3d<T, 2, PHASE>(c, A);
-    default: return launch_cg3d<T, 4, PHASE>(c, A);
+  switch (pick_rj<T>(c, NARROW)) {
+    case 1: return launch_cg3d<T, 1, PHASE, false, 0, NARROW>(c, A);
+    case 2: return launch_cg3d<T, 2, PHASE, false, 0, NARROW>(c, A);
+    default: return launch_cg3d<T, 4, PHASE, false, 0, NARROW>(c, A);
   }
+}
+
+template <typename T, int PHASE>
+static int launch_any(pa_ctx* c, Cg3dArgs<T>& A, int mode) {
+  return mode == 2 ? launch_any_w<T, PHASE, true>(c, A) : launch_any_w<T, PHASE, false>(c, A);
 }
 
 template <typename T>
@@ -770,24 +780,23 @@ static void fill_common(pa_ctx* c, const DevEq<T>& E, Cg3dArgs<T>& A) {
 
 template <typename T>
 int pa_cg3d_phase_a(pa_ctx* c, const DevEq<T>& E, Vec<T> r, Vec<T> d, T* dnew, double* partials, const CgEpi& epi) {
-  if (!cg3d_covered<T>(c, E, r.p, d.p, dnew)) return 0;
-  if (((uintptr_t)r.glo | (uintptr_t)r.ghi | (uintptr_t)d.glo | (uintptr_t)d.ghi) & 15) return 0;
+  const int mode = cg3d_mode<T>(c, E, {r.p, d.p, dnew, r.glo, r.ghi, d.glo, d.ghi});
+  if (!mode) return 0;
   Cg3dArgs<T> A;
   memset(&A, 0, sizeof(A));
   fill_common<T>(c, E, A);
   A.r = r; A.d = d; A.dnew = dnew; A.partials = partials;
   A.epi = epi;
   A.reverse = 0;
-  int n = launch_any<T, 0>(c, A);
+  int n = launch_any<T, 0>(c, A, mode);
   if (n > 0 && hipGetLastError() != hipSuccess) { pa_set_err(c, "k_cg3d phase A launch failed"); return PA_E_HIP; }
   return n;
 }
 
 template <typename T>
 int pa_cg3d_phase_b(pa_ctx* c, const DevEq<T>& E, Vec<T> d, T* x, T* r, double* partials, const CgEpi& epi) {
-  if (!cg3d_covered<T>(c, E, d.p, x, r)) return 0;
-  if (((uintptr_t)d.glo | (uintptr_t)d.ghi) & 15) return 0;
-  if (((uintptr_t)c->r_send_lo | (uintptr_t)c->r_send_hi) & 15) return 0;
+  const int mode = cg3d_mode<T>(c, E, {d.p, x, r, d.glo, d.ghi, c->r_send_lo, c->r_send_hi});
+  if (!mode) return 0;
   Cg3dArgs<T> A;
   memset(&A, 0, sizeof(A));
   fill_common<T>(c, E, A);
@@ -795,7 +804,7 @@ int pa_cg3d_phase_b(pa_ctx* c, const DevEq<T>& E, Vec<T> d, T* x, T* r, double* 
   A.epi = epi;
   A.send_lo = (T*)c->r_send_lo; A.send_hi = (T*)c->r_send_hi;
   A.reverse = 1;
-  int n = launch_any<T, 1>(c, A);
+  int n = launch_any<T, 1>(c, A, mode);
   if (n > 0 && hipGetLastError() != hipSuccess) { pa_set_err(c, "k_cg3d phase B launch failed"); return PA_E_HIP; }
   return n;
 }
@@ -813,13 +822,13 @@ static void fill_h(const pa_ctx* c, Cg3dArgs<T>& A) {
 
 template <typename T>
 int pa_tile3d_aop(pa_ctx* c, const DevEq<T>& E, Vec<T> x, T* y, int interior_only) {
-  if (!cg3d_covered<T>(c, E, x.p, y, y)) return 0;
-  if (((uintptr_t)x.glo | (uintptr_t)x.ghi) & 15) return 0;
+  const int mode = cg3d_mode<T>(c, E, {x.p, y, x.glo, x.ghi});
+  if (!mode) return 0;
   Cg3dArgs<T> A;
   memset(&A, 0, sizeof(A));
   fill_common<T>(c, E, A);
   A.d = x; A.out = y; A.interior_only = interior_only;
-  int n = launch_any<T, 2>(c, A);
+  int n = launch_any<T, 2>(c, A, mode);
   if (n > 0 && hipGetLastError() != hipSuccess) { pa_set_err(c, "k_cg3d A x launch failed"); return PA_E_HIP; }
   return n;
 }
@@ -831,28 +840,28 @@ int pa_tile3d_euler(pa_ctx* c, Vec<T> phi, T* out, int kind, double u, const voi
   memset(&t, 0, sizeof(t));
   t.kind = PA_OP_LAPLACIAN; t.sign = 1.0;
   pa_build_eq<T>(c, 1, &t, E);
-  if (!cg3d_covered<T>(c, E, phi.p, out, u_field ? u_field : out)) return 0;
-  if (((uintptr_t)phi.glo | (uintptr_t)phi.ghi) & 15) return 0;
+  const int mode = cg3d_mode<T>(c, E, {phi.p, out, u_field, phi.glo, phi.ghi});
+  if (!mode) return 0;
   if (kind == PA_OP_DIV_CENTRAL && u_field) return 0;  // needs u at the neighbours: generic kernel
   Cg3dArgs<T> A;
   memset(&A, 0, sizeof(A));
   fill_common<T>(c, E, A);
   fill_h<T>(c, A);
   A.d = phi; A.out = out; A.aux = (const T*)u_field; A.u = (T)u; A.p0 = (T)nu; A.p1 = (T)dt; A.kind = kind;
-  int n = launch_any<T, 3>(c, A);
+  int n = launch_any<T, 3>(c, A, mode);
   if (n > 0 && hipGetLastError() != hipSuccess) { pa_set_err(c, "k_cg3d Euler launch failed"); return PA_E_HIP; }
   return n;
 }
 
 template <typename T>
 int pa_tile3d_jacobi(pa_ctx* c, const DevEq<T>& E, Vec<T> x, const T* rhs, T* xnew, double omega, double* partials) {
-  if (!cg3d_covered<T>(c, E, x.p, rhs, xnew)) return 0;
-  if (((uintptr_t)x.glo | (uintptr_t)x.ghi) & 15) return 0;
+  const int mode = cg3d_mode<T>(c, E, {x.p, rhs, xnew, x.glo, x.ghi});
+  if (!mode) return 0;
   Cg3dArgs<T> A;
   memset(&A, 0, sizeof(A));
   fill_common<T>(c, E, A);
   A.d = x; A.out = xnew; A.aux = rhs; A.p0 = (T)omega; A.partials = partials;
-  int n = launch_any<T, 4>(c, A);
+  int n = launch_any<T, 4>(c, A, mode);
   if (n > 0 && hipGetLastError() != hipSuccess) { pa_set_err(c, "k_cg3d Jacobi launch failed"); return PA_E_HIP; }
   return n;
 }
@@ -860,12 +869,13 @@ int pa_tile3d_jacobi(pa_ctx* c, const DevEq<T>& E, Vec<T> x, const T* rhs, T* xn
 template <typename T>
 int pa_tile3d_bicg_pv(pa_ctx* c, const DevEq<T>& E, Vec<T> r, Vec<T> p, Vec<T> v, const T* r0, T* pnew, T* vnew,
                       double* partials) {
-  if (!cg3d_covered<T>(c, E, r.p, p.p, v.p) || !cg3d_covered<T>(c, E, r0, pnew, vnew)) return 0;
+  const int mode = cg3d_mode<T>(c, E, {r.p, p.p, v.p, r0, pnew, vnew, r.glo, r.ghi, p.glo, p.ghi, v.glo, v.ghi});
+  if (!mode) return 0;
   Cg3dArgs<T> A;
   memset(&A, 0, sizeof(A));
   fill_common<T>(c, E, A);
   A.r = r; A.d = p; A.v = v; A.aux = r0; A.out = pnew; A.out2 = vnew; A.partials = partials;
-  int n = launch_any<T, 5>(c, A);
+  int n = launch_any<T, 5>(c, A, mode);
   if (n > 0 && hipGetLastError() != hipSuccess) { pa_set_err(c, "k_cg3d BiCGSTAB p/v launch failed"); return PA_E_HIP; }
   return n;
 }
@@ -873,12 +883,13 @@ int pa_tile3d_bicg_pv(pa_ctx* c, const DevEq<T>& E, Vec<T> r, Vec<T> p, Vec<T> v
 template <typename T>
 int pa_tile3d_bicg_st(pa_ctx* c, const DevEq<T>& E, Vec<T> r, Vec<T> v, const T* r0, T* s_out, T* t_out,
                       double* partials) {
-  if (!cg3d_covered<T>(c, E, r.p, v.p, r0) || !cg3d_covered<T>(c, E, s_out, t_out, t_out)) return 0;
+  const int mode = cg3d_mode<T>(c, E, {r.p, v.p, r0, s_out, t_out, r.glo, r.ghi, v.glo, v.ghi});
+  if (!mode) return 0;
   Cg3dArgs<T> A;
   memset(&A, 0, sizeof(A));
   fill_common<T>(c, E, A);
   A.r = r; A.d = v; A.aux = r0; A.out = s_out; A.out2 = t_out; A.partials = partials;
-  int n = launch_any<T, 6>(c, A);
+  int n = launch_any<T, 6>(c, A, mode);
   if (n > 0 && hipGetLastError() != hipSuccess) { pa_set_err(c, "k_cg3d BiCGSTAB s/t launch failed"); return PA_E_HIP; }
   return n;
 }

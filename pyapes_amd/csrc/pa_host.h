@@ -8,7 +8,7 @@
 #include "pa_device.h"
 
 #define PA_MAX_GRID 2048  // 256 CUs x 8 resident workgroups of 256 threads
-#define PA_MAX_PARTIALS 16384  // rows of per-block partial sums (2-D tile grids are one block per tile)
+#define PA_MAX_PARTIALS 131072  // rows of per-block partial sums (2-D tile grids are one block per tile; 4 MB of scratch)
 
 // device-resident solver scalars: alpha, beta, the stop test and the iteration count never
 // leave the GPU inside a solve; the host only polls `done`

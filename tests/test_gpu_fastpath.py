@@ -25,6 +25,8 @@ PE = ("periodic", None)
 SHAPES = [
     ((20, 37, 50), "double"), ((9, 16, 128), "double"), ((33, 33, 34), "double"), ((40, 40, 40), "double"),
     ((17, 70, 260), "double"), ((12, 18, 132), "single"), ((24, 40, 64), "single"),
+    # row lengths that are not a multiple of the 16-byte vector: the one-cell-per-lane (NARROW) kernels
+    ((21, 37, 51), "double"), ((17, 33, 129), "double"), ((12, 18, 131), "single"), ((10, 14, 134), "single"),
 ]
 BCS = {
     "dir": [D(0.0)] * 6,

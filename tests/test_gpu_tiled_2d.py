@@ -24,7 +24,8 @@ SY = ("symmetry", None)
 PE = ("periodic", None)
 BCS = {"mix": [D(0.2), N(0.5), N(-0.3), D(1.0)], "sym": [SY, N(0.1), D(0.0), SY], "per": [PE] * 4,
        "xper": [PE, PE, D(0.0), N(0.2)]}
-SHAPES = [((200, 260), "double"), ((37, 132), "double"), ((64, 256), "single"), ((19, 24), "single")]
+SHAPES = [((200, 260), "double"), ((37, 132), "double"), ((64, 256), "single"), ((19, 24), "single"),
+          ((201, 257), "double"), ((37, 131), "double"), ((64, 255), "single"), ((19, 26), "single")]
 
 
 def _cfg(bcs):

@@ -25,6 +25,11 @@ CASES = [
     ((40, 44), "double", [N(0.0), D(0.0), N(0.0), D(1.0)]),
     ((16, 20, 24), "single", [D(0.0)] * 6),
     ((14, 20, 24), "double", [D(0.0), D(0.5), D(0.0), D(0.0), D(1.0), D(0.0)]),
+    # odd row lengths: NARROW kernels
+    ((12, 18, 21), "double", [D(0.0), N(0.5), D(0.3), N(0.0), D(1.0), N(-0.25)]),
+    ((9, 16, 131), "double", [N(0.3), D(0.0), SY, SY, SY, D(2.0)]),
+    ((40, 45), "double", [N(0.0), D(0.0), N(0.0), D(1.0)]),
+    ((16, 20, 27), "double", [D(0.0)] * 6),
 ]
 
 

@@ -32,7 +32,8 @@ BCS = {
     "xper": [PE, PE, D(0.0), D(1.0), N(0.0), N(0.2)],
     "dirper": [D(0.0), D(0.2), PE, PE, D(0.1), D(0.0)],
 }
-SHAPES = [((20, 37, 50), "double"), ((9, 16, 128), "double"), ((17, 70, 260), "double"), ((12, 18, 132), "single")]
+SHAPES = [((20, 37, 50), "double"), ((9, 16, 128), "double"), ((17, 70, 260), "double"), ((12, 18, 132), "single"),
+          ((20, 37, 51), "double"), ((9, 17, 129), "double"), ((12, 18, 133), "single"), ((11, 13, 130), "single")]
 
 
 def _cfg(bcs):
