@@ -85,6 +85,14 @@ struct Vec {
 };
 
 __device__ __forceinline__ void pa_decode(const DevGeom& G, int64_t idx, int64_t& i, int64_t& j, int64_t& k) {
+  if (G.ncell <= 0x7fffffffLL) {  // uniform: 32-bit divisions cost a quarter of the 64-bit ones
+    const uint32_t id = (uint32_t)idx, s0 = (uint32_t)G.s0, s1 = (uint32_t)G.s1;
+    const uint32_t ii = id / s0, rem = id - ii * s0, jj = rem / s1;
+    i = ii;
+    j = jj;
+    k = rem - jj * s1;
+    return;
+  }
   i = idx / G.s0;
   int64_t rem = idx - i * G.s0;
   j = rem / G.s1;
