@@ -680,8 +680,17 @@ static int launch_cg3d(pa_ctx* c, Cg3dArgs<T>& A) {
   constexpr int VEC = NARROW ? 1 : VecOf<T>::N;
   constexpr int TJ = 4 * RJ, TK = 64 * VEC;
   const DevGeom& G = c->G;
-  A.tiles_j = (int)((G.n1 + TJ - 1) / TJ);
-  A.tiles_k = (int)((G.n2 + TK - 1) / TK);
+  // The CG phases only ever change cells of the interior set: the last row / column of a non-periodic
+  // axis is a boundary node whose d', r stay 0 and whose x is left alone, so no tile needs to cover
+  // it.  For the 2^k + 1 extents node-based meshes like, that removes a whole extra tile row and tile
+  // column (257^2 planes: 64 instead of 85 tiles of 16 x 64).  cg_begin zeroes both direction buffers.
+  int64_t n1e = G.n1, n2e = G.n2;
+  if (PHASE == 0 || PHASE == 1) {
+    if (G.bct[3] != PA_BC_PERIODIC && n1e > 2) n1e -= 1;
+    if (G.bct[5] != PA_BC_PERIODIC && n2e > 2) n2e -= 1;
+  }
+  A.tiles_j = (int)((n1e + TJ - 1) / TJ);
+  A.tiles_k = (int)((n2e + TK - 1) / TK);
   const int tiles = A.tiles_j * A.tiles_k;
   const int capacity = cus_of(c) * blocks_per_cu<T, RJ, PHASE, CF, KIND, NARROW>();
   int chunks = capacity / tiles;

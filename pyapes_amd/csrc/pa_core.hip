@@ -2177,6 +2177,9 @@ static int cg_begin_t(pa_ctx* c, T* x, const T* rhs, double tol, int64_t max_it)
   if ((rc = pa_scratch(c, &c->scr[SCR_PART2], &c->cap[SCR_PART2], (size_t)3 * PA_MAX_GRID * sizeof(double)))) return rc;
   if ((rc = pa_scratch(c, &c->scr[SCR_SHELL], &c->cap[SCR_SHELL], 2 * (size_t)shell_elems(c) * sizeof(T)))) return rc;
   if ((rc = init_scalars(c, tol, max_it))) return rc;
+  // the tiled phase kernels do not visit the last boundary row / column of non-periodic axes: the
+  // direction there is 0 by definition and has to be 0 in the buffer the first phase A writes into
+  PA_HIP(c, hipMemsetAsync(c->scr[SCR_D1], 0, fb, c->stream));
   c->cg_x = x;
   c->cur = 0;
   c->bc_static = bc_is_static(c);
