@@ -308,8 +308,13 @@ __global__ void __launch_bounds__(256) k_cg3d(Cg3dArgs<T> A) {
         // x and r are touched exactly once per iteration: non-temporal, so that they do not evict the
         // halo rows / planes of d' other workgroups are about to re-read from L2 (measured -3 % on
         // the iteration at 512^3; non-temporal loads of d / r themselves cost +6 % in phase A)
-        xv[jj] = __builtin_nontemporal_load(reinterpret_cast<const V*>(A.x + o));
-        rv[jj] = __builtin_nontemporal_load(reinterpret_cast<const V*>(A.rw + o));
+        if (NARROW) {   // 8-byte / 4-byte lanes: the streaming hint costs 8-17 % here (interleaved A/B)
+          xv[jj] = *reinterpret_cast<const V*>(A.x + o);
+          rv[jj] = *reinterpret_cast<const V*>(A.rw + o);
+        } else {
+          xv[jj] = __builtin_nontemporal_load(reinterpret_cast<const V*>(A.x + o));
+          rv[jj] = __builtin_nontemporal_load(reinterpret_cast<const V*>(A.rw + o));
+        }
       }
     }
     V cv[RJ];
@@ -593,10 +598,16 @@ __global__ void __launch_bounds__(256) k_cg3d(Cg3dArgs<T> A) {
         } else if (PHASE >= 2) {
           *reinterpret_cast<V*>(A.out + o) = outd;
         } else if (PHASE == 0) {
-          __builtin_nontemporal_store(outd, reinterpret_cast<V*>(A.dnew + o));  // -1.5 % (measured)
+          if (NARROW) *reinterpret_cast<V*>(A.dnew + o) = outd;
+          else __builtin_nontemporal_store(outd, reinterpret_cast<V*>(A.dnew + o));  // -1.5 % (measured)
         } else {
-          __builtin_nontemporal_store(outx, reinterpret_cast<V*>(A.x + o));
-          __builtin_nontemporal_store(outd, reinterpret_cast<V*>(A.rw + o));
+          if (NARROW) {
+            *reinterpret_cast<V*>(A.x + o) = outx;
+            *reinterpret_cast<V*>(A.rw + o) = outd;
+          } else {
+            __builtin_nontemporal_store(outx, reinterpret_cast<V*>(A.x + o));
+            __builtin_nontemporal_store(outd, reinterpret_cast<V*>(A.rw + o));
+          }
           if (A.send_lo && ii == 0) *reinterpret_cast<V*>(A.send_lo + jrow[jj] * G.s1 + kc) = outd;
           if (A.send_hi && ii == G.n0 - 1) *reinterpret_cast<V*>(A.send_hi + jrow[jj] * G.s1 + kc) = outd;
         }
