@@ -2702,9 +2702,45 @@ int pa_cg_finish_iter(pa_ctx* c) {
   return PA_OK;
 }
 
+static int cg_one_iteration(pa_ctx* c) {
+  int rc = c->dtype == PA_F64 ? pa_cg_phase_a_t<double>(c, 2) : pa_cg_phase_a_t<float>(c, 2);
+  if (rc) return rc;
+  return c->dtype == PA_F64 ? pa_cg_phase_b_t<double>(c, 2) : pa_cg_phase_b_t<float>(c, 2);
+}
+
+// PYAPES_HIP_GRAPH=1: replay a captured pair of iterations (the direction buffers ping-pong, so the
+// launch sequence has period 2) as a hipGraph instead of enqueueing every kernel again
+static int cg_iterate_graph(pa_ctx* c, int64_t n, int64_t* done) {
+  *done = 0;
+  if (n < 4 || c->profile || c->overlap) return PA_OK;
+  hipGraph_t graph = nullptr;
+  hipGraphExec_t exec = nullptr;
+  if (hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal) != hipSuccess) { (void)hipGetLastError(); return PA_OK; }
+  int rc = cg_one_iteration(c);
+  if (!rc) rc = cg_one_iteration(c);
+  hipError_t e = hipStreamEndCapture(c->stream, &graph);
+  if (rc || e != hipSuccess || !graph) { (void)hipGetLastError(); if (graph) (void)hipGraphDestroy(graph); return rc ? rc : PA_OK; }
+  if (hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) != hipSuccess) { (void)hipGetLastError(); (void)hipGraphDestroy(graph); return PA_OK; }
+  // the capture itself executed nothing: all n iterations are still to do
+  const int64_t pairs = n / 2;
+  for (int64_t q = 0; q < pairs; ++q)
+    if (hipGraphLaunch(exec, c->stream) != hipSuccess) { rc = pa_hip_fail(c, hipGetLastError(), "hipGraphLaunch"); break; }
+  (void)hipGraphExecDestroy(exec);
+  (void)hipGraphDestroy(graph);
+  if (!rc) *done = 2 * pairs;
+  return rc;
+}
+
 int pa_cg_iterate(pa_ctx* c, int64_t n) {
   if (!c || !c->solver_live) { if (c) pa_set_err(c, "pa_cg_iterate without pa_cg_begin"); return PA_E_STATE; }
   if (c->slab) { pa_set_err(c, "pa_cg_iterate is single-rank; drive the phases on a slab"); return PA_E_STATE; }
+  static int use_graph = -1;
+  if (use_graph < 0) { const char* g = getenv("PYAPES_HIP_GRAPH"); use_graph = (g && atoi(g) != 0) ? 1 : 0; }
+  if (use_graph) {
+    int64_t done = 0;
+    if (int rc = cg_iterate_graph(c, n, &done)) return rc;
+    n -= done;
+  }
   for (int64_t q = 0; q < n; ++q) {
     int rc = c->dtype == PA_F64 ? pa_cg_phase_a_t<double>(c, 2) : pa_cg_phase_a_t<float>(c, 2);
     if (rc) return rc;

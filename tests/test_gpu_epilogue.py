@@ -67,3 +67,45 @@ def test_epilogue_single_precision_and_large_grid(monkeypatch):
         a, ra = _solve(n, BCS["static"], {"PYAPES_HIP_EPILOGUE": "1"}, monkeypatch, -1.0, 12, dtype)
         b, rb = _solve(n, BCS["static"], {"PYAPES_HIP_EPILOGUE": "0"}, monkeypatch, -1.0, 12, dtype)
         assert torch.equal(a, b) and ra["tol"] == rb["tol"] and ra["itr"] == rb["itr"] == 13
+
+
+def test_graph_replay_equals_plain_enqueue(monkeypatch):
+    """PYAPES_HIP_GRAPH=1 (opt-in: the loop is bound by the GPU-side dependent-dispatch latency, not by
+    the host's launch rate, so the replay measures no gain): pa_cg_iterate replays a captured pair of
+    iterations as a hipGraph -- same kernels, same order, so the iterate is bit-identical."""
+    import subprocess
+    import sys
+    from conftest import ROOT
+    code = r"""
+import sys, warnings, torch
+sys.path.insert(0, %r)
+warnings.simplefilter("ignore")
+from pyapes_amd.geometry import Box
+from pyapes_amd.mesh import Mesh
+from pyapes_amd.hip import lib as L
+from pyapes_amd.hip.context import context_for
+from pyapes_amd.variables import Field
+from pyapes_amd.variables.bcs import mixed_bcs
+mesh = Mesh(Box[0:1, 0:1, 0:1], None, [24, 20, 132], "cuda", "double")
+var = Field("p", 1, mesh, {"domain": mixed_bcs([0.0, 0.5, 0.3, 0.0, 1.0, -0.25], ["dirichlet", "neumann"] * 3), "obstacle": None})
+rhs = torch.randn((1, 24, 20, 132), generator=torch.Generator().manual_seed(3), dtype=torch.float64).cuda()
+ctx = context_for(mesh)
+ctx.bind_bcs(var(), var.bcs, 0)
+ctx.set_terms([{"kind": L.OP_LAPLACIAN, "sign": 1.0, "coeff": 1.0}])
+ctx.rhs_adjust(rhs[0])
+ctx.cg_begin(var()[0], rhs[0], -1.0, 100)
+ctx.cg_iterate(11)          # odd count: 5 replayed pairs + 1 plain iteration
+rep = ctx.cg_end()
+torch.save({"x": var().cpu(), "itr": int(rep.itr), "tol": float(rep.tol)}, sys.argv[1])
+""" % ROOT
+    import os
+    res = {}
+    for g in ("1", "0"):
+        out = f"/tmp/pa_graph_{g}_{os.getpid()}.pt"
+        env = dict(os.environ, PYAPES_HIP_GRAPH=g)
+        p = subprocess.run([sys.executable, "-c", code, out], capture_output=True, text=True, timeout=300, env=env)
+        assert p.returncode == 0, p.stderr[-2000:]
+        res[g] = torch.load(out)
+        os.remove(out)
+    assert res["1"]["itr"] == res["0"]["itr"] == 11 and res["1"]["tol"] == res["0"]["tol"]
+    assert torch.equal(res["1"]["x"], res["0"]["x"])
