@@ -1,0 +1,135 @@
+"""-m gpu: seeded differential fuzz (500 cases) -- random extents (3 .. 70, so the tiled kernels see every kind of
+partial tile, odd row lengths and the NARROW layout), dimensions, face-type mixes and dtypes:
+  * CG for a few iterations through the product == the oracle (1e-10 fp64 / 1e-5 fp32),
+  * tiled kernels == generic kernels (iterates to 1e-12 / 1e-5: the partial sums differ, nothing else),
+  * explicit Laplacian == oracle, bit for bit.
+One process, a few hundred small cases, ~20 s."""
+import random
+import warnings
+
+import pytest
+import torch
+
+import pyapes_oracle as O
+from helpers import rel_err
+
+pytestmark = pytest.mark.gpu
+
+from pyapes_amd.geometry import Box
+from pyapes_amd.mesh import Mesh
+from pyapes_amd.solver.fdc import FDC
+from pyapes_amd.solver.fdm import FDM
+from pyapes_amd.solver.ops import Solver
+from pyapes_amd.variables import Field
+
+
+def _random_case(rng):
+    nd = rng.choice([1, 2, 2, 3, 3, 3])
+    n = [rng.choice([3, 4, 5, 6, 7, 8, 9, 12, 16, 17, 20, 31, 33, 40]) for _ in range(nd)]
+    if nd >= 2 and rng.random() < 0.5:
+        n[-1] = rng.choice([5, 9, 17, 33, 34, 47, 64, 65, 66, 70])     # k extent: odd / even / around a tile
+    bcs = []
+    for a in range(nd):
+        kind = rng.random()
+        if kind < 0.2 and n[a] >= 5:
+            bcs += [("periodic", None), ("periodic", None)]
+        else:
+            for _ in range(2):
+                t = rng.choice(["dirichlet", "dirichlet", "neumann", "symmetry"])
+                bcs.append((t, None if t == "symmetry" else round(rng.uniform(-1, 1), 3)))
+    dtype = "double" if rng.random() < 0.75 else "single"
+    if any(t == "periodic" for t, _ in bcs):
+        dtype = "double"   # CG on the reference's periodic operator amplifies rounding: fp32 is noise
+    return n, bcs, dtype
+
+
+def _product(n, bcs, dtype, rhs, x0, K, fast, monkeypatch):
+    monkeypatch.setenv("PYAPES_HIP_FASTPATH", "1" if fast else "0")
+    nd = len(n)
+    mesh = Mesh(Box([0.0] * nd, [1.0 + 0.1 * a for a in range(nd)]), None, list(n), "cuda", dtype)
+    cfg = [{"bc_face": O.FACES[i], "bc_type": t, "bc_val": v, "bc_val_opt": None} for i, (t, v) in enumerate(bcs)]
+    var = Field("p", 1, mesh, {"domain": cfg, "obstacle": None})
+    var.set_var_tensor(x0.cuda().clone())
+    lap = None
+    if fast:
+        var.apply_bcs()
+        lap = FDC({"laplacian": {"edge": False}}).laplacian(var).cpu()
+        var.set_var_tensor(x0.cuda().clone())
+    s = Solver({"fdm": {"method": "cg", "tol": -1.0, "max_it": K - 1, "report": False}})
+    s.set_eq(-FDM().laplacian(0.8, var) == rhs.cuda().clone())
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        rep = s.solve()
+    return var().cpu(), rep, lap
+
+
+def test_seeded_fuzz(monkeypatch):
+    rng = random.Random(20261004)
+    bad = []
+    for case in range(500):
+        n, bcs, dtype = _random_case(rng)
+        if any(t == "periodic" for t, _ in bcs) and min(n) < 5:
+            continue
+        if not any(t == "dirichlet" for t, _ in bcs):
+            continue   # singular operator: CG amplifies rounding without bound, nothing to compare
+        tdt = torch.float64 if dtype == "double" else torch.float32
+        g = torch.Generator().manual_seed(case)
+        rhs = torch.randn((1, *n), generator=g, dtype=torch.float64).to(tdt)
+        x0 = torch.randn((1, *n), generator=g, dtype=torch.float64).to(tdt)
+        K = 3
+        om = O.OMesh([0.0] * len(n), [1.0 + 0.1 * a for a in range(len(n))], list(n), dtype)
+        ocfg = [{"bc_face": O.FACES[i], "bc_type": t, "bc_val": v} for i, (t, v) in enumerate(bcs)]
+        try:
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                xo, ro = O.solve_poisson(om, ocfg, rhs.clone(), x0=x0.clone(), method="cg", tol=-1.0, max_it=K - 1,
+                                         coeff=0.8, sign=-1.0)
+        except RuntimeError:
+            # degenerate operator (e.g. a 3-node axis between two neumann faces): the reference's stop test
+            # sees a NaN and raises (linalg.py:334-336) -- so must the product, on both kernel paths
+            for fast in (True, False):
+                with pytest.raises(RuntimeError):
+                    _product(n, bcs, dtype, rhs, x0, K, fast, monkeypatch)
+            continue
+        xb = x0.clone()
+        obcs = O.make_bcs(om, ocfg)
+        O.bc_fill(xb, obcs)
+        lap_o = O.apply_laplacian(O.laplacian_tables(xb, om, obcs), xb, len(n))
+        xf, rf, lap = _product(n, bcs, dtype, rhs, x0, K, True, monkeypatch)
+        xg, rg, _ = _product(n, bcs, dtype, rhs, x0, K, False, monkeypatch)
+        tol = 1e-10 if dtype == "double" else 2e-5
+        ok = (rf["itr"] == rg["itr"] == ro["itr"] and rel_err(xf, xo) <= tol and rel_err(xg, xo) <= tol
+              and rel_err(xf, xg) <= (1e-12 if dtype == "double" else 1e-5) and torch.equal(lap, lap_o))
+        if not ok:
+            bad.append((case, n, [t for t, _ in bcs], dtype, rel_err(xf, xo), rel_err(xg, xo), rel_err(xf, xg),
+                        bool(torch.equal(lap, lap_o))))
+            continue
+        if case % 3 == 0 and not any(t == "periodic" for t, _ in bcs):
+            # explicit Euler step (intended upwind) and two Jacobi sweeps on the same inputs
+            from pyapes_amd.solver.march import euler_step
+            nd = len(n)
+            mesh = Mesh(Box([0.0] * nd, [1.0 + 0.1 * a for a in range(nd)]), None, list(n), "cuda", dtype)
+            cfg = [{"bc_face": O.FACES[i], "bc_type": t, "bc_val": v, "bc_val_opt": None} for i, (t, v) in enumerate(bcs)]
+            phi = Field("phi", 1, mesh, {"domain": cfg, "obstacle": None})
+            phi.set_var_tensor(xb.cuda().clone())
+            euler_step(phi, 0.7, 1e-2, 1e-3, {"div": {"limiter": "upwind"}})
+            po = O.euler_step(xb.clone(), 0.7, 1e-2, 1e-3, om, obcs, "upwind")
+            if rel_err(phi().cpu(), po) > (1e-13 if dtype == "double" else 1e-6):
+                bad.append((case, n, [t for t, _ in bcs], dtype, "euler", rel_err(phi().cpu(), po)))
+            try:
+                with warnings.catch_warnings():
+                    warnings.simplefilter("ignore")
+                    xj, rj = O.solve_poisson(om, ocfg, rhs.clone(), x0=x0.clone(), method="jacobi", tol=-1.0, max_it=1,
+                                             coeff=0.8, sign=-1.0)
+            except RuntimeError:
+                continue
+            var = Field("p", 1, mesh, {"domain": cfg, "obstacle": None})
+            var.set_var_tensor(x0.cuda().clone())
+            sj = Solver({"fdm": {"method": "jacobi", "tol": -1.0, "max_it": 1, "report": False}})
+            sj.set_eq(-FDM().laplacian(0.8, var) == rhs.cuda().clone())
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                rpj = sj.solve()
+            if rpj["itr"] != rj["itr"] or rel_err(var().cpu(), xj) > tol:
+                bad.append((case, n, [t for t, _ in bcs], dtype, "jacobi", rel_err(var().cpu(), xj)))
+    assert not bad, bad[:6]
