@@ -133,3 +133,64 @@ def test_seeded_fuzz(monkeypatch):
             if rpj["itr"] != rj["itr"] or rel_err(var().cpu(), xj) > tol:
                 bad.append((case, n, [t for t, _ in bcs], dtype, "jacobi", rel_err(var().cpu(), xj)))
     assert not bad, bad[:6]
+
+
+def test_seeded_fuzz_explicit_operators():
+    """general Div (float / tensor / Jac advection, scalar and vector targets, edge or not, all three
+    schemes), Grad, DiffFlux, jacobian / hessian and -- on rz meshes -- friction / diffusion, against the
+    oracle, bit for bit, on random small extents."""
+    from pyapes_amd.geometry import Cylinder
+    from pyapes_amd.solver.fdc import hessian, jacobian
+    from pyapes_amd.solver.rfp import RFP
+    rng = random.Random(77)
+    bad = []
+    for case in range(120):
+        rz = rng.random() < 0.4
+        nd = 2 if rz else rng.choice([1, 2, 3])
+        n = [rng.choice([4, 5, 6, 7, 9, 12, 17]) for _ in range(nd)]
+        dtype = rng.choice(["double", "double", "single"])
+        tdt = torch.float64 if dtype == "double" else torch.float32
+        lo = [rng.choice([0.0, 0.5])] + [-1.0] * (nd - 1) if rz else [0.0] * nd
+        up = [lo[0] + 1.5] + [1.0] * (nd - 1) if rz else [1.0 + 0.2 * a for a in range(nd)]
+        geo = Cylinder if rz else Box
+        mesh = Mesh(geo(lo, up), None, list(n), "cuda", dtype)
+        om = O.OMesh(lo, up, list(n), dtype, "rz" if rz else "xyz")
+        g = torch.Generator().manual_seed(1000 + case)
+        rnd = lambda *shape: torch.randn(shape, generator=g, dtype=torch.float64).to(tdt)   # noqa: E731
+        phi, H, G = rnd(1, *n), rnd(1, *n), rnd(1, *n)
+        ut = rnd(nd, *n)
+        mk = lambda name, t: Field(name, t.shape[0], mesh, {"domain": None, "obstacle": None}).set_var_tensor(t.cuda().clone())   # noqa: E731
+        fphi, fH, fG = mk("phi", phi), mk("H", H), mk("G", G)
+        jac, hess = jacobian(fH), hessian(fG)
+        jo, ho = O.jacobian(H[0], om), O.hessian(G[0], om)
+        L = om.letters
+        checks = [("jac", all(torch.equal(jac[L[a]].cpu(), jo[L[a]]) for a in range(nd))),
+                  ("hess", all(torch.equal(hess[L[a] + L[b]].cpu(), ho[L[a] + L[b]]) for a in range(nd) for b in range(a, nd)))]
+        flux = FDC().diffFlux(hess, fphi)
+        fo = O.diff_flux(ho, phi[0], om)
+        checks.append(("flux", torch.equal(flux().cpu(), fo)))
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            for lim in ("none", "upwind"):
+                for edge in (True, False):
+                    fdc = FDC({"div": {"limiter": lim, "edge": edge, "compat": True}})
+                    e = (om, None)
+                    a1 = fdc.div(jac, fphi).cpu()
+                    o1 = O.apply_div(O.div_tables(jo, phi, om, [], lim), phi, nd, (om, jo) if edge else None)
+                    a2 = fdc.div(ut.cuda(), flux).cpu()
+                    o2 = O.apply_div(O.div_tables(ut, fo, om, [], lim), fo, nd, (om, ut) if edge else None)
+                    a3 = fdc.div(0.7, flux).cpu()
+                    o3 = O.apply_div(O.div_tables(0.7, fo, om, [], lim), fo, nd, (om, 0.7) if edge else None)
+                    checks.append((f"div {lim} edge={edge}", torch.equal(a1, o1) and torch.equal(a2, o2) and torch.equal(a3, o3)))
+            gr = FDC({"grad": {"edge": True}}).grad(fphi).cpu()
+            go = O.apply_grad(O.grad_tables(phi, om, []), phi, nd)
+            O.edge_grad(go, phi, om)
+            checks.append(("grad", torch.equal(gr, go)))
+        if rz:
+            rfp = RFP()
+            checks.append(("friction", torch.equal(rfp.friction(jac, fphi).cpu(), O.rfp_friction(jo, phi[0], om))))
+            checks.append(("diffusion", torch.equal(rfp.diffusion(hess, fphi).cpu(), O.rfp_diffusion(ho, phi[0], om))))
+        failed = [name for name, ok in checks if not ok]
+        if failed:
+            bad.append((case, "rz" if rz else "xyz", n, dtype, failed))
+    assert not bad, bad[:8]
