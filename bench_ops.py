@@ -123,6 +123,17 @@ def main():
     ms, wall, itr, N = solver_ms(lambda: Mesh(Box[0:1, 0:1, 0:1], None, [n, n, n], "cuda", "double"),
                                  mixed_bcs([0, 0, 0, 0, 1, 0], ["dirichlet", "neumann"] * 3), "bicgstab", 100)
     emit(f"bicgstab 3-D {n}^3 f64 mixed", N, ms, 22, 8, {"wall_ms_per_iter": wall, "iters": itr})
+    def advdiff_ms(n):
+        mesh = Mesh(Box[0:1, 0:1, 0:1], None, [n, n, n], "cuda", "double")
+        var = Field("p", 1, mesh, {"domain": homogeneous_bcs(3, 0.0, "dirichlet"), "obstacle": None})
+        s = Solver({"fdm": {"method": "bicgstab", "tol": -1.0, "max_it": 60, "report": False}})
+        fdm = FDM({"div": {"limiter": "upwind", "edge": False}})
+        s.set_eq(fdm.div(1.0, var) - fdm.laplacian(0.05, var) == torch.ones_like(var()))
+        rep = s.solve()
+        return var.last_gpu_ms / rep["itr"], rep["itr"], mesh.N
+
+    ms, itr, N = advdiff_ms(n)
+    emit(f"bicgstab 3-D {n}^3 f64 steady advection-diffusion (upwind Div + Laplacian)", N, ms, 22, 8, {"iters": itr})
     m2 = 1024 if q else 4096
     ms, wall, itr, N = solver_ms(lambda: Mesh(Box[0:1, 0:1], None, [m2, m2], "cuda", "double"),
                                  homogeneous_bcs(2, 0.0, "dirichlet"), "cg", 100)

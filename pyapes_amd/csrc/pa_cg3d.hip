@@ -121,7 +121,7 @@ __global__ void __launch_bounds__(256) k_cg3d(Cg3dArgs<T> A) {
     if (rc == 2) rowHi |= 1u << jj;
   }
   unsigned rowPLo = 0, rowPHi = 0, colPLo = 0, colPHi = 0;  // periodic rows of the central Div (fdc.py:596-602)
-  if (PHASE == 3) {
+  if (PHASE == 3 || KIND != 0) {
 #pragma unroll
     for (int jj = 0; jj < RJ; ++jj) {
       const int64_t jg = j0 + wv * RJ + jj;
@@ -280,7 +280,8 @@ __global__ void __launch_bounds__(256) k_cg3d(Cg3dArgs<T> A) {
   const int hasc = A.has_coeff;
   // the stencil works on whole V rows (packed fp32 multiplies / adds; the explicit Euler step moves only
   // 8 B / cell and is VALU-bound when written per component): per-component k-axis coefficients
-  constexpr bool VROW = (PHASE == 2 || PHASE == 3 || PHASE == 4);   // CG / BiCGSTAB phases: per component (A/B: -9 % on fp32 CG as V rows)
+  // CG / BiCGSTAB phases of a pure Laplacian: per component (A/B: -9 % on fp32 CG as V rows)
+  constexpr bool VROW = (PHASE == 2 || PHASE == 3 || PHASE == 4 || KIND != 0);
   V cPkV, cCkV, cMkV;
   if (VROW) {
 #pragma unroll
@@ -341,8 +342,8 @@ __global__ void __launch_bounds__(256) k_cg3d(Cg3dArgs<T> A) {
       if (rc == 1) { cPi = A.lap.c23[0]; cCi = -A.lap.c23[0]; cMi = (T)0; }
       if (rc == 2) { cPi = (T)0; cCi = -A.lap.c23[0]; cMi = A.lap.c23[0]; }
     }
-    const bool iPLo = PHASE == 3 && G.bct[0] == 4 && gi == 1;
-    const bool iPHi = PHASE == 3 && G.bct[1] == 4 && gi == G.g0 - 2;
+    const bool iPLo = (PHASE == 3 || KIND != 0) && G.bct[0] == 4 && gi == 1;
+    const bool iPHi = (PHASE == 3 || KIND != 0) && G.bct[1] == 4 && gi == G.g0 - 2;
     V res[RJ];
 #pragma unroll
     for (int jj = 0; jj < RJ; ++jj) {
@@ -392,10 +393,9 @@ __global__ void __launch_bounds__(256) k_cg3d(Cg3dArgs<T> A) {
           }
           axv = axv * sgn;
         }
-        if constexpr (PHASE == 3) {
-          const V ax = axv;
-          V uc;
-          if (A.aux) uc = xv[jj]; else uc = (V)A.u;
+        // Div(u phi) of this row with the scheme KIND (fdc.py:708-772; 4 = upwind as tests/test_fdm.py:239
+        // states it): shared by the explicit Euler step and the Laplacian + Div operators
+        auto div_row = [&](const V& uc) -> V {
           const V xp3[3] = {xpi, dn, xpk}, xm3[3] = {xmi, up, xmk};
           V adv = (V)(T)0;
           if (KIND == 4) {  // upwind as the reference's test states it
@@ -457,11 +457,25 @@ __global__ void __launch_bounds__(256) k_cg3d(Cg3dArgs<T> A) {
               adv = adv + t;
             }
           }
+          return adv;
+        };
+        if constexpr (PHASE == 3) {
+          const V ax = axv;
+          V uc;
+          if (A.aux) uc = xv[jj]; else uc = (V)A.u;
+          const V adv = div_row(uc);
           V q = A.p0 * ax;
           q = q - adv;
           q = A.p1 * q;
           res[jj] = xc + q;
           continue;
+        }
+        if constexpr (KIND != 0 && PHASE != 3) {
+          // sum_k sign_k Aop_k (ops.py:122-154) of {Laplacian, Div(scalar u)}: p0 = sign of the Div term,
+          // p1 != 0: the Div term comes first in the equation
+          V dv = div_row((V)A.u);
+          dv = dv * A.p0;
+          if (A.p1 != (T)0) axv = dv + axv; else axv = axv + dv;
         }
   #pragma unroll
         for (int v = 0; v < VEC; ++v) {
@@ -645,15 +659,33 @@ __global__ void __launch_bounds__(256) k_cg3d(Cg3dArgs<T> A) {
 }
 
 // ---- host side -------------------------------------------------------------------------------
+// The equations the tiled kernels evaluate: one Laplacian term, or -- for A x and the BiCGSTAB phases --
+// a Laplacian with a scalar coefficient plus a Div with a scalar advection speed, in either order
+// (steady advection-diffusion).  il / id: positions of the two terms (id = -1: no Div).
+template <typename T>
+static bool eq_lap_div(const DevEq<T>& E, int& il, int& id) {
+  il = id = -1;
+  if (E.nterms == 1 && E.t[0].kind == PA_OP_LAPLACIAN) { il = 0; return true; }
+  if (E.nterms != 2) return false;
+  for (int q = 0; q < 2; ++q) {
+    const int k = E.t[q].kind;
+    if (k == PA_OP_LAPLACIAN) il = q;
+    else if ((k == PA_OP_DIV_CENTRAL || k == PA_OP_DIV_UPWIND_COMPAT || k == PA_OP_DIV_UPWIND) && !E.t[q].u_f) id = q;
+  }
+  return il >= 0 && id >= 0 && !E.t[il].coeff_f;
+}
+
 // 0: not for the tiled kernels; 1: 16-byte vector lanes; 2: one cell per lane (NARROW)
 template <typename T>
-static int cg3d_mode(const pa_ctx* c, const DevEq<T>& E, std::initializer_list<const void*> ptrs) {
+static int cg3d_mode(const pa_ctx* c, const DevEq<T>& E, std::initializer_list<const void*> ptrs,
+                     bool allow_div = false) {
   if (!c->fastpath) return 0;
   if (c->coord != PA_COORD_XYZ) return 0;  // r-dependent rows: generic kernels
   if (c->ndim != 3 && c->ndim != 2) return 0;
-  if (E.nterms != 1 || E.t[0].kind != PA_OP_LAPLACIAN) return 0;
+  int il, id;
+  if (!eq_lap_div<T>(E, il, id) || (id >= 0 && !allow_div)) return 0;
   if ((c->ndim == 3 && c->G.n0 < 3) || c->G.n1 < 3 || c->G.n2 < 3) return 0;
-  uintptr_t bits = (uintptr_t)E.t[0].coeff_f;
+  uintptr_t bits = (uintptr_t)E.t[il].coeff_f;
   for (const void* q : ptrs) bits |= (uintptr_t)q;
   if (bits & (sizeof(T) - 1)) return 0;
   constexpr int VEC = VecOf<T>::N;
@@ -775,6 +807,22 @@ static int launch_any_w(pa_ctx* c, Cg3dArgs<T>& A) {
     }
 #undef PA_EULER_CASE
   }
+  if constexpr (PHASE == 2 || PHASE == 5 || PHASE == 6) {
+    if (A.kind != 0) {  // Laplacian + Div(scalar u): one instantiation per scheme, two or four rows per thread
+      const bool four = pick_rj<T>(c, NARROW) == 4;
+#define PA_DIV_CASE(K)                                                                   \
+      case K:                                                                            \
+        return four ? launch_cg3d<T, 4, PHASE, false, K, NARROW>(c, A)                   \
+                    : launch_cg3d<T, 2, PHASE, false, K, NARROW>(c, A);
+      switch (A.kind) {
+        PA_DIV_CASE(PA_OP_DIV_CENTRAL)
+        PA_DIV_CASE(PA_OP_DIV_UPWIND_COMPAT)
+        PA_DIV_CASE(PA_OP_DIV_UPWIND)
+        default: return 0;
+      }
+#undef PA_DIV_CASE
+    }
+  }
   switch (pick_rj<T>(c, NARROW)) {
     case 1: return launch_cg3d<T, 1, PHASE, false, 0, NARROW>(c, A);
     case 2: return launch_cg3d<T, 2, PHASE, false, 0, NARROW>(c, A);
@@ -789,13 +837,28 @@ static int launch_any(pa_ctx* c, Cg3dArgs<T>& A, int mode) {
 
 template <typename T>
 static void fill_common(pa_ctx* c, const DevEq<T>& E, Cg3dArgs<T>& A) {
+  int il = 0, id = -1;
+  (void)eq_lap_div<T>(E, il, id);
+  if (il < 0) il = 0;
   A.G = c->G;
   A.lap = E.lap;
-  A.coeff = E.t[0].coeff;
-  A.coeff_f = E.t[0].coeff_f;
-  A.sign = E.t[0].sign;
-  A.has_coeff = E.t[0].has_coeff;
+  A.coeff = E.t[il].coeff;
+  A.coeff_f = E.t[il].coeff_f;
+  A.sign = E.t[il].sign;
+  A.has_coeff = E.t[il].has_coeff;
   A.sc = c->sc;
+  if (id >= 0) {  // Laplacian + Div: scheme, speed, sign of the Div term, and whether it is listed first
+    for (int a = 0; a < 3; ++a) {
+      T h = (T)c->dx[a];
+      A.hh[a] = h;
+      A.h2[a] = (T)2 * h;
+      A.ih[a] = (T)1 / h;
+    }
+    A.kind = E.t[id].kind;
+    A.u = E.t[id].u;
+    A.p0 = E.t[id].sign;
+    A.p1 = id < il ? (T)1 : (T)0;
+  }
 }
 
 template <typename T>
@@ -842,7 +905,7 @@ static void fill_h(const pa_ctx* c, Cg3dArgs<T>& A) {
 
 template <typename T>
 int pa_tile3d_aop(pa_ctx* c, const DevEq<T>& E, Vec<T> x, T* y, int interior_only) {
-  const int mode = cg3d_mode<T>(c, E, {x.p, y, x.glo, x.ghi});
+  const int mode = cg3d_mode<T>(c, E, {x.p, y, x.glo, x.ghi}, true);
   if (!mode) return 0;
   Cg3dArgs<T> A;
   memset(&A, 0, sizeof(A));
@@ -889,7 +952,7 @@ int pa_tile3d_jacobi(pa_ctx* c, const DevEq<T>& E, Vec<T> x, const T* rhs, T* xn
 template <typename T>
 int pa_tile3d_bicg_pv(pa_ctx* c, const DevEq<T>& E, Vec<T> r, Vec<T> p, Vec<T> v, const T* r0, T* pnew, T* vnew,
                       double* partials) {
-  const int mode = cg3d_mode<T>(c, E, {r.p, p.p, v.p, r0, pnew, vnew, r.glo, r.ghi, p.glo, p.ghi, v.glo, v.ghi});
+  const int mode = cg3d_mode<T>(c, E, {r.p, p.p, v.p, r0, pnew, vnew, r.glo, r.ghi, p.glo, p.ghi, v.glo, v.ghi}, true);
   if (!mode) return 0;
   Cg3dArgs<T> A;
   memset(&A, 0, sizeof(A));
@@ -903,7 +966,7 @@ int pa_tile3d_bicg_pv(pa_ctx* c, const DevEq<T>& E, Vec<T> r, Vec<T> p, Vec<T> v
 template <typename T>
 int pa_tile3d_bicg_st(pa_ctx* c, const DevEq<T>& E, Vec<T> r, Vec<T> v, const T* r0, T* s_out, T* t_out,
                       double* partials) {
-  const int mode = cg3d_mode<T>(c, E, {r.p, v.p, r0, s_out, t_out, r.glo, r.ghi, v.glo, v.ghi});
+  const int mode = cg3d_mode<T>(c, E, {r.p, v.p, r0, s_out, t_out, r.glo, r.ghi, v.glo, v.ghi}, true);
   if (!mode) return 0;
   Cg3dArgs<T> A;
   memset(&A, 0, sizeof(A));
