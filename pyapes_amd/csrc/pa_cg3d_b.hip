@@ -1,0 +1,51 @@
+// pa_cg3d_b.hip -- instantiations of the tiled kernel: A x (Laplacian, or Laplacian + Div) and the two
+// BiCGSTAB phases (kernel and launch helpers: pa_cg3d_kernel.h)
+#include "pa_cg3d_kernel.h"
+
+template <typename T>
+int pa_tile3d_aop(pa_ctx* c, const DevEq<T>& E, Vec<T> x, T* y, int interior_only) {
+  const int mode = cg3d_mode<T>(c, E, {x.p, y, x.glo, x.ghi}, true);
+  if (!mode) return 0;
+  Cg3dArgs<T> A;
+  memset(&A, 0, sizeof(A));
+  fill_common<T>(c, E, A);
+  A.d = x; A.out = y; A.interior_only = interior_only;
+  int n = launch_any<T, 2>(c, A, mode);
+  if (n > 0 && hipGetLastError() != hipSuccess) { pa_set_err(c, "k_cg3d A x launch failed"); return PA_E_HIP; }
+  return n;
+}
+
+template <typename T>
+int pa_tile3d_bicg_pv(pa_ctx* c, const DevEq<T>& E, Vec<T> r, Vec<T> p, Vec<T> v, const T* r0, T* pnew, T* vnew,
+                      double* partials) {
+  const int mode = cg3d_mode<T>(c, E, {r.p, p.p, v.p, r0, pnew, vnew, r.glo, r.ghi, p.glo, p.ghi, v.glo, v.ghi}, true);
+  if (!mode) return 0;
+  Cg3dArgs<T> A;
+  memset(&A, 0, sizeof(A));
+  fill_common<T>(c, E, A);
+  A.r = r; A.d = p; A.v = v; A.aux = r0; A.out = pnew; A.out2 = vnew; A.partials = partials;
+  int n = launch_any<T, 5>(c, A, mode);
+  if (n > 0 && hipGetLastError() != hipSuccess) { pa_set_err(c, "k_cg3d BiCGSTAB p/v launch failed"); return PA_E_HIP; }
+  return n;
+}
+
+template <typename T>
+int pa_tile3d_bicg_st(pa_ctx* c, const DevEq<T>& E, Vec<T> r, Vec<T> v, const T* r0, T* s_out, T* t_out,
+                      double* partials) {
+  const int mode = cg3d_mode<T>(c, E, {r.p, v.p, r0, s_out, t_out, r.glo, r.ghi, v.glo, v.ghi}, true);
+  if (!mode) return 0;
+  Cg3dArgs<T> A;
+  memset(&A, 0, sizeof(A));
+  fill_common<T>(c, E, A);
+  A.r = r; A.d = v; A.aux = r0; A.out = s_out; A.out2 = t_out; A.partials = partials;
+  int n = launch_any<T, 6>(c, A, mode);
+  if (n > 0 && hipGetLastError() != hipSuccess) { pa_set_err(c, "k_cg3d BiCGSTAB s/t launch failed"); return PA_E_HIP; }
+  return n;
+}
+
+template int pa_tile3d_bicg_pv<float>(pa_ctx*, const DevEq<float>&, Vec<float>, Vec<float>, Vec<float>, const float*, float*, float*, double*);
+template int pa_tile3d_bicg_pv<double>(pa_ctx*, const DevEq<double>&, Vec<double>, Vec<double>, Vec<double>, const double*, double*, double*, double*);
+template int pa_tile3d_bicg_st<float>(pa_ctx*, const DevEq<float>&, Vec<float>, Vec<float>, const float*, float*, float*, double*);
+template int pa_tile3d_bicg_st<double>(pa_ctx*, const DevEq<double>&, Vec<double>, Vec<double>, const double*, double*, double*, double*);
+template int pa_tile3d_aop<float>(pa_ctx*, const DevEq<float>&, Vec<float>, float*, int);
+template int pa_tile3d_aop<double>(pa_ctx*, const DevEq<double>&, Vec<double>, double*, int);

@@ -1,0 +1,877 @@
+// pa_cg3d_kernel.h -- the tiled marching kernel k_cg3d and its launch helpers, shared by the two
+// translation units that instantiate it (pa_cg3d.hip: CG phases, Euler step, Jacobi sweep;
+// pa_cg3d_b.hip: A x and the BiCGSTAB phases) so that they compile in parallel.
+#pragma once
+// The tiled fast path (2-D / 3-D) of the CG phases, the single-field phases and the BiCGSTAB phases for gfx950 (MI355X).
+//
+// Equation covered: one Laplacian term (scalar or no coefficient), any BC mix, fp64 / fp32,
+// single GPU or slab (ghost planes through Vec<T>).  Anything else returns 0 and the caller
+// launches the generic kernels of pa_core.hip.
+//
+// Data movement (both phases are HBM-bound; no MFMA):
+//   phase A  reads r, d      writes d' = r + beta d          + sum d'.(A d')      3 array passes
+//   phase B  reads x, r, d'  writes x += alpha d', r -= alpha A d'  + sums        5 array passes
+// A d' is never stored: phase B recomputes it from d' (13 flops) instead of moving 16 B/cell
+// through HBM twice, so an iteration moves 8 passes where the algorithmic count is 10.
+//
+// Tiling.  A workgroup (256 threads = 4 wave64) owns an in-plane tile of TJ = 4*RJ rows by
+// TK = 64*VEC contiguous k cells (VEC = 16 B / sizeof(T): every global access is a 16-byte
+// lane access, a wave covers 1 KiB of one row) and MARCHES along the slow axis i over a chunk
+// of planes.  Per thread the planes i-1, i, i+1 of its own RJ x VEC cells stay in registers;
+// the current plane, plus a halo ring (one row above / below, one cell left / right, loaded
+// with wrap-around indices = torch.roll semantics), is staged in LDS (double buffered, one
+// barrier per plane) for the j+-1 / k+-1 neighbours.  Each value is therefore read from
+// HBM/L2 once per chunk; the halo ring and the two extra planes per chunk are the only
+// re-reads and are mostly L2 hits because the tiles of one chunk run on one XCD at the same
+// time (blockIdx -> (chunk, tile) is XCD-aware: blocks b and b+8 share an XCD's L2).
+// Phase B marches the chunk in the opposite direction, so the planes phase A touched last
+// (still in the 256 MiB Infinity Cache) are the ones phase B reads first, and vice versa.
+//
+// The grid is exactly one resident wave of workgroups: chunks = capacity / tiles, so every
+// CU carries the same number of identical work items and nothing queues behind a tail.
+#include "pa_host.h"
+#include "pa_epilogue.h"
+
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+template <typename T> struct VecOf;
+template <> struct VecOf<double> { static constexpr int N = 2; typedef double type __attribute__((ext_vector_type(2))); };
+template <> struct VecOf<float>  { static constexpr int N = 4; typedef float type __attribute__((ext_vector_type(4))); };
+
+template <typename T>
+struct Cg3dArgs {
+  DevGeom G;
+  LapCoef<T> lap;
+  T coeff, sign;
+  int has_coeff;
+  const T* coeff_f;     // tensor coefficient Gamma(x) of laplacian(Gamma, phi) (fdm.py:166-169) or null
+  const SolverScalars* sc;
+  Vec<T> r, d;          // phase A: r and the old direction; phase B: d = new direction
+  T* dnew;              // phase A output
+  T* x;                 // phase B in/out
+  T* rw;                // phase B in/out (residual)
+  T* send_lo;           // phase B: copies of r's first / last owned plane (slab) or null
+  T* send_hi;
+  double* partials;
+  int tiles_j, tiles_k, chunks, reverse;
+  // single-field phases (2 = A x, 3 = explicit Euler step, 4 = Jacobi sweep): the field is `d`
+  const T* aux;         // Jacobi: rhs ; Euler: advection field u (or null) ; BiCGSTAB: r0
+  T* out;               // result field
+  // BiCGSTAB phases (5: p' = r + beta (p - omega v), v' = A p' ; 6: s = r - alpha v, t = A s)
+  Vec<T> v;             // third input field of phase 5 (v) ; phase 6 uses r and d (= v)
+  T* out2;              // second result field (v' / t)
+  T p0, p1, u;          // Euler: nu, dt, scalar u ; Jacobi: omega
+  T hh[3], h2[3], ih[3];  // h, fl(2h), fl(1/h) per axis
+  int kind;             // Euler: PA_OP_DIV_*
+  int interior_only;    // A x: zero outside the interior set
+  CgEpi epi;            // phases 0 / 1: the last block finishes the reduction (pa_epilogue.h)
+};
+
+__device__ __forceinline__ int pa_xcd_remap(int b, int nb) {
+  // blocks b, b+8, b+16 ... share an XCD: give each XCD a contiguous range of work items
+  const int q = nb >> 3, r = nb & 7, xcd = b & 7, w = b >> 3;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + w;
+}
+
+__device__ __forceinline__ int64_t pa_wrapmod(int64_t v, int64_t n) {
+  v %= n;
+  return v < 0 ? v + n : v;
+}
+
+// KIND: the Div scheme of the explicit Euler step (PHASE 3) as a compile-time constant -- with all three
+// schemes in one body the uniform operands no longer fit the scalar registers and get spilled into
+// vector lanes (v_readlane / v_writelane were a third of the VALU instructions of that kernel)
+// NARROW: one cell per lane instead of a 16-byte vector.  For rows whose length is not a multiple of
+// the vector width (node-based meshes love 2^k + 1) or operands that are not 16-byte aligned: no
+// partial vectors, no alignment demand beyond sizeof(T); everything else is the same code.
+template <typename T, int RJ, int PHASE, bool CF = false, int KIND = 0, bool NARROW = false>
+__global__ void __launch_bounds__(256) k_cg3d(Cg3dArgs<T> A) {
+  constexpr int VEC = NARROW ? 1 : VecOf<T>::N;
+  typedef T V __attribute__((ext_vector_type(VEC)));
+  constexpr int TJ = 4 * RJ, TK = 64 * VEC, TKP = TK + 2 * VEC;
+  __shared__ __attribute__((aligned(16))) T tile[2][TJ + 2][TKP];
+
+  if (PHASE != 2 && PHASE != 3 && A.sc->done) return;
+  (void)sizeof(int[PHASE >= 0 && PHASE <= 6 ? 1 : -1]);
+  const DevGeom& G = A.G;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int vb = pa_xcd_remap(blockIdx.x, gridDim.x);
+  const int tiles = A.tiles_j * A.tiles_k;
+  const int chunk = vb / tiles, tl = vb - chunk * tiles;
+  const int tjb = tl / A.tiles_k, tkb = tl - tjb * A.tiles_k;
+  const int64_t i0 = (int64_t)chunk * G.n0 / A.chunks, i1 = (int64_t)(chunk + 1) * G.n0 / A.chunks;
+  const int CI = (int)(i1 - i0);
+  const int64_t j0 = (int64_t)tjb * TJ, k0 = (int64_t)tkb * TK;
+  const int rev = A.reverse;
+
+  // ---- per-thread geometry: RJ rows x VEC columns --------------------------------
+  const int64_t kg = k0 + (int64_t)lane * VEC;            // global k of element 0 (may be >= n2)
+  const int64_t kc = pa_wrapmod(kg, G.n2);                // wrapped column used for loads
+  const bool kvalid = kg < G.n2;
+  int64_t jrow[RJ];
+  unsigned rowS = 0, rowShell = 0, rowValid = 0, rowLo = 0, rowHi = 0;
+#pragma unroll
+  for (int jj = 0; jj < RJ; ++jj) {
+    const int64_t jg = j0 + wv * RJ + jj;
+    jrow[jj] = pa_wrapmod(jg, G.n1);
+    const bool valid = jg < G.n1;
+    if (valid) rowValid |= 1u << jj;
+    if (valid && jg >= G.slo[1] && jg <= G.shi[1]) rowS |= 1u << jj;
+    if (jg == 0 || jg == G.n1 - 1) rowShell |= 1u << jj;
+    const int rc = pa_row_case(G, 1, jg, G.n1, G.treat);
+    if (rc == 1) rowLo |= 1u << jj;
+    if (rc == 2) rowHi |= 1u << jj;
+  }
+  unsigned rowPLo = 0, rowPHi = 0, colPLo = 0, colPHi = 0;  // periodic rows of the central Div (fdc.py:596-602)
+  if (PHASE == 3 || KIND != 0) {
+#pragma unroll
+    for (int jj = 0; jj < RJ; ++jj) {
+      const int64_t jg = j0 + wv * RJ + jj;
+      if (G.bct[2] == 4 && jg == 1) rowPLo |= 1u << jj;
+      if (G.bct[3] == 4 && jg == G.n1 - 2) rowPHi |= 1u << jj;
+    }
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) {
+      if (G.bct[4] == 4 && kg + v == 1) colPLo |= 1u << v;
+      if (G.bct[5] == 4 && kg + v == G.n2 - 2) colPHi |= 1u << v;
+    }
+  }
+  unsigned colS = 0, colShell = 0, colLo = 0, colHi = 0;
+#pragma unroll
+  for (int v = 0; v < VEC; ++v) {
+    const int64_t kk = kg + v;
+    if (kvalid && kk >= G.slo[2] && kk <= G.shi[2]) colS |= 1u << v;
+    if (kk == 0 || kk == G.n2 - 1) colShell |= 1u << v;
+    const int rc = pa_row_case(G, 2, kk, G.n2, G.treat);
+    if (rc == 1) colLo |= 1u << v;
+    if (rc == 2) colHi |= 1u << v;
+  }
+  // halo duty of this wave: wave 0 -> row above the tile, wave 3 -> row below (vector loads);
+  // wave 1, lanes < 2*TJ -> the single cells left / right of each tile row (scalar loads)
+  const int64_t hrow = (wv == 0) ? pa_wrapmod(j0 - 1, G.n1) : pa_wrapmod(j0 + TJ, G.n1);
+  const bool hvec = (wv == 0 || wv == 3);
+  const bool hsc = (wv == 1 && lane < 2 * TJ);
+  const int hs_row = lane >> 1, hs_side = lane & 1;
+  const int64_t hs_off = pa_wrapmod(j0 + hs_row, G.n1) * G.s1 +
+                         (hs_side ? pa_wrapmod(k0 + TK, G.n2) : pa_wrapmod(k0 - 1, G.n2));
+
+  T beta = (T)0, alpha = (T)0;
+  T omega = (T)0;
+  if (PHASE == 0) beta = (T)A.sc->beta;
+  if (PHASE == 1) alpha = (T)A.sc->alpha;
+  if (PHASE == 5) { beta = (T)A.sc->beta; omega = (T)A.sc->omega; }
+  if (PHASE == 6) alpha = (T)A.sc->alpha;
+
+  auto plane_of = [&](int q) -> int64_t { return rev ? (i1 - 1 - q) : (i0 + q); };
+  auto pptr = [&](const Vec<T>& v, int64_t ii) -> const T* {
+    return ii < 0 ? v.glo : (ii >= G.n0 ? v.ghi : v.p + ii * G.s0);
+  };
+
+  // Raw loads of one plane (own cells + this wave's share of the halo ring).  They are only
+  // ISSUED here; the arithmetic that consumes them (finish_*) is placed after the stencil of the
+  // current plane, so the s_waitcnt lands there and the loads fly during the stencil.
+  struct Raw {
+    V d[RJ];
+    V r[RJ];   // phases A, 5, 6
+    V q[RJ];   // phase 5 (v)
+    V hd, hr, hq;  // halo row (waves 0 and 3)
+    T sd, sr, sq;  // halo cell (wave 1)
+  };
+  constexpr bool HAS_R = (PHASE == 0 || PHASE == 5 || PHASE == 6);
+  constexpr bool HAS_Q = (PHASE == 5);
+  auto issue = [&](int64_t ii, Raw& w, bool with_halo) {
+    const T* dp = pptr(A.d, ii);
+    const T* rp = HAS_R ? pptr(A.r, ii) : dp;
+    const T* qp = HAS_Q ? pptr(A.v, ii) : dp;
+#pragma unroll
+    for (int jj = 0; jj < RJ; ++jj) {
+      const int64_t o = jrow[jj] * G.s1 + kc;
+      w.d[jj] = *reinterpret_cast<const V*>(dp + o);
+      if (HAS_R) w.r[jj] = *reinterpret_cast<const V*>(rp + o);
+      if (HAS_Q) w.q[jj] = *reinterpret_cast<const V*>(qp + o);
+    }
+    if (with_halo) {
+      if (hvec) {
+        const int64_t o = hrow * G.s1 + kc;
+        w.hd = *reinterpret_cast<const V*>(dp + o);
+        if (HAS_R) w.hr = *reinterpret_cast<const V*>(rp + o);
+        if (HAS_Q) w.hq = *reinterpret_cast<const V*>(qp + o);
+      }
+      if (hsc) {
+        w.sd = dp[hs_off];
+        if (HAS_R) w.sr = rp[hs_off];
+        if (HAS_Q) w.sq = qp[hs_off];
+      }
+    }
+  };
+  // the staged field from the raw loads: phase A r + beta d ; phase 5 r + beta (p - omega v)
+  // (linalg.py:217) ; phase 6 r - alpha v (linalg.py:230) ; else the field itself
+  auto combine = [&](T rr_, T dd_, T qq_) -> T {
+    if (PHASE == 0) {
+      T bd = beta * dd_;
+      return rr_ + bd;
+    } else if (PHASE == 5) {
+      T t = omega * qq_;
+      t = dd_ - t;
+      t = beta * t;
+      return rr_ + t;
+    } else if (PHASE == 6) {
+      T av = alpha * dd_;
+      return rr_ - av;
+    }
+    return dd_;
+  };
+  auto finish_own = [&](const Raw& w, V (&e)[RJ]) {
+#pragma unroll
+    for (int jj = 0; jj < RJ; ++jj) {
+#pragma unroll
+      for (int v = 0; v < VEC; ++v)
+        e[jj][v] = combine(HAS_R ? w.r[jj][v] : (T)0, w.d[jj][v], HAS_Q ? w.q[jj][v] : (T)0);
+    }
+  };
+  auto finish_halo = [&](const Raw& w, V& hv, T& hs) {
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) hv[v] = combine(HAS_R ? w.hr[v] : (T)0, w.hd[v], HAS_Q ? w.hq[v] : (T)0);
+    hs = combine(HAS_R ? w.sr : (T)0, w.sd, HAS_Q ? w.sq : (T)0);
+  };
+  auto stage = [&](int buf, const V (&e)[RJ], const V& hv, const T& hs) {
+#pragma unroll
+    for (int jj = 0; jj < RJ; ++jj)
+      *reinterpret_cast<V*>(&tile[buf][wv * RJ + jj + 1][VEC + lane * VEC]) = e[jj];
+    if (hvec) *reinterpret_cast<V*>(&tile[buf][wv == 0 ? 0 : TJ + 1][VEC + lane * VEC]) = hv;
+    if (hsc) tile[buf][hs_row + 1][hs_side ? VEC + TK : VEC - 1] = hs;
+  };
+
+  V ea[RJ], ec[RJ], eb[RJ];  // behind / current / ahead in march order
+  V hv;
+  T hs = (T)0;
+  Raw w;
+#pragma unroll
+  for (int v = 0; v < VEC; ++v) { hv[v] = (T)0; w.hd[v] = (T)0; w.hr[v] = (T)0; w.hq[v] = (T)0; }
+  w.sd = (T)0; w.sr = (T)0; w.sq = (T)0;
+
+  // ---- prologue -----------------------------------------------------------------------
+  const bool act0 = G.act[0] != 0;   // 2-D meshes occupy internal axes 1,2: a single plane, no i-neighbours
+  if (act0) {
+    issue(plane_of(-1), w, false);
+    finish_own(w, ea);
+  } else {
+#pragma unroll
+    for (int jj = 0; jj < RJ; ++jj)
+#pragma unroll
+      for (int v = 0; v < VEC; ++v) ea[jj][v] = (T)0;
+  }
+  issue(plane_of(0), w, true);
+  finish_own(w, ec);
+  finish_halo(w, hv, hs);
+  stage(0, ec, hv, hs);
+  if (act0) {
+    issue(plane_of(1), w, CI > 1);
+    finish_own(w, eb);
+    finish_halo(w, hv, hs);
+  } else {
+#pragma unroll
+    for (int jj = 0; jj < RJ; ++jj)
+#pragma unroll
+      for (int v = 0; v < VEC; ++v) eb[jj][v] = (T)0;
+  }
+  __syncthreads();
+
+  double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+  const T sgn = A.sign, cf = A.coeff;
+  const int hasc = A.has_coeff;
+  // the stencil works on whole V rows (packed fp32 multiplies / adds; the explicit Euler step moves only
+  // 8 B / cell and is VALU-bound when written per component): per-component k-axis coefficients
+  // CG / BiCGSTAB phases of a pure Laplacian: per component (A/B: -9 % on fp32 CG as V rows)
+  constexpr bool VROW = (PHASE == 2 || PHASE == 3 || PHASE == 4 || KIND != 0);
+  V cPkV, cCkV, cMkV;
+  if (VROW) {
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) {
+      T p = A.lap.inv[2], c0 = A.lap.m2inv[2], mq = A.lap.inv[2];
+      if (colLo >> v & 1) { p = A.lap.c23[2]; c0 = -A.lap.c23[2]; mq = (T)0; }
+      if (colHi >> v & 1) { p = (T)0; c0 = -A.lap.c23[2]; mq = A.lap.c23[2]; }
+      cPkV[v] = p; cCkV[v] = c0; cMkV[v] = mq;
+    }
+  }
+
+  for (int m = 0; m < CI; ++m) {
+    const int buf = m & 1;
+    const int64_t ii = plane_of(m);
+    const bool more = m + 1 < CI;
+    // plane m+1 into the other LDS buffer (its last readers passed the barrier of step m-1)
+    if (more) stage(buf ^ 1, eb, hv, hs);
+    // phase B: the thread's x and r of THIS plane, issued first so that their wait (at the update,
+    // below the stencil) does not have to cover the younger loads of plane m+2
+    V xv[RJ], rv[RJ];
+    if (PHASE == 1) {
+#pragma unroll
+      for (int jj = 0; jj < RJ; ++jj) {
+        const int64_t o = ii * G.s0 + jrow[jj] * G.s1 + kc;
+        // x and r are touched exactly once per iteration: non-temporal, so that they do not evict the
+        // halo rows / planes of d' other workgroups are about to re-read from L2 (measured -3 % on
+        // the iteration at 512^3; non-temporal loads of d / r themselves cost +6 % in phase A)
+        if (NARROW) {   // 8-byte / 4-byte lanes: the streaming hint costs 8-17 % here (interleaved A/B)
+          xv[jj] = *reinterpret_cast<const V*>(A.x + o);
+          rv[jj] = *reinterpret_cast<const V*>(A.rw + o);
+        } else {
+          xv[jj] = __builtin_nontemporal_load(reinterpret_cast<const V*>(A.x + o));
+          rv[jj] = __builtin_nontemporal_load(reinterpret_cast<const V*>(A.rw + o));
+        }
+      }
+    }
+    V cv[RJ];
+    if (CF) {
+#pragma unroll
+      for (int jj = 0; jj < RJ; ++jj)
+        cv[jj] = *reinterpret_cast<const V*>(A.coeff_f + ii * G.s0 + jrow[jj] * G.s1 + kc);
+    }
+    if (PHASE == 4 || PHASE == 5 || PHASE == 6 || (PHASE == 3 && A.aux)) {  // rhs / u / r0 of this plane
+#pragma unroll
+      for (int jj = 0; jj < RJ; ++jj)
+        xv[jj] = *reinterpret_cast<const V*>(A.aux + ii * G.s0 + jrow[jj] * G.s1 + kc);
+    }
+    // loads of plane m+2 (own cells + halo): in flight during the stencil below
+    if (more) issue(plane_of(m + 2), w, m + 2 < CI);
+
+    // ---- stencil on plane ii, every cell of the thread (masks are applied afterwards) --------
+    const int64_t gi = ii + G.off0;
+    const bool iS = gi >= G.slo[0] && gi <= G.shi[0];
+    const bool iShell = act0 && (gi == 0 || gi == G.g0 - 1);
+    T cPi = A.lap.inv[0], cCi = A.lap.m2inv[0], cMi = A.lap.inv[0];
+    {
+      const int rc = pa_row_case(G, 0, gi, G.g0, G.treat);
+      if (rc == 1) { cPi = A.lap.c23[0]; cCi = -A.lap.c23[0]; cMi = (T)0; }
+      if (rc == 2) { cPi = (T)0; cCi = -A.lap.c23[0]; cMi = A.lap.c23[0]; }
+    }
+    const bool iPLo = (PHASE == 3 || KIND != 0) && G.bct[0] == 4 && gi == 1;
+    const bool iPHi = (PHASE == 3 || KIND != 0) && G.bct[1] == 4 && gi == G.g0 - 2;
+    V res[RJ];
+#pragma unroll
+    for (int jj = 0; jj < RJ; ++jj) {
+      const int R = wv * RJ + jj + 1;
+      T cPj = A.lap.inv[1], cCj = A.lap.m2inv[1], cMj = A.lap.inv[1];
+      if (rowLo >> jj & 1) { cPj = A.lap.c23[1]; cCj = -A.lap.c23[1]; cMj = (T)0; }
+      if (rowHi >> jj & 1) { cPj = (T)0; cCj = -A.lap.c23[1]; cMj = A.lap.c23[1]; }
+      // j-1 / j+1: registers inside the thread's row block, LDS across it
+      V up, dn;
+      if (jj > 0) up = ec[jj - 1]; else up = *reinterpret_cast<const V*>(&tile[buf][R - 1][VEC + lane * VEC]);
+      if (jj < RJ - 1) dn = ec[jj + 1]; else dn = *reinterpret_cast<const V*>(&tile[buf][R + 1][VEC + lane * VEC]);
+      const T left = tile[buf][R][VEC + lane * VEC - 1];
+      const T right = tile[buf][R][VEC + lane * VEC + VEC];
+      if constexpr (VROW) {
+        // A x of this row, one V at a time: the same operations in the same order as a per-component loop
+        const V xc = ec[jj];
+        const V xpi = rev ? ea[jj] : eb[jj];
+        const V xmi = rev ? eb[jj] : ea[jj];
+        V xpk, xmk;
+  #pragma unroll
+        for (int v = 0; v < VEC; ++v) {
+          xpk[v] = (v < VEC - 1) ? xc[v + 1 < VEC ? v + 1 : v] : right;
+          xmk[v] = (v > 0) ? xc[v > 0 ? v - 1 : 0] : left;
+        }
+        V axv;
+        {
+          V s = cPi * xpi;
+          V mm = cCi * xc;
+          s = s + mm;
+          mm = cMi * xmi;
+          s = s + mm;
+          if (act0) axv = s; else axv = (V)(T)0;
+          s = cPj * dn;
+          mm = cCj * xc;
+          s = s + mm;
+          mm = cMj * up;
+          s = s + mm;
+          axv = axv + s;
+          s = cPkV * xpk;
+          mm = cCkV * xc;
+          s = s + mm;
+          mm = cMkV * xmk;
+          s = s + mm;
+          axv = axv + s;
+          if (hasc) {
+            if (CF) axv = axv * cv[jj]; else axv = axv * cf;
+          }
+          axv = axv * sgn;
+        }
+        // Div(u phi) of this row with the scheme KIND (fdc.py:708-772; 4 = upwind as tests/test_fdm.py:239
+        // states it): shared by the explicit Euler step and the Laplacian + Div operators
+        auto div_row = [&](const V& uc) -> V {
+          const V xp3[3] = {xpi, dn, xpk}, xm3[3] = {xmi, up, xmk};
+          V adv = (V)(T)0;
+          if (KIND == 4) {  // upwind as the reference's test states it
+            V upl, umi;
+  #pragma unroll
+            for (int v = 0; v < VEC; ++v) {
+              upl[v] = uc[v] > (T)0 ? uc[v] : (T)0;
+              umi[v] = uc[v] < (T)0 ? uc[v] : (T)0;
+            }
+  #pragma unroll
+            for (int a = 0; a < 3; ++a) {
+              if (a == 0 && !act0) continue;
+              V bwd = xc - xm3[a];
+              V fwd = xp3[a] - xc;
+              V t = upl * bwd;
+              V m2 = umi * fwd;
+              t = t + m2;
+              t = t * A.ih[a];
+              adv = adv + t;
+            }
+          } else if (KIND == 3) {  // literal reference upwind
+            V cP, cC, cM;
+  #pragma unroll
+            for (int v = 0; v < VEC; ++v) {
+              cP[v] = (T)2 * (uc[v] < (T)0 ? uc[v] : (T)0);
+              cC[v] = (T)0 * ((T)2 * uc[v]);
+              cM[v] = (T)2 * (uc[v] > (T)0 ? uc[v] : (T)0);
+            }
+  #pragma unroll
+            for (int a = 0; a < 3; ++a) {
+              if (a == 0 && !act0) continue;
+              V t = cP * xp3[a];
+              V m2 = cC * xc;
+              t = t + m2;
+              m2 = cM * xm3[a];
+              t = t + m2;
+              adv = adv + t;
+            }
+          } else {  // central, scalar u
+  #pragma unroll
+            for (int a = 0; a < 3; ++a) {
+              if (a == 0 && !act0) continue;
+              V cP = uc, cC = (T)0 * uc, cM = -uc;
+  #pragma unroll
+              for (int v = 0; v < VEC; ++v) {
+                const bool lo = a == 0 ? iPLo : (a == 1 ? (bool)(rowPLo >> jj & 1) : (bool)(colPLo >> v & 1));
+                const bool hi = a == 0 ? iPHi : (a == 1 ? (bool)(rowPHi >> jj & 1) : (bool)(colPHi >> v & 1));
+                if (lo) cM[v] = (T)0;
+                if (hi) cP[v] = (T)0;
+              }
+              cP = cP / A.h2[a];
+              cC = cC / A.h2[a];
+              cM = cM / A.h2[a];
+              V t = cP * xp3[a];
+              V m2 = cC * xc;
+              t = t + m2;
+              m2 = cM * xm3[a];
+              t = t + m2;
+              adv = adv + t;
+            }
+          }
+          return adv;
+        };
+        if constexpr (PHASE == 3) {
+          const V ax = axv;
+          V uc;
+          if (A.aux) uc = xv[jj]; else uc = (V)A.u;
+          const V adv = div_row(uc);
+          V q = A.p0 * ax;
+          q = q - adv;
+          q = A.p1 * q;
+          res[jj] = xc + q;
+          continue;
+        }
+        if constexpr (KIND != 0 && PHASE != 3) {
+          // sum_k sign_k Aop_k (ops.py:122-154) of {Laplacian, Div(scalar u)}: p0 = sign of the Div term,
+          // p1 != 0: the Div term comes first in the equation
+          V dv = div_row((V)A.u);
+          dv = dv * A.p0;
+          if (A.p1 != (T)0) axv = dv + axv; else axv = axv + dv;
+        }
+  #pragma unroll
+        for (int v = 0; v < VEC; ++v) {
+          T ax = axv[v];
+          T cCk = cCkV[v];
+          if (PHASE == 4) {
+            // Jacobi:  x + omega (b - A x) / diag(A)   (k_jacobi, pa_core.hip)
+            T dg = act0 ? cCi : (T)0;
+            dg = dg + cCj;
+            dg = dg + cCk;
+            if (hasc) dg = dg * (CF ? cv[jj][v] : cf);
+            dg = dg * sgn;
+            T q = xv[jj][v] - ax;
+            q = q / dg;
+            q = A.p0 * q;
+            ax = xc[v] + q;
+          }
+          res[jj][v] = ax;
+        }
+      } else {
+  #pragma unroll
+        for (int v = 0; v < VEC; ++v) {
+          const T xc = ec[jj][v];
+          const T xpi = rev ? ea[jj][v] : eb[jj][v];
+          const T xmi = rev ? eb[jj][v] : ea[jj][v];
+          T s = cPi * xpi;
+          T mm = cCi * xc;
+          s = s + mm;
+          mm = cMi * xmi;
+          s = s + mm;
+          T ax = act0 ? s : (T)0;
+          s = cPj * dn[v];
+          mm = cCj * xc;
+          s = s + mm;
+          mm = cMj * up[v];
+          s = s + mm;
+          ax = ax + s;
+          T cPk = A.lap.inv[2], cCk = A.lap.m2inv[2], cMk = A.lap.inv[2];
+          if (colLo >> v & 1) { cPk = A.lap.c23[2]; cCk = -A.lap.c23[2]; cMk = (T)0; }
+          if (colHi >> v & 1) { cPk = (T)0; cCk = -A.lap.c23[2]; cMk = A.lap.c23[2]; }
+          const T xpk = (v < VEC - 1) ? ec[jj][v + 1 < VEC ? v + 1 : v] : right;
+          const T xmk = (v > 0) ? ec[jj][v > 0 ? v - 1 : 0] : left;
+          s = cPk * xpk;
+          mm = cCk * xc;
+          s = s + mm;
+          mm = cMk * xmk;
+          s = s + mm;
+          ax = ax + s;
+          if (hasc) ax = ax * (CF ? cv[jj][v] : cf);
+          ax = ax * sgn;
+          if (PHASE == 4) {
+            // Jacobi:  x + omega (b - A x) / diag(A)   (k_jacobi, pa_core.hip)
+            T dg = act0 ? cCi : (T)0;
+            dg = dg + cCj;
+            dg = dg + cCk;
+            if (hasc) dg = dg * (CF ? cv[jj][v] : cf);
+            dg = dg * sgn;
+            T q = xv[jj][v] - ax;
+            q = q / dg;
+            q = A.p0 * q;
+            ax = xc + q;
+          }
+          res[jj][v] = ax;
+        }
+      }
+    }
+
+    // ---- outputs of plane ii --------------------------------------------------------------------
+#pragma unroll
+    for (int jj = 0; jj < RJ; ++jj) {
+      V outd;   // phase A: d' ; phase B: new r
+      V outx;   // phase B: new x
+#pragma unroll
+      for (int v = 0; v < VEC; ++v) {
+        const bool inS = iS && (rowS >> jj & 1) && (colS >> v & 1);
+        const T xc = ec[jj][v];
+        if (PHASE == 5 || PHASE == 6) {
+          // own cells: p' (or s) everywhere, v' = A p' (or t = A s) on the interior set
+          const bool mine = kvalid && (rowValid >> jj & 1);
+          const T an = inS ? res[jj][v] : (T)0;
+          outd[v] = xc;
+          outx[v] = an;
+          const T r0c = xv[jj][v];
+          if (PHASE == 5) {
+            T p = r0c * an;
+            s0 += inS ? (double)p : 0.0;
+          } else {
+            T p = xc * xc;
+            s0 += mine ? (double)p : 0.0;   // |s|^2 over every node (tol of linalg.py:233)
+            T a = an * xc, b = an * an, cc = r0c * an;
+            s1 += inS ? (double)a : 0.0;
+            s2 += inS ? (double)b : 0.0;
+            s3 += inS ? (double)cc : 0.0;
+          }
+        } else if (PHASE == 2) {
+          outd[v] = (inS || !A.interior_only) ? res[jj][v] : (T)0;
+        } else if (PHASE == 3) {
+          outd[v] = inS ? res[jj][v] : xc;
+        } else if (PHASE == 4) {
+          const T xn = inS ? res[jj][v] : xc;
+          const bool offshell = inS && !(iShell || (rowShell >> jj & 1) || (colShell >> v & 1));
+          T df = xn - xc;
+          T p2 = df * df;
+          s1 += offshell ? (double)p2 : 0.0;
+          outd[v] = xn;
+        } else if (PHASE == 0) {
+          const T e = inS ? xc : (T)0;
+          outd[v] = e;
+          T p = e * res[jj][v];
+          s0 += inS ? (double)p : 0.0;
+        } else {
+          const T xo = xv[jj][v];
+          T ad = alpha * xc;
+          T xn = xo + ad;
+          T aAd = alpha * res[jj][v];
+          T rn = rv[jj][v] - aAd;
+          xn = inS ? xn : xo;
+          rn = inS ? rn : (T)0;
+          T p = rn * rn;
+          s0 += inS ? (double)p : 0.0;
+          const bool offshell = inS && !(iShell || (rowShell >> jj & 1) || (colShell >> v & 1));
+          T df = xn - xo;
+          T p2 = df * df;
+          s1 += offshell ? (double)p2 : 0.0;
+          outd[v] = rn;
+          outx[v] = xn;
+        }
+      }
+      if (kvalid && (rowValid >> jj & 1)) {
+        const int64_t o = ii * G.s0 + jrow[jj] * G.s1 + kc;
+        if (PHASE == 5 || PHASE == 6) {
+          *reinterpret_cast<V*>(A.out + o) = outd;
+          *reinterpret_cast<V*>(A.out2 + o) = outx;
+        } else if (PHASE >= 2) {
+          *reinterpret_cast<V*>(A.out + o) = outd;
+        } else if (PHASE == 0) {
+          if (NARROW) *reinterpret_cast<V*>(A.dnew + o) = outd;
+          else __builtin_nontemporal_store(outd, reinterpret_cast<V*>(A.dnew + o));  // -1.5 % (measured)
+        } else {
+          if (NARROW) {
+            *reinterpret_cast<V*>(A.x + o) = outx;
+            *reinterpret_cast<V*>(A.rw + o) = outd;
+          } else {
+            __builtin_nontemporal_store(outx, reinterpret_cast<V*>(A.x + o));
+            __builtin_nontemporal_store(outd, reinterpret_cast<V*>(A.rw + o));
+          }
+          if (A.send_lo && ii == 0) *reinterpret_cast<V*>(A.send_lo + jrow[jj] * G.s1 + kc) = outd;
+          if (A.send_hi && ii == G.n0 - 1) *reinterpret_cast<V*>(A.send_hi + jrow[jj] * G.s1 + kc) = outd;
+        }
+      }
+    }
+
+    // ---- rotate the register planes; plane m+2 becomes "ahead" (first use of its loads) --------
+#pragma unroll
+    for (int jj = 0; jj < RJ; ++jj) {
+      ea[jj] = ec[jj];
+      ec[jj] = eb[jj];
+    }
+    if (more) {
+      finish_own(w, eb);
+      finish_halo(w, hv, hs);
+    }
+    __syncthreads();
+  }
+
+  if (PHASE == 0) {
+    double s[1] = {s0};
+    pa_block_reduce_store<1>(s, A.partials);
+    pa_cg_epilogue<T>(A.epi);
+  } else if (PHASE == 1 || PHASE == 4) {
+    double s[2] = {s0, s1};
+    pa_block_reduce_store<2>(s, A.partials);
+    if (PHASE == 1) pa_cg_epilogue<T>(A.epi);
+  } else if (PHASE == 5) {
+    double s[1] = {s0};
+    pa_block_reduce_store<1>(s, A.partials);
+  } else if (PHASE == 6) {
+    double s[4] = {s0, s1, s2, s3};
+    pa_block_reduce_store<4>(s, A.partials);
+  }
+}
+
+// ---- host side -------------------------------------------------------------------------------
+// The equations the tiled kernels evaluate: one Laplacian term, or -- for A x and the BiCGSTAB phases --
+// a Laplacian with a scalar coefficient plus a Div with a scalar advection speed, in either order
+// (steady advection-diffusion).  il / id: positions of the two terms (id = -1: no Div).
+template <typename T>
+static bool eq_lap_div(const DevEq<T>& E, int& il, int& id) {
+  il = id = -1;
+  if (E.nterms == 1 && E.t[0].kind == PA_OP_LAPLACIAN) { il = 0; return true; }
+  if (E.nterms != 2) return false;
+  for (int q = 0; q < 2; ++q) {
+    const int k = E.t[q].kind;
+    if (k == PA_OP_LAPLACIAN) il = q;
+    else if ((k == PA_OP_DIV_CENTRAL || k == PA_OP_DIV_UPWIND_COMPAT || k == PA_OP_DIV_UPWIND) && !E.t[q].u_f) id = q;
+  }
+  return il >= 0 && id >= 0 && !E.t[il].coeff_f;
+}
+
+// 0: not for the tiled kernels; 1: 16-byte vector lanes; 2: one cell per lane (NARROW)
+template <typename T>
+static int cg3d_mode(const pa_ctx* c, const DevEq<T>& E, std::initializer_list<const void*> ptrs,
+                     bool allow_div = false) {
+  if (!c->fastpath) return 0;
+  if (c->coord != PA_COORD_XYZ) return 0;  // r-dependent rows: generic kernels
+  if (c->ndim != 3 && c->ndim != 2) return 0;
+  int il, id;
+  if (!eq_lap_div<T>(E, il, id) || (id >= 0 && !allow_div)) return 0;
+  if ((c->ndim == 3 && c->G.n0 < 3) || c->G.n1 < 3 || c->G.n2 < 3) return 0;
+  uintptr_t bits = (uintptr_t)E.t[il].coeff_f;
+  for (const void* q : ptrs) bits |= (uintptr_t)q;
+  if (bits & (sizeof(T) - 1)) return 0;
+  constexpr int VEC = VecOf<T>::N;
+  const char* force = getenv("PYAPES_HIP_NARROW");
+  if ((bits & 15) || c->G.n2 % VEC != 0 || c->G.n2 < 2 * VEC || (force && atoi(force) != 0)) return 2;
+  return 1;
+}
+
+static int cus_of(pa_ctx* c) {
+  static int cus = 0;
+  if (!cus) {
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, c->device) == hipSuccess) cus = prop.multiProcessorCount;
+    if (cus <= 0) cus = 256;
+  }
+  return cus;
+}
+
+template <typename T, int RJ, int PHASE, bool CF, int KIND = 0, bool NARROW = false>
+static int blocks_per_cu() {
+  static int cached = 0;
+  if (!cached) {
+    const char* e = getenv(PHASE == 0 ? "PYAPES_HIP_BPC_A" : (PHASE == 1 ? "PYAPES_HIP_BPC_B" : "PYAPES_HIP_BPC_X"));
+    int n = e ? atoi(e) : 0;
+    if (n <= 0) {
+      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_cg3d<T, RJ, PHASE, CF, KIND, NARROW>, 256, 0) != hipSuccess || n <= 0) n = 2;
+    }
+    cached = n;
+  }
+  return cached;
+}
+
+template <typename T, int RJ, int PHASE, bool CF = false, int KIND = 0, bool NARROW = false>
+static int launch_cg3d(pa_ctx* c, Cg3dArgs<T>& A) {
+  constexpr int VEC = NARROW ? 1 : VecOf<T>::N;
+  constexpr int TJ = 4 * RJ, TK = 64 * VEC;
+  const DevGeom& G = c->G;
+  // The CG phases only ever change cells of the interior set: the last row / column of a non-periodic
+  // axis is a boundary node whose d', r stay 0 and whose x is left alone, so no tile needs to cover
+  // it.  For the 2^k + 1 extents node-based meshes like, that removes a whole extra tile row and tile
+  // column (257^2 planes: 64 instead of 85 tiles of 16 x 64).  cg_begin zeroes both direction buffers.
+  int64_t n1e = G.n1, n2e = G.n2;
+  if (PHASE == 0 || PHASE == 1) {
+    if (G.bct[3] != PA_BC_PERIODIC && n1e > 2) n1e -= 1;
+    if (G.bct[5] != PA_BC_PERIODIC && n2e > 2) n2e -= 1;
+  }
+  A.tiles_j = (int)((n1e + TJ - 1) / TJ);
+  A.tiles_k = (int)((n2e + TK - 1) / TK);
+  const int tiles = A.tiles_j * A.tiles_k;
+  const int capacity = cus_of(c) * blocks_per_cu<T, RJ, PHASE, CF, KIND, NARROW>();
+  int chunks = capacity / tiles;
+  if (chunks < 1) chunks = 1;
+  if (chunks > G.n0) chunks = (int)G.n0;
+  A.chunks = chunks;
+  const int nblk = tiles * chunks;
+  if (nblk > PA_MAX_PARTIALS) return 0;
+  static int dbg = -1;
+  if (dbg < 0) dbg = getenv("PYAPES_HIP_DEBUG") ? 8 : 0;
+  if (dbg > 0) {
+    --dbg;
+    fprintf(stderr, "[pyapes_hip] k_cg3d phase %c%s: tiles %dx%d chunks %d (CI ~%lld) blocks %d, %d blocks/CU x %d CUs\n",
+            (char)('A' + PHASE), NARROW ? " (narrow)" : "", A.tiles_j, A.tiles_k, chunks, (long long)(G.n0 / chunks), nblk,
+            blocks_per_cu<T, RJ, PHASE, CF, KIND, NARROW>(), cus_of(c));
+  }
+  hipLaunchKernelGGL((k_cg3d<T, RJ, PHASE, CF, KIND, NARROW>), dim3(nblk), dim3(256), 0, c->stream, A);
+  return nblk;
+}
+
+// rows per thread: 4 (16-row tiles) for big planes; fewer rows = more tiles = longer marching chunks
+// when a plane has too few 16-row tiles to give every resident workgroup >= 32 planes
+template <typename T, int PHASE = 0>
+static int pick_rj(pa_ctx* c, bool narrow = false) {
+  if (const char* e = getenv("PYAPES_HIP_RJ")) {
+    int v = atoi(e);
+    if (v == 1 || v == 2 || v == 4) return v;
+  }
+  const int VEC = narrow ? 1 : VecOf<T>::N;
+  const DevGeom& G = c->G;
+  if (!G.act[0]) return 4;  // 2-D: one plane, nothing to march; the biggest tile has the least halo
+  const int64_t tk = (G.n2 + 64 * VEC - 1) / (64 * VEC);
+  const int cap = cus_of(c) * 2;
+  for (int rj = 4; rj >= 2; rj >>= 1) {
+    const int64_t tiles = ((G.n1 + 4 * rj - 1) / (4 * rj)) * tk;
+    const int64_t chunks = cap / tiles > 0 ? cap / tiles : 1;
+    // the explicit Euler step is instruction-bound: more rows per thread amortise the per-plane
+    // bookkeeping, and it tolerates shorter chunks (256^3 fp32: RJ 2 48 us / step, RJ 1 52)
+    if (G.n0 / chunks >= (PHASE == 3 ? 12 : 24)) return rj;
+  }
+  return 1;
+}
+
+template <typename T, int PHASE, bool NARROW>
+static int launch_any_w(pa_ctx* c, Cg3dArgs<T>& A) {
+  constexpr bool CF_OK = (PHASE == 0 || PHASE == 1 || PHASE == 2 || PHASE == 4);
+  if (A.coeff_f) {  // tensor coefficient: separate instantiation, so the scalar-coefficient kernels stay lean
+    if (!CF_OK) return 0;
+    if constexpr (CF_OK) {
+      switch (pick_rj<T>(c, NARROW)) {
+        case 1: return launch_cg3d<T, 1, PHASE, true, 0, NARROW>(c, A);
+        case 2: return launch_cg3d<T, 2, PHASE, true, 0, NARROW>(c, A);
+        default: return launch_cg3d<T, 4, PHASE, true, 0, NARROW>(c, A);
+      }
+    }
+  }
+  if constexpr (PHASE == 3) {  // one instantiation per Div scheme
+    const int rj = pick_rj<T, 3>(c, NARROW);
+#define PA_EULER_CASE(K)                                                   \
+    case K:                                                                \
+      switch (rj) {                                                        \
+        case 1: return launch_cg3d<T, 1, 3, false, K, NARROW>(c, A);       \
+        case 2: return launch_cg3d<T, 2, 3, false, K, NARROW>(c, A);       \
+        default: return launch_cg3d<T, 4, 3, false, K, NARROW>(c, A);      \
+      }
+    switch (A.kind) {
+      PA_EULER_CASE(PA_OP_DIV_CENTRAL)
+      PA_EULER_CASE(PA_OP_DIV_UPWIND_COMPAT)
+      PA_EULER_CASE(PA_OP_DIV_UPWIND)
+      default: return 0;
+    }
+#undef PA_EULER_CASE
+  }
+  if constexpr (PHASE == 2 || PHASE == 5 || PHASE == 6) {
+    if (A.kind != 0) {  // Laplacian + Div(scalar u): one instantiation per scheme, two or four rows per thread
+      const bool four = pick_rj<T>(c, NARROW) == 4;
+#define PA_DIV_CASE(K)                                                                   \
+      case K:                                                                            \
+        return four ? launch_cg3d<T, 4, PHASE, false, K, NARROW>(c, A)                   \
+                    : launch_cg3d<T, 2, PHASE, false, K, NARROW>(c, A);
+      switch (A.kind) {
+        PA_DIV_CASE(PA_OP_DIV_CENTRAL)
+        PA_DIV_CASE(PA_OP_DIV_UPWIND_COMPAT)
+        PA_DIV_CASE(PA_OP_DIV_UPWIND)
+        default: return 0;
+      }
+#undef PA_DIV_CASE
+    }
+  }
+  switch (pick_rj<T>(c, NARROW)) {
+    case 1: return launch_cg3d<T, 1, PHASE, false, 0, NARROW>(c, A);
+    case 2: return launch_cg3d<T, 2, PHASE, false, 0, NARROW>(c, A);
+    default: return launch_cg3d<T, 4, PHASE, false, 0, NARROW>(c, A);
+  }
+}
+
+template <typename T, int PHASE>
+static int launch_any(pa_ctx* c, Cg3dArgs<T>& A, int mode) {
+  return mode == 2 ? launch_any_w<T, PHASE, true>(c, A) : launch_any_w<T, PHASE, false>(c, A);
+}
+
+template <typename T>
+static void fill_common(pa_ctx* c, const DevEq<T>& E, Cg3dArgs<T>& A) {
+  int il = 0, id = -1;
+  (void)eq_lap_div<T>(E, il, id);
+  if (il < 0) il = 0;
+  A.G = c->G;
+  A.lap = E.lap;
+  A.coeff = E.t[il].coeff;
+  A.coeff_f = E.t[il].coeff_f;
+  A.sign = E.t[il].sign;
+  A.has_coeff = E.t[il].has_coeff;
+  A.sc = c->sc;
+  if (id >= 0) {  // Laplacian + Div: scheme, speed, sign of the Div term, and whether it is listed first
+    for (int a = 0; a < 3; ++a) {
+      T h = (T)c->dx[a];
+      A.hh[a] = h;
+      A.h2[a] = (T)2 * h;
+      A.ih[a] = (T)1 / h;
+    }
+    A.kind = E.t[id].kind;
+    A.u = E.t[id].u;
+    A.p0 = E.t[id].sign;
+    A.p1 = id < il ? (T)1 : (T)0;
+  }
+}
+
+template <typename T>
+static void fill_h(const pa_ctx* c, Cg3dArgs<T>& A) {
+  for (int a = 0; a < 3; ++a) {
+    T h = (T)c->dx[a];
+    A.hh[a] = h;
+    A.h2[a] = (T)2 * h;
+    A.ih[a] = (T)1 / h;
+  }
+}
+
