@@ -12,8 +12,20 @@ int pa_cg3d_phase_a(pa_ctx* c, const DevEq<T>& E, Vec<T> r, Vec<T> d, T* dnew, d
   A.r = r; A.d = d; A.dnew = dnew; A.partials = partials;
   A.epi = epi;
   A.reverse = 0;
+  if (c->fold_b_n > 0) {  // close the previous iteration in this kernel's prologue (next state -> the other slot)
+    A.pre_part = (const double*)c->scr[SCR_PART];
+    A.pre_n = c->fold_b_n;
+    A.pre_shell = (const double*)c->scr[SCR_PART2];
+    A.pre_nsh = c->fold_b_nsh;
+    A.sc_w = c->sc_alt;
+    A.pre_sums = pa_sums(c);
+  }
   int n = launch_any<T, 0>(c, A, mode);
   if (n > 0 && hipGetLastError() != hipSuccess) { pa_set_err(c, "k_cg3d phase A launch failed"); return PA_E_HIP; }
+  if (n > 0 && c->fold_b_n > 0) {
+    SolverScalars* t = c->sc; c->sc = c->sc_alt; c->sc_alt = t;
+    c->fold_b_n = c->fold_b_nsh = 0;
+  }
   return n;
 }
 
@@ -28,8 +40,15 @@ int pa_cg3d_phase_b(pa_ctx* c, const DevEq<T>& E, Vec<T> d, T* x, T* r, double* 
   A.epi = epi;
   A.send_lo = (T*)c->r_send_lo; A.send_hi = (T*)c->r_send_hi;
   A.reverse = 1;
+  if (c->fold_a_n > 0) {  // alpha of this iteration in this kernel's prologue
+    A.pre_part = (const double*)c->scr[SCR_PART] + 2 * (size_t)PA_MAX_PARTIALS;
+    A.pre_n = c->fold_a_n;
+    A.sc_w = c->sc;
+    A.pre_sums = pa_sums(c);
+  }
   int n = launch_any<T, 1>(c, A, mode);
   if (n > 0 && hipGetLastError() != hipSuccess) { pa_set_err(c, "k_cg3d phase B launch failed"); return PA_E_HIP; }
+  if (n > 0) c->fold_a_n = 0;
   return n;
 }
 

@@ -67,6 +67,16 @@ struct Cg3dArgs {
   int kind;             // Euler: PA_OP_DIV_*
   int interior_only;    // A x: zero outside the interior set
   CgEpi epi;            // phases 0 / 1: the last block finishes the reduction (pa_epilogue.h)
+  // folded scalar step (pre_n > 0; single GPU inside pa_cg_iterate): EVERY block first reduces the partial
+  // rows the previous kernel left (same fixed order as k_cg_post_a / k_cg_post_b -> the same bits in
+  // every block, no fence, no atomics: the kernel boundary made the rows visible) and runs the scalar
+  // logic on registers; block 0 alone stores the state -- phase A into the OTHER scalar slot (sc_w),
+  // because blocks of this launch may still be reading `sc`
+  const double* pre_part;
+  const double* pre_shell;
+  int pre_n, pre_nsh;
+  SolverScalars* sc_w;
+  double* pre_sums;
 };
 
 __device__ __forceinline__ int pa_xcd_remap(int b, int nb) {
@@ -93,8 +103,105 @@ __global__ void __launch_bounds__(256) k_cg3d(Cg3dArgs<T> A) {
   constexpr int TJ = 4 * RJ, TK = 64 * VEC, TKP = TK + 2 * VEC;
   __shared__ __attribute__((aligned(16))) T tile[2][TJ + 2][TKP];
 
-  if (PHASE != 2 && PHASE != 3 && A.sc->done) return;
   (void)sizeof(int[PHASE >= 0 && PHASE <= 6 ? 1 : -1]);
+  T beta = (T)0, alpha = (T)0;
+  T omega = (T)0;
+  if (PHASE == 0 && A.pre_n > 0) {
+    // the scalar step that closes the PREVIOUS iteration (linalg.py:128-141, 321-338).  Every load of
+    // the prologue is issued before the first wait -- one memory round trip (~1-2 us right after a
+    // kernel boundary), not one per reduction.  Summation order = pa_reduce_partials, column by column.
+    __shared__ double pre_sm[16];
+    const SolverScalars* si = A.sc;
+    const int done_in = si->done;
+    const double rr_in = si->rr, beta_in = si->beta, tol_lim = si->tolerance;
+    const long long itr_in = si->itr, max_it = si->max_it;
+    double v0 = 0.0, v1 = 0.0, v2 = 0.0;
+    for (int b = threadIdx.x; b < A.pre_n; b += 256) {
+      v0 += A.pre_part[2 * (int64_t)b];
+      v1 += A.pre_part[2 * (int64_t)b + 1];
+    }
+    for (int b = threadIdx.x; b < A.pre_nsh; b += 256) v2 += A.pre_shell[b];
+    if (done_in) {
+      if (blockIdx.x == 0 && threadIdx.x == 0) *A.sc_w = *si;
+      return;
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+      v0 += __shfl_down(v0, off, 64);
+      v1 += __shfl_down(v1, off, 64);
+      v2 += __shfl_down(v2, off, 64);
+    }
+    if ((threadIdx.x & 63) == 0) {
+      const int w = threadIdx.x >> 6;
+      pre_sm[3 * w] = v0;
+      pre_sm[3 * w + 1] = v1;
+      pre_sm[3 * w + 2] = v2;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      double rr = 0.0, dx2 = 0.0, sh = 0.0;
+      for (int w = 0; w < 4; ++w) { rr += pre_sm[3 * w]; dx2 += pre_sm[3 * w + 1]; sh += pre_sm[3 * w + 2]; }
+      // pa_logic_b on registers: a local SolverScalars puts the kernel on scratch memory, and a kernel
+      // with a private segment costs ~10 us more to dispatch (measured)
+      const T rr_new = (T)rr;
+      const T tolv = (T)sqrt(dx2 + sh);
+      const bool bad = isnan(tolv) || isinf(tolv);   // linalg.py:334-336 raises before beta / itr
+      const T rr_old = (T)rr_in;
+      const double bq = bad ? beta_in : (double)(rr_new / rr_old);
+      const long long itr = itr_in + (bad ? 0 : 1);
+      const int done = (bad || itr > max_it || !((double)tolv > tol_lim)) ? 1 : 0;
+      pre_sm[12] = bq;
+      pre_sm[13] = done ? 1.0 : 0.0;
+      if (blockIdx.x == 0) {
+        SolverScalars* so = A.sc_w;
+        *so = *si;
+        so->tol = (double)tolv;
+        so->done = done;
+        if (bad) {
+          so->err = 1;
+        } else {
+          so->rr_old = (double)rr_old;
+          so->beta = bq;
+          so->rr = (double)rr_new;
+          so->itr = itr;
+        }
+        A.pre_sums[1] = rr;
+        A.pre_sums[2] = dx2 + sh;
+      }
+    }
+    __syncthreads();
+    if (pre_sm[13] != 0.0) return;
+    beta = (T)pre_sm[12];
+  } else if (PHASE == 1 && A.pre_n > 0) {
+    // alpha = r.r / d.Ad of THIS iteration (linalg.py:118-120); loads first, as above
+    __shared__ double pre_sm[8];
+    const int done_in = A.sc->done;
+    const double rr_in = A.sc->rr;
+    double v0 = 0.0;
+    for (int b = threadIdx.x; b < A.pre_n; b += 256) v0 += A.pre_part[b];
+    if (done_in) return;
+    for (int off = 32; off > 0; off >>= 1) v0 += __shfl_down(v0, off, 64);
+    if ((threadIdx.x & 63) == 0) pre_sm[threadIdx.x >> 6] = v0;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      double v = 0.0;
+      for (int w = 0; w < 4; ++w) v += pre_sm[w];
+      const T dAd = (T)v;
+      const T a = (T)rr_in / dAd;
+      const double al = (isnan(a) || isinf(a)) ? 0.0 : (double)a;
+      pre_sm[4] = al;
+      if (blockIdx.x == 0) {
+        A.sc_w->dAd = (double)dAd;
+        A.sc_w->alpha = al;
+        A.pre_sums[0] = v;
+      }
+    }
+    __syncthreads();
+    alpha = (T)pre_sm[4];
+  } else {
+    if (PHASE != 2 && PHASE != 3 && A.sc->done) return;
+    if (PHASE == 0) beta = (T)A.sc->beta;
+    if (PHASE == 1) alpha = (T)A.sc->alpha;
+  }
   const DevGeom& G = A.G;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int vb = pa_xcd_remap(blockIdx.x, gridDim.x);
@@ -157,10 +264,6 @@ __global__ void __launch_bounds__(256) k_cg3d(Cg3dArgs<T> A) {
   const int64_t hs_off = pa_wrapmod(j0 + hs_row, G.n1) * G.s1 +
                          (hs_side ? pa_wrapmod(k0 + TK, G.n2) : pa_wrapmod(k0 - 1, G.n2));
 
-  T beta = (T)0, alpha = (T)0;
-  T omega = (T)0;
-  if (PHASE == 0) beta = (T)A.sc->beta;
-  if (PHASE == 1) alpha = (T)A.sc->alpha;
   if (PHASE == 5) { beta = (T)A.sc->beta; omega = (T)A.sc->omega; }
   if (PHASE == 6) alpha = (T)A.sc->alpha;
 

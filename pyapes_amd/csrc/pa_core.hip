@@ -317,6 +317,16 @@ __global__ void __launch_bounds__(PA_BLOCK) k_cg_init(DevGeom G, DevEq<T> E, Vec
   pa_block_reduce_store<1>(s, partials);
 }
 
+// A kernel argument struct that is indexed with a run-time index (E.t[q], B.f[face]) gets copied to
+// scratch memory by the compiler, and a kernel with a private segment costs ~10 us more per dispatch
+// on MI355X (measured: 64^3 CG iteration 29 -> 52 us).  Reading the struct in place -- through the
+// kernarg segment pointer -- keeps such kernels off scratch.  `off` = byte offset of the parameter.
+template <typename S>
+__device__ __forceinline__ const S& pa_kernarg(size_t off) {
+  return *(const S*)((const char*)__builtin_amdgcn_kernarg_segment_ptr() + off);
+}
+static_assert(sizeof(DevGeom) % 8 == 0, "second kernel parameter starts at sizeof(DevGeom)");
+
 // ---- CG phase A: d' = r + beta d ; partial sum d'.(A d')  (linalg.py:115-120, 141) ----
 template <typename T>
 __global__ void __launch_bounds__(PA_BLOCK) k_cg_a(DevGeom G, DevEq<T> E, const SolverScalars* __restrict__ sc,
@@ -603,11 +613,12 @@ __device__ __forceinline__ bool pa_shell_node(const DevGeom& G, int64_t q, const
 }
 
 template <typename T>
-__global__ void __launch_bounds__(PA_BLOCK) k_bc_compute(DevGeom G, BCAll<T> B, const int* __restrict__ done,
+__global__ void __launch_bounds__(PA_BLOCK) k_bc_compute(DevGeom G, BCAll<T> B_, const int* __restrict__ done,
                                                           const T* __restrict__ x, const T* __restrict__ shell_old,
                                                           T* __restrict__ shell_new, double* __restrict__ partials,
                                                           int with_delta) {
   if (done && *done) return;
+  const BCAll<T>& B = pa_kernarg<BCAll<T>>(sizeof(DevGeom));
   const int64_t sz[3] = {G.n1 * G.n2, G.n0 * G.n2, G.n0 * G.n1};
   int64_t total = 0, start[6];
   for (int f = 0; f < 6; ++f) { start[f] = total; total += G.act[f >> 1] ? sz[f >> 1] : 0; }
@@ -1049,10 +1060,13 @@ struct BicgPAcc {
   Vec<T> r, p, v;
   T beta, omega;
   __device__ __forceinline__ T at(const DevGeom& G, int64_t i, int64_t j, int64_t k) const {
-    T rv, pv, vv;
-    if (i < 0) { int64_t o = j * G.s1 + k; rv = r.glo[o]; pv = p.glo[o]; vv = v.glo[o]; }
-    else if (i >= G.n0) { int64_t o = j * G.s1 + k; rv = r.ghi[o]; pv = p.ghi[o]; vv = v.ghi[o]; }
-    else { int64_t o = i * G.s0 + j * G.s1 + k; rv = r.p[o]; pv = p.p[o]; vv = v.p[o]; }
+    const int64_t o = j * G.s1 + k;  // pointers first, one load per field after (see DirAcc)
+    const T* rb = r.p + i * G.s0;
+    const T* pb = p.p + i * G.s0;
+    const T* vb = v.p + i * G.s0;
+    if (i < 0) { rb = r.glo; pb = p.glo; vb = v.glo; }
+    if (i >= G.n0) { rb = r.ghi; pb = p.ghi; vb = v.ghi; }
+    const T rv = rb[o], pv = pb[o], vv = vb[o];
     T t = omega * vv;
     t = pv - t;
     t = beta * t;
@@ -1448,7 +1462,7 @@ int pa_ctx_create(int device, void* hip_stream, pa_ctx** out) {
   c->stream = (hipStream_t)hip_stream;
   c->err[0] = 0;
   if (const char* fp = getenv("PYAPES_HIP_FASTPATH")) c->fastpath = atoi(fp) != 0;
-  if (hipMalloc((void**)&c->sc, sizeof(SolverScalars)) != hipSuccess ||
+  if (hipMalloc((void**)&c->sc_base, 2 * sizeof(SolverScalars)) != hipSuccess ||
       hipMalloc((void**)&c->sums, PA_NSUM * sizeof(double)) != hipSuccess ||
       hipMalloc((void**)&c->tickets, 4 * sizeof(unsigned int)) != hipSuccess ||
       hipHostMalloc((void**)&c->h_sc, sizeof(SolverScalars)) != hipSuccess ||
@@ -1457,7 +1471,10 @@ int pa_ctx_create(int device, void* hip_stream, pa_ctx** out) {
     delete c;
     return PA_E_HIP;
   }
-  (void)hipMemsetAsync(c->sc, 0, sizeof(SolverScalars), c->stream);
+  c->sc = c->sc_base;
+  c->sc_alt = c->sc_base + 1;
+  (void)hipMemsetAsync(c->sc_base, 0, 2 * sizeof(SolverScalars), c->stream);
+  if (const char* fo = getenv("PYAPES_HIP_FOLD")) c->fold = atoi(fo) != 0;
   (void)hipMemsetAsync(c->sums, 0, PA_NSUM * sizeof(double), c->stream);
   (void)hipMemsetAsync(c->tickets, 0, 4 * sizeof(unsigned int), c->stream);
   if (const char* ep = getenv("PYAPES_HIP_EPILOGUE")) c->epilogue = atoi(ep) != 0;
@@ -1472,7 +1489,7 @@ int pa_ctx_destroy(pa_ctx* c) {
   if (c->comm) (void)pa_comm_destroy(c);
   for (int q = 0; q < PA_NSCRATCH; ++q)
     if (c->scr[q]) (void)hipFree(c->scr[q]);
-  if (c->sc) (void)hipFree(c->sc);
+  if (c->sc_base) (void)hipFree(c->sc_base);
   if (c->sums) (void)hipFree(c->sums);
   if (c->tickets) (void)hipFree(c->tickets);
   if (c->h_sc) (void)hipHostFree(c->h_sc);
@@ -2279,6 +2296,22 @@ static Vec<T> cg_vec(pa_ctx* c, const T* p, int which /*0 r, 1 d cur*/) {
   return v;
 }
 
+// scalar steps that were left to the prologue of a tiled kernel that is not coming (the generic kernel
+// runs instead, or the batch of iterations ends): run them as the single-block kernels they replace
+template <typename T>
+static void cg_flush_fold(pa_ctx* c) {
+  if (c->fold_a_n > 0) {
+    hipLaunchKernelGGL(k_cg_post_a<T>, dim3(1), dim3(PA_BLOCK), 0, c->stream, c->sc,
+                       (const double*)c->scr[SCR_PART] + 2 * (size_t)PA_MAX_PARTIALS, c->fold_a_n, pa_sums(c), 2);
+    c->fold_a_n = 0;
+  }
+  if (c->fold_b_n > 0) {
+    hipLaunchKernelGGL(k_cg_post_b<T>, dim3(1), dim3(PA_BLOCK), 0, c->stream, c->sc, (const double*)c->scr[SCR_PART],
+                       c->fold_b_n, (const double*)c->scr[SCR_PART2], c->fold_b_nsh, pa_sums(c), 2);
+    c->fold_b_n = c->fold_b_nsh = 0;
+  }
+}
+
 template <typename T>
 int pa_cg_phase_a_t(pa_ctx* c, int stage_post) {
   const DevGeom& G = c->G;
@@ -2289,6 +2322,12 @@ int pa_cg_phase_a_t(pa_ctx* c, int stage_post) {
   T* dold = (T*)c->scr[c->cur ? SCR_D1 : SCR_D0];
   T* dnew = (T*)c->scr[c->cur ? SCR_D0 : SCR_D1];
   double* part = (double*)c->scr[SCR_PART];
+  // inside pa_cg_iterate on one GPU the two single-block scalar kernels of an iteration are folded into
+  // the prologue of the tiled kernel that follows them (pa_cg3d_kernel.h); d.Ad rows then live in the
+  // upper half of SCR_PART, because phase B writes its own rows while its blocks still read these
+  const bool foldable = c->fold && c->in_iterate && stage_post == 2 && !c->slab && !c->overlap && !c->profile &&
+                        !c->epilogue;
+  if (foldable) part += 2 * (size_t)PA_MAX_PARTIALS;
   if (c->pending_init_logic) {  // slab: sum r.r has been all-reduced by the driver
     hipLaunchKernelGGL(k_cg_post_init<T>, dim3(1), dim3(PA_BLOCK), 0, c->stream, c->sc, (const double*)nullptr, 0,
                        pa_sums(c), 1);
@@ -2306,12 +2345,15 @@ int pa_cg_phase_a_t(pa_ctx* c, int stage_post) {
   if (rc < 0) return rc;
   int used_blocks = rc;
   if (rc == 0) {
+    cg_flush_fold<T>(c);  // the tiled kernel declined: the previous iteration is closed by its own kernel
     hipLaunchKernelGGL(k_cg_a<T>, dim3(nblk), dim3(PA_BLOCK), 0, c->stream, G, E, c->sc, rv, dv, dnew, part, epa);
     used_blocks = nblk;
   }
   if (c->profile) pa_profile_stop(c, 0);
   c->cur ^= 1;
-  if (!epa.kind)
+  if (foldable && !epa.kind && used_blocks <= PA_MAX_GRID)
+    c->fold_a_n = used_blocks;  // phase B's prologue (or cg_flush_fold) computes alpha
+  else if (!epa.kind)
     hipLaunchKernelGGL(k_cg_post_a<T>, dim3(1), dim3(PA_BLOCK), 0, c->stream, c->sc, part, used_blocks, pa_sums(c),
                        stage_post);
   PA_HIP(c, hipGetLastError());
@@ -2340,6 +2382,7 @@ int pa_cg_phase_b_t(pa_ctx* c, int stage_post) {
   if (rc < 0) return rc;
   int used_blocks = rc;
   if (rc == 0) {
+    cg_flush_fold<T>(c);  // alpha by its own kernel
     hipLaunchKernelGGL(k_cg_b<T>, dim3(nblk), dim3(PA_BLOCK), 0, c->stream, G, E, c->sc, dv, x, r,
                        (T*)c->r_send_lo, (T*)c->r_send_hi, part, epb);
     used_blocks = nblk;
@@ -2395,9 +2438,15 @@ int pa_cg_phase_b_t(pa_ctx* c, int stage_post) {
                          (T*)c->scr[SCR_SHELL], part2, 1);
     }
   }
-  if (!c->b_tail_done)
+  const bool foldable = c->fold && c->in_iterate && stage_post == 2 && !c->slab && !c->profile && !c->epilogue &&
+                        used_blocks <= PA_MAX_GRID && nsh <= PA_MAX_GRID;
+  if (!c->b_tail_done && foldable) {
+    c->fold_b_n = used_blocks;  // the next phase A's prologue (or cg_flush_fold) closes this iteration
+    c->fold_b_nsh = nsh;
+  } else if (!c->b_tail_done) {
     hipLaunchKernelGGL(k_cg_post_b<T>, dim3(1), dim3(PA_BLOCK), 0, c->stream, c->sc, part, used_blocks, part2, nsh,
                        pa_sums(c), stage_post);
+  }
   PA_HIP(c, hipGetLastError());
   return PA_OK;
 }
@@ -2741,12 +2790,15 @@ int pa_cg_iterate(pa_ctx* c, int64_t n) {
     if (int rc = cg_iterate_graph(c, n, &done)) return rc;
     n -= done;
   }
-  for (int64_t q = 0; q < n; ++q) {
-    int rc = c->dtype == PA_F64 ? pa_cg_phase_a_t<double>(c, 2) : pa_cg_phase_a_t<float>(c, 2);
-    if (rc) return rc;
-    rc = c->dtype == PA_F64 ? pa_cg_phase_b_t<double>(c, 2) : pa_cg_phase_b_t<float>(c, 2);
-    if (rc) return rc;
+  c->in_iterate = use_graph ? 0 : 1;
+  int rc = PA_OK;
+  for (int64_t q = 0; q < n && !rc; ++q) {
+    rc = c->dtype == PA_F64 ? pa_cg_phase_a_t<double>(c, 2) : pa_cg_phase_a_t<float>(c, 2);
+    if (!rc) rc = c->dtype == PA_F64 ? pa_cg_phase_b_t<double>(c, 2) : pa_cg_phase_b_t<float>(c, 2);
   }
+  c->in_iterate = 0;
+  if (c->dtype == PA_F64) cg_flush_fold<double>(c); else cg_flush_fold<float>(c);  // the last iteration's stop test
+  if (rc) return rc;
   return pa_join_side(c);  // the ctx stream now covers everything that was enqueued
 }
 

@@ -62,7 +62,14 @@ struct pa_ctx {
   // scratch
   void* scr[PA_NSCRATCH] = {nullptr};
   size_t cap[PA_NSCRATCH] = {0};
-  SolverScalars* sc = nullptr;    // device
+  SolverScalars* sc = nullptr;    // device: the CURRENT scalars (one of the two slots of sc_base)
+  SolverScalars* sc_alt = nullptr;  // the other slot: a folded phase A writes the next state there, then they swap
+  SolverScalars* sc_base = nullptr;
+  // folded scalar steps (pa_cg_iterate on one GPU): the single-block kernels between the phases are
+  // gone, every block of the NEXT tiled kernel reduces the partial rows itself (pa_cg3d_kernel.h)
+  int fold = 1, in_iterate = 0;
+  int fold_a_n = 0;                 // rows of d.Ad partials waiting for phase B's prologue
+  int fold_b_n = 0, fold_b_nsh = 0; // rows of phase-B / shell partials waiting for the next phase A
   SolverScalars* h_sc = nullptr;  // pinned host mirror
   double* sums = nullptr;         // device, PA_NSUM (internal)
   double* ext_sums = nullptr;     // slab: caller-owned sums buffer (all-reduced by the host driver)
