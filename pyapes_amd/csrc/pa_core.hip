@@ -614,9 +614,9 @@ __device__ __forceinline__ bool pa_shell_node(const DevGeom& G, int64_t q, const
 
 template <typename T>
 __global__ void __launch_bounds__(PA_BLOCK) k_bc_compute(DevGeom G, BCAll<T> B_, const int* __restrict__ done,
-                                                          const T* __restrict__ x, const T* __restrict__ shell_old,
+                                                          const T* x, const T* __restrict__ shell_old,
                                                           T* __restrict__ shell_new, double* __restrict__ partials,
-                                                          int with_delta) {
+                                                          int with_delta, T* xw) {
   if (done && *done) return;
   const BCAll<T>& B = pa_kernarg<BCAll<T>>(sizeof(DevGeom));
   const int64_t sz[3] = {G.n1 * G.n2, G.n0 * G.n2, G.n0 * G.n1};
@@ -639,6 +639,7 @@ __global__ void __launch_bounds__(PA_BLOCK) k_bc_compute(DevGeom G, BCAll<T> B_,
     }
 #endif
     shell_new[q] = v;
+    if (xw) xw[i * G.s0 + j * G.s1 + k] = v;  // single pass (see bc_shell_fused): no later read sees this node
     if (with_delta) {
       T df = v - shell_old[q];
       T p = df * df;
@@ -1999,9 +2000,18 @@ static int bc_shell_fused(pa_ctx* c, T* x, double* part2, int with_delta, bool g
     sn = base + (c->shell_cur ? 0 : half);
   }
   const int* done = guarded ? pa_done_flag(c) : nullptr;
+  // Without a periodic face the closed form only ever READS nodes that no face writes: a face value is a
+  // formula over the nodes 1 and 2 (N-2, N-3) steps inside along its axis at the stage before it, and
+  // following that down ends at nodes that lie on no face with a BC (every axis has >= 5 nodes).  So the
+  // compute kernel may store into x itself and the scatter launch is dropped.  A periodic face reads
+  // x[N-1] / x[N-2] raw -- shell nodes other threads write -- and keeps the two passes.
+  bool direct = !c->slab && !getenv("PYAPES_HIP_BC_TWO_PASS");
+  for (int f = 0; f < 6; ++f)
+    if (c->bc[f].type == PA_BC_PERIODIC) direct = false;
   hipLaunchKernelGGL(k_bc_compute<T>, dim3(nb), dim3(PA_BLOCK), 0, pa_ls(c), c->G, B, done, (const T*)x,
-                     (const T*)so, sn, part2, with_delta);
-  hipLaunchKernelGGL(k_bc_scatter<T>, dim3(nb), dim3(PA_BLOCK), 0, pa_ls(c), c->G, done, x, (const T*)sn);
+                     (const T*)so, sn, part2, with_delta, direct ? x : (T*)nullptr);
+  if (!direct)
+    hipLaunchKernelGGL(k_bc_scatter<T>, dim3(nb), dim3(PA_BLOCK), 0, pa_ls(c), c->G, done, x, (const T*)sn);
   if (!standalone) c->shell_cur ^= 1;
   if (nsh) *nsh = nb;
   PA_HIP(c, hipGetLastError());
