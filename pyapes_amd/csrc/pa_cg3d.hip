@@ -13,7 +13,7 @@ int pa_cg3d_phase_a(pa_ctx* c, const DevEq<T>& E, Vec<T> r, Vec<T> d, T* dnew, d
   A.epi = epi;
   A.reverse = 0;
   if (c->fold_b_n > 0) {  // close the previous iteration in this kernel's prologue (next state -> the other slot)
-    A.pre_part = (const double*)c->scr[SCR_PART];
+    A.pre_part = c->fold_b_part;
     A.pre_n = c->fold_b_n;
     A.pre_shell = (const double*)c->scr[SCR_PART2];
     A.pre_nsh = c->fold_b_nsh;
@@ -81,8 +81,20 @@ int pa_tile3d_jacobi(pa_ctx* c, const DevEq<T>& E, Vec<T> x, const T* rhs, T* xn
   memset(&A, 0, sizeof(A));
   fill_common<T>(c, E, A);
   A.d = x; A.out = xnew; A.aux = rhs; A.p0 = (T)omega; A.partials = partials;
+  if (c->fold_b_n > 0) {  // stop test + iteration count of the previous sweep in this kernel's prologue
+    A.pre_part = c->fold_b_part;
+    A.pre_n = c->fold_b_n;
+    A.pre_shell = (const double*)c->scr[SCR_PART2];
+    A.pre_nsh = c->fold_b_nsh;
+    A.sc_w = c->sc_alt;
+    A.pre_sums = pa_sums(c);
+  }
   int n = launch_any<T, 4>(c, A, mode);
   if (n > 0 && hipGetLastError() != hipSuccess) { pa_set_err(c, "k_cg3d Jacobi launch failed"); return PA_E_HIP; }
+  if (n > 0 && c->fold_b_n > 0) {
+    SolverScalars* t = c->sc; c->sc = c->sc_alt; c->sc_alt = t;
+    c->fold_b_n = c->fold_b_nsh = 0;
+  }
   return n;
 }
 

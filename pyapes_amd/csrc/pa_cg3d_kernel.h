@@ -106,8 +106,9 @@ __global__ void __launch_bounds__(256) k_cg3d(Cg3dArgs<T> A) {
   (void)sizeof(int[PHASE >= 0 && PHASE <= 6 ? 1 : -1]);
   T beta = (T)0, alpha = (T)0;
   T omega = (T)0;
-  if (PHASE == 0 && A.pre_n > 0) {
-    // the scalar step that closes the PREVIOUS iteration (linalg.py:128-141, 321-338).  Every load of
+  if ((PHASE == 0 || PHASE == 4) && A.pre_n > 0) {
+    // the scalar step that closes the PREVIOUS iteration (CG: linalg.py:128-141, 321-338; the Jacobi
+    // sweep has the stop test and the iteration count only).  Every load of
     // the prologue is issued before the first wait -- one memory round trip (~1-2 us right after a
     // kernel boundary), not one per reduction.  Summation order = pa_reduce_partials, column by column.
     __shared__ double pre_sm[16];
@@ -117,7 +118,7 @@ __global__ void __launch_bounds__(256) k_cg3d(Cg3dArgs<T> A) {
     const long long itr_in = si->itr, max_it = si->max_it;
     double v0 = 0.0, v1 = 0.0, v2 = 0.0;
     for (int b = threadIdx.x; b < A.pre_n; b += 256) {
-      v0 += A.pre_part[2 * (int64_t)b];
+      if (PHASE == 0) v0 += A.pre_part[2 * (int64_t)b];
       v1 += A.pre_part[2 * (int64_t)b + 1];
     }
     for (int b = threadIdx.x; b < A.pre_nsh; b += 256) v2 += A.pre_shell[b];
@@ -159,12 +160,14 @@ __global__ void __launch_bounds__(256) k_cg3d(Cg3dArgs<T> A) {
         if (bad) {
           so->err = 1;
         } else {
-          so->rr_old = (double)rr_old;
-          so->beta = bq;
-          so->rr = (double)rr_new;
+          if (PHASE == 0) {
+            so->rr_old = (double)rr_old;
+            so->beta = bq;
+            so->rr = (double)rr_new;
+          }
           so->itr = itr;
         }
-        A.pre_sums[1] = rr;
+        if (PHASE == 0) A.pre_sums[1] = rr;
         A.pre_sums[2] = dx2 + sh;
       }
     }

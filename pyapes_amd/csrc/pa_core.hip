@@ -2316,7 +2316,7 @@ static void cg_flush_fold(pa_ctx* c) {
     c->fold_a_n = 0;
   }
   if (c->fold_b_n > 0) {
-    hipLaunchKernelGGL(k_cg_post_b<T>, dim3(1), dim3(PA_BLOCK), 0, c->stream, c->sc, (const double*)c->scr[SCR_PART],
+    hipLaunchKernelGGL(k_cg_post_b<T>, dim3(1), dim3(PA_BLOCK), 0, c->stream, c->sc, c->fold_b_part,
                        c->fold_b_n, (const double*)c->scr[SCR_PART2], c->fold_b_nsh, pa_sums(c), 2);
     c->fold_b_n = c->fold_b_nsh = 0;
   }
@@ -2453,6 +2453,7 @@ int pa_cg_phase_b_t(pa_ctx* c, int stage_post) {
   if (!c->b_tail_done && foldable) {
     c->fold_b_n = used_blocks;  // the next phase A's prologue (or cg_flush_fold) closes this iteration
     c->fold_b_nsh = nsh;
+    c->fold_b_part = part;
   } else if (!c->b_tail_done) {
     hipLaunchKernelGGL(k_cg_post_b<T>, dim3(1), dim3(PA_BLOCK), 0, c->stream, c->sc, part, used_blocks, part2, nsh,
                        pa_sums(c), stage_post);
@@ -2528,48 +2529,84 @@ static int jacobi_run_t(pa_ctx* c, T* x, const T* rhs, double tol, int64_t max_i
   if ((rc = pa_scratch(c, &c->scr[SCR_D0], &c->cap[SCR_D0], fb))) return rc;
   if ((rc = pa_scratch(c, &c->scr[SCR_PART], &c->cap[SCR_PART], (size_t)PA_MAX_PARTIALS * 4 * sizeof(double)))) return rc;
   if ((rc = pa_scratch(c, &c->scr[SCR_PART2], &c->cap[SCR_PART2], (size_t)3 * PA_MAX_GRID * sizeof(double)))) return rc;
-  if ((rc = pa_scratch(c, &c->scr[SCR_SHELL], &c->cap[SCR_SHELL], (size_t)shell_elems(c) * sizeof(T)))) return rc;
+  if ((rc = pa_scratch(c, &c->scr[SCR_SHELL], &c->cap[SCR_SHELL], 2 * (size_t)shell_elems(c) * sizeof(T)))) return rc;
   if ((rc = init_scalars(c, tol, max_it))) return rc;
   DevEq<T> E;
   pa_build_eq<T>(c, c->nterms, c->terms, E);
-  if ((rc = bc_apply_t<T>(c, x))) return rc;
   const bool stat = bc_is_static(c);
   double* part = (double*)c->scr[SCR_PART];
   double* part2 = (double*)c->scr[SCR_PART2];
-  hipLaunchKernelGGL(k_shell<T>, dim3(shell_blocks(c)), dim3(PA_BLOCK), 0, c->stream, G, c->sc, (const T*)x,
-                     (T*)c->scr[SCR_SHELL], part2, 0);
+  // BC fill by the cheapest launch sequence, as in CG: closed form / one launch per axis / one per face
+  c->bc_fused = bc_fusable(c);
+  c->bc_pair = (!c->bc_fused && bc_pairable(c)) ? 1 : 0;
+  c->shell_cur = 0;
+  c->fold_a_n = c->fold_b_n = c->fold_b_nsh = 0;
+  if (c->bc_fused) {
+    if ((rc = bc_shell_fused<T>(c, x, nullptr, 0, false, nullptr, false))) return rc;
+  } else if (c->bc_pair) {
+    if ((rc = bc_pair_apply<T>(c, x, nullptr, 2, false, nullptr))) return rc;
+  } else {
+    if ((rc = bc_apply_t<T>(c, x))) return rc;
+    hipLaunchKernelGGL(k_shell<T>, dim3(shell_blocks(c)), dim3(PA_BLOCK), 0, c->stream, G, c->sc, (const T*)x,
+                       (T*)c->scr[SCR_SHELL], part2, 0);
+  }
   T* buf[2] = {x, (T*)c->scr[SCR_D0]};
   int cur = 0;
   const int poll = poll_interval(c);
   PA_HIP(c, hipEventRecord(c->ev0, c->stream));
   int64_t enq = 0;
   int next_poll = 1;
+  // the stop test of sweep q is left to the prologue of sweep q+1 (pa_cg3d_kernel.h) when both are
+  // tiled; this runs it as the single-block kernel it replaces (before a poll, before a generic sweep)
+  auto flush = [&]() {
+    if (c->fold_b_n > 0)
+      hipLaunchKernelGGL(k_jacobi_post<T>, dim3(1), dim3(PA_BLOCK), 0, c->stream, c->sc, c->fold_b_part, c->fold_b_n,
+                         (const double*)part2, c->fold_b_nsh, pa_sums(c));
+    c->fold_b_n = c->fold_b_nsh = 0;
+  };
   for (;;) {
     // two sweeps per round so that the iterate is back in the caller's buffer at every poll
     for (int half = 0; half < 2; ++half) {
       Vec<T> xv = pa_vec_self<T>(c, buf[cur]);
-      int used = pa_tile3d_jacobi<T>(c, E, xv, rhs, buf[cur ^ 1], omega, part);
+      // partial rows alternate between the halves of SCR_PART: the next sweep reads these while it writes its own
+      double* part_q = part + (cur ? 2 * (size_t)PA_MAX_PARTIALS : 0);
+      int used = pa_tile3d_jacobi<T>(c, E, xv, rhs, buf[cur ^ 1], omega, part_q);
       if (used < 0) return used;
-      if (used == 0) {
+      const bool tiled = used > 0;
+      if (!tiled) {
+        flush();
         hipLaunchKernelGGL(k_jacobi<T>, dim3(nblk), dim3(PA_BLOCK), 0, c->stream, G, E, c->sc, xv, rhs, buf[cur ^ 1],
-                           (T)omega, part);
+                           (T)omega, part_q);
         used = nblk;
       }
       int nsh = 0;
       // NOTE: when done is set the sweep kernels return early, so buf[cur^1] is stale: the copy-back
       // below is guarded by the iteration parity recorded on the device (itr).
       if (!stat) {
-        if ((rc = bc_apply_t<T>(c, buf[cur ^ 1], true))) return rc;
-        nsh = shell_blocks(c);
-        hipLaunchKernelGGL(k_shell<T>, dim3(nsh), dim3(PA_BLOCK), 0, c->stream, G, c->sc, (const T*)buf[cur ^ 1],
-                           (T*)c->scr[SCR_SHELL], part2, 1);
+        if (c->bc_fused) {
+          if ((rc = bc_shell_fused<T>(c, buf[cur ^ 1], part2, 1, true, &nsh, false))) return rc;
+        } else if (c->bc_pair) {
+          if ((rc = bc_pair_apply<T>(c, buf[cur ^ 1], part2, 1, true, &nsh))) return rc;
+        } else {
+          if ((rc = bc_apply_t<T>(c, buf[cur ^ 1], true))) return rc;
+          nsh = shell_blocks(c);
+          hipLaunchKernelGGL(k_shell<T>, dim3(nsh), dim3(PA_BLOCK), 0, c->stream, G, c->sc, (const T*)buf[cur ^ 1],
+                             (T*)c->scr[SCR_SHELL], part2, 1);
+        }
       }
-      hipLaunchKernelGGL(k_jacobi_post<T>, dim3(1), dim3(PA_BLOCK), 0, c->stream, c->sc, part, used, part2, nsh,
-                         pa_sums(c));
+      if (c->fold && tiled && used <= PA_MAX_GRID && nsh <= PA_MAX_GRID) {
+        c->fold_b_n = used;
+        c->fold_b_nsh = nsh;
+        c->fold_b_part = part_q;
+      } else {
+        hipLaunchKernelGGL(k_jacobi_post<T>, dim3(1), dim3(PA_BLOCK), 0, c->stream, c->sc, part_q, used, part2, nsh,
+                           pa_sums(c));
+      }
       cur ^= 1;
       ++enq;
     }
     if (enq >= next_poll || enq > max_it) {
+      flush();
       if ((rc = read_scalars(c))) return rc;
       if (c->h_sc->done) break;
       next_poll = (int)std::min<int64_t>(enq + std::min<int64_t>(2 * poll, std::max<int64_t>(2, enq)), max_it + 2);

@@ -69,7 +69,8 @@ struct pa_ctx {
   // gone, every block of the NEXT tiled kernel reduces the partial rows itself (pa_cg3d_kernel.h)
   int fold = 1, in_iterate = 0;
   int fold_a_n = 0;                 // rows of d.Ad partials waiting for phase B's prologue
-  int fold_b_n = 0, fold_b_nsh = 0; // rows of phase-B / shell partials waiting for the next phase A
+  int fold_b_n = 0, fold_b_nsh = 0; // rows of phase-B (Jacobi: sweep) / shell partials waiting for the next phase A (sweep)
+  const double* fold_b_part = nullptr;
   SolverScalars* h_sc = nullptr;  // pinned host mirror
   double* sums = nullptr;         // device, PA_NSUM (internal)
   double* ext_sums = nullptr;     // slab: caller-owned sums buffer (all-reduced by the host driver)
