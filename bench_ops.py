@@ -116,6 +116,12 @@ def main():
     ms, wall, itr, N = solver_ms(lambda: Mesh(Box[0:1, 0:1], None, [128, 128], "cuda", "double"), poisson_bcs(2),
                                  "cg", 271, poisson_rhs_nd)
     emit("cg 2-D 128x128 f64 dirichlet (config 1 inputs)", N, ms, 10, 8, {"wall_ms_per_iter": wall, "iters": itr})
+    # the sizes pyapes users run: launch latency, not bytes, sets the time (DESIGN.md "small meshes")
+    for meth, its, passes in (("jacobi", K, 3), ("cg", 60, 10), ("bicgstab", 40, 22)):
+        ms, wall, itr, N = solver_ms(lambda: Mesh(Box[0:1, 0:1, 0:1], None, [64, 64, 64], "cuda", "double"),
+                                     mixed_bcs([0, 0, 0, 0, 1, 0], ["dirichlet", "neumann"] * 3), meth, its)
+        emit(f"{meth} 3-D 64^3 f64 dirichlet/neumann faces (BC fill every iteration)", N, ms, passes,
+             8, {"wall_ms_per_iter": wall, "iters": itr})
     n = 128 if q else 256
     ms, wall, itr, N = solver_ms(lambda: Mesh(Box[0:1, 0:1, 0:1], None, [n, n, n], "cuda", "double"),
                                  homogeneous_bcs(3, 0.0, "dirichlet"), "jacobi", K)
