@@ -1280,9 +1280,18 @@ int pa_grid_blocks(int64_t work) {
 
 int pa_scratch(pa_ctx* c, void** slot, size_t* cap, size_t bytes) {
   if (*cap >= bytes && *slot) return PA_OK;
-  if (*slot) { (void)hipFree(*slot); *slot = nullptr; *cap = 0; }
+  const int q = (int)(slot - c->scr);  // every caller passes &c->scr[id]
+  if (*slot) { (void)hipFree(c->scr_base[q]); c->scr_base[q] = nullptr; *slot = nullptr; *cap = 0; }
   if (bytes == 0) return PA_OK;
-  PA_HIP(c, hipMalloc(slot, bytes));
+  // hipMalloc returns 2 MB-aligned blocks; fields that are streamed in lockstep (r, d, d') would then
+  // sit at the same offset of their pages at every moment.  Slot q starts q * stagger bytes in.
+  static long stagger = -1;
+  if (stagger < 0) { const char* e = getenv("PYAPES_HIP_STAGGER"); stagger = e ? atol(e) & ~255L : 0; }
+  const size_t off = (size_t)q * (size_t)stagger;
+  void* base = nullptr;
+  PA_HIP(c, hipMalloc(&base, bytes + off));
+  c->scr_base[q] = base;
+  *slot = (char*)base + off;
   *cap = bytes;
   return PA_OK;
 }
@@ -1489,7 +1498,7 @@ int pa_ctx_destroy(pa_ctx* c) {
   (void)hipStreamSynchronize(c->stream);
   if (c->comm) (void)pa_comm_destroy(c);
   for (int q = 0; q < PA_NSCRATCH; ++q)
-    if (c->scr[q]) (void)hipFree(c->scr[q]);
+    if (c->scr_base[q]) (void)hipFree(c->scr_base[q]);
   if (c->sc_base) (void)hipFree(c->sc_base);
   if (c->sums) (void)hipFree(c->sums);
   if (c->tickets) (void)hipFree(c->tickets);
@@ -2449,7 +2458,7 @@ int pa_cg_phase_b_t(pa_ctx* c, int stage_post) {
     }
   }
   const bool foldable = c->fold && c->in_iterate && stage_post == 2 && !c->slab && !c->profile && !c->epilogue &&
-                        used_blocks <= PA_MAX_GRID && nsh <= PA_MAX_GRID;
+                        used_blocks <= PA_MAX_GRID && nsh <= 3 * PA_MAX_GRID;
   if (!c->b_tail_done && foldable) {
     c->fold_b_n = used_blocks;  // the next phase A's prologue (or cg_flush_fold) closes this iteration
     c->fold_b_nsh = nsh;
@@ -2594,7 +2603,7 @@ static int jacobi_run_t(pa_ctx* c, T* x, const T* rhs, double tol, int64_t max_i
                              (T*)c->scr[SCR_SHELL], part2, 1);
         }
       }
-      if (c->fold && tiled && used <= PA_MAX_GRID && nsh <= PA_MAX_GRID) {
+      if (c->fold && tiled && used <= PA_MAX_GRID && nsh <= 3 * PA_MAX_GRID) {
         c->fold_b_n = used;
         c->fold_b_nsh = nsh;
         c->fold_b_part = part_q;

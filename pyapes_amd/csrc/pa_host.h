@@ -61,6 +61,7 @@ struct pa_ctx {
   pa_term terms[PA_MAX_TERMS];
   // scratch
   void* scr[PA_NSCRATCH] = {nullptr};
+  void* scr_base[PA_NSCRATCH] = {nullptr};  // what hipMalloc returned (scr[q] = base + q * stagger)
   size_t cap[PA_NSCRATCH] = {0};
   SolverScalars* sc = nullptr;    // device: the CURRENT scalars (one of the two slots of sc_base)
   SolverScalars* sc_alt = nullptr;  // the other slot: a folded phase A writes the next state there, then they swap
