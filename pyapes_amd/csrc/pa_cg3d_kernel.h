@@ -849,6 +849,9 @@ static int launch_cg3d(pa_ctx* c, Cg3dArgs<T>& A) {
   int chunks = capacity / tiles;
   if (chunks < 1) chunks = 1;
   if (chunks > G.n0) chunks = (int)G.n0;
+  static int minci = -1;
+  if (minci < 0) { const char* e = getenv("PYAPES_HIP_MINCI"); minci = e ? atoi(e) : 1; if (minci < 1) minci = 1; }
+  if (chunks > 1 && G.n0 / chunks < minci) chunks = (int)(G.n0 / minci > 0 ? G.n0 / minci : 1);
   A.chunks = chunks;
   const int nblk = tiles * chunks;
   if (nblk > PA_MAX_PARTIALS) return 0;
@@ -864,8 +867,11 @@ static int launch_cg3d(pa_ctx* c, Cg3dArgs<T>& A) {
   return nblk;
 }
 
-// rows per thread: 4 (16-row tiles) for big planes; fewer rows = more tiles = longer marching chunks
-// when a plane has too few 16-row tiles to give every resident workgroup >= 32 planes
+// rows per thread.  Measured over 48^3 .. 512^3, long and flat boxes, fp64 and fp32: for
+// the CG / A x / Jacobi / BiCGSTAB phases 4 rows (16-row tiles) are best or within 1.5 % of best
+// everywhere and 1 row is never best (64^3: 20.9 vs 24.8 us / iteration, 192^3: 101 vs 117); 2 rows win
+// by a hair exactly where 16-row tiles leave chunks shorter than 24 planes and 8-row tiles do not (256^3
+// fp64).  The explicit Euler step is instruction-bound and keeps its own rule.
 template <typename T, int PHASE = 0>
 static int pick_rj(pa_ctx* c, bool narrow = false) {
   if (const char* e = getenv("PYAPES_HIP_RJ")) {
@@ -877,14 +883,21 @@ static int pick_rj(pa_ctx* c, bool narrow = false) {
   if (!G.act[0]) return 4;  // 2-D: one plane, nothing to march; the biggest tile has the least halo
   const int64_t tk = (G.n2 + 64 * VEC - 1) / (64 * VEC);
   const int cap = cus_of(c) * 2;
-  for (int rj = 4; rj >= 2; rj >>= 1) {
+  auto chunk_len = [&](int rj) {
     const int64_t tiles = ((G.n1 + 4 * rj - 1) / (4 * rj)) * tk;
     const int64_t chunks = cap / tiles > 0 ? cap / tiles : 1;
-    // the explicit Euler step is instruction-bound: more rows per thread amortise the per-plane
-    // bookkeeping, and it tolerates shorter chunks (256^3 fp32: RJ 2 48 us / step, RJ 1 52)
-    if (G.n0 / chunks >= (PHASE == 3 ? 12 : 24)) return rj;
+    return G.n0 / chunks;
+  };
+  if (PHASE == 3) {
+    // more rows per thread amortise the per-plane bookkeeping, and the step tolerates shorter chunks
+    // (256^3 fp32: RJ 2 48 us / step, RJ 1 52)
+    for (int rj = 4; rj >= 2; rj >>= 1)
+      if (chunk_len(rj) >= 12) return rj;
+    return 1;
   }
-  return 1;
+  if (G.n1 <= 4) return 1;
+  if (G.n1 <= 8) return 2;
+  return (chunk_len(4) < 24 && chunk_len(2) >= 24) ? 2 : 4;
 }
 
 template <typename T, int PHASE, bool NARROW>
