@@ -890,10 +890,9 @@ static int pick_rj(pa_ctx* c, bool narrow = false) {
   };
   if (PHASE == 3) {
     // more rows per thread amortise the per-plane bookkeeping, and the step tolerates shorter chunks
-    // (256^3 fp32: RJ 2 48 us / step, RJ 1 52)
-    for (int rj = 4; rj >= 2; rj >>= 1)
-      if (chunk_len(rj) >= 12) return rj;
-    return 1;
+    // (256^3 fp32: RJ 2 48 us / step, RJ 1 54); below that 2 rows stay best (fp32 64^3 12.9 vs 14.1 us,
+    // 128^3 19.9 vs 22.0, 192^3 34.3 vs 38.3; fp64 indifferent), 1 row never is
+    return chunk_len(4) >= 12 ? 4 : 2;
   }
   if (G.n1 <= 4) return 1;
   if (G.n1 <= 8) return 2;
