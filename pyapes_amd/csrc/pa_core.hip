@@ -2218,6 +2218,7 @@ static int cg_begin_t(pa_ctx* c, T* x, const T* rhs, double tol, int64_t max_it)
   PA_HIP(c, hipMemsetAsync(c->scr[SCR_D1], 0, fb, c->stream));
   c->cg_x = x;
   c->cur = 0;
+  c->fold_a_n = c->fold_b_n = c->fold_b_nsh = 0;  // nothing of an earlier (possibly failed) solve is pending
   c->bc_static = bc_is_static(c);
   c->bc_fused = bc_fusable(c);
   c->bc_pair = (!c->bc_fused && bc_pairable(c)) ? 1 : 0;
