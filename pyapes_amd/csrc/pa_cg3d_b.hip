@@ -24,8 +24,17 @@ int pa_tile3d_bicg_pv(pa_ctx* c, const DevEq<T>& E, Vec<T> r, Vec<T> p, Vec<T> v
   memset(&A, 0, sizeof(A));
   fill_common<T>(c, E, A);
   A.r = r; A.d = p; A.v = v; A.aux = r0; A.out = pnew; A.out2 = vnew; A.partials = partials;
+  if (c->fold_b_n > 0) {  // close the previous iteration in this kernel's prologue (next state -> the other slot)
+    A.pre_part = c->fold_b_part;
+    A.pre_n = c->fold_b_n;
+    A.sc_w = c->sc_alt;
+  }
   int n = launch_any<T, 5>(c, A, mode);
   if (n > 0 && hipGetLastError() != hipSuccess) { pa_set_err(c, "k_cg3d BiCGSTAB p/v launch failed"); return PA_E_HIP; }
+  if (n > 0 && c->fold_b_n > 0) {
+    SolverScalars* t = c->sc; c->sc = c->sc_alt; c->sc_alt = t;
+    c->fold_b_n = 0;
+  }
   return n;
 }
 
@@ -38,6 +47,11 @@ int pa_tile3d_bicg_st(pa_ctx* c, const DevEq<T>& E, Vec<T> r, Vec<T> v, const T*
   memset(&A, 0, sizeof(A));
   fill_common<T>(c, E, A);
   A.r = r; A.d = v; A.aux = r0; A.out = s_out; A.out2 = t_out; A.partials = partials;
+  if (c->fold_a_n > 0) {  // alpha (and the iteration count) in this kernel's prologue
+    A.pre_part = (const double*)c->scr[SCR_PART];
+    A.pre_n = c->fold_a_n;
+    A.sc_w = c->sc;
+  }
   int n = launch_any<T, 6>(c, A, mode);
   if (n > 0 && hipGetLastError() != hipSuccess) { pa_set_err(c, "k_cg3d BiCGSTAB s/t launch failed"); return PA_E_HIP; }
   return n;

@@ -200,10 +200,89 @@ __global__ void __launch_bounds__(256) k_cg3d(Cg3dArgs<T> A) {
     }
     __syncthreads();
     alpha = (T)pre_sm[4];
+  } else if (PHASE == 5 && A.pre_n > 0) {
+    // BiCGSTAB: the step that closes the PREVIOUS iteration (k_bicg_post stage 3; linalg.py:212-214,
+    // 236-262): early exit, stop test 2, next beta, rho <- rho_next.  Next state -> the other slot.
+    __shared__ double pre_sm[8];
+    const SolverScalars* si = A.sc;
+    const int done_in = si->done, fe = si->finished_early;
+    const double tol_lim = si->tolerance, rho_next = si->rho_next, rho_in = si->rho, alpha_in = si->alpha,
+                 omega_in = si->omega;
+    const long long itr_in = si->itr, max_it = si->max_it;
+    double v0 = 0.0;
+    for (int b = threadIdx.x; b < A.pre_n; b += 256) v0 += A.pre_part[b];
+    if (done_in) {
+      if (blockIdx.x == 0 && threadIdx.x == 0) *A.sc_w = *si;
+      return;
+    }
+    for (int off = 32; off > 0; off >>= 1) v0 += __shfl_down(v0, off, 64);
+    if ((threadIdx.x & 63) == 0) pre_sm[threadIdx.x >> 6] = v0;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      double v = 0.0;
+      for (int w = 0; w < 4; ++w) v += pre_sm[w];
+      const T tolv = (T)sqrt(v);
+      const bool bad = !fe && (isnan(tolv) || isinf(tolv));
+      int done = (fe || bad) ? 1 : 0;
+      T bq = (T)0;
+      if (!fe && !bad) {
+        if ((double)tolv <= tol_lim) done = 1;
+        if (itr_in >= max_it) done = 1;
+        bq = (T)rho_next / (T)rho_in;
+        bq = bq * (T)alpha_in;
+        bq = bq / (T)omega_in;
+      }
+      pre_sm[4] = (double)bq;
+      pre_sm[5] = done ? 1.0 : 0.0;
+      if (blockIdx.x == 0) {
+        SolverScalars* so = A.sc_w;
+        *so = *si;
+        so->done = done;
+        if (!fe) {
+          so->tol = (double)tolv;
+          if (bad) {
+            so->err = 1;
+          } else {
+            so->beta = (double)bq;
+            so->rho = rho_next;
+          }
+        }
+      }
+    }
+    __syncthreads();
+    if (pre_sm[5] != 0.0) return;
+    beta = (T)pre_sm[4];
+    omega = (T)omega_in;
+  } else if (PHASE == 6 && A.pre_n > 0) {
+    // BiCGSTAB: alpha = rho / (r0 . v) of THIS iteration, iteration count (k_bicg_post stage 0)
+    __shared__ double pre_sm[8];
+    const int done_in = A.sc->done;
+    const double rho_in = A.sc->rho;
+    double v0 = 0.0;
+    for (int b = threadIdx.x; b < A.pre_n; b += 256) v0 += A.pre_part[b];
+    if (done_in) return;
+    for (int off = 32; off > 0; off >>= 1) v0 += __shfl_down(v0, off, 64);
+    if ((threadIdx.x & 63) == 0) pre_sm[threadIdx.x >> 6] = v0;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      double v = 0.0;
+      for (int w = 0; w < 4; ++w) v += pre_sm[w];
+      const T q = (T)rho_in / (T)v;
+      const double al = (isnan(q) || isinf(q)) ? 0.0 : (double)q;  // linalg.py:302-305
+      pre_sm[4] = al;
+      if (blockIdx.x == 0) {
+        A.sc_w->itr += 1;   // no other block of this launch reads itr
+        A.sc_w->alpha = al;
+      }
+    }
+    __syncthreads();
+    alpha = (T)pre_sm[4];
   } else {
     if (PHASE != 2 && PHASE != 3 && A.sc->done) return;
     if (PHASE == 0) beta = (T)A.sc->beta;
     if (PHASE == 1) alpha = (T)A.sc->alpha;
+    if (PHASE == 5) { beta = (T)A.sc->beta; omega = (T)A.sc->omega; }
+    if (PHASE == 6) alpha = (T)A.sc->alpha;
   }
   const DevGeom& G = A.G;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -266,9 +345,6 @@ __global__ void __launch_bounds__(256) k_cg3d(Cg3dArgs<T> A) {
   const int hs_row = lane >> 1, hs_side = lane & 1;
   const int64_t hs_off = pa_wrapmod(j0 + hs_row, G.n1) * G.s1 +
                          (hs_side ? pa_wrapmod(k0 + TK, G.n2) : pa_wrapmod(k0 - 1, G.n2));
-
-  if (PHASE == 5) { beta = (T)A.sc->beta; omega = (T)A.sc->omega; }
-  if (PHASE == 6) alpha = (T)A.sc->alpha;
 
   auto plane_of = [&](int q) -> int64_t { return rev ? (i1 - 1 - q) : (i0 + q); };
   auto pptr = [&](const Vec<T>& v, int64_t ii) -> const T* {

@@ -1152,10 +1152,70 @@ template <typename T>
 __global__ void __launch_bounds__(PA_BLOCK) k_bicg_x(DevGeom G, const SolverScalars* __restrict__ sc,
                                                       T* __restrict__ x, const T* __restrict__ p,
                                                       const T* __restrict__ s_in, const T* __restrict__ t_in,
-                                                      T* __restrict__ r, double* __restrict__ partials) {
-  if (sc->done) return;
-  const T alpha = (T)sc->alpha, omega = (T)sc->omega;
-  const int early = sc->finished_early;
+                                                      T* __restrict__ r, double* __restrict__ partials,
+                                                      const double* pre_part, int pre_n, SolverScalars* sc_w) {
+  const T alpha = (T)sc->alpha;
+  T omega;
+  int early;
+  if (pre_n > 0) {
+    // folded k_bicg_post stage 12 (rows {|s|^2, t.s, t.t, r0.t} of the fused s / t kernel): stop test 1,
+    // then omega and rho_next -- every block on its own, same summation order; block 0 stores
+    __shared__ double pre_sm[24];
+    const int done_in = sc->done;
+    const double tol_lim = sc->tolerance, omega_in = sc->omega;
+    double v[4] = {0.0, 0.0, 0.0, 0.0};
+    for (int b = threadIdx.x; b < pre_n; b += PA_BLOCK) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) v[q] += pre_part[4 * (int64_t)b + q];
+    }
+    if (done_in) return;
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      for (int off = 32; off > 0; off >>= 1) v[q] += __shfl_down(v[q], off, 64);
+    if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) pre_sm[4 * (threadIdx.x >> 6) + q] = v[q];
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      double t4[4] = {0.0, 0.0, 0.0, 0.0};
+      for (int w = 0; w < PA_BLOCK / 64; ++w) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) t4[q] += pre_sm[4 * w + q];
+      }
+      const T tol = (T)sqrt(t4[0]);
+      const bool bad = isnan(tol) || isinf(tol);
+      const int fe = (!bad && (double)tol <= tol_lim) ? 1 : 0;
+      T om = (T)omega_in;
+      if (!bad && !fe) om = (T)pa_nan_to_num<T>((T)t4[1] / (T)t4[2]);
+      pre_sm[16] = (double)om;
+      pre_sm[17] = fe ? 1.0 : 0.0;
+      pre_sm[18] = bad ? 1.0 : 0.0;
+      if (blockIdx.x == 0) {
+        sc_w->tol = (double)tol;
+        if (bad) {
+          sc_w->err = 1;
+          sc_w->done = 1;
+        } else {
+          sc_w->finished_early = fe;
+          if (!fe) {
+            sc_w->omega = (double)om;
+            T rn = -om;
+            rn = rn * (T)t4[3];
+            sc_w->rho_next = (double)rn;
+          }
+        }
+      }
+    }
+    __syncthreads();
+    if (pre_sm[18] != 0.0) return;
+    omega = (T)pre_sm[16];
+    early = pre_sm[17] != 0.0;
+  } else {
+    if (sc->done) return;
+    omega = (T)sc->omega;
+    early = sc->finished_early;
+  }
   double s[1] = {0.0};
   for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < G.ncell;
        idx += (int64_t)gridDim.x * blockDim.x) {
@@ -2644,7 +2704,7 @@ static int bicg_run_t(pa_ctx* c, T* x, const T* rhs, double tol, int64_t max_it,
   const int ids[] = {SCR_R, SCR_D0, SCR_D1, SCR_R0, SCR_V0, SCR_V1, SCR_S, SCR_TT};
   for (int id : ids)
     if ((rc = pa_scratch(c, &c->scr[id], &c->cap[id], fb))) return rc;
-  if ((rc = pa_scratch(c, &c->scr[SCR_PART], &c->cap[SCR_PART], (size_t)PA_MAX_PARTIALS * 4 * sizeof(double)))) return rc;
+  if ((rc = pa_scratch(c, &c->scr[SCR_PART], &c->cap[SCR_PART], (size_t)PA_MAX_PARTIALS * 6 * sizeof(double)))) return rc;
   if ((rc = init_scalars(c, tol, max_it))) return rc;
   DevEq<T> E;
   pa_build_eq<T>(c, c->nterms, c->terms, E);
@@ -2683,36 +2743,66 @@ static int bicg_run_t(pa_ctx* c, T* x, const T* rhs, double tol, int64_t max_it,
   PA_HIP(c, hipEventRecord(c->ev0, c->stream));
   int64_t enq = 0;
   int next_poll = 1;
+  // The three single-block scalar kernels of an iteration are folded into the prologue of the kernel
+  // that follows each (pa_cg3d_kernel.h phases 5 / 6, k_bicg_x) when that kernel is a tiled one / the
+  // row counts are small; each producer has its own region of SCR_PART, because its consumer reads the
+  // rows while writing its own.  `pend*` = rows waiting for a prologue.
+  double* const reg0 = part;                                   // r0.v'            (1 column)
+  double* const reg1 = part + (size_t)PA_MAX_PARTIALS;         // |s|^2 t.s t.t r0.t (4 columns)
+  double* const reg2 = part + 5 * (size_t)PA_MAX_PARTIALS;     // |r|^2            (1 column)
+  const bool fold = c->fold && !c->slab;
+  int pend3 = 0;
+  c->fold_a_n = c->fold_b_n = c->fold_b_nsh = 0;
+  auto flush3 = [&]() {
+    if (pend3 > 0) hipLaunchKernelGGL(k_bicg_post<T>, dim3(1), dim3(PA_BLOCK), 0, c->stream, c->sc, reg2, pend3, 3);
+    pend3 = 0;
+    c->fold_b_n = 0;
+  };
   for (;;) {
     Vec<T> rv = pa_vec_self<T>(c, r), pv = pa_vec_self<T>(c, p[cur]), vv = pa_vec_self<T>(c, v[cur]);
-    int used = pa_tile3d_bicg_pv<T>(c, E, rv, pv, vv, (const T*)r0, p[cur ^ 1], v[cur ^ 1], part);
-    if (used < 0) return used;
-    if (used == 0) {
-      hipLaunchKernelGGL(k_bicg_pv<T>, dim3(nblk), dim3(PA_BLOCK), 0, c->stream, G, E, c->sc, rv, pv, vv, (const T*)r0,
-                         p[cur ^ 1], v[cur ^ 1], part);
-      used = nblk;
-    }
-    hipLaunchKernelGGL(k_bicg_post<T>, dim3(1), dim3(PA_BLOCK), 0, c->stream, c->sc, part, used, 0);
-    Vec<T> vnv = pa_vec_self<T>(c, v[cur ^ 1]);
-    used = pa_tile3d_bicg_st<T>(c, E, rv, vnv, (const T*)r0, s, t, part);
+    c->fold_b_n = pend3;          // phase 5 closes the previous iteration (and swaps the scalar slots)
+    c->fold_b_part = reg2;
+    int used = pa_tile3d_bicg_pv<T>(c, E, rv, pv, vv, (const T*)r0, p[cur ^ 1], v[cur ^ 1], reg0);
     if (used < 0) return used;
     if (used > 0) {
-      hipLaunchKernelGGL(k_bicg_post<T>, dim3(1), dim3(PA_BLOCK), 0, c->stream, c->sc, part, used, 12);
+      pend3 = 0;
     } else {
+      flush3();
+      hipLaunchKernelGGL(k_bicg_pv<T>, dim3(nblk), dim3(PA_BLOCK), 0, c->stream, G, E, c->sc, rv, pv, vv, (const T*)r0,
+                         p[cur ^ 1], v[cur ^ 1], reg0);
+      used = nblk;
+    }
+    int pend0 = (fold && used <= PA_MAX_GRID) ? used : 0;
+    if (!pend0) hipLaunchKernelGGL(k_bicg_post<T>, dim3(1), dim3(PA_BLOCK), 0, c->stream, c->sc, reg0, used, 0);
+    Vec<T> vnv = pa_vec_self<T>(c, v[cur ^ 1]);
+    c->fold_a_n = pend0;          // phase 6 computes alpha itself
+    int used2 = pa_tile3d_bicg_st<T>(c, E, rv, vnv, (const T*)r0, s, t, reg1);
+    c->fold_a_n = 0;
+    if (used2 < 0) return used2;
+    int pend12 = 0;
+    if (used2 > 0) {
+      pend12 = (fold && used2 <= PA_MAX_GRID) ? used2 : 0;
+      if (!pend12) hipLaunchKernelGGL(k_bicg_post<T>, dim3(1), dim3(PA_BLOCK), 0, c->stream, c->sc, reg1, used2, 12);
+    } else {
+      if (pend0) hipLaunchKernelGGL(k_bicg_post<T>, dim3(1), dim3(PA_BLOCK), 0, c->stream, c->sc, reg0, pend0, 0);
       hipLaunchKernelGGL(k_bicg_s<T>, dim3(nblk), dim3(PA_BLOCK), 0, c->stream, G, c->sc, (const T*)r,
-                         (const T*)v[cur ^ 1], s, part);
-      hipLaunchKernelGGL(k_bicg_post<T>, dim3(1), dim3(PA_BLOCK), 0, c->stream, c->sc, part, nblk, 1);
+                         (const T*)v[cur ^ 1], s, reg1);
+      hipLaunchKernelGGL(k_bicg_post<T>, dim3(1), dim3(PA_BLOCK), 0, c->stream, c->sc, reg1, nblk, 1);
       Vec<T> sv = pa_vec_self<T>(c, s);
-      hipLaunchKernelGGL(k_bicg_t<T>, dim3(nblk), dim3(PA_BLOCK), 0, c->stream, G, E, c->sc, sv, (const T*)r0, t, part);
-      hipLaunchKernelGGL(k_bicg_post<T>, dim3(1), dim3(PA_BLOCK), 0, c->stream, c->sc, part, nblk, 2);
+      hipLaunchKernelGGL(k_bicg_t<T>, dim3(nblk), dim3(PA_BLOCK), 0, c->stream, G, E, c->sc, sv, (const T*)r0, t, reg1);
+      hipLaunchKernelGGL(k_bicg_post<T>, dim3(1), dim3(PA_BLOCK), 0, c->stream, c->sc, reg1, nblk, 2);
     }
     hipLaunchKernelGGL(k_bicg_x<T>, dim3(nblk), dim3(PA_BLOCK), 0, c->stream, G, c->sc, x, (const T*)p[cur ^ 1],
-                       (const T*)s, (const T*)t, r, part);
+                       (const T*)s, (const T*)t, r, reg2, (const double*)reg1, pend12, c->sc);
     if ((rc = bc_apply_auto<T>(c, x, true))) return rc;
-    hipLaunchKernelGGL(k_bicg_post<T>, dim3(1), dim3(PA_BLOCK), 0, c->stream, c->sc, part, nblk, 3);
+    if (fold && nblk <= PA_MAX_GRID)
+      pend3 = nblk;
+    else
+      hipLaunchKernelGGL(k_bicg_post<T>, dim3(1), dim3(PA_BLOCK), 0, c->stream, c->sc, reg2, nblk, 3);
     cur ^= 1;
     ++enq;
     if (enq >= next_poll || enq >= max_it) {
+      flush3();
       if ((rc = read_scalars(c))) return rc;
       if (c->h_sc->done) break;
       next_poll = (int)std::min<int64_t>(enq + std::min<int64_t>(poll, std::max<int64_t>(1, enq)), max_it);
