@@ -1536,6 +1536,10 @@ int pa_ctx_create(int device, void* hip_stream, pa_ctx** out) {
       hipMalloc((void**)&c->sums, PA_NSUM * sizeof(double)) != hipSuccess ||
       hipMalloc((void**)&c->tickets, 4 * sizeof(unsigned int)) != hipSuccess ||
       hipHostMalloc((void**)&c->h_sc, sizeof(SolverScalars)) != hipSuccess ||
+      hipHostMalloc((void**)&c->h_poll[0], sizeof(SolverScalars)) != hipSuccess ||
+      hipHostMalloc((void**)&c->h_poll[1], sizeof(SolverScalars)) != hipSuccess ||
+      hipEventCreateWithFlags(&c->ev_poll[0], hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&c->ev_poll[1], hipEventDisableTiming) != hipSuccess ||
       hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess) {
     pa_set_err(nullptr, "pa_ctx_create: allocation failed");
     delete c;
@@ -1563,6 +1567,10 @@ int pa_ctx_destroy(pa_ctx* c) {
   if (c->sums) (void)hipFree(c->sums);
   if (c->tickets) (void)hipFree(c->tickets);
   if (c->h_sc) (void)hipHostFree(c->h_sc);
+  for (int q = 0; q < 2; ++q) {
+    if (c->h_poll[q]) (void)hipHostFree(c->h_poll[q]);
+    if (c->ev_poll[q]) (void)hipEventDestroy(c->ev_poll[q]);
+  }
   if (c->ev0) (void)hipEventDestroy(c->ev0);
   if (c->ev1) (void)hipEventDestroy(c->ev1);
   for (int q = 0; q < 4; ++q)
@@ -2243,6 +2251,37 @@ static int read_scalars(pa_ctx* c) {
   return PA_OK;
 }
 
+// Pipelined poll: after a batch of iterations has been enqueued (and its pending scalar step flushed),
+// queue a copy of the device scalars and wait for the copy of the PREVIOUS batch.  The GPU already has
+// the next batch to work on while the host looks at the flag; when the flag was set, that batch is
+// no-ops (every kernel starts with `if (done) return`), so results and iteration counts are unchanged.
+// A synchronous poll leaves the GPU idle for a host round trip (~250 us) every ~300 us of work on the
+// meshes of the reference's tests.
+struct PollPipe {
+  int pending = -1, slot = 0;
+};
+static int poll_submit(pa_ctx* c, PollPipe& P, bool* done) {
+  *done = false;
+  if (int rcj = pa_join_side(c)) return rcj;
+  PA_HIP(c, hipMemcpyAsync(c->h_poll[P.slot], c->sc, sizeof(SolverScalars), hipMemcpyDeviceToHost, c->stream));
+  PA_HIP(c, hipEventRecord(c->ev_poll[P.slot], c->stream));
+  if (P.pending >= 0) {
+    PA_HIP(c, hipEventSynchronize(c->ev_poll[P.pending]));
+    *done = c->h_poll[P.pending]->done != 0;
+  }
+  P.pending = P.slot;
+  P.slot ^= 1;
+  return PA_OK;
+}
+static int poll_drain(pa_ctx* c, PollPipe& P, bool* done) {
+  *done = false;
+  if (P.pending < 0) return PA_OK;
+  PA_HIP(c, hipEventSynchronize(c->ev_poll[P.pending]));
+  *done = c->h_poll[P.pending]->done != 0;
+  P.pending = -1;
+  return PA_OK;
+}
+
 static int poll_interval(const pa_ctx* c) {
   // keep >= ~300 us of queued GPU work between host polls of the done flag
   double est_us = (double)c->G.ncell * 80.0 / 4.0e6 + 30.0;
@@ -2567,17 +2606,30 @@ static int cg_run_t(pa_ctx* c, T* x, const T* rhs, double tol, int64_t max_it, p
   const int poll = poll_interval(c);
   PA_HIP(c, hipEventRecord(c->ev0, c->stream));
   int64_t enq = 0;
-  int next_poll = 1;
-  for (;;) {
-    if ((rc = pa_cg_phase_a_t<T>(c, 2))) return rc;
-    if ((rc = pa_cg_phase_b_t<T>(c, 2))) return rc;
-    ++enq;
-    if (enq >= next_poll || enq > max_it) {
-      if ((rc = read_scalars(c))) return rc;
-      if (c->h_sc->done) break;
-      next_poll = (int)std::min<int64_t>(enq + std::min<int64_t>(poll, std::max<int64_t>(1, enq)), max_it + 1);
+  c->in_iterate = 1;  // scalar steps folded into the next tiled kernel's prologue (flushed before every poll)
+  PollPipe P;
+  bool done = false;
+  int64_t batch = 1;
+  while (!done && !rc) {
+    // the device stops by itself after max_it + 1 iterations (linalg.py K+1 quirk): never enqueue more
+    int64_t nb = std::min<int64_t>(batch, max_it + 1 - enq);
+    if (nb <= 0) {
+      if ((rc = poll_drain(c, P, &done)) || done) break;
+      nb = 1;  // not reached by construction; keeps the loop live if it ever is
     }
+    for (int64_t q = 0; q < nb && !rc; ++q) {
+      if ((rc = pa_cg_phase_a_t<T>(c, 2))) break;
+      rc = pa_cg_phase_b_t<T>(c, 2);
+      ++enq;
+    }
+    if (rc) break;
+    cg_flush_fold<T>(c);
+    rc = poll_submit(c, P, &done);
+    batch = std::min<int64_t>(poll, std::max<int64_t>(1, enq));
   }
+  if (!rc) rc = read_scalars(c);
+  c->in_iterate = 0;
+  if (rc) { c->fold_a_n = c->fold_b_n = c->fold_b_nsh = 0; return rc; }
   PA_HIP(c, hipEventRecord(c->ev1, c->stream));
   PA_HIP(c, hipEventSynchronize(c->ev1));
   float ms = 0.f;
@@ -2625,7 +2677,6 @@ static int jacobi_run_t(pa_ctx* c, T* x, const T* rhs, double tol, int64_t max_i
   const int poll = poll_interval(c);
   PA_HIP(c, hipEventRecord(c->ev0, c->stream));
   int64_t enq = 0;
-  int next_poll = 1;
   // the stop test of sweep q is left to the prologue of sweep q+1 (pa_cg3d_kernel.h) when both are
   // tiled; this runs it as the single-block kernel it replaces (before a poll, before a generic sweep)
   auto flush = [&]() {
@@ -2634,9 +2685,19 @@ static int jacobi_run_t(pa_ctx* c, T* x, const T* rhs, double tol, int64_t max_i
                          (const double*)part2, c->fold_b_nsh, pa_sums(c));
     c->fold_b_n = c->fold_b_nsh = 0;
   };
-  for (;;) {
+  PollPipe P;
+  bool done = false;
+  int64_t batch = 2;
+  while (!done) {
+    // the device stops by itself after max_it + 1 sweeps; sweeps are enqueued in pairs
+    int64_t nb = std::min<int64_t>(batch, max_it + 2 - enq);
+    if (nb <= 0) {
+      if ((rc = poll_drain(c, P, &done))) return rc;
+      if (done) break;
+      nb = 2;
+    }
     // two sweeps per round so that the iterate is back in the caller's buffer at every poll
-    for (int half = 0; half < 2; ++half) {
+    for (int64_t half = 0; half < ((nb + 1) & ~(int64_t)1); ++half) {
       Vec<T> xv = pa_vec_self<T>(c, buf[cur]);
       // partial rows alternate between the halves of SCR_PART: the next sweep reads these while it writes its own
       double* part_q = part + (cur ? 2 * (size_t)PA_MAX_PARTIALS : 0);
@@ -2675,13 +2736,11 @@ static int jacobi_run_t(pa_ctx* c, T* x, const T* rhs, double tol, int64_t max_i
       cur ^= 1;
       ++enq;
     }
-    if (enq >= next_poll || enq > max_it) {
-      flush();
-      if ((rc = read_scalars(c))) return rc;
-      if (c->h_sc->done) break;
-      next_poll = (int)std::min<int64_t>(enq + std::min<int64_t>(2 * poll, std::max<int64_t>(2, enq)), max_it + 2);
-    }
+    flush();
+    if ((rc = poll_submit(c, P, &done))) return rc;
+    batch = std::min<int64_t>(2 * poll, std::max<int64_t>(2, enq));
   }
+  if ((rc = read_scalars(c))) return rc;
   // the final iterate lives in buf[itr & 1]
   if (c->h_sc->itr & 1) {
     hipLaunchKernelGGL(k_copy<T>, dim3(nblk), dim3(PA_BLOCK), 0, c->stream, (const T*)buf[1], x, G.ncell);
@@ -2742,7 +2801,6 @@ static int bicg_run_t(pa_ctx* c, T* x, const T* rhs, double tol, int64_t max_it,
   const int poll = poll_interval(c);
   PA_HIP(c, hipEventRecord(c->ev0, c->stream));
   int64_t enq = 0;
-  int next_poll = 1;
   // The three single-block scalar kernels of an iteration are folded into the prologue of the kernel
   // that follows each (pa_cg3d_kernel.h phases 5 / 6, k_bicg_x) when that kernel is a tiled one / the
   // row counts are small; each producer has its own region of SCR_PART, because its consumer reads the
@@ -2758,7 +2816,18 @@ static int bicg_run_t(pa_ctx* c, T* x, const T* rhs, double tol, int64_t max_it,
     pend3 = 0;
     c->fold_b_n = 0;
   };
-  for (;;) {
+  PollPipe P;
+  bool done = false;
+  int64_t batch = 1;
+  const int64_t max_enq = std::max<int64_t>(max_it, 1);  // the device stops by itself after max_it iterations
+  while (!done) {
+    int64_t nb = std::min<int64_t>(batch, max_enq - enq);
+    if (nb <= 0) {
+      if ((rc = poll_drain(c, P, &done))) return rc;
+      if (done) break;
+      nb = 1;
+    }
+   for (int64_t qi = 0; qi < nb; ++qi) {
     Vec<T> rv = pa_vec_self<T>(c, r), pv = pa_vec_self<T>(c, p[cur]), vv = pa_vec_self<T>(c, v[cur]);
     c->fold_b_n = pend3;          // phase 5 closes the previous iteration (and swaps the scalar slots)
     c->fold_b_part = reg2;
@@ -2801,13 +2870,12 @@ static int bicg_run_t(pa_ctx* c, T* x, const T* rhs, double tol, int64_t max_it,
       hipLaunchKernelGGL(k_bicg_post<T>, dim3(1), dim3(PA_BLOCK), 0, c->stream, c->sc, reg2, nblk, 3);
     cur ^= 1;
     ++enq;
-    if (enq >= next_poll || enq >= max_it) {
-      flush3();
-      if ((rc = read_scalars(c))) return rc;
-      if (c->h_sc->done) break;
-      next_poll = (int)std::min<int64_t>(enq + std::min<int64_t>(poll, std::max<int64_t>(1, enq)), max_it);
-    }
+   }
+    flush3();
+    if ((rc = poll_submit(c, P, &done))) return rc;
+    batch = std::min<int64_t>(poll, std::max<int64_t>(1, enq));
   }
+  if ((rc = read_scalars(c))) return rc;
   PA_HIP(c, hipEventRecord(c->ev1, c->stream));
   PA_HIP(c, hipEventSynchronize(c->ev1));
   float ms = 0.f;

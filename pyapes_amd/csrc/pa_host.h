@@ -73,6 +73,10 @@ struct pa_ctx {
   int fold_b_n = 0, fold_b_nsh = 0; // rows of phase-B (Jacobi: sweep) / shell partials waiting for the next phase A (sweep)
   const double* fold_b_part = nullptr;
   SolverScalars* h_sc = nullptr;  // pinned host mirror
+  // pipelined polls of the done flag: the copy of batch b's scalars is waited for after batch b+1 has
+  // been enqueued, so the GPU never idles between batches (the over-enqueued batch is no-ops)
+  SolverScalars* h_poll[2] = {nullptr, nullptr};
+  hipEvent_t ev_poll[2] = {nullptr, nullptr};
   double* sums = nullptr;         // device, PA_NSUM (internal)
   double* ext_sums = nullptr;     // slab: caller-owned sums buffer (all-reduced by the host driver)
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
