@@ -106,6 +106,168 @@ __global__ void __launch_bounds__(256) k_cg3d(Cg3dArgs<T> A) {
   (void)sizeof(int[PHASE >= 0 && PHASE <= 6 ? 1 : -1]);
   T beta = (T)0, alpha = (T)0;
   T omega = (T)0;
+  const DevGeom& G = A.G;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int vb = pa_xcd_remap(blockIdx.x, gridDim.x);
+  const int tiles = A.tiles_j * A.tiles_k;
+  const int chunk = vb / tiles, tl = vb - chunk * tiles;
+  const int tjb = tl / A.tiles_k, tkb = tl - tjb * A.tiles_k;
+  const int64_t i0 = (int64_t)chunk * G.n0 / A.chunks, i1 = (int64_t)(chunk + 1) * G.n0 / A.chunks;
+  const int CI = (int)(i1 - i0);
+  const int64_t j0 = (int64_t)tjb * TJ, k0 = (int64_t)tkb * TK;
+  const int rev = A.reverse;
+
+  // ---- per-thread geometry: RJ rows x VEC columns --------------------------------
+  const int64_t kg = k0 + (int64_t)lane * VEC;            // global k of element 0 (may be >= n2)
+  const int64_t kc = pa_wrapmod(kg, G.n2);                // wrapped column used for loads
+  const bool kvalid = kg < G.n2;
+  int64_t jrow[RJ];
+  unsigned rowS = 0, rowShell = 0, rowValid = 0, rowLo = 0, rowHi = 0;
+#pragma unroll
+  for (int jj = 0; jj < RJ; ++jj) {
+    const int64_t jg = j0 + wv * RJ + jj;
+    jrow[jj] = pa_wrapmod(jg, G.n1);
+    const bool valid = jg < G.n1;
+    if (valid) rowValid |= 1u << jj;
+    if (valid && jg >= G.slo[1] && jg <= G.shi[1]) rowS |= 1u << jj;
+    if (jg == 0 || jg == G.n1 - 1) rowShell |= 1u << jj;
+    const int rc = pa_row_case(G, 1, jg, G.n1, G.treat);
+    if (rc == 1) rowLo |= 1u << jj;
+    if (rc == 2) rowHi |= 1u << jj;
+  }
+  unsigned rowPLo = 0, rowPHi = 0, colPLo = 0, colPHi = 0;  // periodic rows of the central Div (fdc.py:596-602)
+  if (PHASE == 3 || KIND != 0) {
+#pragma unroll
+    for (int jj = 0; jj < RJ; ++jj) {
+      const int64_t jg = j0 + wv * RJ + jj;
+      if (G.bct[2] == 4 && jg == 1) rowPLo |= 1u << jj;
+      if (G.bct[3] == 4 && jg == G.n1 - 2) rowPHi |= 1u << jj;
+    }
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) {
+      if (G.bct[4] == 4 && kg + v == 1) colPLo |= 1u << v;
+      if (G.bct[5] == 4 && kg + v == G.n2 - 2) colPHi |= 1u << v;
+    }
+  }
+  unsigned colS = 0, colShell = 0, colLo = 0, colHi = 0;
+#pragma unroll
+  for (int v = 0; v < VEC; ++v) {
+    const int64_t kk = kg + v;
+    if (kvalid && kk >= G.slo[2] && kk <= G.shi[2]) colS |= 1u << v;
+    if (kk == 0 || kk == G.n2 - 1) colShell |= 1u << v;
+    const int rc = pa_row_case(G, 2, kk, G.n2, G.treat);
+    if (rc == 1) colLo |= 1u << v;
+    if (rc == 2) colHi |= 1u << v;
+  }
+  // halo duty of this wave: wave 0 -> row above the tile, wave 3 -> row below (vector loads);
+  // wave 1, lanes < 2*TJ -> the single cells left / right of each tile row (scalar loads)
+  const int64_t hrow = (wv == 0) ? pa_wrapmod(j0 - 1, G.n1) : pa_wrapmod(j0 + TJ, G.n1);
+  const bool hvec = (wv == 0 || wv == 3);
+  const bool hsc = (wv == 1 && lane < 2 * TJ);
+  const int hs_row = lane >> 1, hs_side = lane & 1;
+  const int64_t hs_off = pa_wrapmod(j0 + hs_row, G.n1) * G.s1 +
+                         (hs_side ? pa_wrapmod(k0 + TK, G.n2) : pa_wrapmod(k0 - 1, G.n2));
+
+  auto plane_of = [&](int q) -> int64_t { return rev ? (i1 - 1 - q) : (i0 + q); };
+  auto pptr = [&](const Vec<T>& v, int64_t ii) -> const T* {
+    return ii < 0 ? v.glo : (ii >= G.n0 ? v.ghi : v.p + ii * G.s0);
+  };
+
+  // Raw loads of one plane (own cells + this wave's share of the halo ring).  They are only
+  // ISSUED here; the arithmetic that consumes them (finish_*) is placed after the stencil of the
+  // current plane, so the s_waitcnt lands there and the loads fly during the stencil.
+  struct Raw {
+    V d[RJ];
+    V r[RJ];   // phases A, 5, 6
+    V q[RJ];   // phase 5 (v)
+    V hd, hr, hq;  // halo row (waves 0 and 3)
+    T sd, sr, sq;  // halo cell (wave 1)
+  };
+  constexpr bool HAS_R = (PHASE == 0 || PHASE == 5 || PHASE == 6);
+  constexpr bool HAS_Q = (PHASE == 5);
+  auto issue = [&](int64_t ii, Raw& w, bool with_halo) {
+    const T* dp = pptr(A.d, ii);
+    const T* rp = HAS_R ? pptr(A.r, ii) : dp;
+    const T* qp = HAS_Q ? pptr(A.v, ii) : dp;
+#pragma unroll
+    for (int jj = 0; jj < RJ; ++jj) {
+      const int64_t o = jrow[jj] * G.s1 + kc;
+      w.d[jj] = *reinterpret_cast<const V*>(dp + o);
+      if (HAS_R) w.r[jj] = *reinterpret_cast<const V*>(rp + o);
+      if (HAS_Q) w.q[jj] = *reinterpret_cast<const V*>(qp + o);
+    }
+    if (with_halo) {
+      if (hvec) {
+        const int64_t o = hrow * G.s1 + kc;
+        w.hd = *reinterpret_cast<const V*>(dp + o);
+        if (HAS_R) w.hr = *reinterpret_cast<const V*>(rp + o);
+        if (HAS_Q) w.hq = *reinterpret_cast<const V*>(qp + o);
+      }
+      if (hsc) {
+        w.sd = dp[hs_off];
+        if (HAS_R) w.sr = rp[hs_off];
+        if (HAS_Q) w.sq = qp[hs_off];
+      }
+    }
+  };
+  // the staged field from the raw loads: phase A r + beta d ; phase 5 r + beta (p - omega v)
+  // (linalg.py:217) ; phase 6 r - alpha v (linalg.py:230) ; else the field itself
+  auto combine = [&](T rr_, T dd_, T qq_) -> T {
+    if (PHASE == 0) {
+      T bd = beta * dd_;
+      return rr_ + bd;
+    } else if (PHASE == 5) {
+      T t = omega * qq_;
+      t = dd_ - t;
+      t = beta * t;
+      return rr_ + t;
+    } else if (PHASE == 6) {
+      T av = alpha * dd_;
+      return rr_ - av;
+    }
+    return dd_;
+  };
+  auto finish_own = [&](const Raw& w, V (&e)[RJ]) {
+#pragma unroll
+    for (int jj = 0; jj < RJ; ++jj) {
+#pragma unroll
+      for (int v = 0; v < VEC; ++v)
+        e[jj][v] = combine(HAS_R ? w.r[jj][v] : (T)0, w.d[jj][v], HAS_Q ? w.q[jj][v] : (T)0);
+    }
+  };
+  auto finish_halo = [&](const Raw& w, V& hv, T& hs) {
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) hv[v] = combine(HAS_R ? w.hr[v] : (T)0, w.hd[v], HAS_Q ? w.hq[v] : (T)0);
+    hs = combine(HAS_R ? w.sr : (T)0, w.sd, HAS_Q ? w.sq : (T)0);
+  };
+  auto stage = [&](int buf, const V (&e)[RJ], const V& hv, const T& hs) {
+#pragma unroll
+    for (int jj = 0; jj < RJ; ++jj)
+      *reinterpret_cast<V*>(&tile[buf][wv * RJ + jj + 1][VEC + lane * VEC]) = e[jj];
+    if (hvec) *reinterpret_cast<V*>(&tile[buf][wv == 0 ? 0 : TJ + 1][VEC + lane * VEC]) = hv;
+    if (hsc) tile[buf][hs_row + 1][hs_side ? VEC + TK : VEC - 1] = hs;
+  };
+
+  V ea[RJ], ec[RJ], eb[RJ];  // behind / current / ahead in march order
+  V hv;
+  T hs = (T)0;
+  Raw w;
+#pragma unroll
+  for (int v = 0; v < VEC; ++v) { hv[v] = (T)0; w.hd[v] = (T)0; w.hr[v] = (T)0; w.hq[v] = (T)0; }
+  w.sd = (T)0; w.sr = (T)0; w.sq = (T)0;
+
+  // ---- prologue -----------------------------------------------------------------------
+  // All loads a workgroup needs before its first stencil are issued back to back -- the three planes
+  // behind / at / ahead of the chunk start, then (below) the flag, the scalars and the partial rows of
+  // the folded scalar step -- and waited for once.  Issued one `finish` at a time they were five
+  // dependent round trips of 1-2 us each, i.e. half of a 10 us kernel on the meshes where a workgroup
+  // only ever sees one or two planes (<= 128^3).
+  const bool act0 = G.act[0] != 0;   // 2-D meshes occupy internal axes 1,2: a single plane, no i-neighbours
+  Raw wa = w, wc = w;                // planes -1 and 0; `w` takes plane +1 and stays the loop's buffer
+  if (act0) issue(plane_of(-1), wa, false);
+  issue(plane_of(0), wc, true);
+  if (act0) issue(plane_of(1), w, CI > 1);
+
   if ((PHASE == 0 || PHASE == 4) && A.pre_n > 0) {
     // the scalar step that closes the PREVIOUS iteration (CG: linalg.py:128-141, 321-338; the Jacobi
     // sweep has the stop test and the iteration count only).  Every load of
@@ -284,173 +446,19 @@ __global__ void __launch_bounds__(256) k_cg3d(Cg3dArgs<T> A) {
     if (PHASE == 5) { beta = (T)A.sc->beta; omega = (T)A.sc->omega; }
     if (PHASE == 6) alpha = (T)A.sc->alpha;
   }
-  const DevGeom& G = A.G;
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const int vb = pa_xcd_remap(blockIdx.x, gridDim.x);
-  const int tiles = A.tiles_j * A.tiles_k;
-  const int chunk = vb / tiles, tl = vb - chunk * tiles;
-  const int tjb = tl / A.tiles_k, tkb = tl - tjb * A.tiles_k;
-  const int64_t i0 = (int64_t)chunk * G.n0 / A.chunks, i1 = (int64_t)(chunk + 1) * G.n0 / A.chunks;
-  const int CI = (int)(i1 - i0);
-  const int64_t j0 = (int64_t)tjb * TJ, k0 = (int64_t)tkb * TK;
-  const int rev = A.reverse;
 
-  // ---- per-thread geometry: RJ rows x VEC columns --------------------------------
-  const int64_t kg = k0 + (int64_t)lane * VEC;            // global k of element 0 (may be >= n2)
-  const int64_t kc = pa_wrapmod(kg, G.n2);                // wrapped column used for loads
-  const bool kvalid = kg < G.n2;
-  int64_t jrow[RJ];
-  unsigned rowS = 0, rowShell = 0, rowValid = 0, rowLo = 0, rowHi = 0;
-#pragma unroll
-  for (int jj = 0; jj < RJ; ++jj) {
-    const int64_t jg = j0 + wv * RJ + jj;
-    jrow[jj] = pa_wrapmod(jg, G.n1);
-    const bool valid = jg < G.n1;
-    if (valid) rowValid |= 1u << jj;
-    if (valid && jg >= G.slo[1] && jg <= G.shi[1]) rowS |= 1u << jj;
-    if (jg == 0 || jg == G.n1 - 1) rowShell |= 1u << jj;
-    const int rc = pa_row_case(G, 1, jg, G.n1, G.treat);
-    if (rc == 1) rowLo |= 1u << jj;
-    if (rc == 2) rowHi |= 1u << jj;
-  }
-  unsigned rowPLo = 0, rowPHi = 0, colPLo = 0, colPHi = 0;  // periodic rows of the central Div (fdc.py:596-602)
-  if (PHASE == 3 || KIND != 0) {
-#pragma unroll
-    for (int jj = 0; jj < RJ; ++jj) {
-      const int64_t jg = j0 + wv * RJ + jj;
-      if (G.bct[2] == 4 && jg == 1) rowPLo |= 1u << jj;
-      if (G.bct[3] == 4 && jg == G.n1 - 2) rowPHi |= 1u << jj;
-    }
-#pragma unroll
-    for (int v = 0; v < VEC; ++v) {
-      if (G.bct[4] == 4 && kg + v == 1) colPLo |= 1u << v;
-      if (G.bct[5] == 4 && kg + v == G.n2 - 2) colPHi |= 1u << v;
-    }
-  }
-  unsigned colS = 0, colShell = 0, colLo = 0, colHi = 0;
-#pragma unroll
-  for (int v = 0; v < VEC; ++v) {
-    const int64_t kk = kg + v;
-    if (kvalid && kk >= G.slo[2] && kk <= G.shi[2]) colS |= 1u << v;
-    if (kk == 0 || kk == G.n2 - 1) colShell |= 1u << v;
-    const int rc = pa_row_case(G, 2, kk, G.n2, G.treat);
-    if (rc == 1) colLo |= 1u << v;
-    if (rc == 2) colHi |= 1u << v;
-  }
-  // halo duty of this wave: wave 0 -> row above the tile, wave 3 -> row below (vector loads);
-  // wave 1, lanes < 2*TJ -> the single cells left / right of each tile row (scalar loads)
-  const int64_t hrow = (wv == 0) ? pa_wrapmod(j0 - 1, G.n1) : pa_wrapmod(j0 + TJ, G.n1);
-  const bool hvec = (wv == 0 || wv == 3);
-  const bool hsc = (wv == 1 && lane < 2 * TJ);
-  const int hs_row = lane >> 1, hs_side = lane & 1;
-  const int64_t hs_off = pa_wrapmod(j0 + hs_row, G.n1) * G.s1 +
-                         (hs_side ? pa_wrapmod(k0 + TK, G.n2) : pa_wrapmod(k0 - 1, G.n2));
-
-  auto plane_of = [&](int q) -> int64_t { return rev ? (i1 - 1 - q) : (i0 + q); };
-  auto pptr = [&](const Vec<T>& v, int64_t ii) -> const T* {
-    return ii < 0 ? v.glo : (ii >= G.n0 ? v.ghi : v.p + ii * G.s0);
-  };
-
-  // Raw loads of one plane (own cells + this wave's share of the halo ring).  They are only
-  // ISSUED here; the arithmetic that consumes them (finish_*) is placed after the stencil of the
-  // current plane, so the s_waitcnt lands there and the loads fly during the stencil.
-  struct Raw {
-    V d[RJ];
-    V r[RJ];   // phases A, 5, 6
-    V q[RJ];   // phase 5 (v)
-    V hd, hr, hq;  // halo row (waves 0 and 3)
-    T sd, sr, sq;  // halo cell (wave 1)
-  };
-  constexpr bool HAS_R = (PHASE == 0 || PHASE == 5 || PHASE == 6);
-  constexpr bool HAS_Q = (PHASE == 5);
-  auto issue = [&](int64_t ii, Raw& w, bool with_halo) {
-    const T* dp = pptr(A.d, ii);
-    const T* rp = HAS_R ? pptr(A.r, ii) : dp;
-    const T* qp = HAS_Q ? pptr(A.v, ii) : dp;
-#pragma unroll
-    for (int jj = 0; jj < RJ; ++jj) {
-      const int64_t o = jrow[jj] * G.s1 + kc;
-      w.d[jj] = *reinterpret_cast<const V*>(dp + o);
-      if (HAS_R) w.r[jj] = *reinterpret_cast<const V*>(rp + o);
-      if (HAS_Q) w.q[jj] = *reinterpret_cast<const V*>(qp + o);
-    }
-    if (with_halo) {
-      if (hvec) {
-        const int64_t o = hrow * G.s1 + kc;
-        w.hd = *reinterpret_cast<const V*>(dp + o);
-        if (HAS_R) w.hr = *reinterpret_cast<const V*>(rp + o);
-        if (HAS_Q) w.hq = *reinterpret_cast<const V*>(qp + o);
-      }
-      if (hsc) {
-        w.sd = dp[hs_off];
-        if (HAS_R) w.sr = rp[hs_off];
-        if (HAS_Q) w.sq = qp[hs_off];
-      }
-    }
-  };
-  // the staged field from the raw loads: phase A r + beta d ; phase 5 r + beta (p - omega v)
-  // (linalg.py:217) ; phase 6 r - alpha v (linalg.py:230) ; else the field itself
-  auto combine = [&](T rr_, T dd_, T qq_) -> T {
-    if (PHASE == 0) {
-      T bd = beta * dd_;
-      return rr_ + bd;
-    } else if (PHASE == 5) {
-      T t = omega * qq_;
-      t = dd_ - t;
-      t = beta * t;
-      return rr_ + t;
-    } else if (PHASE == 6) {
-      T av = alpha * dd_;
-      return rr_ - av;
-    }
-    return dd_;
-  };
-  auto finish_own = [&](const Raw& w, V (&e)[RJ]) {
-#pragma unroll
-    for (int jj = 0; jj < RJ; ++jj) {
-#pragma unroll
-      for (int v = 0; v < VEC; ++v)
-        e[jj][v] = combine(HAS_R ? w.r[jj][v] : (T)0, w.d[jj][v], HAS_Q ? w.q[jj][v] : (T)0);
-    }
-  };
-  auto finish_halo = [&](const Raw& w, V& hv, T& hs) {
-#pragma unroll
-    for (int v = 0; v < VEC; ++v) hv[v] = combine(HAS_R ? w.hr[v] : (T)0, w.hd[v], HAS_Q ? w.hq[v] : (T)0);
-    hs = combine(HAS_R ? w.sr : (T)0, w.sd, HAS_Q ? w.sq : (T)0);
-  };
-  auto stage = [&](int buf, const V (&e)[RJ], const V& hv, const T& hs) {
-#pragma unroll
-    for (int jj = 0; jj < RJ; ++jj)
-      *reinterpret_cast<V*>(&tile[buf][wv * RJ + jj + 1][VEC + lane * VEC]) = e[jj];
-    if (hvec) *reinterpret_cast<V*>(&tile[buf][wv == 0 ? 0 : TJ + 1][VEC + lane * VEC]) = hv;
-    if (hsc) tile[buf][hs_row + 1][hs_side ? VEC + TK : VEC - 1] = hs;
-  };
-
-  V ea[RJ], ec[RJ], eb[RJ];  // behind / current / ahead in march order
-  V hv;
-  T hs = (T)0;
-  Raw w;
-#pragma unroll
-  for (int v = 0; v < VEC; ++v) { hv[v] = (T)0; w.hd[v] = (T)0; w.hr[v] = (T)0; w.hq[v] = (T)0; }
-  w.sd = (T)0; w.sr = (T)0; w.sq = (T)0;
-
-  // ---- prologue -----------------------------------------------------------------------
-  const bool act0 = G.act[0] != 0;   // 2-D meshes occupy internal axes 1,2: a single plane, no i-neighbours
   if (act0) {
-    issue(plane_of(-1), w, false);
-    finish_own(w, ea);
+    finish_own(wa, ea);
   } else {
 #pragma unroll
     for (int jj = 0; jj < RJ; ++jj)
 #pragma unroll
       for (int v = 0; v < VEC; ++v) ea[jj][v] = (T)0;
   }
-  issue(plane_of(0), w, true);
-  finish_own(w, ec);
-  finish_halo(w, hv, hs);
+  finish_own(wc, ec);
+  finish_halo(wc, hv, hs);
   stage(0, ec, hv, hs);
   if (act0) {
-    issue(plane_of(1), w, CI > 1);
     finish_own(w, eb);
     finish_halo(w, hv, hs);
   } else {
