@@ -259,9 +259,9 @@ __global__ void __launch_bounds__(256) k_cg3d(Cg3dArgs<T> A) {
   // ---- prologue -----------------------------------------------------------------------
   // All loads a workgroup needs before its first stencil are issued back to back -- the three planes
   // behind / at / ahead of the chunk start, then (below) the flag, the scalars and the partial rows of
-  // the folded scalar step -- and waited for once.  Issued one `finish` at a time they were five
-  // dependent round trips of 1-2 us each, i.e. half of a 10 us kernel on the meshes where a workgroup
-  // only ever sees one or two planes (<= 128^3).
+  // the folded scalar step -- and waited for once instead of one `finish` at a time (five dependent
+  // round trips).  Worth little, as it turned out: 64^3 fp64 CG 20.9 -> 20.1 us per iteration, 128^3
+  // 39.7 -> 39.3 -- the trips hit in L2; what is left of a ~10 us kernel on such meshes is its dispatch.
   const bool act0 = G.act[0] != 0;   // 2-D meshes occupy internal axes 1,2: a single plane, no i-neighbours
   Raw wa = w, wc = w;                // planes -1 and 0; `w` takes plane +1 and stays the loop's buffer
   if (act0) issue(plane_of(-1), wa, false);
