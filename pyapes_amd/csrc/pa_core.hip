@@ -220,6 +220,11 @@ struct RhsArgs {
   int nfaces;
   T c23, c13;     // (T)(2/3), (T)(1/3)
   T h[3];
+  // only nodes one step inside a Neumann face are touched: the kernel visits those layers, not the mesh
+  int nlay;             // number of layers (<= 6); 0: visit every cell
+  int lay_axis[6];      // internal axis of layer w
+  int64_t lay_pos[6];   // its LOCAL index along that axis
+  int64_t lay_start[7]; // prefix sums of the layer sizes
 };
 
 template <typename T>
@@ -234,10 +239,34 @@ __device__ __forceinline__ T pa_face_val(const DevGeom& G, const RhsFace<T>& F, 
 template <typename T>
 __global__ void __launch_bounds__(PA_BLOCK) k_rhs_adjust(DevGeom G, DevEq<T> E, RhsArgs<T> R,
                                                           T* __restrict__ rhs) {
-  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < G.ncell;
-       idx += (int64_t)gridDim.x * blockDim.x) {
-    int64_t i, j, k;
-    pa_decode(G, idx, i, j, k);
+  const int64_t total = R.nlay ? R.lay_start[R.nlay] : G.ncell;
+  for (int64_t tix = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; tix < total;
+       tix += (int64_t)gridDim.x * blockDim.x) {
+    int64_t idx = tix, i, j, k;
+    if (R.nlay) {
+      // which layer, which node of it; a node on two layers belongs to the first one
+      int wsel = 0, ax = 0;
+      int64_t q = 0, pos = 0;
+#pragma unroll
+      for (int w = 0; w < 6; ++w)
+        if (w < R.nlay && tix >= R.lay_start[w] && tix < R.lay_start[w + 1]) {
+          wsel = w; ax = R.lay_axis[w]; pos = R.lay_pos[w]; q = tix - R.lay_start[w];
+        }
+      if (ax == 0) { i = pos; j = q / G.n2; k = q - j * G.n2; }
+      else if (ax == 1) { j = pos; i = q / G.n2; k = q - i * G.n2; }
+      else { k = pos; i = q / G.n1; j = q - i * G.n1; }
+      bool dup = false;
+#pragma unroll
+      for (int w = 0; w < 6; ++w)
+        if (w < wsel) {
+          const int64_t cw = R.lay_axis[w] == 0 ? i : (R.lay_axis[w] == 1 ? j : k);
+          if (cw == R.lay_pos[w]) dup = true;
+        }
+      if (dup) continue;
+      idx = i * G.s0 + j * G.s1 + k;
+    } else {
+      pa_decode(G, idx, i, j, k);
+    }
     int64_t g[3], N[3];
     pa_gidx(G, i, j, k, g, N);
     T val = rhs[idx];
@@ -306,6 +335,31 @@ __global__ void __launch_bounds__(PA_BLOCK) k_cg_init(DevGeom G, DevEq<T> E, Vec
     if (pa_in_S(G, i, j, k)) {
       T ax = pa_apply_terms<T>(G, E, acc, i, j, k, xv.p[idx]);
       rv = rhs[idx] - ax;
+      T p = rv * rv;
+      s[0] += (double)p;
+    }
+    r[idx] = rv;
+    if (d) d[idx] = rv;
+    if (send_lo && i == 0) send_lo[j * G.s1 + k] = rv;
+    if (send_hi && i == G.n0 - 1) send_hi[j * G.s1 + k] = rv;
+  }
+  pa_block_reduce_store<1>(s, partials);
+}
+
+// the same, from A x already computed by the tiled kernel (zero outside S) and sitting in `r`: same
+// loop, same grid, same partial sums -- r, d and the sum r.r come out bit-identical to k_cg_init
+template <typename T>
+__global__ void __launch_bounds__(PA_BLOCK) k_cg_init_ax(DevGeom G, const T* __restrict__ rhs, T* __restrict__ r,
+                                                          T* __restrict__ d, T* __restrict__ send_lo,
+                                                          T* __restrict__ send_hi, double* __restrict__ partials) {
+  double s[1] = {0.0};
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < G.ncell;
+       idx += (int64_t)gridDim.x * blockDim.x) {
+    int64_t i, j, k;
+    pa_decode(G, idx, i, j, k);
+    T rv = (T)0;
+    if (pa_in_S(G, i, j, k)) {
+      rv = rhs[idx] - r[idx];
       T p = rv * rv;
       s[0] += (double)p;
     }
@@ -1750,8 +1804,28 @@ static int rhs_adjust_t(pa_ctx* c, T* rhs) {
   R.c13 = (T)(1.0 / 3.0);
   for (int a = 0; a < 3; ++a) R.h[a] = (T)c->dx[a];
   if (!any) return PA_OK;
-  hipLaunchKernelGGL(k_rhs_adjust<T>, dim3(pa_grid_blocks(c->G.ncell)), dim3(PA_BLOCK), 0, c->stream, c->G, E, R,
-                     rhs);
+  // the layers one step inside each Neumann face (global node 1 / N-2 of its axis), as far as this rank owns them
+  const DevGeom& G = c->G;
+  const int64_t Ng[3] = {G.g0, G.n1, G.n2}, nl[3] = {G.n0, G.n1, G.n2};
+  R.nlay = 0;
+  R.lay_start[0] = 0;
+  for (int f = 0; f < 6; ++f) {
+    const int a = f >> 1;
+    if (c->bc[f].type != PA_BC_NEUMANN || !G.act[a]) continue;
+    int64_t prev = (f & 1) == 0 ? 1 : Ng[a] - 2;
+    prev = ((prev % Ng[a]) + Ng[a]) % Ng[a];
+    const int64_t pos = a == 0 ? prev - G.off0 : prev;
+    if (pos < 0 || pos >= nl[a]) continue;   // another rank's plane
+    const int64_t size = a == 0 ? G.n1 * G.n2 : (a == 1 ? G.n0 * G.n2 : G.n0 * G.n1);
+    R.lay_axis[R.nlay] = a;
+    R.lay_pos[R.nlay] = pos;
+    R.lay_start[R.nlay + 1] = R.lay_start[R.nlay] + size;
+    ++R.nlay;
+  }
+  if (R.nlay == 0) return PA_OK;             // no Neumann layer on this rank
+  if (getenv("PYAPES_HIP_RHS_FULL")) R.nlay = 0;
+  const int64_t work = R.nlay ? R.lay_start[R.nlay] : G.ncell;
+  hipLaunchKernelGGL(k_rhs_adjust<T>, dim3(pa_grid_blocks(work)), dim3(PA_BLOCK), 0, c->stream, c->G, E, R, rhs);
   PA_HIP(c, hipGetLastError());
   return PA_OK;
 }
@@ -2299,6 +2373,29 @@ static void fill_report(pa_ctx* c, pa_report* out, float ms) {
   out->gpu_ms = ms;
 }
 
+// r = (b - A x) on S (0 elsewhere), d = r, per-block partial sums of r.r: the tiled A x kernel plus one
+// streaming pass where the tiled kernel applies, else the generic kernel
+template <typename T>
+static int cg_residual_init(pa_ctx* c, const DevEq<T>& E, Vec<T> xv, const T* rhs, T* r, T* d, T* send_lo,
+                            T* send_hi, double* part) {
+  const int nblk = pa_grid_blocks(c->G.ncell);
+  // slab: a NULL ghost plane marks a physical (non-periodic) end.  No result ever uses that plane (the
+  // end plane is a boundary node, outside S), but the tiled kernel loads it speculatively: the field's
+  // own end plane stands in, so the load stays inside valid memory.
+  Vec<T> xt = xv;
+  if (!xt.glo) xt.glo = xt.p;
+  if (!xt.ghi) xt.ghi = xt.p + (c->G.n0 - 1) * c->G.s0;
+  int fr = (rhs != r && (const T*)xv.p != r) ? pa_tile3d_aop<T>(c, E, xt, r, 1) : 0;
+  if (fr < 0) return fr;
+  if (fr > 0)
+    hipLaunchKernelGGL(k_cg_init_ax<T>, dim3(nblk), dim3(PA_BLOCK), 0, c->stream, c->G, rhs, r, d, send_lo, send_hi,
+                       part);
+  else
+    hipLaunchKernelGGL(k_cg_init<T>, dim3(nblk), dim3(PA_BLOCK), 0, c->stream, c->G, E, xv, rhs, r, d, send_lo,
+                       send_hi, part);
+  return PA_OK;
+}
+
 template <typename T>
 static int cg_begin_t(pa_ctx* c, T* x, const T* rhs, double tol, int64_t max_it) {
   const DevGeom& G = c->G;
@@ -2365,8 +2462,7 @@ static int cg_begin_t(pa_ctx* c, T* x, const T* rhs, double tol, int64_t max_it)
   double* part = (double*)c->scr[SCR_PART];
   Vec<T> xv = pa_vec_self<T>(c, x);
   if (c->slab) { xv.glo = (const T*)c->x_glo; xv.ghi = (const T*)c->x_ghi; }
-  hipLaunchKernelGGL(k_cg_init<T>, dim3(nblk), dim3(PA_BLOCK), 0, c->stream, G, E, xv, rhs, r, d,
-                     (T*)c->r_send_lo, (T*)c->r_send_hi, part);
+  if ((rc = cg_residual_init<T>(c, E, xv, rhs, r, d, (T*)c->r_send_lo, (T*)c->r_send_hi, part))) return rc;
   hipLaunchKernelGGL(k_cg_post_init<T>, dim3(1), dim3(PA_BLOCK), 0, c->stream, c->sc, part, nblk, pa_sums(c),
                      c->slab ? 0 : 2);
   c->pending_init_logic = c->slab ? 1 : 0;
@@ -2776,8 +2872,7 @@ static int bicg_run_t(pa_ctx* c, T* x, const T* rhs, double tol, int64_t max_it,
   T* t = (T*)c->scr[SCR_TT];
   double* part = (double*)c->scr[SCR_PART];
   Vec<T> xv = pa_vec_self<T>(c, x);
-  hipLaunchKernelGGL(k_cg_init<T>, dim3(nblk), dim3(PA_BLOCK), 0, c->stream, G, E, xv, rhs, r0, r, (T*)nullptr,
-                     (T*)nullptr, part);
+  if ((rc = cg_residual_init<T>(c, E, xv, rhs, r0, r, (T*)nullptr, (T*)nullptr, part))) return rc;
   PA_HIP(c, hipMemsetAsync(p[0], 0, fb, c->stream));
   PA_HIP(c, hipMemsetAsync(v[0], 0, fb, c->stream));
   // rho_next = sum r0.r0 ; tol0 = sqrt(rho_next) ; first beta = rho_next / 1 * 1 / 1 (linalg.py:201-212)

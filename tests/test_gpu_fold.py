@@ -95,3 +95,45 @@ def test_folded_sequence_is_bit_identical(monkeypatch, method):
         assert torch.equal(xa, xb), (case, n, bcs, dtype, float((xa - xb).abs().max()))
         checked += 1
     assert checked >= ncases // 2
+
+
+def test_rhs_adjust_on_the_neumann_layers_only(monkeypatch):
+    """The rhs adjustment touches the nodes one step inside a Neumann face; the kernel visits those layers
+    (a node on two layers once) instead of the whole mesh (PYAPES_HIP_RHS_FULL=1): same bits."""
+    from pyapes_amd.hip import lib as L
+    from pyapes_amd.hip.context import context_for
+    rng = random.Random(99)
+    seen = 0
+    for case in range(60):
+        nd = rng.choice([1, 2, 3])
+        n = [rng.choice([3, 4, 5, 8, 17, 33]) for _ in range(nd)]
+        bcs = []
+        for a in range(nd):
+            for _ in range(2):
+                t = rng.choice(["dirichlet", "neumann", "neumann", "symmetry"])
+                bcs.append((t, None if t == "symmetry" else round(rng.uniform(-1, 1), 3)))
+        if not any(t == "neumann" for t, _ in bcs):
+            continue
+        dtype = rng.choice(["double", "single"])
+        tdt = torch.float64 if dtype == "double" else torch.float32
+        mesh = Mesh(Box([0.0] * nd, [1.0 + 0.1 * a for a in range(nd)]), None, list(n), "cuda", dtype)
+        cfg = [{"bc_face": _faces()[i], "bc_type": t, "bc_val": v, "bc_val_opt": None} for i, (t, v) in enumerate(bcs)]
+        var = Field("p", 1, mesh, {"domain": cfg, "obstacle": None})
+        ctx = context_for(mesh)
+        ctx.bind_bcs(var(), var.bcs, 0)
+        terms = [{"kind": L.OP_LAPLACIAN, "sign": -1.0, "coeff": 0.7}]
+        if nd == 1:
+            terms.append({"kind": L.OP_GRAD, "sign": 1.0, "coeff": 0.3})
+        ctx.set_terms(terms)
+        g = torch.Generator().manual_seed(case)
+        rhs = torch.randn((1, *n), generator=g, dtype=torch.float64).to(tdt).cuda()
+        a, b = rhs.clone(), rhs.clone()
+        monkeypatch.delenv("PYAPES_HIP_RHS_FULL", raising=False)
+        ctx.rhs_adjust(a[0])
+        monkeypatch.setenv("PYAPES_HIP_RHS_FULL", "1")
+        ctx.rhs_adjust(b[0])
+        monkeypatch.delenv("PYAPES_HIP_RHS_FULL", raising=False)
+        assert torch.equal(a, b), (case, n, bcs, dtype)
+        assert not torch.equal(a, rhs) or all(v == 0 for t, v in bcs if t == "neumann")
+        seen += 1
+    assert seen >= 30
