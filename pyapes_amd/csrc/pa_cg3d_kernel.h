@@ -65,6 +65,7 @@ struct Cg3dArgs {
   T p0, p1, u;          // Euler: nu, dt, scalar u ; Jacobi: omega
   T hh[3], h2[3], ih[3];  // h, fl(2h), fl(1/h) per axis
   int kind;             // Euler: PA_OP_DIV_*
+  int lap_off;          // KIND != 0: the equation is the Div term alone (explicit Div, pure advection)
   int interior_only;    // A x: zero outside the interior set
   CgEpi epi;            // phases 0 / 1: the last block finishes the reduction (pa_epilogue.h)
   // folded scalar step (pre_n > 0; single GPU inside pa_cg_iterate): EVERY block first reduces the partial
@@ -669,6 +670,7 @@ __global__ void __launch_bounds__(256) k_cg3d(Cg3dArgs<T> A) {
           // p1 != 0: the Div term comes first in the equation
           V dv = div_row((V)A.u);
           dv = dv * A.p0;
+          if (A.lap_off) axv = (V)(T)0;   // Div alone: 0 + sign * Div, as the generic kernel's running sum
           if (A.p1 != (T)0) axv = dv + axv; else axv = axv + dv;
         }
   #pragma unroll
@@ -860,6 +862,12 @@ template <typename T>
 static bool eq_lap_div(const DevEq<T>& E, int& il, int& id) {
   il = id = -1;
   if (E.nterms == 1 && E.t[0].kind == PA_OP_LAPLACIAN) { il = 0; return true; }
+  if (E.nterms == 1) {  // the Div term alone (explicit Div of a scalar speed): il stays -1
+    const int k = E.t[0].kind;
+    if ((k == PA_OP_DIV_CENTRAL || k == PA_OP_DIV_UPWIND_COMPAT || k == PA_OP_DIV_UPWIND) && !E.t[0].u_f &&
+        !E.t[0].coeff_f) { id = 0; return true; }
+    return false;
+  }
   if (E.nterms != 2) return false;
   for (int q = 0; q < 2; ++q) {
     const int k = E.t[q].kind;
@@ -879,7 +887,7 @@ static int cg3d_mode(const pa_ctx* c, const DevEq<T>& E, std::initializer_list<c
   int il, id;
   if (!eq_lap_div<T>(E, il, id) || (id >= 0 && !allow_div)) return 0;
   if ((c->ndim == 3 && c->G.n0 < 3) || c->G.n1 < 3 || c->G.n2 < 3) return 0;
-  uintptr_t bits = (uintptr_t)E.t[il].coeff_f;
+  uintptr_t bits = il >= 0 ? (uintptr_t)E.t[il].coeff_f : 0;
   for (const void* q : ptrs) bits |= (uintptr_t)q;
   if (bits & (sizeof(T) - 1)) return 0;
   constexpr int VEC = VecOf<T>::N;
@@ -1045,6 +1053,7 @@ template <typename T>
 static void fill_common(pa_ctx* c, const DevEq<T>& E, Cg3dArgs<T>& A) {
   int il = 0, id = -1;
   (void)eq_lap_div<T>(E, il, id);
+  A.lap_off = (il < 0 && id >= 0) ? 1 : 0;
   if (il < 0) il = 0;
   A.G = c->G;
   A.lap = E.lap;
