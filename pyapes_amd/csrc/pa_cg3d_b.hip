@@ -4,12 +4,13 @@
 
 template <typename T>
 int pa_tile3d_aop(pa_ctx* c, const DevEq<T>& E, Vec<T> x, T* y, int interior_only) {
-  const int mode = cg3d_mode<T>(c, E, {x.p, y, x.glo, x.ghi}, true);
+  const int mode = cg3d_mode<T>(c, E, {x.p, y, x.glo, x.ghi}, true, true);
   if (!mode) return 0;
   Cg3dArgs<T> A;
   memset(&A, 0, sizeof(A));
   fill_common<T>(c, E, A);
   A.d = x; A.out = y; A.interior_only = interior_only;
+  if (A.lap_off) A.aux = E.t[0].u_f;  // explicit upwind Div with a speed field (null: scalar speed)
   int n = launch_any<T, 2>(c, A, mode);
   if (n > 0 && hipGetLastError() != hipSuccess) { pa_set_err(c, "k_cg3d A x launch failed"); return PA_E_HIP; }
   return n;

@@ -519,7 +519,7 @@ __global__ void __launch_bounds__(256) k_cg3d(Cg3dArgs<T> A) {
       for (int jj = 0; jj < RJ; ++jj)
         cv[jj] = *reinterpret_cast<const V*>(A.coeff_f + ii * G.s0 + jrow[jj] * G.s1 + kc);
     }
-    if (PHASE == 4 || PHASE == 5 || PHASE == 6 || (PHASE == 3 && A.aux)) {  // rhs / u / r0 of this plane
+    if (PHASE == 4 || PHASE == 5 || PHASE == 6 || ((PHASE == 3 || (PHASE == 2 && KIND != 0)) && A.aux)) {  // rhs / u / r0 of this plane
 #pragma unroll
       for (int jj = 0; jj < RJ; ++jj)
         xv[jj] = *reinterpret_cast<const V*>(A.aux + ii * G.s0 + jrow[jj] * G.s1 + kc);
@@ -668,7 +668,7 @@ __global__ void __launch_bounds__(256) k_cg3d(Cg3dArgs<T> A) {
         if constexpr (KIND != 0 && PHASE != 3) {
           // sum_k sign_k Aop_k (ops.py:122-154) of {Laplacian, Div(scalar u)}: p0 = sign of the Div term,
           // p1 != 0: the Div term comes first in the equation
-          V dv = div_row((V)A.u);
+          V dv = div_row((PHASE == 2 && A.aux) ? xv[jj] : (V)A.u);   // A x: the speed may be a field (upwind)
           dv = dv * A.p0;
           if (A.lap_off) axv = (V)(T)0;   // Div alone: 0 + sign * Div, as the generic kernel's running sum
           if (A.p1 != (T)0) axv = dv + axv; else axv = axv + dv;
@@ -859,12 +859,14 @@ __global__ void __launch_bounds__(256) k_cg3d(Cg3dArgs<T> A) {
 // a Laplacian with a scalar coefficient plus a Div with a scalar advection speed, in either order
 // (steady advection-diffusion).  il / id: positions of the two terms (id = -1: no Div).
 template <typename T>
-static bool eq_lap_div(const DevEq<T>& E, int& il, int& id) {
+static bool eq_lap_div(const DevEq<T>& E, int& il, int& id, bool field_speed = false) {
   il = id = -1;
   if (E.nterms == 1 && E.t[0].kind == PA_OP_LAPLACIAN) { il = 0; return true; }
   if (E.nterms == 1) {  // the Div term alone (explicit Div of a scalar speed): il stays -1
     const int k = E.t[0].kind;
-    if ((k == PA_OP_DIV_CENTRAL || k == PA_OP_DIV_UPWIND_COMPAT || k == PA_OP_DIV_UPWIND) && !E.t[0].u_f &&
+    // a speed FIELD only for the upwind schemes (they read u at the cell; central reads its neighbours too)
+    const bool speed_ok = !E.t[0].u_f || (field_speed && k != PA_OP_DIV_CENTRAL);
+    if ((k == PA_OP_DIV_CENTRAL || k == PA_OP_DIV_UPWIND_COMPAT || k == PA_OP_DIV_UPWIND) && speed_ok &&
         !E.t[0].coeff_f) { id = 0; return true; }
     return false;
   }
@@ -880,14 +882,15 @@ static bool eq_lap_div(const DevEq<T>& E, int& il, int& id) {
 // 0: not for the tiled kernels; 1: 16-byte vector lanes; 2: one cell per lane (NARROW)
 template <typename T>
 static int cg3d_mode(const pa_ctx* c, const DevEq<T>& E, std::initializer_list<const void*> ptrs,
-                     bool allow_div = false) {
+                     bool allow_div = false, bool field_speed = false) {
   if (!c->fastpath) return 0;
   if (c->coord != PA_COORD_XYZ) return 0;  // r-dependent rows: generic kernels
   if (c->ndim != 3 && c->ndim != 2) return 0;
   int il, id;
-  if (!eq_lap_div<T>(E, il, id) || (id >= 0 && !allow_div)) return 0;
+  if (!eq_lap_div<T>(E, il, id, field_speed) || (id >= 0 && !allow_div)) return 0;
   if ((c->ndim == 3 && c->G.n0 < 3) || c->G.n1 < 3 || c->G.n2 < 3) return 0;
   uintptr_t bits = il >= 0 ? (uintptr_t)E.t[il].coeff_f : 0;
+  if (id >= 0) bits |= (uintptr_t)E.t[id].u_f;
   for (const void* q : ptrs) bits |= (uintptr_t)q;
   if (bits & (sizeof(T) - 1)) return 0;
   constexpr int VEC = VecOf<T>::N;
@@ -1052,7 +1055,7 @@ static int launch_any(pa_ctx* c, Cg3dArgs<T>& A, int mode) {
 template <typename T>
 static void fill_common(pa_ctx* c, const DevEq<T>& E, Cg3dArgs<T>& A) {
   int il = 0, id = -1;
-  (void)eq_lap_div<T>(E, il, id);
+  (void)eq_lap_div<T>(E, il, id, true);
   A.lap_off = (il < 0 && id >= 0) ? 1 : 0;
   if (il < 0) il = 0;
   A.G = c->G;

@@ -76,6 +76,9 @@ def test_tiled_equals_generic_bitwise(shape, bc, monkeypatch):
                     for _ in range(3):
                         euler_step(v2, u, 1e-3, 2e-3, cfg)
                     res[f"euler_{lim}_{uname}"] = v2().cpu()
+                    # the explicit operator itself (the Div term alone in the tiled A x kernel)
+                    dcfg = {"div": dict(cfg["div"], edge=False)}
+                    res[f"div_{lim}_{uname}"] = FDC(dcfg).div(u, var).cpu()
         out[fast] = res
     for k in out[True]:
         assert torch.equal(out[True][k], out[False][k]), (k, float((out[True][k] - out[False][k]).abs().max()))
