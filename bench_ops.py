@@ -72,7 +72,7 @@ def main():
     ms = timed(lambda: fdc.div(1.0, var), 10)
     emit(f"div apply {n}^3 f64 upwind, scalar speed (incl. output alloc)", n ** 3, ms, 2, 8)
     ms = timed(lambda: fdc.grad(var), 10)
-    emit(f"grad apply {n}^3 f64 -> 3 components (generic kernel; incl. output alloc)", n ** 3, ms, 4, 8)
+    emit(f"grad apply {n}^3 f64 -> 3 components (incl. output alloc)", n ** 3, ms, 4, 8)
     del var, mesh
 
     # --- config 4: explicit adv-diff march 256^3 fp32, upwind, Neumann / Symmetry ------------------

@@ -66,6 +66,8 @@ struct Cg3dArgs {
   T hh[3], h2[3], ih[3];  // h, fl(2h), fl(1/h) per axis
   int kind;             // Euler: PA_OP_DIV_*
   int lap_off;          // KIND != 0: the equation is the Div term alone (explicit Div, pure advection)
+  GradCoef<T> grd;      // phase 7 (explicit gradient): the row coefficients of k_grad
+  int gnd;              // phase 7: mesh dimension (components written: gnd, one field of ncell each)
   int interior_only;    // A x: zero outside the interior set
   CgEpi epi;            // phases 0 / 1: the last block finishes the reduction (pa_epilogue.h)
   // folded scalar step (pre_n > 0; single GPU inside pa_cg_iterate): EVERY block first reduces the partial
@@ -104,7 +106,7 @@ __global__ void __launch_bounds__(256) k_cg3d(Cg3dArgs<T> A) {
   constexpr int TJ = 4 * RJ, TK = 64 * VEC, TKP = TK + 2 * VEC;
   __shared__ __attribute__((aligned(16))) T tile[2][TJ + 2][TKP];
 
-  (void)sizeof(int[PHASE >= 0 && PHASE <= 6 ? 1 : -1]);
+  (void)sizeof(int[PHASE >= 0 && PHASE <= 7 ? 1 : -1]);
   T beta = (T)0, alpha = (T)0;
   T omega = (T)0;
   const DevGeom& G = A.G;
@@ -137,7 +139,7 @@ __global__ void __launch_bounds__(256) k_cg3d(Cg3dArgs<T> A) {
     if (rc == 2) rowHi |= 1u << jj;
   }
   unsigned rowPLo = 0, rowPHi = 0, colPLo = 0, colPHi = 0;  // periodic rows of the central Div (fdc.py:596-602)
-  if (PHASE == 3 || KIND != 0) {
+  if (PHASE == 3 || PHASE == 7 || KIND != 0) {
 #pragma unroll
     for (int jj = 0; jj < RJ; ++jj) {
       const int64_t jg = j0 + wv * RJ + jj;
@@ -441,7 +443,7 @@ __global__ void __launch_bounds__(256) k_cg3d(Cg3dArgs<T> A) {
     __syncthreads();
     alpha = (T)pre_sm[4];
   } else {
-    if (PHASE != 2 && PHASE != 3 && A.sc->done) return;
+    if (PHASE != 2 && PHASE != 3 && PHASE != 7 && A.sc->done) return;
     if (PHASE == 0) beta = (T)A.sc->beta;
     if (PHASE == 1) alpha = (T)A.sc->alpha;
     if (PHASE == 5) { beta = (T)A.sc->beta; omega = (T)A.sc->omega; }
@@ -476,7 +478,7 @@ __global__ void __launch_bounds__(256) k_cg3d(Cg3dArgs<T> A) {
   // the stencil works on whole V rows (packed fp32 multiplies / adds; the explicit Euler step moves only
   // 8 B / cell and is VALU-bound when written per component): per-component k-axis coefficients
   // CG / BiCGSTAB phases of a pure Laplacian: per component (A/B: -9 % on fp32 CG as V rows)
-  constexpr bool VROW = (PHASE == 2 || PHASE == 3 || PHASE == 4 || KIND != 0);
+  constexpr bool VROW = (PHASE == 2 || PHASE == 3 || PHASE == 4 || PHASE == 7 || KIND != 0);
   V cPkV, cCkV, cMkV;
   if (VROW) {
 #pragma unroll
@@ -485,6 +487,18 @@ __global__ void __launch_bounds__(256) k_cg3d(Cg3dArgs<T> A) {
       if (colLo >> v & 1) { p = A.lap.c23[2]; c0 = -A.lap.c23[2]; mq = (T)0; }
       if (colHi >> v & 1) { p = (T)0; c0 = -A.lap.c23[2]; mq = A.lap.c23[2]; }
       cPkV[v] = p; cCkV[v] = c0; cMkV[v] = mq;
+    }
+  }
+  V gPkV, gCkV, gMkV;   // phase 7: k-axis rows of the gradient (k_grad, pa_core.hip)
+  if (PHASE == 7) {
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) {
+      T p = A.grd.g[2], c0 = (T)0, mq = A.grd.mg[2];
+      if (colLo >> v & 1) { p = A.grd.lo_p[2]; c0 = A.grd.lo_c[2]; mq = (T)0; }
+      if (colHi >> v & 1) { p = (T)0; c0 = A.grd.hi_c[2]; mq = A.grd.hi_m[2]; }
+      if (colPLo >> v & 1) mq = (T)0;
+      if (colPHi >> v & 1) p = (T)0;
+      gPkV[v] = p; gCkV[v] = c0; gMkV[v] = mq;
     }
   }
 
@@ -537,9 +551,18 @@ __global__ void __launch_bounds__(256) k_cg3d(Cg3dArgs<T> A) {
       if (rc == 1) { cPi = A.lap.c23[0]; cCi = -A.lap.c23[0]; cMi = (T)0; }
       if (rc == 2) { cPi = (T)0; cCi = -A.lap.c23[0]; cMi = A.lap.c23[0]; }
     }
-    const bool iPLo = (PHASE == 3 || KIND != 0) && G.bct[0] == 4 && gi == 1;
-    const bool iPHi = (PHASE == 3 || KIND != 0) && G.bct[1] == 4 && gi == G.g0 - 2;
+    const bool iPLo = (PHASE == 3 || PHASE == 7 || KIND != 0) && G.bct[0] == 4 && gi == 1;
+    const bool iPHi = (PHASE == 3 || PHASE == 7 || KIND != 0) && G.bct[1] == 4 && gi == G.g0 - 2;
+    T gP0 = A.grd.g[0], gC0 = (T)0, gM0 = A.grd.mg[0];
+    if (PHASE == 7) {
+      const int rc = pa_row_case(G, 0, gi, G.g0, G.treat);
+      if (rc == 1) { gP0 = A.grd.lo_p[0]; gC0 = A.grd.lo_c[0]; gM0 = (T)0; }
+      if (rc == 2) { gP0 = (T)0; gC0 = A.grd.hi_c[0]; gM0 = A.grd.hi_m[0]; }
+      if (iPLo) gM0 = (T)0;
+      if (iPHi) gP0 = (T)0;
+    }
     V res[RJ];
+    V g0r[RJ], g1r[RJ], g2r[RJ];   // phase 7: the three components of this plane's rows
 #pragma unroll
     for (int jj = 0; jj < RJ; ++jj) {
       const int R = wv * RJ + jj + 1;
@@ -562,6 +585,30 @@ __global__ void __launch_bounds__(256) k_cg3d(Cg3dArgs<T> A) {
         for (int v = 0; v < VEC; ++v) {
           xpk[v] = (v < VEC - 1) ? xc[v + 1 < VEC ? v + 1 : v] : right;
           xmk[v] = (v > 0) ? xc[v > 0 ? v - 1 : 0] : left;
+        }
+        if constexpr (PHASE == 7) {
+          // grad: y[a] = cP xp + cC xc + cM xm with the rows of k_grad (fdc.py:80-87, 543-609), same order
+          T pj = A.grd.g[1], cj = (T)0, mj = A.grd.mg[1];
+          if (rowLo >> jj & 1) { pj = A.grd.lo_p[1]; cj = A.grd.lo_c[1]; mj = (T)0; }
+          if (rowHi >> jj & 1) { pj = (T)0; cj = A.grd.hi_c[1]; mj = A.grd.hi_m[1]; }
+          if (rowPLo >> jj & 1) mj = (T)0;
+          if (rowPHi >> jj & 1) pj = (T)0;
+          V s = gP0 * xpi;
+          V mm = gC0 * xc;
+          s = s + mm;
+          mm = gM0 * xmi;
+          g0r[jj] = s + mm;
+          s = pj * dn;
+          mm = cj * xc;
+          s = s + mm;
+          mm = mj * up;
+          g1r[jj] = s + mm;
+          s = gPkV * xpk;
+          mm = gCkV * xc;
+          s = s + mm;
+          mm = gMkV * xmk;
+          g2r[jj] = s + mm;
+          continue;
         }
         V axv;
         {
@@ -742,6 +789,16 @@ __global__ void __launch_bounds__(256) k_cg3d(Cg3dArgs<T> A) {
     // ---- outputs of plane ii --------------------------------------------------------------------
 #pragma unroll
     for (int jj = 0; jj < RJ; ++jj) {
+      if constexpr (PHASE == 7) {
+        if (kvalid && (rowValid >> jj & 1)) {
+          const int64_t o = ii * G.s0 + jrow[jj] * G.s1 + kc;
+          const int c0 = A.gnd - 3;   // component of internal axis a is a - (3 - nd)
+          if (act0) *reinterpret_cast<V*>(A.out + (int64_t)c0 * G.ncell + o) = g0r[jj];
+          *reinterpret_cast<V*>(A.out + (int64_t)(c0 + 1) * G.ncell + o) = g1r[jj];
+          *reinterpret_cast<V*>(A.out + (int64_t)(c0 + 2) * G.ncell + o) = g2r[jj];
+        }
+        continue;
+      }
       V outd;   // phase A: d' ; phase B: new r
       V outx;   // phase B: new x
 #pragma unroll

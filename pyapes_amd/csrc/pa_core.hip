@@ -1864,8 +1864,11 @@ static int grad_t(pa_ctx* c, const T* x, T* y, int edge) {
     if (!c->x_glo || !c->x_ghi) { pa_set_err(c, "pa_grad on a slab needs ghost planes"); return PA_E_STATE; }
     xv.glo = (const T*)c->x_glo; xv.ghi = (const T*)c->x_ghi;
   }
-  hipLaunchKernelGGL(k_grad<T>, dim3(pa_grid_blocks(c->G.ncell)), dim3(PA_BLOCK), 0, c->stream, c->G, E, xv, y,
-                     c->ndim);
+  int fr = pa_tile3d_grad<T>(c, xv, y, c->ndim);
+  if (fr < 0) return fr;
+  if (fr == 0)
+    hipLaunchKernelGGL(k_grad<T>, dim3(pa_grid_blocks(c->G.ncell)), dim3(PA_BLOCK), 0, c->stream, c->G, E, xv, y,
+                       c->ndim);
   if (edge) {
     if (c->G.n0 != c->G.g0 && c->ndim == 3) { pa_set_err(c, "edge operators are single-GPU only"); return PA_E_ARG; }
     hipLaunchKernelGGL(k_edge<T>, dim3(pa_grid_blocks(c->G.ncell)), dim3(PA_BLOCK), 0, c->stream, c->G, E, x, y,

@@ -58,6 +58,7 @@ def test_2d_fast_generic_oracle(shape, bc, monkeypatch):
             v2.set_var_tensor(x0.cuda().clone())
             v2.apply_bcs()
             out["lap"] = FDC({"laplacian": {"edge": False}}).laplacian(v2).cpu()
+            out["grad"] = FDC({"grad": {"edge": False}}).grad(v2).cpu()
             for _ in range(3):
                 euler_step(v2, 0.9, 1e-3, 1e-3, {"div": {"limiter": "upwind"}})
             out["euler"] = v2().cpu()
@@ -70,7 +71,7 @@ def test_2d_fast_generic_oracle(shape, bc, monkeypatch):
     f, gk = res[True], res[False]
     assert f["rep"]["itr"] == gk["rep"]["itr"] == K + 1
     assert rel_err(f["cg"], gk["cg"]) <= (1e-12 if dtype == "double" else 2e-5)
-    for k in ("lap", "euler", "jac"):
+    for k in ("lap", "grad", "euler", "jac"):
         assert torch.equal(f[k], gk[k]), k
     assert abs(f["jac_rep"]["tol"] - gk["jac_rep"]["tol"]) <= 1e-6 * abs(gk["jac_rep"]["tol"])
     om = O.OMesh([0, 0], [1, 0.7], list(n), dtype)

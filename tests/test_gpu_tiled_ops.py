@@ -63,6 +63,7 @@ def test_tiled_equals_generic_bitwise(shape, bc, monkeypatch):
         with warnings.catch_warnings():
             warnings.simplefilter("ignore")
             res = {"lap": FDC({"laplacian": {"edge": False}}).laplacian(var).cpu()}
+            res["grad"] = FDC({"grad": {"edge": False}}).grad(var).cpu()
             solver = Solver({"fdm": {"method": "cg", "tol": 1e-6, "max_it": 1, "report": False}})
             solver.set_eq(-FDM().laplacian(0.7, var) == torch.zeros_like(var()))
             res["aop"] = solver.Aop(var).cpu()
