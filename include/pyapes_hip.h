@@ -226,7 +226,10 @@ int pa_cg_phase_a(pa_ctx* ctx);
 int pa_cg_phase_b(pa_ctx* ctx);
 int pa_cg_bc(pa_ctx* ctx);
 int pa_cg_finish_iter(pa_ctx* ctx);
-/* P = 1 only: enqueue n whole iterations back to back */
+/* P = 1 only: enqueue n whole iterations back to back.  Inside the batch the scalar step between two
+ * kernels (alpha; beta, stop test, iteration count) runs in the prologue of the kernel that follows
+ * instead of in a single-block kernel of its own; the batch's last step is flushed before the call
+ * returns, so pa_report_read / pa_cg_end see the same state as after n x { phase_a, phase_b }. */
 int pa_cg_iterate(pa_ctx* ctx, int64_t n);
 int pa_cg_end(pa_ctx* ctx, pa_report* out);       /* synchronises */
 int pa_report_read(pa_ctx* ctx, pa_report* out);  /* synchronises */
