@@ -1,63 +1,137 @@
 #!/usr/bin/env python3
-"""bench.py -- headline benchmark: cell-updates x iterations / second of the fused CG
-iteration on a 3-D Poisson problem (BASELINE.json metric), plus its HBM roofline
-fraction and the CPU baseline timed on the host of the same box.
+"""bench.py -- headline benchmark: cell-updates x iterations / second of the hot path on the
+BASELINE.json configurations, plus the HBM roofline of the dominant kernel and the CPU baseline
+timed on the host cores of the same box.
 
-A "step" is ONE CG iteration (stencil apply + AXPYs + two dot reductions + BC fill +
-stop test) over the whole grid.  Default workload at every N: BASELINE config 3, the
-configuration the metric is quoted on -- 3-D Poisson 512^3 fp64, periodic BCs, CG --
-slab-decomposed along axis 0 for N > 1 (strong scaling: the global grid is fixed).
+A "step" is ONE pass of the hot path over the whole grid: a CG iteration (stencil apply + AXPYs +
+two dot reductions + BC fill + stop test) for c2 / c3 / c5, an explicit Euler step (stencil + BC
+fill) for c4, a Jacobi sweep for c1.  Default workload at every N: BASELINE config 3, the
+configuration the metric is quoted on -- 3-D Poisson 512^3 fp64, periodic BCs, CG -- slab-
+decomposed along axis 0 for N > 1 (strong scaling: the global grid is fixed).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c3|c2|c5] [--size n0,n1,n2]
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c3|c2|c5|c4|c4t|c4_512|c1]
+                    [--size n0,n1,n2]
 
-Prints ONE JSON line on rank 0.
+``--gpus N`` with N > 1 and no WORLD_SIZE in the environment starts the N ranks itself (a child
+``python -m torch.distributed.run`` on 127.0.0.1, one rank per GPU; the parent never touches the GPU),
+relays rank 0's JSON line and returns the child's exit code.  Under an external
+``torch.distributed.run`` each process is one rank.  Prints ONE JSON line on rank 0.
 """
 from __future__ import annotations
 
 import argparse
+import hashlib
 import json
 import math
 import os
+import socket
+import subprocess
 import sys
 import time
 import warnings
 
-import torch
-
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6.3 TB/s is achievable
-# algorithmic HBM bytes per cell per CG iteration: 10 array passes
+HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak (MI355X_MICROARCH.md:36, :296)
+HBM_ACHIEVABLE_GBS = 6300.0  # what a float4 streaming copy reaches on this part (same guide: 6.29 TB/s measured)
+# algorithmic HBM bytes per cell per step in array passes
 ALG_PASSES_CG = 10
 ALG_PASSES_PHASE = {"a": 4, "b": 6}
 
 WORKLOADS = {
-    # name: (global nodes, dtype, bc kind, box upper)
-    "c3": ((512, 512, 512), "double", "periodic", (1.0, 1.0, 1.0)),
-    "c2": ((256, 256, 256), "double", "dirichlet", (1.0, 1.0, 1.0)),
-    "c5": ((1024, 1024, 512), "single", "mixed", (1.0, 1.0, 0.5)),
+    # name: (solver, global nodes, dtype, bc kind, box upper, BASELINE config)
+    "c3": ("cg", (512, 512, 512), "double", "periodic", (1.0, 1.0, 1.0), 3),
+    "c2": ("cg", (256, 256, 256), "double", "dirichlet", (1.0, 1.0, 1.0), 2),
+    "c5": ("cg", (1024, 1024, 512), "single", "mixed", (1.0, 1.0, 0.5), 5),
+    # explicit adv-diff march, upwind Div + Laplacian, Neumann(x) / Symmetry(y, z): scalar u (2 passes),
+    # speed tensor (3 passes), and a size that does not sit in the 256 MiB Infinity Cache
+    "c4": ("euler", (256, 256, 256), "single", "neusym", (1.0, 1.0, 1.0), 4),
+    "c4t": ("euler_t", (256, 256, 256), "single", "neusym", (1.0, 1.0, 1.0), 4),
+    "c4_512": ("euler", (512, 512, 512), "single", "neusym", (1.0, 1.0, 1.0), 4),
+    "c1": ("jacobi", (128, 128), "double", "poisson2d", (1.0, 1.0), 1),
 }
 
 
+def log(msg):
+    print(f"[bench] {msg}", file=sys.stderr, flush=True)
+
+
+# ------------------------------------------------------------------------------------------------
+#  N > 1 without an external launcher: the parent starts the ranks (and never touches the GPU)
+# ------------------------------------------------------------------------------------------------
+def _free_port() -> int:
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launch_ranks(n: int, argv: list[str]) -> int:
+    """Start ``python -m torch.distributed.run --nproc-per-node n bench.py <argv>`` as a CHILD process,
+    pass its stderr through, print the one JSON line rank 0 wrote, return the child's exit code.
+    Nothing here imports torch.cuda or calls HIP: a process that has initialised the GPU must not be
+    replaced or forked into ranks."""
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env["BENCH_SELF_LAUNCHED"] = "1"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + argv
+    log(f"starting {n} ranks: {' '.join(cmd[1:])}")
+    p = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env, text=True)
+    out, _ = p.communicate()
+    line = None
+    for ln in out.splitlines():
+        s = ln.strip()
+        if s.startswith("{") and '"metric"' in s:
+            line = s
+        elif s:
+            print(s, file=sys.stderr)
+    if line is not None:
+        print(line, flush=True)
+    elif p.returncode == 0:
+        log("the ranks exited 0 but printed no JSON line")
+        return 1
+    return p.returncode
+
+
+# ------------------------------------------------------------------------------------------------
+#  synthetic inputs
+# ------------------------------------------------------------------------------------------------
 def make_bcs(kind):
     from pyapes_amd.variables.bcs import homogeneous_bcs, mixed_bcs
     if kind == "periodic":
         return homogeneous_bcs(3, None, "periodic")
     if kind == "dirichlet":
         return homogeneous_bcs(3, 0.0, "dirichlet")
+    if kind == "neusym":
+        return mixed_bcs([0.0, 0.0, None, None, None, None],
+                         ["neumann", "neumann", "symmetry", "symmetry", "symmetry", "symmetry"])
+    if kind == "poisson2d":
+        from pyapes_amd.testing.poisson import poisson_bcs
+        return poisson_bcs(2)
     return mixed_bcs([0, 0, 0, 0, 1, 0], ["dirichlet", "neumann", "dirichlet", "neumann", "dirichlet", "neumann"])
 
 
-def synth_rhs(mesh, kind):
+def oracle_cfg(O, kind):
+    if kind == "periodic":
+        return O.homogeneous_cfg(3, None, "periodic")
+    if kind == "dirichlet":
+        return O.homogeneous_cfg(3, 0.0, "dirichlet")
+    if kind == "neusym":
+        return O.mixed_cfg([0.0, 0.0, None, None, None, None],
+                           ["neumann", "neumann", "symmetry", "symmetry", "symmetry", "symmetry"])
+    if kind == "poisson2d":
+        return O.poisson_cfg(2)
+    return O.mixed_cfg([0, 0, 0, 0, 1, 0], ["dirichlet", "neumann", "dirichlet", "neumann", "dirichlet", "neumann"])
+
+
+def synth_rhs(gn, i_off, n0, kind, fdtype, dev):
     """Deterministic synthetic right-hand side as a function of the GLOBAL node index, so every
-    decomposition sees the same problem.  periodic: ring-mean-zero product of sines plus a
-    zero-mean deterministic 'noise' (SURVEY 8d C3); otherwise sin(pi x) sin(pi y) sin(pi z) + noise."""
-    f = mesh.dtype.float
-    dev = mesh.device
-    gn = mesh.global_nx
-    idx = [torch.arange(mesh.i_off, mesh.i_off + mesh.nx[0], device=dev, dtype=torch.float64),
+    decomposition (and the CPU baseline) sees the same problem family.  periodic: ring-mean-zero
+    product of sines plus a zero-mean deterministic 'noise' (SURVEY 8d C3); otherwise
+    sin(pi x) sin(pi y) sin(pi z) + noise."""
+    import torch
+    idx = [torch.arange(i_off, i_off + n0, device=dev, dtype=torch.float64),
            torch.arange(gn[1], device=dev, dtype=torch.float64),
            torch.arange(gn[2], device=dev, dtype=torch.float64)]
     I, J, K = torch.meshgrid(idx, indexing="ij")
@@ -68,7 +142,16 @@ def synth_rhs(mesh, kind):
     else:
         base = torch.sin(math.pi * I / (gn[0] - 1)) * torch.sin(math.pi * J / (gn[1] - 1)) * torch.sin(math.pi * K / (gn[2] - 1))
         noise = 0.25 * torch.sin(12.9898 * I + 78.233 * J + 37.719 * K)
-    return (base + noise).to(f).unsqueeze(0).contiguous()
+    return (base + noise).to(fdtype).unsqueeze(0).contiguous()
+
+
+def gaussian(X, Y, Z):
+    import torch
+    return torch.exp(-((X - 0.5) ** 2 + (Y - 0.5) ** 2 + (Z - 0.5) ** 2) / 0.02)
+
+
+def euler_params(dx, u=1.0, nu=1e-3):
+    return nu, 0.2 * min(dx * dx / (6 * nu), dx / abs(u))
 
 
 def host_cores() -> int:
@@ -87,56 +170,129 @@ def host_cores() -> int:
     return n
 
 
-def log(msg):
-    print(f"[bench] {msg}", file=sys.stderr, flush=True)
-
-
-def cpu_baseline(kind, dtype, target_s=12.0):
-    """The oracle (literal torch-CPU restatement of the reference algorithm) timed on this box's
-    host cores on a bounded sample of the same workload family.  Checker code used ONLY as the
-    reported baseline, never on the measured path."""
+# ------------------------------------------------------------------------------------------------
+#  CPU baseline: the oracle (checker code) timed on this box's host cores -- reported, never measured path
+# ------------------------------------------------------------------------------------------------
+def cpu_baseline(solver, kind, dtype, gn):
+    """The oracle (literal torch-CPU restatement of the reference algorithm) on a BOUNDED sample of the
+    same workload family (same BCs, same synthetic input formula, smaller grid where the full one would
+    take minutes), on every host core the box grants."""
+    import torch
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import pyapes_oracle as O
     cores = host_cores()
     torch.set_num_threads(cores)
-    log(f"cpu_baseline: oracle CG on {cores} host threads ...")
-    n = 256
-    its = 24
-    mesh = O.OMesh([0, 0, 0], [1, 1, 1], [n, n, n], dtype)
-    if kind == "periodic":
-        cfg = O.homogeneous_cfg(3, None, "periodic")
-    elif kind == "dirichlet":
-        cfg = O.homogeneous_cfg(3, 0.0, "dirichlet")
-    else:
-        cfg = O.mixed_cfg([0, 0, 0, 0, 1, 0], ["dirichlet", "neumann", "dirichlet", "neumann", "dirichlet", "neumann"])
-    g = torch.Generator().manual_seed(0)
-    rhs = torch.randn((1, n, n, n), generator=g, dtype=torch.float64).to(mesh.dtype)
-    rhs -= rhs.mean()
-    bcs = O.make_bcs(mesh, cfg)
-    x = torch.zeros(1, n, n, n, dtype=mesh.dtype)
-    tabs = O.laplacian_tables(x, mesh, bcs)
-    rhs += O.laplacian_rhs_adjust(x, mesh, bcs)
-    terms = [O.OTerm("laplacian", tabs, 1.0, 1.0)]
+    fd = torch.float64 if dtype == "double" else torch.float32
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
-        t0 = time.perf_counter()
-        _, rep = O.cg(x, rhs, terms, mesh, bcs, -1.0, its - 1)
-        dt = time.perf_counter() - t0
-    val = n ** 3 * rep["itr"] / dt
-    return {"value": val, "unit": "cell-updates*iters/s", "cores": cores, "kind": "port",
-            "sample": f"oracle CG (torch-CPU literal restatement), {n}^3 {dtype} {kind}, {rep['itr']} iterations, {dt:.1f} s"}
+        if solver == "cg":
+            n = [min(256, gn[0]), min(256, gn[1]), min(256, gn[2] if kind != "mixed" else 128)]
+            its = 24
+            up = [1.0, 1.0, 0.5 if kind == "mixed" else 1.0]
+            mesh = O.OMesh([0, 0, 0], up, n, dtype)
+            bcs = O.make_bcs(mesh, oracle_cfg(O, kind))
+            rhs = synth_rhs(n, 0, n[0], kind, fd, "cpu")
+            x = torch.zeros(1, *n, dtype=mesh.dtype)
+            tabs = O.laplacian_tables(x, mesh, bcs)
+            rhs += O.laplacian_rhs_adjust(x, mesh, bcs)
+            terms = [O.OTerm("laplacian", tabs, 1.0, 1.0)]
+            log(f"cpu_baseline: oracle CG {n} on {cores} host threads ...")
+            t0 = time.perf_counter()
+            _, rep = O.cg(x, rhs, terms, mesh, bcs, -1.0, its - 1)
+            dt = time.perf_counter() - t0
+            steps, what = rep["itr"], "CG iterations"
+        elif solver in ("euler", "euler_t"):
+            n = [min(256, v) for v in gn]
+            mesh = O.OMesh([0, 0, 0], [1, 1, 1], n, dtype)
+            bcs = O.make_bcs(mesh, oracle_cfg(O, kind))
+            phi = gaussian(*mesh.grid).to(fd).unsqueeze(0).contiguous()
+            O.bc_fill(phi, bcs)
+            u = 1.0 if solver == "euler" else torch.full_like(phi, 0.7)
+            nu, dts = euler_params(float(mesh.dx[0]))
+            steps, what = 6, "explicit Euler steps (upwind Div + Laplacian + BC fill)"
+            log(f"cpu_baseline: oracle Euler march {n} on {cores} host threads ...")
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                phi = O.euler_step(phi, u, nu, dts, mesh, bcs, "upwind")
+            dt = time.perf_counter() - t0
+        else:  # jacobi, config 1: the reference-runnable plumbing case, at its own size
+            n = list(gn)
+            mesh = O.OMesh([0, 0], [1, 1], n, dtype)
+            steps, what = 2000, "Jacobi sweeps"
+            rhs = O.poisson_rhs(mesh)
+            log(f"cpu_baseline: oracle Jacobi {n} on {cores} host threads ...")
+            t0 = time.perf_counter()
+            _, rep = O.solve_poisson(mesh, O.poisson_cfg(2), rhs, method="jacobi", tol=-1.0, max_it=steps - 1)
+            dt = time.perf_counter() - t0
+            steps = rep["itr"]
+    cells = 1
+    for v in n:
+        cells *= v
+    return {"value": cells * steps / dt, "unit": "cell-updates*iters/s", "cores": cores, "kind": "port",
+            "sample": f"oracle (torch-CPU literal restatement of the reference algorithm), {'x'.join(map(str, n))} {dtype} "
+                      f"{kind} BCs, same synthetic input family as the GPU leg, {steps} {what}, {dt:.1f} s"}
 
 
+# ------------------------------------------------------------------------------------------------
+#  roofline record
+# ------------------------------------------------------------------------------------------------
+def source_hash() -> str:
+    """Hash of the kernel sources the built library comes from: profiles/traffic.json entries carry it
+    and are ignored once the kernels have changed."""
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "pyapes_amd", "csrc")
+    for name in sorted(os.listdir(d)):
+        if name.endswith((".hip", ".h")):
+            with open(os.path.join(d, name), "rb") as f:
+                h.update(name.encode())
+                h.update(f.read())
+    return h.hexdigest()[:16]
+
+
+def roofline(kernel, ms, alg_bytes, wl_key, custom_size, extra=None):
+    ach = alg_bytes / (ms * 1e-3) / 1e9
+    roof = {"bound": "hbm", "kernel": kernel, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": ach / HBM_PEAK_GBS, "traffic": None, "frac_traffic": None,
+            "achievable": HBM_ACHIEVABLE_GBS, "achievable_source": "MI355X_MICROARCH.md: 6.29 TB/s float4 copy (79 % of spec)",
+            "kernel_ms": ms, "alg_bytes_per_launch": alg_bytes,
+            "note": "achieved / frac count ALGORITHMIC bytes (SURVEY 8d); frac_traffic = PMC HBM bytes per launch / "
+                    "kernel_ms / peak is what the memory system really moved"}
+    if extra:
+        roof.update(extra)
+    tr = os.path.join(ROOT, "profiles", "traffic.json")
+    if os.path.exists(tr) and not custom_size:
+        try:
+            with open(tr) as f:
+                t = json.load(f)
+            e = t.get(f"{wl_key}:{kernel}")
+            if e and e.get("source_hash") == source_hash():
+                roof["traffic"] = e["bytes_per_launch"]
+                roof["traffic_source"] = e.get("source")
+                roof["frac_traffic"] = e["bytes_per_launch"] / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS
+            elif e:
+                roof["traffic_source"] = "profiles/traffic.json entry is from other kernel sources (hash mismatch): dropped"
+        except Exception:
+            pass
+    return roof
+
+
+# ------------------------------------------------------------------------------------------------
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="c3", choices=list(WORKLOADS))
-    ap.add_argument("--size", dest="n", default=None, help="override global node counts n0,n1,n2 (testing)")
+    ap.add_argument("--size", dest="n", default=None, help="override global node counts n0,n1[,n2] (testing)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline-probe", action="store_true")
     args = ap.parse_args()
+
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # no launcher around us: be the launcher (before anything can touch the GPU)
+        raise SystemExit(launch_ranks(args.gpus, sys.argv[1:]))
+
+    import torch
 
     # stdout carries exactly ONE line, the JSON record: anything native libraries print on file
     # descriptor 1 in the meantime (RCCL prints a version banner when a communicator comes up) goes
@@ -148,15 +304,22 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
-        args.gpus = world
+    args.gpus = world
 
-    assert torch.cuda.is_available(), "bench.py needs the MI355X; there is no CPU path"
+    solver, gn, dtype, kind, upper, cfg_no = WORKLOADS[args.workload]
+    if args.n:
+        gn = tuple(int(v) for v in args.n.split(","))
+        assert len(gn) == len(upper), "--size must have the workload's dimension"
+    if world > 1 and solver != "cg":
+        raise SystemExit(f"workload {args.workload} is single-GPU (replicas only); the slab path is the CG solve")
+
     # rehearsal switches (one-GPU box): BENCH_SINGLE_DEVICE=1 puts every rank on cuda:0,
     # BENCH_BACKEND=gloo moves the planes through the host instead of RCCL
-    if os.environ.get("BENCH_SINGLE_DEVICE"):
+    single_dev = bool(os.environ.get("BENCH_SINGLE_DEVICE"))
+    if world > 1 and not single_dev and torch.cuda.device_count() < world:
+        raise SystemExit(f"bench.py --gpus {world}: only {torch.cuda.device_count()} GPUs visible")
+    assert torch.cuda.is_available(), "bench.py needs the MI355X; there is no CPU path"
+    if single_dev:
         local_rank = 0
     torch.cuda.set_device(local_rank)
 
@@ -166,13 +329,15 @@ def main():
     from pyapes_amd.hip.context import context_for
     from pyapes_amd.variables import Field
 
-    gn, dtype, kind, upper = WORKLOADS[args.workload]
-    if args.n:
-        gn = tuple(int(v) for v in args.n.split(","))
     esize = 8 if dtype == "double" else 4
+    nd = len(gn)
+    cells_global = 1
+    for v in gn:
+        cells_global *= v
+    W, K = args.warmup, args.steps
 
     dist = None
-    force_slab = bool(os.environ.get("BENCH_FORCE_SLAB"))  # rehearsal: drive the slab path with one rank
+    force_slab = bool(os.environ.get("BENCH_FORCE_SLAB")) and solver == "cg"  # rehearsal: the slab path with one rank
     if world > 1 or force_slab:
         import torch.distributed as dist_mod
         dist = dist_mod
@@ -181,22 +346,23 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group(backend)
+    slab = world > 1 or force_slab
 
-    mesh = Mesh(Box([0.0, 0.0, 0.0], list(upper)), None, list(gn), "cuda", dtype,
-                slab=(rank, world) if (world > 1 or force_slab) else None)
+    mesh = Mesh(Box([0.0] * nd, list(upper)), None, list(gn), "cuda", dtype, slab=(rank, world) if slab else None)
     var = Field("p", 1, mesh, {"domain": make_bcs(kind), "obstacle": None})
-    rhs = synth_rhs(mesh, kind)
     log(f"rank {rank}/{world}: workload {args.workload} global {gn} local {tuple(mesh.nx)} {dtype} {kind}")
-    cells_global = gn[0] * gn[1] * gn[2]
-    W, K = args.warmup, args.steps
-    terms = [{"kind": L.OP_LAPLACIAN, "sign": 1.0, "coeff": 1.0}]
+    parallelism = "single"
+    roof = None
+    wl_text = None
 
-    if world == 1 and not force_slab:
+    if solver == "cg" and not slab:
+        rhs = synth_rhs(gn, 0, gn[0], kind, mesh.dtype.float, mesh.device)
+        terms = [{"kind": L.OP_LAPLACIAN, "sign": 1.0, "coeff": 1.0}]
         ctx = context_for(mesh)
         ctx.bind_bcs(var(), var.bcs, 0)
         ctx.set_terms(terms)
         ctx.rhs_adjust(rhs[0])
-        # tolerance -1: the stop test can never end the solve; max_it beyond W + K
+        # tolerance -1: the stop test is evaluated but can never end the solve; max_it beyond W + K
         ctx.cg_begin(var()[0], rhs[0], -1.0, W + K + 10)
         ctx.cg_iterate(W)
         torch.cuda.synchronize()
@@ -207,33 +373,27 @@ def main():
         ctx.cg_iterate(K)
         e1.record(ctx.stream)
         torch.cuda.synchronize()
-        wall = time.perf_counter() - t0
+        secs = time.perf_counter() - t0
         ev_ms = e0.elapsed_time(e1)
-        log(f"timed {K} iterations: {wall*1e3/K:.4f} ms/iter")
         rep = ctx.report()
         assert rep.itr == W + K and rep.status == 0, f"work was skipped: itr={rep.itr} status={rep.status}"
-        secs = wall
-        finite = bool(torch.isfinite(var()).all())
-        assert finite, "iterate became non-finite inside the timed region"
-        roof = None
+        assert bool(torch.isfinite(var()).all()), "iterate became non-finite inside the timed region"
         if not args.no_roofline_probe:
             # per-kernel durations of the two dominant kernels, HIP events on the launch stream
             ctx.profile(True)
             ctx.cg_iterate(min(K, 10))
             pr = ctx.profile_read()
             ctx.profile(False)
-            local_cells = mesh.N
             dom = "b" if pr["phase_b_ms"] >= pr["phase_a_ms"] else "a"
-            ms = pr[f"phase_{dom}_ms"]
-            alg_bytes = ALG_PASSES_PHASE[dom] * esize * local_cells
-            ach = alg_bytes / (ms * 1e-3) / 1e9
-            roof = {"bound": "hbm", "kernel": f"cg_phase_{dom}", "achieved": ach, "peak": HBM_PEAK_GBS,
-                    "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
-                    "phase_a_ms": pr["phase_a_ms"], "phase_b_ms": pr["phase_b_ms"],
-                    "alg_bytes_per_launch": alg_bytes}
+            roof = roofline(f"cg_phase_{dom}", pr[f"phase_{dom}_ms"], ALG_PASSES_PHASE[dom] * esize * mesh.N,
+                            args.workload, bool(args.n),
+                            {"phase_a_ms": pr["phase_a_ms"], "phase_b_ms": pr["phase_b_ms"]})
         ctx.cg_end()
-    else:
+        passes = ALG_PASSES_CG
+    elif solver == "cg":
         from pyapes_amd.slab import SlabCG
+        rhs = synth_rhs(gn, mesh.i_off, mesh.nx[0], kind, mesh.dtype.float, mesh.device)
+        terms = [{"kind": L.OP_LAPLACIAN, "sign": 1.0, "coeff": 1.0}]
         drv = SlabCG(mesh, var, rhs, terms, dist)
         drv.begin(-1.0, W + K + 10)
         drv.iterate(W)
@@ -253,28 +413,95 @@ def main():
         rep = drv.be.report()
         assert rep.itr == W + K and rep.status == 0, f"work was skipped: itr={rep.itr} status={rep.status}"
         assert bool(torch.isfinite(var()).all()), "iterate became non-finite inside the timed region"
-        roof = None
         if not args.no_roofline_probe:
             pr = drv.profile(min(K, 10))
             dom = "b" if pr["phase_b_ms"] >= pr["phase_a_ms"] else "a"
-            ms = pr[f"phase_{dom}_ms"]
-            alg_bytes = ALG_PASSES_PHASE[dom] * esize * mesh.N
-            ach = alg_bytes / (ms * 1e-3) / 1e9
-            roof = {"bound": "hbm", "kernel": f"cg_phase_{dom}", "achieved": ach, "peak": HBM_PEAK_GBS,
-                    "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
-                    "phase_a_ms": pr["phase_a_ms"], "phase_b_ms": pr["phase_b_ms"],
-                    "alg_bytes_per_launch": alg_bytes, "scope": "rank 0, per GPU"}
+            roof = roofline(f"cg_phase_{dom}", pr[f"phase_{dom}_ms"], ALG_PASSES_PHASE[dom] * esize * mesh.N,
+                            args.workload, True,
+                            {"phase_a_ms": pr["phase_a_ms"], "phase_b_ms": pr["phase_b_ms"], "scope": "rank 0, per GPU"})
         drv.end()
-        comm_kind = "rccl-in-library" if drv.lib_comm else "torch.distributed-stepwise"
-        if drv.lib_comm:            # release the library's communicator while every rank is still alive
-            torch.cuda.synchronize()
+        n_seen = dist.get_world_size()
+        comm_kind = "rccl-in-library" if drv.lib_comm else f"torch.distributed-stepwise/{dist.get_backend()}"
+        if drv.lib_comm:
+            n_seen = drv.be.comm_size()
+            torch.cuda.synchronize()      # release the library's communicators while every rank is still alive
             drv.be.comm_destroy()
             drv.be.comm_ready = None
+        world = n_seen                      # n_gpus = the ranks the communicator really had
+        parallelism = f"slab{n_seen} ({comm_kind})"
+        passes = ALG_PASSES_CG
+    elif solver in ("euler", "euler_t"):
+        from pyapes_amd.solver.fdc import div_kind
+        phi = gaussian(mesh.X, mesh.Y, mesh.Z).to(mesh.dtype.float).unsqueeze(0).contiguous()
+        var.set_var_tensor(phi)
+        var.apply_bcs()
+        u = 1.0 if solver == "euler" else torch.full_like(var()[0], 0.7)
+        nu, dts = euler_params(mesh.dx_list[0])
+        kindc = div_kind("upwind", False)
+        ctx = context_for(mesh)
+        ctx.bind_bcs(var(), var.bcs, 0)
+        a, b = var()[0], torch.empty_like(var()[0])
+        cur = ctx.euler_march(a, b, kindc, u, nu, dts, W)
+        oth = b if cur is a else a
+        torch.cuda.synchronize()
+        e0 = torch.cuda.Event(enable_timing=True)
+        e1 = torch.cuda.Event(enable_timing=True)
+        t0 = time.perf_counter()
+        e0.record(ctx.stream)
+        fin = ctx.euler_march(cur, oth, kindc, u, nu, dts, K)
+        e1.record(ctx.stream)
+        torch.cuda.synchronize()
+        secs = time.perf_counter() - t0
+        ev_ms = e0.elapsed_time(e1)
+        assert bool(torch.isfinite(fin).all()), "state became non-finite inside the timed region"
+        passes = 2 if solver == "euler" else 3
+        if not args.no_roofline_probe:
+            ctx.profile(True)
+            ctx.euler_march(fin, cur if fin is oth else oth, kindc, u, nu, dts, min(K, 10))
+            pr = ctx.profile_read()
+            ctx.profile(False)
+            roof = roofline("euler_step", pr["phase_a_ms"], passes * esize * mesh.N, args.workload, bool(args.n))
+        wl_text = (f"3-D advection-diffusion {'x'.join(map(str, gn))} {dtype}, Div(upwind)+Laplacian explicit Euler march, "
+                   f"{'scalar u' if solver == 'euler' else 'speed tensor u(x)'}, Neumann/Symmetry BCs (BASELINE config 4)")
+    else:  # jacobi (config 1)
+        from pyapes_amd.testing.poisson import poisson_rhs_nd
+        rhs = poisson_rhs_nd(mesh, var)
+        terms = [{"kind": L.OP_LAPLACIAN, "sign": 1.0, "coeff": 1.0}]
+        ctx = context_for(mesh)
+        ctx.bind_bcs(var(), var.bcs, 0)
+        ctx.set_terms(terms)
+        ctx.rhs_adjust(rhs[0])
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            if W > 0:
+                ctx.solve("jacobi", var()[0], rhs[0], -1.0, W - 1)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            rep = ctx.solve("jacobi", var()[0], rhs[0], -1.0, K - 1)   # max_it = K - 1 -> K sweeps (linalg.py K+1 rule)
+            torch.cuda.synchronize()
+            secs = time.perf_counter() - t0
+        ev_ms = rep.gpu_ms
+        assert rep.itr == K and rep.status == 0, f"work was skipped: itr={rep.itr}"
+        assert bool(torch.isfinite(var()).all())
+        passes = 3
+        if not args.no_roofline_probe:
+            ctx.profile(True)
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                ctx.solve("jacobi", var()[0], rhs[0], -1.0, min(K, 20) - 1)
+            pr = ctx.profile_read()
+            ctx.profile(False)
+            if pr["phase_a_n"] > 0:
+                roof = roofline("jacobi_sweep", pr["phase_a_ms"], passes * esize * mesh.N, args.workload, bool(args.n),
+                                {"remark": "128^2 fp64 = 128 KiB per array: launch-latency bound, not HBM bound"})
+        wl_text = f"2-D Poisson {gn[0]}x{gn[1]} {dtype}, Dirichlet BCs, Jacobi (BASELINE config 1)"
 
     if rank == 0:
         value = cells_global * K / secs
+        if wl_text is None:
+            wl_text = f"3-D Poisson {gn[0]}x{gn[1]}x{gn[2]} {dtype}, {kind} BCs, CG (BASELINE config {cfg_no})"
         out = {
-            "metric": "cell-updates*iters/sec, 3-D Poisson CG",
+            "metric": "cell-updates*iters/sec" + (", 3-D Poisson CG" if solver == "cg" else ""),
             "value": value,
             "unit": "cell-updates*iters/s",
             "n_gpus": world,
@@ -286,27 +513,15 @@ def main():
             "vs_baseline": None,
             "dtype": "f64" if dtype == "double" else "f32",
             "data": "synthetic",
-            "config": {"workload": f"3-D Poisson {gn[0]}x{gn[1]}x{gn[2]} {dtype}, {kind} BCs, CG (BASELINE config {args.workload})",
-                       "global_cells": cells_global, "parallelism": (f"slab{world} ({comm_kind})" if (world > 1 or force_slab) else "single")},
-            "hbm_alg_GBs": ALG_PASSES_CG * esize * cells_global * K / secs / 1e9,
-            "hbm_alg_frac_of_peak": ALG_PASSES_CG * esize * cells_global * K / secs / 1e9 / (HBM_PEAK_GBS * world),
+            "config": {"workload": wl_text, "global_cells": cells_global, "parallelism": parallelism},
+            "hbm_alg_GBs": passes * esize * cells_global * K / secs / 1e9,
+            "hbm_alg_frac_of_peak": passes * esize * cells_global * K / secs / 1e9 / (HBM_PEAK_GBS * world),
             "stream_ms_per_step": ev_ms / K,
         }
         if roof is not None:
-            tr = os.path.join(ROOT, "profiles", "traffic.json")
-            if os.path.exists(tr):
-                try:
-                    with open(tr) as f:
-                        t = json.load(f)
-                    key = f"{args.workload}:{roof['kernel']}"
-                    if key in t and not args.n:
-                        roof["traffic"] = t[key]["bytes_per_launch"]
-                        roof["traffic_source"] = t[key].get("source")
-                except Exception:
-                    pass
             out["roofline"] = roof
-        if not args.no_cpu_baseline and world == 1:   # reported baseline: rank 0 at N = 1 only
-            out["cpu_baseline"] = cpu_baseline(kind, dtype)
+        if not args.no_cpu_baseline and world == 1 and not slab:   # reported baseline: rank 0 at N = 1 only
+            out["cpu_baseline"] = cpu_baseline(solver, kind, dtype, gn)
         sys.stdout.flush()
         os.dup2(real_stdout, 1)
         print(json.dumps(out), flush=True)

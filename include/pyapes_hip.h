@@ -256,7 +256,9 @@ typedef struct {
   void* recv_lo; void* recv_hi;
   int64_t n_send_lo, n_send_hi, n_recv_lo, n_recv_hi;
 } pa_exchange;
+int pa_comm_available(void);                  /* 1: librccl resolved in this process (no communicator needed) */
 int pa_comm_unique_id(void* id128);
+int pa_comm_count(pa_ctx* ctx, int* nranks); /* ncclCommCount of the library's communicator */
 int pa_comm_init(pa_ctx* ctx, int rank, int nranks, const void* id128);
 int pa_comm_selftest(pa_ctx* ctx, double timeout_s);
 int pa_comm_plan(pa_ctx* ctx, const pa_exchange* plan);

@@ -23,6 +23,7 @@ struct Rccl {
   ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
   ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
   ncclResult_t (*CommAbort)(ncclComm_t) = nullptr;
+  ncclResult_t (*CommCount)(const ncclComm_t, int*) = nullptr;
   ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
   ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
   ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
@@ -49,7 +50,7 @@ Rccl* rccl() {
   if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_LOCAL);
   if (!h) return nullptr;
   bool ok = sym(h, "ncclGetUniqueId", R.GetUniqueId) && sym(h, "ncclCommInitRank", R.CommInitRank) &&
-            sym(h, "ncclCommDestroy", R.CommDestroy) && sym(h, "ncclCommAbort", R.CommAbort) &&
+            sym(h, "ncclCommDestroy", R.CommDestroy) && sym(h, "ncclCommAbort", R.CommAbort) && sym(h, "ncclCommCount", R.CommCount) &&
             sym(h, "ncclAllReduce", R.AllReduce) && sym(h, "ncclSend", R.Send) && sym(h, "ncclRecv", R.Recv) &&
             sym(h, "ncclGroupStart", R.GroupStart) && sym(h, "ncclGroupEnd", R.GroupEnd) &&
             sym(h, "ncclGetErrorString", R.GetErrorString);
@@ -108,6 +109,16 @@ int pa_comm_unique_id(void* id128) {
   ncclUniqueId id;
   if (R->GetUniqueId(&id) != ncclSuccess) return PA_E_HIP;
   memcpy(id128, &id, sizeof(id));
+  return PA_OK;
+}
+
+int pa_comm_available(void) { return rccl() ? 1 : 0; }
+
+int pa_comm_count(pa_ctx* c, int* nranks) {
+  if (!c || !nranks) return PA_E_ARG;
+  Rccl* R = rccl();
+  if (!R || !c->comm) { pa_set_err(c, "pa_comm_count without pa_comm_init"); return PA_E_STATE; }
+  PA_NCCL(c, R, R->CommCount((ncclComm_t)c->comm, nranks));
   return PA_OK;
 }
 

@@ -1892,6 +1892,8 @@ static int check_div_kind(pa_ctx* c, int kind) {
   return PA_OK;
 }
 
+static void pa_profile_stop(pa_ctx* c, int which);
+
 template <typename T>
 static int euler_t(pa_ctx* c, const T* in, T* out, int kind, double u, const void* u_field, double nu, double dt) {
   pa_term tl, ta;
@@ -1907,11 +1909,13 @@ static int euler_t(pa_ctx* c, const T* in, T* out, int kind, double u, const voi
     if (!c->x_glo || !c->x_ghi) { pa_set_err(c, "pa_euler_step on a slab needs ghost planes"); return PA_E_STATE; }
     pv.glo = (const T*)c->x_glo; pv.ghi = (const T*)c->x_ghi;
   }
+  if (c->profile) (void)hipEventRecord(c->pev[0], c->stream);   // slot 0: the step kernel (without its BC fill)
   int fr = pa_tile3d_euler<T>(c, pv, out, kind, u, u_field, nu, dt);
   if (fr < 0) return fr;
   if (fr == 0)
     hipLaunchKernelGGL(k_euler<T>, dim3(pa_grid_blocks(c->G.ncell)), dim3(PA_BLOCK), 0, c->stream, c->G, El, Ea, pv,
                        out, (T)nu, (T)dt);
+  if (c->profile) pa_profile_stop(c, 0);
   PA_HIP(c, hipGetLastError());
   return bc_apply_auto<T>(c, out, false);
 }
@@ -2800,6 +2804,7 @@ static int jacobi_run_t(pa_ctx* c, T* x, const T* rhs, double tol, int64_t max_i
       Vec<T> xv = pa_vec_self<T>(c, buf[cur]);
       // partial rows alternate between the halves of SCR_PART: the next sweep reads these while it writes its own
       double* part_q = part + (cur ? 2 * (size_t)PA_MAX_PARTIALS : 0);
+      if (c->profile) (void)hipEventRecord(c->pev[0], c->stream);   // slot 0: the sweep kernel
       int used = pa_tile3d_jacobi<T>(c, E, xv, rhs, buf[cur ^ 1], omega, part_q);
       if (used < 0) return used;
       const bool tiled = used > 0;
@@ -2809,6 +2814,7 @@ static int jacobi_run_t(pa_ctx* c, T* x, const T* rhs, double tol, int64_t max_i
                            (T)omega, part_q);
         used = nblk;
       }
+      if (c->profile) pa_profile_stop(c, 0);
       int nsh = 0;
       // NOTE: when done is set the sweep kernels return early, so buf[cur^1] is stale: the copy-back
       // below is guarded by the iteration parity recorded on the device (itr).

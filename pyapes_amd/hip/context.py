@@ -323,6 +323,14 @@ class HipContext:
             raise L.PaError(rc, "pa_comm_unique_id: librccl not available")
         return buf.raw
 
+    def comm_available(self) -> bool:
+        return bool(self.lib.pa_comm_available())
+
+    def comm_size(self) -> int:
+        n = C.c_int(0)
+        self._rc(self.lib.pa_comm_count(self.h, C.byref(n)))
+        return int(n.value)
+
     def comm_init(self, rank: int, world: int, uid: bytes) -> None:
         buf = C.create_string_buffer(uid, 128)
         self._rc(self.lib.pa_comm_init(self.h, int(rank), int(world), C.cast(buf, C.c_void_p)))

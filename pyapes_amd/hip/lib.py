@@ -98,7 +98,9 @@ SIGNATURES: dict[str, tuple[Any, list[Any]]] = {
     "pa_cg_iterate": (C.c_int, [_VP, C.c_int64]),
     "pa_cg_end": (C.c_int, [_VP, C.POINTER(PaReport)]),
     "pa_slab_set": (C.c_int, [_VP, C.POINTER(PaSlab)]),
+    "pa_comm_available": (C.c_int, []),
     "pa_comm_unique_id": (C.c_int, [_VP]),
+    "pa_comm_count": (C.c_int, [_VP, C.POINTER(C.c_int)]),
     "pa_comm_init": (C.c_int, [_VP, C.c_int, C.c_int, _VP]),
     "pa_comm_selftest": (C.c_int, [_VP, C.c_double]),
     "pa_comm_plan": (C.c_int, [_VP, C.POINTER(PaExchange)]),

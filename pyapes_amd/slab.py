@@ -115,16 +115,19 @@ class SlabCG:
             be.comm_plan(self.nb_lo, self.nb_hi, self.send_lo, self.send_hi, self.recv_lo, self.recv_hi)
             return True
         dev = self.x.device
-        ok = 1
+        # every step that can fail on ONE rank is followed by an agreement (all-reduce MIN of an ok flag)
+        # before any rank enters a call the others must join: ncclCommInitRank blocks until all ranks
+        # arrive, so a rank that could not even load librccl must make everybody skip it
+        ok = 1 if (not hasattr(be, "comm_available") or be.comm_available()) else 0
         uid = torch.zeros(128, dtype=torch.uint8, device=dev)
         try:
-            if self.rank == 0:
+            if ok and self.rank == 0:
                 uid.copy_(torch.frombuffer(bytearray(be.comm_unique_id()), dtype=torch.uint8))
         except Exception:
             ok = 0
         flag = torch.tensor([ok], dtype=torch.int32, device=dev)
         src = d.get_global_rank(self.group, 0) if self.group is not None else 0
-        d.broadcast(flag, src=src, group=self.group)          # rank 0 could not even make an id: all skip
+        d.all_reduce(flag, op=d.ReduceOp.MIN, group=self.group)
         if int(flag.item()) == 0:
             return False
         d.broadcast(uid, src=src, group=self.group)

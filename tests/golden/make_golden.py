@@ -105,6 +105,9 @@ def rhs_of(case, mesh_r):
     if kind == "randn":
         g = torch.Generator().manual_seed(case.get("seed", 0))
         return torch.randn(shape, generator=g, dtype=torch.float64).to(mesh_r.dtype.float)
+    if kind == "randn32":   # fp32-representable values (large cases: the stored fixture compresses to half)
+        g = torch.Generator().manual_seed(case.get("seed", 0))
+        return torch.randn(shape, generator=g, dtype=torch.float32).to(mesh_r.dtype.float)
     if kind == "poisson":
         var = Field("tmp", 1, mesh_r, None)
         return poisson_rhs_nd(mesh_r, var)
@@ -343,6 +346,63 @@ def run_rfp(case):
     return out
 
 
+def run_euler(case):
+    """Explicit Euler steps of BASELINE config 4's family, assembled from the REFERENCE's own pieces: the
+    reference has no time integrator (``Ddt`` is a stub), but every piece of
+    phi <- B( phi + dt (nu lap(phi) - div(u phi)) ) is a reference operator -- ``FDC.laplacian``,
+    ``FDC.div`` (limiter "none": central; limiter "upwind": the literal output),
+    ``boundary_slicer``, ``BC.apply`` -- combined here with plain torch arithmetic in the order the
+    product's kernel uses.  Central Div raises for neumann / symmetry faces in the reference
+    (fdc.py:543-609), so the config-4 BC set carries the literal-upwind variants only."""
+    from pyapes.mesh.tools import boundary_slicer
+    mr, mo = ref_mesh(case), orc_mesh(case)
+    cr, co = bc_cfg(case)
+    nd = mr.dim
+    f = mr.dtype.float
+    g = torch.Generator().manual_seed(case.get("seed", 0) + 11)
+    r2 = sum((gi - 0.5) ** 2 for gi in mr.grid)
+    phi0 = (torch.exp(-r2 / 0.02) + 0.05 * torch.randn(tuple(mr.nx), generator=g, dtype=torch.float64).to(f)).unsqueeze(0)
+    ut = (0.7 + 0.5 * torch.randn((1, *mr.nx), generator=g, dtype=torch.float64)).to(f)
+    nu, dt, u = case["nu"], case["dt"], case["u"]
+    out = {"phi0": npy(phi0), "u_tensor": npy(ut)}
+    treat = any(t in ("neumann", "symmetry") for t, _ in case["bcs"])
+    variants = [("compat_f", "upwind", u), ("compat_t", "upwind", ut)]
+    if not treat:
+        variants += [("none_f", "none", u), ("none_t", "none", ut)]
+    bcs_o = O.make_bcs(mo, co)
+    So = O.interior_slicer(nd, bcs_o)
+    for tag, lim, adv_in in variants:
+        var = Field("phi", 1, mr, {"domain": cr, "obstacle": None})
+        var.set_var_tensor(phi0.clone())
+        for bc in var.bcs:
+            bc.apply(var(), mr.grid, 0)
+        S = tuple(boundary_slicer(nd, var.bcs))
+        po = phi0.clone()
+        O.bc_fill(po, bcs_o)
+        same(po, var(), f"{tag} initial BC fill")
+        for step in range(1, max(case["steps"]) + 1):
+            lap = FDC({"laplacian": {"edge": False}}).laplacian(var)
+            adv = FDC({"div": {"limiter": lim, "edge": False}}).div(adv_in, var)
+            new = var().clone()
+            new[0][S] = var()[0][S] + dt * (nu * lap[0][S] - adv[0][S])
+            var.set_var_tensor(new)
+            for bc in var.bcs:
+                bc.apply(var(), mr.grid, 0)
+            # oracle, same composition from its own pieces
+            lo = O.apply_laplacian(O.laplacian_tables(po, mo, bcs_o), po, nd)
+            ao = O.apply_div(O.div_tables(adv_in, po, mo, bcs_o, lim), po, nd)
+            pn = po.clone()
+            pn[0][So] = po[0][So] + dt * (nu * lo[0][So] - ao[0][So])
+            O.bc_fill(pn, bcs_o)
+            po = pn
+            same(po, var(), f"{tag} step {step}")
+            if lim == "none":
+                pass
+            if step in case["steps"]:
+                out[f"{tag}_s{step}"] = npy(var())
+    return out
+
+
 # ---------------------------------------------------------------- case list
 def D(v=0.0):
     return ["dirichlet", v]
@@ -403,7 +463,7 @@ CASES += [
     mk("cg3d_mix33_f64", "solve", 3, [33, 33, 33], "double",
        [D(0.0), N(0.5), D(0.0), N(0.0), D(1.0), N(-0.25)], rhs="sincosz", method="cg", tol=1e-10,
        max_its=[3, 1000]),                                         # known: 402 its
-    mk("cg3d_mix_65x65x33_f32", "solve", 3, [33, 33, 17], "single",
+    mk("cg3d_mix_33x33x17_f32", "solve", 3, [33, 33, 17], "single",
        [D(0.0), N(0.0), D(0.0), N(0.0), D(1.0), N(0.0)], rhs="sincosz", method="cg", tol=1e-5,
        max_its=[10], box=([0.0, 0.0, 0.0], [1.0, 1.0, 0.5])),       # config-5 shape family, small
     mk("cg3d_per16_f64", "solve", 3, [16, 16, 16], "double", [PE] * 6, rhs="periodic_sin",
@@ -428,6 +488,49 @@ CASES += [
        max_its=[3, 8, 1000], sensitive=True),
     mk("bicg3d_dir17_f32", "solve", 3, [17, 17, 17], "single", [D(0.0)] * 6, rhs="randn",
        method="bicgstab", tol=1e-4, max_its=[5]),
+]
+
+
+# round 2: the instantiations that were pinned through the oracle only.  fp32 with rows that are a multiple
+# of the 16-byte vector (the non-NARROW fp32 solver phases), and an fp64 mesh of several in-plane tiles
+# (5 x 3 tiles of 16 x 128) whose 17 planes also split into marching chunks
+MIX = [D(0.0), N(0.5), D(0.0), N(0.0), D(1.0), N(-0.25)]
+CASES += [
+    mk("cg3d_dir_12x18x132_f32", "solve", 3, [12, 18, 132], "single", [D(0.0)] * 6, rhs="randn",
+       method="cg", tol=1e-30, max_its=[0, 4, 10]),
+    mk("cg3d_mix_16x20x136_f32", "solve", 3, [16, 20, 136], "single", MIX, rhs="sincosz", method="cg", tol=1e-30,
+       max_its=[0, 4, 10], box=([0.0, 0.0, 0.0], [1.0, 1.0, 0.5])),
+    mk("cg3d_per_12x16x128_f32", "solve", 3, [12, 16, 128], "single", [PE] * 6, rhs="periodic_sin", method="cg",
+       tol=1e-30, max_its=[0, 4]),
+    mk("bicg3d_dir_12x18x132_f32", "solve", 3, [12, 18, 132], "single", [D(0.0)] * 6, rhs="randn",
+       method="bicgstab", tol=1e-30, max_its=[0, 4, 10]),
+    mk("bicg3d_mix_16x20x136_f32", "solve", 3, [16, 20, 136], "single", MIX, rhs="sincosz", method="bicgstab",
+       tol=1e-30, max_its=[4], box=([0.0, 0.0, 0.0], [1.0, 1.0, 0.5])),
+    mk("cg3d_mix_17x70x260_f64", "solve", 3, [17, 70, 260], "double", MIX, rhs="randn32", method="cg", tol=1e-30,
+       max_its=[6]),
+    mk("bicg3d_dir_9x40x264_f64", "solve", 3, [9, 40, 264], "double", [D(0.0)] * 6, rhs="randn32",
+       method="bicgstab", tol=1e-30, max_its=[4]),
+]
+
+
+def _euler_case(name, spacing, dtype, bcs, **kw):
+    nu, u = 1e-3, 1.0
+    dx = 1.0 / (min(spacing) - 1)
+    c = mk(name, "euler", 3, spacing, dtype, bcs, nu=nu, u=u, steps=[1, 3], **kw)
+    h = min((up - lo) / (n - 1) for lo, up, n in zip(c["lower"], c["upper"], spacing))
+    c["dt"] = 0.2 * min(h * h / (6 * nu), h / abs(u))
+    return c
+
+
+C4BC = [N(0.0), N(0.0), SY, SY, SY, SY]            # BASELINE config 4: Neumann (x) / Symmetry (y, z)
+CASES += [
+    _euler_case("euler3d_c4_14x12x16_f32", [14, 12, 16], "single", C4BC),
+    _euler_case("euler3d_c4_12x20x136_f32", [12, 20, 136], "single", C4BC),
+    _euler_case("euler3d_c4_12x20x136_f64", [12, 20, 136], "double", C4BC),
+    _euler_case("euler3d_c4v_11x13x17_f64", [11, 13, 17], "double", [N(0.3), N(-0.2), SY, SY, N(0.1), SY]),
+    _euler_case("euler3d_dirper_10x12x132_f32", [10, 12, 132], "single", [D(0.2), D(0.1), PE, PE, D(0.0), D(0.3)]),
+    _euler_case("euler3d_dirper_10x12x132_f64", [10, 12, 132], "double", [D(0.2), D(0.1), PE, PE, D(0.0), D(0.3)]),
+    _euler_case("euler3d_per_8x16x128_f32", [8, 16, 128], "single", [PE] * 6),
 ]
 
 
@@ -480,7 +583,7 @@ CASES += [mk("rfp_rz_32x64_f64", "rfp", 2, [32, 64], "double", [], coord="rz",
 
 def main():
     torch.set_num_threads(8)
-    only = sys.argv[1] if len(sys.argv) > 1 else None   # name prefix: regenerate just those cases
+    only = tuple(sys.argv[1:]) or None   # name prefixes: regenerate just those cases
     index = []
     total = 0
     for case in CASES:
@@ -488,7 +591,8 @@ def main():
             index.append(case)
             continue
         print(f"[golden] {case['name']}")
-        out = {"ops": run_ops, "solve": run_solve, "spatial": run_spatial, "rfp": run_rfp}[case["kind"]](case)
+        out = {"ops": run_ops, "solve": run_solve, "spatial": run_spatial, "rfp": run_rfp,
+               "euler": run_euler}[case["kind"]](case)
         path = os.path.join(HERE, case["name"] + ".npz")
         np.savez_compressed(path, **out)
         total += os.path.getsize(path)

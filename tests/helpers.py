@@ -134,6 +134,54 @@ def summation_band(case, rhs0, K):
     return dev, its
 
 
+def _oracle_solve_random_order(case, rhs0, K, seed):
+    """the oracle with every torch.sum evaluated over a random permutation of its addends, split into a
+    random number of partial sums: one more equally valid summation order of the same algorithm"""
+    import warnings
+    orig = torch.sum
+    gen = torch.Generator().manual_seed(1000 + seed)
+
+    def fsum(t, dim=None, **kw):
+        f = t.contiguous().flatten() if dim is None else t.contiguous().flatten(1)
+        perm = torch.randperm(f.shape[-1], generator=gen)
+        nb = int(torch.randint(2, 64, (1,), generator=gen))
+        acc = None
+        for c in f[..., perm].chunk(nb, dim=-1):
+            s = orig(c, dim=-1)
+            acc = s if acc is None else acc + s
+        return acc
+
+    torch.sum = fsum
+    try:
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            return O.solve_poisson(oracle_mesh(case), oracle_cfg(case), torch.as_tensor(rhs0).clone(),
+                                   method=case["method"], tol=case["tol"], max_it=K,
+                                   coeff=case.get("coeff", 1.0), sign=case.get("sign", 1.0))
+    finally:
+        torch.sum = orig
+
+
+def summation_hull(case, rhs0, K, x_ref, n_random=24):
+    """The REFERENCE ALGORITHM evaluated with 5 structured + ``n_random`` random summation orders of its
+    dot products -> (band, diam, iteration counts): band = largest rel. distance of a sample from ``x_ref``
+    (the reference's own result), diam = largest rel. distance between two samples.
+    See test_solve_vs_reference for how they grade."""
+    xs, its = [], []
+    for v in range(5):
+        x, r = oracle_solve(case, rhs0, K, v)
+        xs.append(x)
+        its.append(r["itr"])
+    for s in range(n_random):
+        x, r = _oracle_solve_random_order(case, rhs0, K, s)
+        xs.append(x)
+        its.append(r["itr"])
+    band = max(rel_err(x, x_ref) for x in xs)
+    n = len(xs)
+    diam = max(rel_err(xs[i], xs[j]) for i in range(n) for j in range(i + 1, n))
+    return band, diam, its
+
+
 def true_residual(case, rhs0, x):
     """|| (b_adj - A x) ||_2 over the interior set, evaluated by the product's own operator."""
     from pyapes_amd.mesh.tools import boundary_slicer

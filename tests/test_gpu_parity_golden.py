@@ -91,10 +91,25 @@ def test_ops_bit_exact(case):
 @pytest.mark.parametrize("case", golden_cases("solve"), ids=lambda c: c["name"])
 def test_solve_vs_reference(case):
     """tolerance: 1e-10 rel (fp64) / 1e-5 (fp32) and identical iteration counts.  Cases flagged
-    ``sensitive`` (BiCGSTAB, CG on the periodic operator) are held to that bar for the short fixed
-    iteration counts; for their long runs the bar is the reference algorithm's own spread over
-    summation orders (helpers.summation_band), which bounds what ANY reordering can reach."""
-    from helpers import summation_band
+    ``sensitive`` (BiCGSTAB, CG on the reference's non-symmetric periodic operator) are held to that bar
+    for the short fixed iteration counts.  Their long runs amplify the rounding of the dot products until
+    the reference ALGORITHM itself, with nothing changed but the order of its ``torch.sum``, moves by
+    iterations and by 1e-2 in the result (tests/test_oracle_golden.py::test_reference_algorithm_is_
+    summation_order_sensitive; the reference's own 321 iterations of tests/test_solver.py:309-358 become
+    311 on a host with another core count).  There the bar is the HULL of the reference algorithm over
+    n = 30 summation orders -- the reference's recorded run, 5 structured and 24 random orders of the
+    oracle (helpers.summation_hull; e.g. 295 ... 333 iterations for that test) -- widened by a quarter of
+    its width W on each side:
+
+      * a further exchangeable draw falls outside the hull of n with probability 2 / (n + 1) = 6 %, so
+        the bare hull would fail a correct implementation in one of every three runs of this suite;
+      * for a normal population the expected range of 30 draws is 4.1 sigma, so W / 4 is one sigma and the
+        widened hull reaches +-3 sigma (0.3 % outside); the factor 1/4 is that and nothing else.
+      * iteration count in [min - W/4, max + W/4] (W at least 4: a count that barely moved among the
+        samples may still sit on a rounding edge of the stop test);
+      * result: rel. distance to the reference <= band + diam / 4, band = largest distance of a sample
+        from the reference run, diam = largest distance between two samples (the hull's width)."""
+    from helpers import summation_hull
     g = golden_load(case["name"])
     rtol = 1e-10 if case["dtype"] == "double" else 1e-5
     for K in case["max_its"]:
@@ -102,12 +117,12 @@ def test_solve_vs_reference(case):
         x, rep, _ = product_solve(case, g["rhs0"], K)
         err = rel_err(x, g[f"x_K{K}"])
         if case.get("sensitive") and K > 10:
-            band, its = summation_band(case, g["rhs0"], K)
-            # the count at which a summation-order-chaotic iteration crosses tol scatters by a few per cent
-            slack = max(3, max(its) - min(its), -(-max(its) // 20))
-            assert min(its) - slack <= rep["itr"] <= max(its) + slack, (case["name"], K, rep, its)
+            band, diam, its = summation_hull(case, g["rhs0"], K, g[f"x_K{K}"])
+            its = its + [ref["itr"]]
+            W = max(4, max(its) - min(its))
+            assert min(its) - W / 4 <= rep["itr"] <= max(its) + W / 4, (case["name"], K, rep, sorted(its))
             assert rep["converge"] == ref["converge"]
-            assert err <= max(rtol, 5 * band), (case["name"], K, err, band)
+            assert err <= max(rtol, band + diam / 4), (case["name"], K, err, band, diam)
             periodic = isinstance(case["bcs"], list) and any(t == "periodic" for t, _ in case["bcs"])
             if rep["converge"] and not periodic:
                 # converged: the true residual of the returned iterate must be at the stop-test level
@@ -119,3 +134,33 @@ def test_solve_vs_reference(case):
         assert err <= rtol, (case["name"], K, err)
         if case["dtype"] == "double":
             assert abs(rep["tol"] - ref["tol"]) <= 1e-6 * abs(ref["tol"]) + 1e-13, (rep, ref)
+
+
+@pytest.mark.parametrize("case", golden_cases("euler"), ids=lambda c: c["name"])
+def test_euler_steps_vs_reference_pieces(case):
+    """BASELINE config 4's family: explicit Euler steps whose Laplacian, Div (central; literal upwind) and
+    BC fill are the REFERENCE's (make_golden.run_euler composes them).  Bit-exact, step by step
+    (euler_step) and as one enqueued march (euler_march), scalar and tensor speed."""
+    from pyapes_amd.solver.march import euler_march, euler_step
+    g = golden_load(case["name"])
+    mesh = product_mesh(case)
+    ut = torch.as_tensor(g["u_tensor"]).to(mesh.device)
+    ran = 0
+    for tag in ("compat_f", "compat_t", "none_f", "none_t"):
+        if f"{tag}_s1" not in g:
+            continue
+        cfg = {"div": {"limiter": "upwind", "compat": True}} if tag.startswith("compat") else {"div": {"limiter": "none"}}
+        u = case["u"] if tag.endswith("_f") else ut
+        phi = product_field(case, mesh, g["phi0"])
+        phi.apply_bcs()
+        for step in range(1, max(case["steps"]) + 1):
+            euler_step(phi, u, case["nu"], case["dt"], cfg)
+            if step in case["steps"]:
+                assert bit_equal(phi(), g[f"{tag}_s{step}"]), (case["name"], tag, step)
+        phi = product_field(case, mesh, g["phi0"])
+        phi.apply_bcs()
+        n = max(case["steps"])
+        euler_march(phi, u, case["nu"], case["dt"], n, cfg)
+        assert bit_equal(phi(), g[f"{tag}_s{n}"]), (case["name"], tag, "march")
+        ran += 1
+    assert ran >= 2

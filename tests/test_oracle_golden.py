@@ -82,6 +82,39 @@ def test_oracle_solve(case):
         assert err <= rtol, (case["name"], K, err)
 
 
+@pytest.mark.parametrize("case", golden_cases("euler"), ids=lambda c: c["name"])
+def test_oracle_euler_pieces(case):
+    """Explicit Euler steps composed of reference operators (make_golden.run_euler): the oracle's pieces in
+    the same composition are bit-exact; for the central scheme that composition IS O.euler_step."""
+    g = golden_load(case["name"])
+    mesh = _mesh(case)
+    nd = mesh.dim
+    bcs = O.make_bcs(mesh, _cfg(case))
+    S = O.interior_slicer(nd, bcs)
+    nu, dt = case["nu"], case["dt"]
+    ut = torch.from_numpy(g["u_tensor"])
+    for tag in ("compat_f", "compat_t", "none_f", "none_t"):
+        if f"{tag}_s1" not in g:
+            continue
+        lim = "upwind" if tag.startswith("compat") else "none"
+        u = case["u"] if tag.endswith("_f") else ut
+        phi = torch.from_numpy(g["phi0"]).clone()
+        O.bc_fill(phi, bcs)
+        alt = phi.clone()
+        for step in range(1, max(case["steps"]) + 1):
+            lap = O.apply_laplacian(O.laplacian_tables(phi, mesh, bcs), phi, nd)
+            adv = O.apply_div(O.div_tables(u, phi, mesh, bcs, lim), phi, nd)
+            new = phi.clone()
+            new[0][S] = phi[0][S] + dt * (nu * lap[0][S] - adv[0][S])
+            O.bc_fill(new, bcs)
+            phi = new
+            if lim == "none":
+                alt = O.euler_step(alt, u, nu, dt, mesh, bcs, "none")
+                _eq(alt, phi, f"{tag} O.euler_step, step {step}")
+            if step in case["steps"]:
+                _eq(phi, g[f"{tag}_s{step}"], f"{tag} step {step}")
+
+
 def test_known_answers():
     """Iteration counts recorded by the reference's demo notebook / survey probes
     (demos/poisson_equations/pure_dirichlet.ipynb:107-108)."""
