@@ -3,14 +3,13 @@
 #include "pa_cg3d_kernel.h"
 
 template <typename T>
-int pa_cg3d_phase_a(pa_ctx* c, const DevEq<T>& E, Vec<T> r, Vec<T> d, T* dnew, double* partials, const CgEpi& epi) {
+int pa_cg3d_phase_a(pa_ctx* c, const DevEq<T>& E, Vec<T> r, Vec<T> d, T* dnew, double* partials) {
   const int mode = cg3d_mode<T>(c, E, {r.p, d.p, dnew, r.glo, r.ghi, d.glo, d.ghi});
   if (!mode) return 0;
   Cg3dArgs<T> A;
   memset(&A, 0, sizeof(A));
   fill_common<T>(c, E, A);
   A.r = r; A.d = d; A.dnew = dnew; A.partials = partials;
-  A.epi = epi;
   A.reverse = 0;
   if (c->fold_b_n > 0) {  // close the previous iteration in this kernel's prologue (next state -> the other slot)
     A.pre_part = c->fold_b_part;
@@ -30,14 +29,13 @@ int pa_cg3d_phase_a(pa_ctx* c, const DevEq<T>& E, Vec<T> r, Vec<T> d, T* dnew, d
 }
 
 template <typename T>
-int pa_cg3d_phase_b(pa_ctx* c, const DevEq<T>& E, Vec<T> d, T* x, T* r, double* partials, const CgEpi& epi) {
+int pa_cg3d_phase_b(pa_ctx* c, const DevEq<T>& E, Vec<T> d, T* x, T* r, double* partials) {
   const int mode = cg3d_mode<T>(c, E, {d.p, x, r, d.glo, d.ghi, c->r_send_lo, c->r_send_hi});
   if (!mode) return 0;
   Cg3dArgs<T> A;
   memset(&A, 0, sizeof(A));
   fill_common<T>(c, E, A);
   A.d = d; A.x = x; A.rw = r; A.partials = partials;
-  A.epi = epi;
   A.send_lo = (T*)c->r_send_lo; A.send_hi = (T*)c->r_send_hi;
   A.reverse = 1;
   if (c->fold_a_n > 0) {  // alpha of this iteration in this kernel's prologue
@@ -102,7 +100,7 @@ template int pa_tile3d_euler<float>(pa_ctx*, Vec<float>, float*, int, double, co
 template int pa_tile3d_euler<double>(pa_ctx*, Vec<double>, double*, int, double, const void*, double, double);
 template int pa_tile3d_jacobi<float>(pa_ctx*, const DevEq<float>&, Vec<float>, const float*, float*, double, double*);
 template int pa_tile3d_jacobi<double>(pa_ctx*, const DevEq<double>&, Vec<double>, const double*, double*, double, double*);
-template int pa_cg3d_phase_a<float>(pa_ctx*, const DevEq<float>&, Vec<float>, Vec<float>, float*, double*, const CgEpi&);
-template int pa_cg3d_phase_a<double>(pa_ctx*, const DevEq<double>&, Vec<double>, Vec<double>, double*, double*, const CgEpi&);
-template int pa_cg3d_phase_b<float>(pa_ctx*, const DevEq<float>&, Vec<float>, float*, float*, double*, const CgEpi&);
-template int pa_cg3d_phase_b<double>(pa_ctx*, const DevEq<double>&, Vec<double>, double*, double*, double*, const CgEpi&);
+template int pa_cg3d_phase_a<float>(pa_ctx*, const DevEq<float>&, Vec<float>, Vec<float>, float*, double*);
+template int pa_cg3d_phase_a<double>(pa_ctx*, const DevEq<double>&, Vec<double>, Vec<double>, double*, double*);
+template int pa_cg3d_phase_b<float>(pa_ctx*, const DevEq<float>&, Vec<float>, float*, float*, double*);
+template int pa_cg3d_phase_b<double>(pa_ctx*, const DevEq<double>&, Vec<double>, double*, double*, double*);

@@ -30,7 +30,6 @@
 // The grid is exactly one resident wave of workgroups: chunks = capacity / tiles, so every
 // CU carries the same number of identical work items and nothing queues behind a tail.
 #include "pa_host.h"
-#include "pa_epilogue.h"
 
 #include <stdio.h>
 #include <stdlib.h>
@@ -69,7 +68,6 @@ struct Cg3dArgs {
   GradCoef<T> grd;      // phase 7 (explicit gradient): the row coefficients of k_grad
   int gnd;              // phase 7: mesh dimension (components written: gnd, one field of ncell each)
   int interior_only;    // A x: zero outside the interior set
-  CgEpi epi;            // phases 0 / 1: the last block finishes the reduction (pa_epilogue.h)
   // folded scalar step (pre_n > 0; single GPU inside pa_cg_iterate): EVERY block first reduces the partial
   // rows the previous kernel left (same fixed order as k_cg_post_a / k_cg_post_b -> the same bits in
   // every block, no fence, no atomics: the kernel boundary made the rows visible) and runs the scalar
@@ -897,11 +895,9 @@ __global__ void __launch_bounds__(256) k_cg3d(Cg3dArgs<T> A) {
   if (PHASE == 0) {
     double s[1] = {s0};
     pa_block_reduce_store<1>(s, A.partials);
-    pa_cg_epilogue<T>(A.epi);
   } else if (PHASE == 1 || PHASE == 4) {
     double s[2] = {s0, s1};
     pa_block_reduce_store<2>(s, A.partials);
-    if (PHASE == 1) pa_cg_epilogue<T>(A.epi);
   } else if (PHASE == 5) {
     double s[1] = {s0};
     pa_block_reduce_store<1>(s, A.partials);

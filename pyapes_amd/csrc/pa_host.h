@@ -19,19 +19,6 @@ struct SolverScalars {
   int done, err, finished_early;
 };
 
-// last-block epilogue of a CG kernel (pa_epilogue.h)
-struct CgEpi {
-  int kind;              // 0 none; 1 tail of phase A: sums[0] (+ alpha); 2 tail of phase B / BC chain: sums[1..2] (+ beta, stop)
-  int logic;             // run the scalar logic too (single GPU); 0 on a slab (the all-reduce comes first)
-  unsigned int* ticket;  // zero before the launch; the last block resets it
-  SolverScalars* sc;
-  double* sums;
-  const double* part;    // kind 1: d.Ad partials (1 column); kind 2: phase-B partials (2 columns)
-  int npart;             // rows of `part`; < 0: one per block of THIS launch
-  const double* part_shell;  // kind 2: boundary-shell partials of the stop test (1 column) or null
-  int nshell;
-};
-
 struct HostBC {
   int type = PA_BC_NONE;
   double value = 0.0;
@@ -84,12 +71,6 @@ struct pa_ctx {
   int solver_live = 0, cur = 0, bc_static = 0, pending_init_logic = 0, b_blocks = 0;
   int bc_pair = 0;  // per-axis pair kernels (lower + upper face + shell stop-test term in one launch)
   int bc_fused = 0, shell_cur = 0;  // fused BC fill: which half of SCR_SHELL holds x_old on the shell
-  // overlap: the BC fill + boundary-shell part of the stop test of iteration k run on a second
-  // stream beside phase A of iteration k+1 (they touch x / the shell only; phase A touches r, d)
-  int overlap = 0, side_pending = 0;
-  hipStream_t side = nullptr;
-  hipStream_t launch_stream = nullptr;  // stream the BC helpers launch on (main unless overlapping)
-  hipEvent_t ev_k2 = nullptr, ev_bc = nullptr;
   void* cg_x = nullptr;
   // slab decomposition (P > 1): externally owned exchange buffers
   int slab = 0;
@@ -114,10 +95,6 @@ struct pa_ctx {
   int64_t prof_n[2] = {0, 0};
   // 3-D fast path switch (PYAPES_HIP_FASTPATH=0 disables; tests compare both)
   int fastpath = 1;
-  // last-block epilogues (pa_epilogue.h): tickets[0] phase A, [1] phase B, [2] BC pair chain
-  unsigned int* tickets = nullptr;
-  int epilogue = 0;              // opt-in (PYAPES_HIP_EPILOGUE=1); default: separate k_cg_post_* launches
-  int b_tail_done = 0;           // the B-chain reduction of this iteration already ran in an epilogue
   // RCCL communicator owned by the library (pa_comm_*): slab iterations without host work
   void* comm = nullptr;          // ncclComm_t
   int comm_rank = 0, comm_n = 0;
@@ -129,12 +106,33 @@ struct pa_ctx {
 
 static inline double* pa_sums(const pa_ctx* c) { return (c->slab && c->ext_sums) ? c->ext_sums : c->sums; }
 
+static inline const int* pa_done_flag(const pa_ctx* c) { return &c->sc->done; }
+
 void pa_set_err(pa_ctx* c, const char* fmt, ...);
 int pa_hip_fail(pa_ctx* c, hipError_t e, const char* what);
 int pa_grid_blocks(int64_t work);
 int pa_scratch(pa_ctx* c, void** slot, size_t* cap, size_t bytes);
 void pa_refresh_geom(pa_ctx* c);
 int pa_bc_apply_any(pa_ctx* c, void* x);
+int pa_check_eq_applicable(pa_ctx* c);   // pa_ops.hip: Grad inside a solver equation is 1-D only
+void pa_profile_stop(pa_ctx* c, int which);   // pa_solver.hip: close the HIP-event bracket of dominant kernel `which`
+
+// ---- BC fill (pa_bc.hip) ---------------------------------------------------------------------------
+int pa_shell_blocks(const pa_ctx* c);
+int64_t pa_shell_elems(const pa_ctx* c);
+bool pa_bc_is_static(const pa_ctx* c);   // every face dirichlet: B(x) is a no-op after the first fill
+bool pa_bc_fusable(const pa_ctx* c);     // closed form applies (factory order, small shell)
+bool pa_bc_pairable(const pa_ctx* c);    // one launch per axis applies (factory order, both faces present)
+template <typename T>
+int pa_bc_apply_faces(pa_ctx* c, T* x, bool guarded = false);   // one launch per face, list order
+template <typename T>
+int pa_bc_apply_auto(pa_ctx* c, T* x, bool guarded);            // fewest launches with the sequential semantics
+template <typename T>
+int pa_bc_shell_fused(pa_ctx* c, T* x, double* part2, int with_delta, bool guarded, int* nsh, bool standalone);
+template <typename T>
+int pa_bc_pair_apply(pa_ctx* c, T* x, double* part2, int mode, bool guarded, int* nsh);
+template <typename T>
+void pa_shell_launch(pa_ctx* c, const T* x, T* shell, double* part2, int with_delta);
 
 #define PA_HIP(c, call)                                              \
   do {                                                               \
@@ -151,9 +149,9 @@ Vec<T> pa_vec_self(const pa_ctx* c, const T* p);
 // kernel ran, 0 when the configuration is not covered (caller falls back to the generic
 // kernel, which is still HIP), < 0 on error.
 template <typename T>
-int pa_cg3d_phase_a(pa_ctx* c, const DevEq<T>& E, Vec<T> r, Vec<T> d, T* dnew, double* partials, const CgEpi& epi);
+int pa_cg3d_phase_a(pa_ctx* c, const DevEq<T>& E, Vec<T> r, Vec<T> d, T* dnew, double* partials);
 template <typename T>
-int pa_cg3d_phase_b(pa_ctx* c, const DevEq<T>& E, Vec<T> d, T* x, T* r, double* partials, const CgEpi& epi);
+int pa_cg3d_phase_b(pa_ctx* c, const DevEq<T>& E, Vec<T> d, T* x, T* r, double* partials);
 
 // single-field tiled kernels (pa_cg3d.hip); same return convention as the CG phases
 template <typename T>

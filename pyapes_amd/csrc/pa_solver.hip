@@ -1,0 +1,1330 @@
+// pa_solver.hip -- CG / Jacobi / BiCGSTAB drivers (linalg.py:33-279) with device-resident scalars, their
+// generic kernels (any dimension / term list; the tiled kernels of pa_cg3d*.hip take over where they
+// apply), the single-block reduction + scalar-step kernels, the stepwise CG entry points.
+#include "pa_host.h"
+
+#include <math.h>
+#include <stdlib.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <algorithm>
+#include <new>
+
+// ---- CG: r = (b - A x) on S, d = r, partial sum r.r (linalg.py:98-107) ---------------
+template <typename T>
+__global__ void __launch_bounds__(PA_BLOCK) k_cg_init(DevGeom G, DevEq<T> E, Vec<T> xv,
+                                                       const T* __restrict__ rhs, T* __restrict__ r,
+                                                       T* __restrict__ d, T* __restrict__ send_lo,
+                                                       T* __restrict__ send_hi, double* __restrict__ partials) {
+  FieldAcc<T> acc{xv};
+  double s[1] = {0.0};
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < G.ncell;
+       idx += (int64_t)gridDim.x * blockDim.x) {
+    int64_t i, j, k;
+    pa_decode(G, idx, i, j, k);
+    T rv = (T)0;
+    if (pa_in_S(G, i, j, k)) {
+      T ax = pa_apply_terms<T>(G, E, acc, i, j, k, xv.p[idx]);
+      rv = rhs[idx] - ax;
+      T p = rv * rv;
+      s[0] += (double)p;
+    }
+    r[idx] = rv;
+    if (d) d[idx] = rv;
+    if (send_lo && i == 0) send_lo[j * G.s1 + k] = rv;
+    if (send_hi && i == G.n0 - 1) send_hi[j * G.s1 + k] = rv;
+  }
+  pa_block_reduce_store<1>(s, partials);
+}
+
+// the same, from A x already computed by the tiled kernel (zero outside S) and sitting in `r`: same
+// loop, same grid, same partial sums -- r, d and the sum r.r come out bit-identical to k_cg_init
+template <typename T>
+__global__ void __launch_bounds__(PA_BLOCK) k_cg_init_ax(DevGeom G, const T* __restrict__ rhs, T* __restrict__ r,
+                                                          T* __restrict__ d, T* __restrict__ send_lo,
+                                                          T* __restrict__ send_hi, double* __restrict__ partials) {
+  double s[1] = {0.0};
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < G.ncell;
+       idx += (int64_t)gridDim.x * blockDim.x) {
+    int64_t i, j, k;
+    pa_decode(G, idx, i, j, k);
+    T rv = (T)0;
+    if (pa_in_S(G, i, j, k)) {
+      rv = rhs[idx] - r[idx];
+      T p = rv * rv;
+      s[0] += (double)p;
+    }
+    r[idx] = rv;
+    if (d) d[idx] = rv;
+    if (send_lo && i == 0) send_lo[j * G.s1 + k] = rv;
+    if (send_hi && i == G.n0 - 1) send_hi[j * G.s1 + k] = rv;
+  }
+  pa_block_reduce_store<1>(s, partials);
+}
+
+// ---- CG phase A: d' = r + beta d ; partial sum d'.(A d')  (linalg.py:115-120, 141) ----
+template <typename T>
+__global__ void __launch_bounds__(PA_BLOCK) k_cg_a(DevGeom G, DevEq<T> E, const SolverScalars* __restrict__ sc,
+                                                    Vec<T> rv, Vec<T> dv, T* __restrict__ dnew,
+                                                    double* __restrict__ partials) {
+  if (sc->done) return;
+  DirAcc<T> acc{rv, dv, (T)sc->beta};
+  double s[1] = {0.0};
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < G.ncell;
+       idx += (int64_t)gridDim.x * blockDim.x) {
+    int64_t i, j, k;
+    pa_decode(G, idx, i, j, k);
+    T e = (T)0;
+    if (pa_in_S(G, i, j, k)) {
+      e = acc.at(G, i, j, k);
+      T Ad = pa_apply_terms<T>(G, E, acc, i, j, k, e);
+      T p = e * Ad;
+      s[0] += (double)p;
+    }
+    dnew[idx] = e;
+  }
+  pa_block_reduce_store<1>(s, partials);
+}
+
+// ---- CG phase B: x += alpha d ; r -= alpha A d ; partial sums r.r and |dx|^2 off-shell
+//      (linalg.py:122-134)
+template <typename T>
+__global__ void __launch_bounds__(PA_BLOCK) k_cg_b(DevGeom G, DevEq<T> E, const SolverScalars* __restrict__ sc,
+                                                    Vec<T> dv, T* __restrict__ x, T* __restrict__ r,
+                                                    T* __restrict__ send_lo, T* __restrict__ send_hi,
+                                                    double* __restrict__ partials) {
+  if (sc->done) return;
+  FieldAcc<T> acc{dv};
+  const T alpha = (T)sc->alpha;
+  double s[2] = {0.0, 0.0};
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < G.ncell;
+       idx += (int64_t)gridDim.x * blockDim.x) {
+    int64_t i, j, k;
+    pa_decode(G, idx, i, j, k);
+    T rn = (T)0;
+    if (pa_in_S(G, i, j, k)) {
+      T dc = dv.p[idx];
+      T Ad = pa_apply_terms<T>(G, E, acc, i, j, k, dc);
+      T xo = x[idx];
+      T ad = alpha * dc;
+      T xn = xo + ad;
+      x[idx] = xn;
+      T aAd = alpha * Ad;
+      rn = r[idx] - aAd;
+      r[idx] = rn;
+      T p = rn * rn;
+      s[0] += (double)p;
+      if (!pa_on_shell(G, i, j, k)) {
+        T df = xn - xo;
+        T p2 = df * df;
+        s[1] += (double)p2;
+      }
+    }
+    if (send_lo && i == 0) send_lo[j * G.s1 + k] = rn;
+    if (send_hi && i == G.n0 - 1) send_hi[j * G.s1 + k] = rn;
+  }
+  pa_block_reduce_store<2>(s, partials);
+}
+
+// ---- reductions of per-block partials + scalar logic ------------------------------------
+// sums[slot[s]] (+)= sum over blocks of partials[b*ns + s]
+__device__ __forceinline__ double pa_reduce_partials(const double* __restrict__ partials, int nblk, int ns,
+                                                     int s, double* sm) {
+  double v = 0.0;
+  for (int b = threadIdx.x; b < nblk; b += blockDim.x) v += partials[(int64_t)b * ns + s];
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+  if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = v;
+  __syncthreads();
+  double t = 0.0;
+  if (threadIdx.x == 0)
+    for (int w = 0; w < (int)(blockDim.x >> 6); ++w) t += sm[w];
+  __syncthreads();
+  return t;  // valid on thread 0
+}
+
+template <typename T>
+__device__ __forceinline__ double pa_nan_to_num(T v) {
+  return (isnan(v) || isinf(v)) ? 0.0 : (double)v;  // linalg.py:302-305
+}
+
+// the scalar steps of a CG iteration on the device-resident state
+template <typename T>
+__device__ __forceinline__ void pa_logic_a(SolverScalars* sc, const double* sums) {  // linalg.py:118-120
+  T dAd = (T)sums[0];
+  T rr = (T)sc->rr;
+  sc->dAd = (double)dAd;
+  T a = rr / dAd;
+  sc->alpha = (isnan(a) || isinf(a)) ? 0.0 : (double)a;
+}
+
+template <typename T>
+__device__ __forceinline__ void pa_logic_b(SolverScalars* sc, const double* sums) {  // linalg.py:128-141, 321-338
+  T rr_new = (T)sums[1];
+  T tol = (T)sqrt(sums[2]);
+  sc->tol = (double)tol;
+  if (isnan(tol) || isinf(tol)) {  // linalg.py:334-336 raises before beta / itr
+    sc->err = 1;
+    sc->done = 1;
+    return;
+  }
+  T rr_old = (T)sc->rr;
+  sc->rr_old = (double)rr_old;
+  sc->beta = (double)(rr_new / rr_old);
+  sc->rr = (double)rr_new;
+  sc->itr += 1;
+  if (sc->itr > sc->max_it || !(sc->tol > sc->tolerance)) sc->done = 1;
+}
+
+// stage 0: reduce only (multi-GPU, before the all-reduce); 1: logic only; 2: both
+template <typename T>
+__global__ void __launch_bounds__(PA_BLOCK) k_cg_post_a(SolverScalars* sc, const double* partials, int nblk,
+                                                         double* sums, int stage) {
+  __shared__ double sm[PA_BLOCK / 64];
+  if (sc->done) return;
+  if (stage != 1) {
+    double v = pa_reduce_partials(partials, nblk, 1, 0, sm);
+    if (threadIdx.x == 0) sums[0] = v;
+  }
+  if (stage != 0 && threadIdx.x == 0) pa_logic_a<T>(sc, sums);
+}
+
+template <typename T>
+__global__ void __launch_bounds__(PA_BLOCK) k_cg_post_b(SolverScalars* sc, const double* partials, int nblk,
+                                                         const double* partials_shell, int nblk_shell,
+                                                         double* sums, int stage) {
+  __shared__ double sm[PA_BLOCK / 64];
+  if (sc->done) return;
+  if (stage != 1) {
+    double rr = pa_reduce_partials(partials, nblk, 2, 0, sm);
+    double dx2 = pa_reduce_partials(partials, nblk, 2, 1, sm);
+    double sh = nblk_shell > 0 ? pa_reduce_partials(partials_shell, nblk_shell, 1, 0, sm) : 0.0;
+    if (threadIdx.x == 0) {
+      sums[1] = rr;
+      sums[2] = dx2 + sh;
+    }
+  }
+  if (stage != 0 && threadIdx.x == 0) pa_logic_b<T>(sc, sums);
+}
+
+template <typename T>
+__global__ void __launch_bounds__(PA_BLOCK) k_cg_post_init(SolverScalars* sc, const double* partials, int nblk,
+                                                            double* sums, int stage) {
+  __shared__ double sm[PA_BLOCK / 64];
+  if (stage != 1) {
+    double v = pa_reduce_partials(partials, nblk, 1, 0, sm);
+    if (threadIdx.x == 0) sums[1] = v;
+  }
+  if (stage != 0 && threadIdx.x == 0) sc->rr = (double)(T)sums[1];
+}
+
+// ---- Jacobi sweep [new, SURVEY a15] -----------------------------------------------------
+template <typename T>
+__global__ void __launch_bounds__(PA_BLOCK) k_jacobi(DevGeom G, DevEq<T> E, const SolverScalars* __restrict__ sc,
+                                                      Vec<T> xv, const T* __restrict__ rhs,
+                                                      T* __restrict__ xnew, T omega,
+                                                      double* __restrict__ partials) {
+  if (sc->done) return;
+  FieldAcc<T> acc{xv};
+  double s[2] = {0.0, 0.0};
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < G.ncell;
+       idx += (int64_t)gridDim.x * blockDim.x) {
+    int64_t i, j, k;
+    pa_decode(G, idx, i, j, k);
+    T xo = xv.p[idx];
+    T xn = xo;
+    if (pa_in_S(G, i, j, k)) {
+      int64_t g[3], N[3];
+      pa_gidx(G, i, j, k, g, N);
+      T diag = (T)0;
+      for (int q = 0; q < E.nterms; ++q) {
+        const DevTerm<T>& t = E.t[q];
+        T dg = (T)0;
+        for (int a = 0; a < 3; ++a) {
+          if (!G.act[a]) continue;
+          int rc = pa_row_case(G, a, g[a], N[a], G.treat);
+          T cB = (E.rz && a == PA_RZ_AXIS) ? E.rz[2 * E.rz_n + g[a]] : E.lap.c23[a];
+          T cC = rc == 0 ? E.lap.m2inv[a] : -cB;
+          dg = dg + cC;
+        }
+        if (t.has_coeff) dg = dg * (t.coeff_f ? t.coeff_f[idx] : t.coeff);
+        dg = dg * t.sign;
+        diag = diag + dg;
+      }
+      T ax = pa_apply_terms<T>(G, E, acc, i, j, k, xo);
+      T res = rhs[idx] - ax;
+      res = res / diag;
+      T w = omega * res;
+      xn = xo + w;
+      if (!pa_on_shell(G, i, j, k)) {
+        T df = xn - xo;
+        T p2 = df * df;
+        s[1] += (double)p2;
+      }
+    }
+    xnew[idx] = xn;
+  }
+  pa_block_reduce_store<2>(s, partials);
+}
+
+template <typename T>
+__global__ void __launch_bounds__(PA_BLOCK) k_jacobi_post(SolverScalars* sc, const double* partials, int nblk,
+                                                           const double* partials_shell, int nblk_shell,
+                                                           double* sums) {
+  __shared__ double sm[PA_BLOCK / 64];
+  if (sc->done) return;
+  double dx2 = pa_reduce_partials(partials, nblk, 2, 1, sm);
+  double sh = nblk_shell > 0 ? pa_reduce_partials(partials_shell, nblk_shell, 1, 0, sm) : 0.0;
+  if (threadIdx.x == 0) {
+    sums[2] = dx2 + sh;
+    T tol = (T)sqrt(sums[2]);
+    sc->tol = (double)tol;
+    if (isnan(tol) || isinf(tol)) { sc->err = 1; sc->done = 1; return; }
+    sc->itr += 1;
+    if (sc->itr > sc->max_it || !(sc->tol > sc->tolerance)) sc->done = 1;
+  }
+}
+
+// slab: ghost planes of the new direction, d'_g = r_g + beta d_g -- bitwise what the neighbour
+// rank computes for its own boundary plane, so no direction planes are ever exchanged
+template <typename T>
+__global__ void __launch_bounds__(PA_BLOCK) k_ghost_dir(const SolverScalars* __restrict__ sc, int64_t n,
+                                                         const T* __restrict__ r_lo, const T* __restrict__ r_hi,
+                                                         const T* __restrict__ d_lo, const T* __restrict__ d_hi,
+                                                         T* __restrict__ o_lo, T* __restrict__ o_hi) {
+  if (sc->done) return;
+  const T beta = (T)sc->beta;
+  for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < n; q += (int64_t)gridDim.x * blockDim.x) {
+    if (r_lo) { T b = beta * d_lo[q]; o_lo[q] = r_lo[q] + b; }
+    if (r_hi) { T b = beta * d_hi[q]; o_hi[q] = r_hi[q] + b; }
+  }
+}
+
+// slab, periodic axis 0: copies of the x planes the other end rank's BC fill needs, placed next to
+// the residual planes in the packed send buffers (one message per neighbour and iteration)
+template <typename T>
+__global__ void __launch_bounds__(PA_BLOCK) k_pack_planes(const SolverScalars* __restrict__ sc, int64_t n,
+                                                           const T* __restrict__ s0, T* __restrict__ d0,
+                                                           const T* __restrict__ s1, T* __restrict__ d1,
+                                                           const T* __restrict__ s2, T* __restrict__ d2) {
+  if (sc->done) return;
+  for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < n; q += (int64_t)gridDim.x * blockDim.x) {
+    if (d0) d0[q] = s0[q];
+    if (d1) d1[q] = s1[q];
+    if (d2) d2[q] = s2[q];
+  }
+}
+
+template <typename T>
+__global__ void k_copy(const T* __restrict__ a, T* __restrict__ b, int64_t n) {
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < n;
+       idx += (int64_t)gridDim.x * blockDim.x)
+    b[idx] = a[idx];
+}
+
+// ---- BiCGSTAB kernels (linalg.py:162-279) ------------------------------------------------
+// p' = r + beta (p - omega v) (with neighbours, so A p' needs no second pass); v' = A p' on S;
+// partial sum r0.v'
+template <typename T>
+struct BicgPAcc {
+  Vec<T> r, p, v;
+  T beta, omega;
+  __device__ __forceinline__ T at(const DevGeom& G, int64_t i, int64_t j, int64_t k) const {
+    const int64_t o = j * G.s1 + k;  // pointers first, one load per field after (see DirAcc)
+    const T* rb = r.p + i * G.s0;
+    const T* pb = p.p + i * G.s0;
+    const T* vb = v.p + i * G.s0;
+    if (i < 0) { rb = r.glo; pb = p.glo; vb = v.glo; }
+    if (i >= G.n0) { rb = r.ghi; pb = p.ghi; vb = v.ghi; }
+    const T rv = rb[o], pv = pb[o], vv = vb[o];
+    T t = omega * vv;
+    t = pv - t;
+    t = beta * t;
+    return rv + t;
+  }
+};
+
+template <typename T>
+__global__ void __launch_bounds__(PA_BLOCK) k_bicg_pv(DevGeom G, DevEq<T> E, const SolverScalars* __restrict__ sc,
+                                                       Vec<T> rv, Vec<T> pv, Vec<T> vv, const T* __restrict__ r0,
+                                                       T* __restrict__ pnew, T* __restrict__ vnew,
+                                                       double* __restrict__ partials) {
+  if (sc->done) return;
+  BicgPAcc<T> acc{rv, pv, vv, (T)sc->beta, (T)sc->omega};
+  double s[1] = {0.0};
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < G.ncell;
+       idx += (int64_t)gridDim.x * blockDim.x) {
+    int64_t i, j, k;
+    pa_decode(G, idx, i, j, k);
+    T pc = acc.at(G, i, j, k);
+    T vn = (T)0;
+    if (pa_in_S(G, i, j, k)) {
+      vn = pa_apply_terms<T>(G, E, acc, i, j, k, pc);
+      T p = r0[idx] * vn;
+      s[0] += (double)p;
+    }
+    pnew[idx] = pc;
+    vnew[idx] = vn;
+  }
+  pa_block_reduce_store<1>(s, partials);
+}
+
+// s = r - alpha v ; partial sum |s|^2 (tol = |r - alpha v|, linalg.py:230-233)
+template <typename T>
+__global__ void __launch_bounds__(PA_BLOCK) k_bicg_s(DevGeom G, const SolverScalars* __restrict__ sc,
+                                                      const T* __restrict__ r, const T* __restrict__ v,
+                                                      T* __restrict__ s_out, double* __restrict__ partials) {
+  if (sc->done) return;
+  const T alpha = (T)sc->alpha;
+  double s[1] = {0.0};
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < G.ncell;
+       idx += (int64_t)gridDim.x * blockDim.x) {
+    T av = alpha * v[idx];
+    T sv = r[idx] - av;
+    s_out[idx] = sv;
+    T p = sv * sv;
+    s[0] += (double)p;
+  }
+  pa_block_reduce_store<1>(s, partials);
+}
+
+// t = A s on S ; partial sums t.s, t.t, r0.t
+template <typename T>
+__global__ void __launch_bounds__(PA_BLOCK) k_bicg_t(DevGeom G, DevEq<T> E, const SolverScalars* __restrict__ sc,
+                                                      Vec<T> sv, const T* __restrict__ r0, T* __restrict__ t_out,
+                                                      double* __restrict__ partials) {
+  if (sc->done || sc->finished_early) return;
+  FieldAcc<T> acc{sv};
+  double s[3] = {0.0, 0.0, 0.0};
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < G.ncell;
+       idx += (int64_t)gridDim.x * blockDim.x) {
+    int64_t i, j, k;
+    pa_decode(G, idx, i, j, k);
+    T tv = (T)0;
+    if (pa_in_S(G, i, j, k)) {
+      T sc_ = sv.p[idx];
+      tv = pa_apply_terms<T>(G, E, acc, i, j, k, sc_);
+      T a = tv * sc_;
+      T b = tv * tv;
+      T c = r0[idx] * tv;
+      s[0] += (double)a;
+      s[1] += (double)b;
+      s[2] += (double)c;
+    }
+    t_out[idx] = tv;
+  }
+  pa_block_reduce_store<3>(s, partials);
+}
+
+// early exit: x += alpha p ; otherwise x = x + alpha p + s omega ; r = s - omega t ; |r|^2
+template <typename T>
+__global__ void __launch_bounds__(PA_BLOCK) k_bicg_x(DevGeom G, const SolverScalars* __restrict__ sc,
+                                                      T* __restrict__ x, const T* __restrict__ p,
+                                                      const T* __restrict__ s_in, const T* __restrict__ t_in,
+                                                      T* __restrict__ r, double* __restrict__ partials,
+                                                      const double* pre_part, int pre_n, SolverScalars* sc_w) {
+  const T alpha = (T)sc->alpha;
+  T omega;
+  int early;
+  if (pre_n > 0) {
+    // folded k_bicg_post stage 12 (rows {|s|^2, t.s, t.t, r0.t} of the fused s / t kernel): stop test 1,
+    // then omega and rho_next -- every block on its own, same summation order; block 0 stores
+    __shared__ double pre_sm[24];
+    const int done_in = sc->done;
+    const double tol_lim = sc->tolerance, omega_in = sc->omega;
+    double v[4] = {0.0, 0.0, 0.0, 0.0};
+    for (int b = threadIdx.x; b < pre_n; b += PA_BLOCK) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) v[q] += pre_part[4 * (int64_t)b + q];
+    }
+    if (done_in) return;
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      for (int off = 32; off > 0; off >>= 1) v[q] += __shfl_down(v[q], off, 64);
+    if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) pre_sm[4 * (threadIdx.x >> 6) + q] = v[q];
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      double t4[4] = {0.0, 0.0, 0.0, 0.0};
+      for (int w = 0; w < PA_BLOCK / 64; ++w) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) t4[q] += pre_sm[4 * w + q];
+      }
+      const T tol = (T)sqrt(t4[0]);
+      const bool bad = isnan(tol) || isinf(tol);
+      const int fe = (!bad && (double)tol <= tol_lim) ? 1 : 0;
+      T om = (T)omega_in;
+      if (!bad && !fe) om = (T)pa_nan_to_num<T>((T)t4[1] / (T)t4[2]);
+      pre_sm[16] = (double)om;
+      pre_sm[17] = fe ? 1.0 : 0.0;
+      pre_sm[18] = bad ? 1.0 : 0.0;
+      if (blockIdx.x == 0) {
+        sc_w->tol = (double)tol;
+        if (bad) {
+          sc_w->err = 1;
+          sc_w->done = 1;
+        } else {
+          sc_w->finished_early = fe;
+          if (!fe) {
+            sc_w->omega = (double)om;
+            T rn = -om;
+            rn = rn * (T)t4[3];
+            sc_w->rho_next = (double)rn;
+          }
+        }
+      }
+    }
+    __syncthreads();
+    if (pre_sm[18] != 0.0) return;
+    omega = (T)pre_sm[16];
+    early = pre_sm[17] != 0.0;
+  } else {
+    if (sc->done) return;
+    omega = (T)sc->omega;
+    early = sc->finished_early;
+  }
+  double s[1] = {0.0};
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < G.ncell;
+       idx += (int64_t)gridDim.x * blockDim.x) {
+    T ap = alpha * p[idx];
+    T xn = x[idx] + ap;
+    if (!early) {
+      T so = s_in[idx] * omega;
+      xn = xn + so;
+      T ot = omega * t_in[idx];
+      T rn = s_in[idx] - ot;
+      r[idx] = rn;
+      T q = rn * rn;
+      s[0] += (double)q;
+    }
+    x[idx] = xn;
+  }
+  pa_block_reduce_store<1>(s, partials);
+}
+
+// stage: 0 after pv (alpha), 1 after s (tol check 1), 2 after t (omega, rho_next), 3 after x (tol check 2)
+template <typename T>
+__global__ void __launch_bounds__(PA_BLOCK) k_bicg_post(SolverScalars* sc, const double* partials, int nblk,
+                                                         int stage) {
+  __shared__ double sm[PA_BLOCK / 64];
+  if (sc->done) return;
+  if (stage == 0) {
+    double v = pa_reduce_partials(partials, nblk, 1, 0, sm);
+    if (threadIdx.x == 0) {
+      sc->itr += 1;
+      T r0v = (T)v;
+      T rho = (T)sc->rho;
+      sc->alpha = pa_nan_to_num<T>(rho / r0v);
+    }
+  } else if (stage == 1) {
+    double v = pa_reduce_partials(partials, nblk, 1, 0, sm);
+    if (threadIdx.x == 0) {
+      T tol = (T)sqrt(v);
+      sc->tol = (double)tol;
+      if (isnan(tol) || isinf(tol)) { sc->err = 1; sc->done = 1; return; }
+      sc->finished_early = (sc->tol <= sc->tolerance) ? 1 : 0;
+    }
+  } else if (stage == 2) {
+    if (sc->finished_early) return;
+    double ts = pa_reduce_partials(partials, nblk, 3, 0, sm);
+    double tt = pa_reduce_partials(partials, nblk, 3, 1, sm);
+    double r0t = pa_reduce_partials(partials, nblk, 3, 2, sm);
+    if (threadIdx.x == 0) {
+      T om = (T)pa_nan_to_num<T>((T)ts / (T)tt);
+      sc->omega = (double)om;
+      T rn = -om;
+      rn = rn * (T)r0t;
+      sc->rho_next = (double)rn;
+    }
+  } else if (stage == 12) {
+    // fused s / t kernel: partial rows are {|s|^2, t.s, t.t, r0.t}: stop test 1, then omega, rho_next
+    double ss = pa_reduce_partials(partials, nblk, 4, 0, sm);
+    double ts = pa_reduce_partials(partials, nblk, 4, 1, sm);
+    double tt = pa_reduce_partials(partials, nblk, 4, 2, sm);
+    double r0t = pa_reduce_partials(partials, nblk, 4, 3, sm);
+    if (threadIdx.x == 0) {
+      T tol = (T)sqrt(ss);
+      sc->tol = (double)tol;
+      if (isnan(tol) || isinf(tol)) { sc->err = 1; sc->done = 1; return; }
+      sc->finished_early = (sc->tol <= sc->tolerance) ? 1 : 0;
+      if (!sc->finished_early) {
+        T om = (T)pa_nan_to_num<T>((T)ts / (T)tt);
+        sc->omega = (double)om;
+        T rn = -om;
+        rn = rn * (T)r0t;
+        sc->rho_next = (double)rn;
+      }
+    }
+  } else {
+    double v = pa_reduce_partials(partials, nblk, 1, 0, sm);
+    if (threadIdx.x == 0) {
+      if (sc->finished_early) { sc->done = 1; return; }
+      T tol = (T)sqrt(v);
+      sc->tol = (double)tol;
+      if (isnan(tol) || isinf(tol)) { sc->err = 1; sc->done = 1; return; }
+      if (sc->tol <= sc->tolerance) sc->done = 1;
+      if (sc->itr >= sc->max_it) sc->done = 1;
+      // next iteration's beta = rho_next / rho * alpha / omega ; rho = rho_next (linalg.py:212-214)
+      T b = (T)sc->rho_next / (T)sc->rho;
+      b = b * (T)sc->alpha;
+      b = b / (T)sc->omega;
+      sc->beta = (double)b;
+      sc->rho = sc->rho_next;
+    }
+  }
+}
+
+// ---- host side ----------------------------------------------------------------------------------
+static int init_scalars(pa_ctx* c, double tol, int64_t max_it) {
+  SolverScalars h;
+  memset(&h, 0, sizeof(h));
+  h.tolerance = tol;
+  h.max_it = max_it;
+  h.tol = 1.0;
+  h.rho = 1.0; h.alpha = 1.0; h.omega = 1.0;
+  h.done = !(1.0 > tol);  // `while tol > tolerance` with tol = 1.0 (linalg.py:90,109)
+  *c->h_sc = h;
+  PA_HIP(c, hipMemcpyAsync(c->sc, c->h_sc, sizeof(h), hipMemcpyHostToDevice, c->stream));
+  PA_HIP(c, hipStreamSynchronize(c->stream));
+  return PA_OK;
+}
+
+static int read_scalars(pa_ctx* c) {
+  PA_HIP(c, hipMemcpyAsync(c->h_sc, c->sc, sizeof(SolverScalars), hipMemcpyDeviceToHost, c->stream));
+  PA_HIP(c, hipStreamSynchronize(c->stream));
+  return PA_OK;
+}
+
+// Pipelined poll: after a batch of iterations has been enqueued (and its pending scalar step flushed),
+// queue a copy of the device scalars and wait for the copy of the PREVIOUS batch.  The GPU already has
+// the next batch to work on while the host looks at the flag; when the flag was set, that batch is
+// no-ops (every kernel starts with `if (done) return`), so results and iteration counts are unchanged.
+// A synchronous poll leaves the GPU idle for a host round trip (~250 us) every ~300 us of work on the
+// meshes of the reference's tests.
+struct PollPipe {
+  int pending = -1, slot = 0;
+};
+static int poll_submit(pa_ctx* c, PollPipe& P, bool* done) {
+  *done = false;
+  PA_HIP(c, hipMemcpyAsync(c->h_poll[P.slot], c->sc, sizeof(SolverScalars), hipMemcpyDeviceToHost, c->stream));
+  PA_HIP(c, hipEventRecord(c->ev_poll[P.slot], c->stream));
+  if (P.pending >= 0) {
+    PA_HIP(c, hipEventSynchronize(c->ev_poll[P.pending]));
+    *done = c->h_poll[P.pending]->done != 0;
+  }
+  P.pending = P.slot;
+  P.slot ^= 1;
+  return PA_OK;
+}
+static int poll_drain(pa_ctx* c, PollPipe& P, bool* done) {
+  *done = false;
+  if (P.pending < 0) return PA_OK;
+  PA_HIP(c, hipEventSynchronize(c->ev_poll[P.pending]));
+  *done = c->h_poll[P.pending]->done != 0;
+  P.pending = -1;
+  return PA_OK;
+}
+
+static int poll_interval(const pa_ctx* c) {
+  // keep >= ~300 us of queued GPU work between host polls of the done flag
+  double est_us = (double)c->G.ncell * 80.0 / 4.0e6 + 30.0;
+  int k = (int)ceil(300.0 / est_us);
+  return std::max(1, std::min(k, 64));
+}
+
+static void fill_report(pa_ctx* c, pa_report* out, float ms) {
+  const SolverScalars& h = *c->h_sc;
+  out->itr = h.itr;
+  out->tol = h.tol;
+  out->converge = h.itr < h.max_it;
+  out->status = h.err ? PA_E_NONFINITE : PA_OK;
+  out->rr = h.rr;
+  out->gpu_ms = ms;
+}
+
+// r = (b - A x) on S (0 elsewhere), d = r, per-block partial sums of r.r: the tiled A x kernel plus one
+// streaming pass where the tiled kernel applies, else the generic kernel
+template <typename T>
+static int cg_residual_init(pa_ctx* c, const DevEq<T>& E, Vec<T> xv, const T* rhs, T* r, T* d, T* send_lo,
+                            T* send_hi, double* part) {
+  const int nblk = pa_grid_blocks(c->G.ncell);
+  // slab: a NULL ghost plane marks a physical (non-periodic) end.  No result ever uses that plane (the
+  // end plane is a boundary node, outside S), but the tiled kernel loads it speculatively: the field's
+  // own end plane stands in, so the load stays inside valid memory.
+  Vec<T> xt = xv;
+  if (!xt.glo) xt.glo = xt.p;
+  if (!xt.ghi) xt.ghi = xt.p + (c->G.n0 - 1) * c->G.s0;
+  int fr = (rhs != r && (const T*)xv.p != r) ? pa_tile3d_aop<T>(c, E, xt, r, 1) : 0;
+  if (fr < 0) return fr;
+  if (fr > 0)
+    hipLaunchKernelGGL(k_cg_init_ax<T>, dim3(nblk), dim3(PA_BLOCK), 0, c->stream, c->G, rhs, r, d, send_lo, send_hi,
+                       part);
+  else
+    hipLaunchKernelGGL(k_cg_init<T>, dim3(nblk), dim3(PA_BLOCK), 0, c->stream, c->G, E, xv, rhs, r, d, send_lo,
+                       send_hi, part);
+  return PA_OK;
+}
+
+template <typename T>
+static int cg_begin_t(pa_ctx* c, T* x, const T* rhs, double tol, int64_t max_it) {
+  const DevGeom& G = c->G;
+  const size_t fb = (size_t)G.ncell * sizeof(T);
+  const int nblk = pa_grid_blocks(G.ncell);
+  int rc;
+  if ((rc = pa_scratch(c, &c->scr[SCR_R], &c->cap[SCR_R], fb))) return rc;
+  if ((rc = pa_scratch(c, &c->scr[SCR_D0], &c->cap[SCR_D0], fb))) return rc;
+  if ((rc = pa_scratch(c, &c->scr[SCR_D1], &c->cap[SCR_D1], fb))) return rc;
+  if ((rc = pa_scratch(c, &c->scr[SCR_PART], &c->cap[SCR_PART], (size_t)PA_MAX_PARTIALS * 4 * sizeof(double)))) return rc;
+  if ((rc = pa_scratch(c, &c->scr[SCR_PART2], &c->cap[SCR_PART2], (size_t)3 * PA_MAX_GRID * sizeof(double)))) return rc;
+  if ((rc = pa_scratch(c, &c->scr[SCR_SHELL], &c->cap[SCR_SHELL], 2 * (size_t)pa_shell_elems(c) * sizeof(T)))) return rc;
+  if ((rc = init_scalars(c, tol, max_it))) return rc;
+  // the tiled phase kernels do not visit the last boundary row / column of non-periodic axes: the
+  // direction there is 0 by definition and has to be 0 in the buffer the first phase A writes into
+  PA_HIP(c, hipMemsetAsync(c->scr[SCR_D1], 0, fb, c->stream));
+  c->cg_x = x;
+  c->cur = 0;
+  c->fold_a_n = c->fold_b_n = c->fold_b_nsh = 0;  // nothing of an earlier (possibly failed) solve is pending
+  c->bc_static = pa_bc_is_static(c);
+  c->bc_fused = pa_bc_fusable(c);
+  c->bc_pair = (!c->bc_fused && pa_bc_pairable(c)) ? 1 : 0;
+  c->shell_cur = 0;
+  c->solver_live = 1;
+  DevEq<T> E;
+  pa_build_eq<T>(c, c->nterms, c->terms, E);
+  // linalg.py:97.  On a slab the driver fills the BCs itself (pa_apply_bc) BEFORE it exchanges
+  // the ghost planes of x, so the fill must not run again here.
+  bool shell_ready = false;
+  if (!c->slab) {
+    if (c->bc_fused) {  // fill + remember the filled shell as x_old in one go
+      if ((rc = pa_bc_shell_fused<T>(c, x, nullptr, 0, false, nullptr, false))) return rc;
+      shell_ready = true;
+    } else if (c->bc_pair) {
+      if ((rc = pa_bc_pair_apply<T>(c, x, nullptr, 2, false, nullptr))) return rc;
+      shell_ready = true;
+    } else if ((rc = pa_bc_apply_faces<T>(c, x))) {
+      return rc;
+    }
+  } else if (c->bc_pair) {  // slab: the driver has filled the BCs already; only record the shell
+    if ((rc = pa_bc_pair_apply<T>(c, x, nullptr, 3, false, nullptr))) return rc;
+    shell_ready = true;
+  }
+  T* r = (T*)c->scr[SCR_R];
+  T* d = (T*)c->scr[SCR_D0];
+  double* part = (double*)c->scr[SCR_PART];
+  Vec<T> xv = pa_vec_self<T>(c, x);
+  if (c->slab) { xv.glo = (const T*)c->x_glo; xv.ghi = (const T*)c->x_ghi; }
+  if ((rc = cg_residual_init<T>(c, E, xv, rhs, r, d, (T*)c->r_send_lo, (T*)c->r_send_hi, part))) return rc;
+  hipLaunchKernelGGL(k_cg_post_init<T>, dim3(1), dim3(PA_BLOCK), 0, c->stream, c->sc, part, nblk, pa_sums(c),
+                     c->slab ? 0 : 2);
+  c->pending_init_logic = c->slab ? 1 : 0;
+  if (c->slab) {
+    // ghost planes of the two direction buffers: lo/hi x ping/pong, zero = "d = r" with beta = 0
+    const size_t pb = (size_t)G.s0 * sizeof(T);
+    if ((rc = pa_scratch(c, &c->scr[SCR_GHOST], &c->cap[SCR_GHOST], 4 * pb))) return rc;
+    PA_HIP(c, hipMemsetAsync(c->scr[SCR_GHOST], 0, 4 * pb, c->stream));
+    char* g = (char*)c->scr[SCR_GHOST];
+    c->d_glo[0] = g; c->d_ghi[0] = g + pb; c->d_glo[1] = g + 2 * pb; c->d_ghi[1] = g + 3 * pb;
+  }
+  if (!shell_ready)
+    pa_shell_launch<T>(c, (const T*)x, (T*)c->scr[SCR_SHELL] + (c->shell_cur ? pa_shell_elems(c) : 0), (double*)c->scr[SCR_PART2], 0);
+  PA_HIP(c, hipGetLastError());
+  return PA_OK;
+}
+
+// profiling build of the launch path: HIP events on the ctx stream bracket exactly one
+// dominant kernel; the host waits for each, so use it in a dedicated measurement loop only
+void pa_profile_stop(pa_ctx* c, int which) {
+  hipEvent_t e0 = c->pev[2 * which], e1 = c->pev[2 * which + 1];
+  (void)hipEventRecord(e1, c->stream);
+  (void)hipEventSynchronize(e1);
+  float ms = 0.f;
+  if (hipEventElapsedTime(&ms, e0, e1) == hipSuccess) {
+    c->prof_ms[which] += ms;
+    c->prof_n[which] += 1;
+  }
+}
+
+template <typename T>
+static Vec<T> cg_vec(pa_ctx* c, const T* p, int which /*0 r, 1 d cur*/) {
+  Vec<T> v = pa_vec_self<T>(c, p);
+  if (c->slab) {
+    // a NULL recv pointer marks a physical (non-periodic) end: that ghost plane is never used in a
+    // result, the field's own plane stands in so that speculative loads stay inside valid memory
+    if (which == 0) {
+      if (c->r_recv_lo) v.glo = (const T*)c->r_recv_lo;
+      if (c->r_recv_hi) v.ghi = (const T*)c->r_recv_hi;
+    } else {
+      if (c->r_recv_lo) v.glo = (const T*)c->d_glo[c->cur];
+      if (c->r_recv_hi) v.ghi = (const T*)c->d_ghi[c->cur];
+    }
+  }
+  return v;
+}
+
+// scalar steps that were left to the prologue of a tiled kernel that is not coming (the generic kernel
+// runs instead, or the batch of iterations ends): run them as the single-block kernels they replace
+template <typename T>
+static void cg_flush_fold(pa_ctx* c) {
+  if (c->fold_a_n > 0) {
+    hipLaunchKernelGGL(k_cg_post_a<T>, dim3(1), dim3(PA_BLOCK), 0, c->stream, c->sc,
+                       (const double*)c->scr[SCR_PART] + 2 * (size_t)PA_MAX_PARTIALS, c->fold_a_n, pa_sums(c), 2);
+    c->fold_a_n = 0;
+  }
+  if (c->fold_b_n > 0) {
+    hipLaunchKernelGGL(k_cg_post_b<T>, dim3(1), dim3(PA_BLOCK), 0, c->stream, c->sc, c->fold_b_part,
+                       c->fold_b_n, (const double*)c->scr[SCR_PART2], c->fold_b_nsh, pa_sums(c), 2);
+    c->fold_b_n = c->fold_b_nsh = 0;
+  }
+}
+
+template <typename T>
+int pa_cg_phase_a_t(pa_ctx* c, int stage_post) {
+  const DevGeom& G = c->G;
+  const int nblk = pa_grid_blocks(G.ncell);
+  DevEq<T> E;
+  pa_build_eq<T>(c, c->nterms, c->terms, E);
+  T* r = (T*)c->scr[SCR_R];
+  T* dold = (T*)c->scr[c->cur ? SCR_D1 : SCR_D0];
+  T* dnew = (T*)c->scr[c->cur ? SCR_D0 : SCR_D1];
+  double* part = (double*)c->scr[SCR_PART];
+  // inside pa_cg_iterate on one GPU the two single-block scalar kernels of an iteration are folded into
+  // the prologue of the tiled kernel that follows them (pa_cg3d_kernel.h); d.Ad rows then live in the
+  // upper half of SCR_PART, because phase B writes its own rows while its blocks still read these
+  const bool foldable = c->fold && c->in_iterate && stage_post == 2 && !c->slab && !c->profile;
+  if (foldable) part += 2 * (size_t)PA_MAX_PARTIALS;
+  if (c->pending_init_logic) {  // slab: sum r.r has been all-reduced by the driver
+    hipLaunchKernelGGL(k_cg_post_init<T>, dim3(1), dim3(PA_BLOCK), 0, c->stream, c->sc, (const double*)nullptr, 0,
+                       pa_sums(c), 1);
+    c->pending_init_logic = 0;
+  }
+  Vec<T> rv = cg_vec<T>(c, r, 0), dv = cg_vec<T>(c, dold, 1);
+  if (c->slab && (c->r_recv_lo || c->r_recv_hi)) {
+    hipLaunchKernelGGL(k_ghost_dir<T>, dim3(pa_grid_blocks(G.s0)), dim3(PA_BLOCK), 0, c->stream, c->sc, G.s0,
+                       (const T*)c->r_recv_lo, (const T*)c->r_recv_hi, (const T*)c->d_glo[c->cur],
+                       (const T*)c->d_ghi[c->cur], (T*)c->d_glo[c->cur ^ 1], (T*)c->d_ghi[c->cur ^ 1]);
+  }
+  if (c->profile) (void)hipEventRecord(c->pev[0], c->stream);
+  int rc = pa_cg3d_phase_a<T>(c, E, rv, dv, dnew, part);
+  if (rc < 0) return rc;
+  int used_blocks = rc;
+  if (rc == 0) {
+    cg_flush_fold<T>(c);  // the tiled kernel declined: the previous iteration is closed by its own kernel
+    hipLaunchKernelGGL(k_cg_a<T>, dim3(nblk), dim3(PA_BLOCK), 0, c->stream, G, E, c->sc, rv, dv, dnew, part);
+    used_blocks = nblk;
+  }
+  if (c->profile) pa_profile_stop(c, 0);
+  c->cur ^= 1;
+  if (foldable && used_blocks <= PA_MAX_GRID)
+    c->fold_a_n = used_blocks;  // phase B's prologue (or cg_flush_fold) computes alpha
+  else
+    hipLaunchKernelGGL(k_cg_post_a<T>, dim3(1), dim3(PA_BLOCK), 0, c->stream, c->sc, part, used_blocks, pa_sums(c),
+                       stage_post);
+  PA_HIP(c, hipGetLastError());
+  return PA_OK;
+}
+
+template <typename T>
+int pa_cg_phase_b_t(pa_ctx* c, int stage_post) {
+  const DevGeom& G = c->G;
+  const int nblk = pa_grid_blocks(G.ncell);
+  DevEq<T> E;
+  pa_build_eq<T>(c, c->nterms, c->terms, E);
+  T* r = (T*)c->scr[SCR_R];
+  T* d = (T*)c->scr[c->cur ? SCR_D1 : SCR_D0];
+  T* x = (T*)c->cg_x;
+  double* part = (double*)c->scr[SCR_PART];
+  double* part2 = (double*)c->scr[SCR_PART2];
+  Vec<T> dv = cg_vec<T>(c, d, 1);
+  if (c->profile) (void)hipEventRecord(c->pev[2], c->stream);
+  int rc = pa_cg3d_phase_b<T>(c, E, dv, x, r, part);
+  if (rc < 0) return rc;
+  int used_blocks = rc;
+  if (rc == 0) {
+    cg_flush_fold<T>(c);  // alpha by its own kernel
+    hipLaunchKernelGGL(k_cg_b<T>, dim3(nblk), dim3(PA_BLOCK), 0, c->stream, G, E, c->sc, dv, x, r,
+                       (T*)c->r_send_lo, (T*)c->r_send_hi, part);
+    used_blocks = nblk;
+  }
+  if (c->profile) pa_profile_stop(c, 1);
+  c->b_blocks = used_blocks;
+  if (c->slab) {  // BC fill + shell + reduction happen in pa_cg_bc, after the driver's plane exchange
+    if (c->x_pack_lo1 || c->x_pack_hi0 || c->x_pack_hi1) {
+      const T* xr = (const T*)x;
+      hipLaunchKernelGGL(k_pack_planes<T>, dim3(pa_grid_blocks(G.s0)), dim3(PA_BLOCK), 0, c->stream, c->sc, G.s0,
+                         xr + 1 * G.s0, (T*)c->x_pack_lo1, xr + (G.n0 - 1) * G.s0, (T*)c->x_pack_hi0,
+                         xr + (G.n0 - 2) * G.s0, (T*)c->x_pack_hi1);
+    }
+    PA_HIP(c, hipGetLastError());
+    return PA_OK;
+  }
+  int nsh = 0;
+  if (!c->bc_static) {
+    if (c->bc_fused) {
+      if ((rc = pa_bc_shell_fused<T>(c, x, part2, 1, true, &nsh, false))) return rc;
+    } else if (c->bc_pair) {
+      if ((rc = pa_bc_pair_apply<T>(c, x, part2, 1, true, &nsh))) return rc;
+    } else {
+      if ((rc = pa_bc_apply_faces<T>(c, x, true))) return rc;
+      nsh = pa_shell_blocks(c);
+      pa_shell_launch<T>(c, (const T*)x, (T*)c->scr[SCR_SHELL], part2, 1);
+    }
+  }
+  const bool foldable = c->fold && c->in_iterate && stage_post == 2 && !c->slab && !c->profile &&
+                        used_blocks <= PA_MAX_GRID && nsh <= 3 * PA_MAX_GRID;
+  if (foldable) {
+    c->fold_b_n = used_blocks;  // the next phase A's prologue (or cg_flush_fold) closes this iteration
+    c->fold_b_nsh = nsh;
+    c->fold_b_part = part;
+  } else {
+    hipLaunchKernelGGL(k_cg_post_b<T>, dim3(1), dim3(PA_BLOCK), 0, c->stream, c->sc, part, used_blocks, part2, nsh,
+                       pa_sums(c), stage_post);
+  }
+  PA_HIP(c, hipGetLastError());
+  return PA_OK;
+}
+
+// slab: BC fill of x (needs the far planes the driver just exchanged when axis 0 is periodic),
+// boundary-shell part of the stop test, local partial sums -> sums[1], sums[2]
+template <typename T>
+int pa_cg_bc_t(pa_ctx* c) {
+  const DevGeom& G = c->G;
+  T* x = (T*)c->cg_x;
+  double* part = (double*)c->scr[SCR_PART];
+  double* part2 = (double*)c->scr[SCR_PART2];
+  int nsh = 0, rc;
+  if (!c->bc_static) {
+    if (c->bc_fused) {
+      if ((rc = pa_bc_shell_fused<T>(c, x, part2, 1, true, &nsh, false))) return rc;
+    } else if (c->bc_pair) {
+      if ((rc = pa_bc_pair_apply<T>(c, x, part2, 1, true, &nsh))) return rc;
+    } else {
+      if ((rc = pa_bc_apply_faces<T>(c, x, true))) return rc;
+      nsh = pa_shell_blocks(c);
+      pa_shell_launch<T>(c, (const T*)x, (T*)c->scr[SCR_SHELL], part2, 1);
+    }
+  }
+  hipLaunchKernelGGL(k_cg_post_b<T>, dim3(1), dim3(PA_BLOCK), 0, c->stream, c->sc, part, c->b_blocks, part2, nsh,
+                       pa_sums(c), 0);
+  PA_HIP(c, hipGetLastError());
+  return PA_OK;
+}
+
+template <typename T>
+static int cg_run_t(pa_ctx* c, T* x, const T* rhs, double tol, int64_t max_it, pa_report* out) {
+  int rc = cg_begin_t<T>(c, x, rhs, tol, max_it);
+  if (rc) return rc;
+  const int poll = poll_interval(c);
+  PA_HIP(c, hipEventRecord(c->ev0, c->stream));
+  int64_t enq = 0;
+  c->in_iterate = 1;  // scalar steps folded into the next tiled kernel's prologue (flushed before every poll)
+  PollPipe P;
+  bool done = false;
+  int64_t batch = 1;
+  while (!done && !rc) {
+    // the device stops by itself after max_it + 1 iterations (linalg.py K+1 quirk): never enqueue more
+    int64_t nb = std::min<int64_t>(batch, max_it + 1 - enq);
+    if (nb <= 0) {
+      if ((rc = poll_drain(c, P, &done)) || done) break;
+      nb = 1;  // not reached by construction; keeps the loop live if it ever is
+    }
+    for (int64_t q = 0; q < nb && !rc; ++q) {
+      if ((rc = pa_cg_phase_a_t<T>(c, 2))) break;
+      rc = pa_cg_phase_b_t<T>(c, 2);
+      ++enq;
+    }
+    if (rc) break;
+    cg_flush_fold<T>(c);
+    rc = poll_submit(c, P, &done);
+    batch = std::min<int64_t>(poll, std::max<int64_t>(1, enq));
+  }
+  if (!rc) rc = read_scalars(c);
+  c->in_iterate = 0;
+  if (rc) { c->fold_a_n = c->fold_b_n = c->fold_b_nsh = 0; return rc; }
+  PA_HIP(c, hipEventRecord(c->ev1, c->stream));
+  PA_HIP(c, hipEventSynchronize(c->ev1));
+  float ms = 0.f;
+  (void)hipEventElapsedTime(&ms, c->ev0, c->ev1);
+  fill_report(c, out, ms);
+  c->solver_live = 0;
+  return c->h_sc->err ? PA_E_NONFINITE : PA_OK;
+}
+
+template <typename T>
+static int jacobi_run_t(pa_ctx* c, T* x, const T* rhs, double tol, int64_t max_it, double omega, pa_report* out) {
+  const DevGeom& G = c->G;
+  for (int q = 0; q < c->nterms; ++q)
+    if (c->terms[q].kind != PA_OP_LAPLACIAN) { pa_set_err(c, "pa_jacobi: laplacian terms only"); return PA_E_ARG; }
+  if (c->slab) { pa_set_err(c, "pa_jacobi is single-GPU only"); return PA_E_ARG; }
+  const size_t fb = (size_t)G.ncell * sizeof(T);
+  const int nblk = pa_grid_blocks(G.ncell);
+  int rc;
+  if ((rc = pa_scratch(c, &c->scr[SCR_D0], &c->cap[SCR_D0], fb))) return rc;
+  if ((rc = pa_scratch(c, &c->scr[SCR_PART], &c->cap[SCR_PART], (size_t)PA_MAX_PARTIALS * 4 * sizeof(double)))) return rc;
+  if ((rc = pa_scratch(c, &c->scr[SCR_PART2], &c->cap[SCR_PART2], (size_t)3 * PA_MAX_GRID * sizeof(double)))) return rc;
+  if ((rc = pa_scratch(c, &c->scr[SCR_SHELL], &c->cap[SCR_SHELL], 2 * (size_t)pa_shell_elems(c) * sizeof(T)))) return rc;
+  if ((rc = init_scalars(c, tol, max_it))) return rc;
+  DevEq<T> E;
+  pa_build_eq<T>(c, c->nterms, c->terms, E);
+  const bool stat = pa_bc_is_static(c);
+  double* part = (double*)c->scr[SCR_PART];
+  double* part2 = (double*)c->scr[SCR_PART2];
+  // BC fill by the cheapest launch sequence, as in CG: closed form / one launch per axis / one per face
+  c->bc_fused = pa_bc_fusable(c);
+  c->bc_pair = (!c->bc_fused && pa_bc_pairable(c)) ? 1 : 0;
+  c->shell_cur = 0;
+  c->fold_a_n = c->fold_b_n = c->fold_b_nsh = 0;
+  if (c->bc_fused) {
+    if ((rc = pa_bc_shell_fused<T>(c, x, nullptr, 0, false, nullptr, false))) return rc;
+  } else if (c->bc_pair) {
+    if ((rc = pa_bc_pair_apply<T>(c, x, nullptr, 2, false, nullptr))) return rc;
+  } else {
+    if ((rc = pa_bc_apply_faces<T>(c, x))) return rc;
+    pa_shell_launch<T>(c, (const T*)x, (T*)c->scr[SCR_SHELL], part2, 0);
+  }
+  T* buf[2] = {x, (T*)c->scr[SCR_D0]};
+  int cur = 0;
+  const int poll = poll_interval(c);
+  PA_HIP(c, hipEventRecord(c->ev0, c->stream));
+  int64_t enq = 0;
+  // the stop test of sweep q is left to the prologue of sweep q+1 (pa_cg3d_kernel.h) when both are
+  // tiled; this runs it as the single-block kernel it replaces (before a poll, before a generic sweep)
+  auto flush = [&]() {
+    if (c->fold_b_n > 0)
+      hipLaunchKernelGGL(k_jacobi_post<T>, dim3(1), dim3(PA_BLOCK), 0, c->stream, c->sc, c->fold_b_part, c->fold_b_n,
+                         (const double*)part2, c->fold_b_nsh, pa_sums(c));
+    c->fold_b_n = c->fold_b_nsh = 0;
+  };
+  PollPipe P;
+  bool done = false;
+  int64_t batch = 2;
+  while (!done) {
+    // the device stops by itself after max_it + 1 sweeps; sweeps are enqueued in pairs
+    int64_t nb = std::min<int64_t>(batch, max_it + 2 - enq);
+    if (nb <= 0) {
+      if ((rc = poll_drain(c, P, &done))) return rc;
+      if (done) break;
+      nb = 2;
+    }
+    // two sweeps per round so that the iterate is back in the caller's buffer at every poll
+    for (int64_t half = 0; half < ((nb + 1) & ~(int64_t)1); ++half) {
+      Vec<T> xv = pa_vec_self<T>(c, buf[cur]);
+      // partial rows alternate between the halves of SCR_PART: the next sweep reads these while it writes its own
+      double* part_q = part + (cur ? 2 * (size_t)PA_MAX_PARTIALS : 0);
+      if (c->profile) (void)hipEventRecord(c->pev[0], c->stream);   // slot 0: the sweep kernel
+      int used = pa_tile3d_jacobi<T>(c, E, xv, rhs, buf[cur ^ 1], omega, part_q);
+      if (used < 0) return used;
+      const bool tiled = used > 0;
+      if (!tiled) {
+        flush();
+        hipLaunchKernelGGL(k_jacobi<T>, dim3(nblk), dim3(PA_BLOCK), 0, c->stream, G, E, c->sc, xv, rhs, buf[cur ^ 1],
+                           (T)omega, part_q);
+        used = nblk;
+      }
+      if (c->profile) pa_profile_stop(c, 0);
+      int nsh = 0;
+      // NOTE: when done is set the sweep kernels return early, so buf[cur^1] is stale: the copy-back
+      // below is guarded by the iteration parity recorded on the device (itr).
+      if (!stat) {
+        if (c->bc_fused) {
+          if ((rc = pa_bc_shell_fused<T>(c, buf[cur ^ 1], part2, 1, true, &nsh, false))) return rc;
+        } else if (c->bc_pair) {
+          if ((rc = pa_bc_pair_apply<T>(c, buf[cur ^ 1], part2, 1, true, &nsh))) return rc;
+        } else {
+          if ((rc = pa_bc_apply_faces<T>(c, buf[cur ^ 1], true))) return rc;
+          nsh = pa_shell_blocks(c);
+          pa_shell_launch<T>(c, (const T*)buf[cur ^ 1], (T*)c->scr[SCR_SHELL], part2, 1);
+        }
+      }
+      if (c->fold && tiled && used <= PA_MAX_GRID && nsh <= 3 * PA_MAX_GRID) {
+        c->fold_b_n = used;
+        c->fold_b_nsh = nsh;
+        c->fold_b_part = part_q;
+      } else {
+        hipLaunchKernelGGL(k_jacobi_post<T>, dim3(1), dim3(PA_BLOCK), 0, c->stream, c->sc, part_q, used, part2, nsh,
+                           pa_sums(c));
+      }
+      cur ^= 1;
+      ++enq;
+    }
+    flush();
+    if ((rc = poll_submit(c, P, &done))) return rc;
+    batch = std::min<int64_t>(2 * poll, std::max<int64_t>(2, enq));
+  }
+  if ((rc = read_scalars(c))) return rc;
+  // the final iterate lives in buf[itr & 1]
+  if (c->h_sc->itr & 1) {
+    hipLaunchKernelGGL(k_copy<T>, dim3(nblk), dim3(PA_BLOCK), 0, c->stream, (const T*)buf[1], x, G.ncell);
+  }
+  PA_HIP(c, hipEventRecord(c->ev1, c->stream));
+  PA_HIP(c, hipEventSynchronize(c->ev1));
+  float ms = 0.f;
+  (void)hipEventElapsedTime(&ms, c->ev0, c->ev1);
+  fill_report(c, out, ms);
+  return c->h_sc->err ? PA_E_NONFINITE : PA_OK;
+}
+
+template <typename T>
+static int bicg_run_t(pa_ctx* c, T* x, const T* rhs, double tol, int64_t max_it, pa_report* out) {
+  const DevGeom& G = c->G;
+  if (c->slab) { pa_set_err(c, "pa_bicgstab is single-GPU only in this build"); return PA_E_ARG; }
+  const size_t fb = (size_t)G.ncell * sizeof(T);
+  const int nblk = pa_grid_blocks(G.ncell);
+  int rc;
+  const int ids[] = {SCR_R, SCR_D0, SCR_D1, SCR_R0, SCR_V0, SCR_V1, SCR_S, SCR_TT};
+  for (int id : ids)
+    if ((rc = pa_scratch(c, &c->scr[id], &c->cap[id], fb))) return rc;
+  if ((rc = pa_scratch(c, &c->scr[SCR_PART], &c->cap[SCR_PART], (size_t)PA_MAX_PARTIALS * 6 * sizeof(double)))) return rc;
+  if ((rc = init_scalars(c, tol, max_it))) return rc;
+  DevEq<T> E;
+  pa_build_eq<T>(c, c->nterms, c->terms, E);
+  if ((rc = pa_bc_apply_faces<T>(c, x))) return rc;
+  T* r = (T*)c->scr[SCR_R];
+  T* r0 = (T*)c->scr[SCR_R0];
+  T* p[2] = {(T*)c->scr[SCR_D0], (T*)c->scr[SCR_D1]};
+  T* v[2] = {(T*)c->scr[SCR_V0], (T*)c->scr[SCR_V1]};
+  T* s = (T*)c->scr[SCR_S];
+  T* t = (T*)c->scr[SCR_TT];
+  double* part = (double*)c->scr[SCR_PART];
+  Vec<T> xv = pa_vec_self<T>(c, x);
+  if ((rc = cg_residual_init<T>(c, E, xv, rhs, r0, r, (T*)nullptr, (T*)nullptr, part))) return rc;
+  PA_HIP(c, hipMemsetAsync(p[0], 0, fb, c->stream));
+  PA_HIP(c, hipMemsetAsync(v[0], 0, fb, c->stream));
+  // rho_next = sum r0.r0 ; tol0 = sqrt(rho_next) ; first beta = rho_next / 1 * 1 / 1 (linalg.py:201-212)
+  hipLaunchKernelGGL(k_cg_post_init<T>, dim3(1), dim3(PA_BLOCK), 0, c->stream, c->sc, part, nblk, pa_sums(c), 2);
+  if ((rc = read_scalars(c))) return rc;
+  {
+    SolverScalars h = *c->h_sc;
+    h.rho_next = h.rr;
+    h.tol = (double)(T)sqrt((T)h.rr);
+    T b = (T)h.rho_next / (T)1.0;
+    b = b * (T)1.0;
+    b = b / (T)1.0;
+    h.beta = (double)b;
+    h.rho = h.rho_next;
+    h.done = 0;  // `while not finished`: at least one iteration
+    *c->h_sc = h;
+    PA_HIP(c, hipMemcpyAsync(c->sc, c->h_sc, sizeof(h), hipMemcpyHostToDevice, c->stream));
+    PA_HIP(c, hipStreamSynchronize(c->stream));
+  }
+  int cur = 0;
+  const int poll = poll_interval(c);
+  PA_HIP(c, hipEventRecord(c->ev0, c->stream));
+  int64_t enq = 0;
+  // The three single-block scalar kernels of an iteration are folded into the prologue of the kernel
+  // that follows each (pa_cg3d_kernel.h phases 5 / 6, k_bicg_x) when that kernel is a tiled one / the
+  // row counts are small; each producer has its own region of SCR_PART, because its consumer reads the
+  // rows while writing its own.  `pend*` = rows waiting for a prologue.
+  double* const reg0 = part;                                   // r0.v'            (1 column)
+  double* const reg1 = part + (size_t)PA_MAX_PARTIALS;         // |s|^2 t.s t.t r0.t (4 columns)
+  double* const reg2 = part + 5 * (size_t)PA_MAX_PARTIALS;     // |r|^2            (1 column)
+  const bool fold = c->fold && !c->slab;
+  int pend3 = 0;
+  c->fold_a_n = c->fold_b_n = c->fold_b_nsh = 0;
+  auto flush3 = [&]() {
+    if (pend3 > 0) hipLaunchKernelGGL(k_bicg_post<T>, dim3(1), dim3(PA_BLOCK), 0, c->stream, c->sc, reg2, pend3, 3);
+    pend3 = 0;
+    c->fold_b_n = 0;
+  };
+  PollPipe P;
+  bool done = false;
+  int64_t batch = 1;
+  const int64_t max_enq = std::max<int64_t>(max_it, 1);  // the device stops by itself after max_it iterations
+  while (!done) {
+    int64_t nb = std::min<int64_t>(batch, max_enq - enq);
+    if (nb <= 0) {
+      if ((rc = poll_drain(c, P, &done))) return rc;
+      if (done) break;
+      nb = 1;
+    }
+   for (int64_t qi = 0; qi < nb; ++qi) {
+    Vec<T> rv = pa_vec_self<T>(c, r), pv = pa_vec_self<T>(c, p[cur]), vv = pa_vec_self<T>(c, v[cur]);
+    c->fold_b_n = pend3;          // phase 5 closes the previous iteration (and swaps the scalar slots)
+    c->fold_b_part = reg2;
+    int used = pa_tile3d_bicg_pv<T>(c, E, rv, pv, vv, (const T*)r0, p[cur ^ 1], v[cur ^ 1], reg0);
+    if (used < 0) return used;
+    if (used > 0) {
+      pend3 = 0;
+    } else {
+      flush3();
+      hipLaunchKernelGGL(k_bicg_pv<T>, dim3(nblk), dim3(PA_BLOCK), 0, c->stream, G, E, c->sc, rv, pv, vv, (const T*)r0,
+                         p[cur ^ 1], v[cur ^ 1], reg0);
+      used = nblk;
+    }
+    int pend0 = (fold && used <= PA_MAX_GRID) ? used : 0;
+    if (!pend0) hipLaunchKernelGGL(k_bicg_post<T>, dim3(1), dim3(PA_BLOCK), 0, c->stream, c->sc, reg0, used, 0);
+    Vec<T> vnv = pa_vec_self<T>(c, v[cur ^ 1]);
+    c->fold_a_n = pend0;          // phase 6 computes alpha itself
+    int used2 = pa_tile3d_bicg_st<T>(c, E, rv, vnv, (const T*)r0, s, t, reg1);
+    c->fold_a_n = 0;
+    if (used2 < 0) return used2;
+    int pend12 = 0;
+    if (used2 > 0) {
+      pend12 = (fold && used2 <= PA_MAX_GRID) ? used2 : 0;
+      if (!pend12) hipLaunchKernelGGL(k_bicg_post<T>, dim3(1), dim3(PA_BLOCK), 0, c->stream, c->sc, reg1, used2, 12);
+    } else {
+      if (pend0) hipLaunchKernelGGL(k_bicg_post<T>, dim3(1), dim3(PA_BLOCK), 0, c->stream, c->sc, reg0, pend0, 0);
+      hipLaunchKernelGGL(k_bicg_s<T>, dim3(nblk), dim3(PA_BLOCK), 0, c->stream, G, c->sc, (const T*)r,
+                         (const T*)v[cur ^ 1], s, reg1);
+      hipLaunchKernelGGL(k_bicg_post<T>, dim3(1), dim3(PA_BLOCK), 0, c->stream, c->sc, reg1, nblk, 1);
+      Vec<T> sv = pa_vec_self<T>(c, s);
+      hipLaunchKernelGGL(k_bicg_t<T>, dim3(nblk), dim3(PA_BLOCK), 0, c->stream, G, E, c->sc, sv, (const T*)r0, t, reg1);
+      hipLaunchKernelGGL(k_bicg_post<T>, dim3(1), dim3(PA_BLOCK), 0, c->stream, c->sc, reg1, nblk, 2);
+    }
+    hipLaunchKernelGGL(k_bicg_x<T>, dim3(nblk), dim3(PA_BLOCK), 0, c->stream, G, c->sc, x, (const T*)p[cur ^ 1],
+                       (const T*)s, (const T*)t, r, reg2, (const double*)reg1, pend12, c->sc);
+    if ((rc = pa_bc_apply_auto<T>(c, x, true))) return rc;
+    if (fold && nblk <= PA_MAX_GRID)
+      pend3 = nblk;
+    else
+      hipLaunchKernelGGL(k_bicg_post<T>, dim3(1), dim3(PA_BLOCK), 0, c->stream, c->sc, reg2, nblk, 3);
+    cur ^= 1;
+    ++enq;
+   }
+    flush3();
+    if ((rc = poll_submit(c, P, &done))) return rc;
+    batch = std::min<int64_t>(poll, std::max<int64_t>(1, enq));
+  }
+  if ((rc = read_scalars(c))) return rc;
+  PA_HIP(c, hipEventRecord(c->ev1, c->stream));
+  PA_HIP(c, hipEventSynchronize(c->ev1));
+  float ms = 0.f;
+  (void)hipEventElapsedTime(&ms, c->ev0, c->ev1);
+  fill_report(c, out, ms);
+  return c->h_sc->err ? PA_E_NONFINITE : PA_OK;
+}
+
+extern "C" {
+
+int pa_cg(pa_ctx* c, void* x, const void* rhs, double tol, int64_t max_it, pa_report* out) {
+  if (!c || !c->grid_set || !c->eq_set) { if (c) pa_set_err(c, "pa_cg: grid/equation not set"); return PA_E_STATE; }
+  if (int rc0 = pa_check_eq_applicable(c)) return rc0;
+  if (!out) return PA_E_ARG;
+  if (c->slab) { pa_set_err(c, "pa_cg is the single-GPU loop; use the stepwise API on a slab"); return PA_E_STATE; }
+  PA_HIP(c, hipSetDevice(c->device));
+  return c->dtype == PA_F64 ? cg_run_t<double>(c, (double*)x, (const double*)rhs, tol, max_it, out)
+                            : cg_run_t<float>(c, (float*)x, (const float*)rhs, tol, max_it, out);
+}
+
+int pa_bicgstab(pa_ctx* c, void* x, const void* rhs, double tol, int64_t max_it, pa_report* out) {
+  if (!c || !c->grid_set || !c->eq_set) { if (c) pa_set_err(c, "pa_bicgstab: grid/equation not set"); return PA_E_STATE; }
+  if (int rc0 = pa_check_eq_applicable(c)) return rc0;
+  if (!out) return PA_E_ARG;
+  PA_HIP(c, hipSetDevice(c->device));
+  return c->dtype == PA_F64 ? bicg_run_t<double>(c, (double*)x, (const double*)rhs, tol, max_it, out)
+                            : bicg_run_t<float>(c, (float*)x, (const float*)rhs, tol, max_it, out);
+}
+
+int pa_jacobi(pa_ctx* c, void* x, const void* rhs, double tol, int64_t max_it, double omega, pa_report* out) {
+  if (!c || !c->grid_set || !c->eq_set) { if (c) pa_set_err(c, "pa_jacobi: grid/equation not set"); return PA_E_STATE; }
+  if (int rc0 = pa_check_eq_applicable(c)) return rc0;
+  if (!out) return PA_E_ARG;
+  PA_HIP(c, hipSetDevice(c->device));
+  return c->dtype == PA_F64 ? jacobi_run_t<double>(c, (double*)x, (const double*)rhs, tol, max_it, omega, out)
+                            : jacobi_run_t<float>(c, (float*)x, (const float*)rhs, tol, max_it, omega, out);
+}
+
+}  // extern "C"
+
+// ============================================================================
+//  stepwise CG (bench.py, slab-decomposed driver)
+// ============================================================================
+extern "C" {
+
+int pa_cg_begin(pa_ctx* c, void* x, const void* rhs, double tol, int64_t max_it) {
+  if (!c || !c->grid_set || !c->eq_set) { if (c) pa_set_err(c, "pa_cg_begin: grid/equation not set"); return PA_E_STATE; }
+  if (int rc0 = pa_check_eq_applicable(c)) return rc0;
+  PA_HIP(c, hipSetDevice(c->device));
+  return c->dtype == PA_F64 ? cg_begin_t<double>(c, (double*)x, (const double*)rhs, tol, max_it)
+                            : cg_begin_t<float>(c, (float*)x, (const float*)rhs, tol, max_it);
+}
+
+int pa_cg_phase_a(pa_ctx* c) {
+  if (!c || !c->solver_live) { if (c) pa_set_err(c, "pa_cg_phase_a without pa_cg_begin"); return PA_E_STATE; }
+  const int st = c->slab ? 0 : 2;
+  return c->dtype == PA_F64 ? pa_cg_phase_a_t<double>(c, st) : pa_cg_phase_a_t<float>(c, st);
+}
+
+int pa_cg_phase_b(pa_ctx* c) {
+  if (!c || !c->solver_live) { if (c) pa_set_err(c, "pa_cg_phase_b without pa_cg_begin"); return PA_E_STATE; }
+  if (c->slab) {  // alpha from the all-reduced sum d.Ad
+    if (c->dtype == PA_F64)
+      hipLaunchKernelGGL(k_cg_post_a<double>, dim3(1), dim3(PA_BLOCK), 0, c->stream, c->sc, (const double*)nullptr, 0, pa_sums(c), 1);
+    else
+      hipLaunchKernelGGL(k_cg_post_a<float>, dim3(1), dim3(PA_BLOCK), 0, c->stream, c->sc, (const double*)nullptr, 0, pa_sums(c), 1);
+  }
+  const int st = c->slab ? 0 : 2;
+  return c->dtype == PA_F64 ? pa_cg_phase_b_t<double>(c, st) : pa_cg_phase_b_t<float>(c, st);
+}
+
+int pa_cg_bc(pa_ctx* c) {
+  if (!c || !c->solver_live) { if (c) pa_set_err(c, "pa_cg_bc without pa_cg_begin"); return PA_E_STATE; }
+  if (!c->slab) return PA_OK;  // done inside phase_b
+  return c->dtype == PA_F64 ? pa_cg_bc_t<double>(c) : pa_cg_bc_t<float>(c);
+}
+
+int pa_cg_finish_iter(pa_ctx* c) {
+  if (!c || !c->solver_live) { if (c) pa_set_err(c, "pa_cg_finish_iter without pa_cg_begin"); return PA_E_STATE; }
+  if (!c->slab) return PA_OK;  // logic already ran inside phase_b
+  if (c->dtype == PA_F64)
+    hipLaunchKernelGGL(k_cg_post_b<double>, dim3(1), dim3(PA_BLOCK), 0, c->stream, c->sc, (const double*)nullptr, 0,
+                       (const double*)nullptr, 0, pa_sums(c), 1);
+  else
+    hipLaunchKernelGGL(k_cg_post_b<float>, dim3(1), dim3(PA_BLOCK), 0, c->stream, c->sc, (const double*)nullptr, 0,
+                       (const double*)nullptr, 0, pa_sums(c), 1);
+  PA_HIP(c, hipGetLastError());
+  return PA_OK;
+}
+
+int pa_cg_iterate(pa_ctx* c, int64_t n) {
+  if (!c || !c->solver_live) { if (c) pa_set_err(c, "pa_cg_iterate without pa_cg_begin"); return PA_E_STATE; }
+  if (c->slab) { pa_set_err(c, "pa_cg_iterate is single-rank; drive the phases on a slab"); return PA_E_STATE; }
+  c->in_iterate = 1;
+  int rc = PA_OK;
+  for (int64_t q = 0; q < n && !rc; ++q) {
+    rc = c->dtype == PA_F64 ? pa_cg_phase_a_t<double>(c, 2) : pa_cg_phase_a_t<float>(c, 2);
+    if (!rc) rc = c->dtype == PA_F64 ? pa_cg_phase_b_t<double>(c, 2) : pa_cg_phase_b_t<float>(c, 2);
+  }
+  c->in_iterate = 0;
+  if (c->dtype == PA_F64) cg_flush_fold<double>(c); else cg_flush_fold<float>(c);  // the last iteration's stop test
+  return rc;
+}
+
+int pa_profile_set(pa_ctx* c, int on) {
+  if (!c) return PA_E_ARG;
+  if (on && !c->pev[0])
+    for (int q = 0; q < 4; ++q) PA_HIP(c, hipEventCreate(&c->pev[q]));
+  c->profile = on ? 1 : 0;
+  c->prof_ms[0] = c->prof_ms[1] = 0.0;
+  c->prof_n[0] = c->prof_n[1] = 0;
+  return PA_OK;
+}
+
+int pa_profile_read(pa_ctx* c, double* ms_a, int64_t* n_a, double* ms_b, int64_t* n_b) {
+  if (!c) return PA_E_ARG;
+  if (ms_a) *ms_a = c->prof_ms[0];
+  if (n_a) *n_a = c->prof_n[0];
+  if (ms_b) *ms_b = c->prof_ms[1];
+  if (n_b) *n_b = c->prof_n[1];
+  return PA_OK;
+}
+
+int pa_report_read(pa_ctx* c, pa_report* out) {
+  if (!c || !out) return PA_E_ARG;
+  int rc = read_scalars(c);
+  if (rc) return rc;
+  fill_report(c, out, 0.f);
+  return PA_OK;
+}
+
+int pa_cg_end(pa_ctx* c, pa_report* out) {
+  if (!c || !c->solver_live) { if (c) pa_set_err(c, "pa_cg_end without pa_cg_begin"); return PA_E_STATE; }
+  int rc = out ? pa_report_read(c, out) : PA_OK;
+  c->solver_live = 0;
+  if (rc) return rc;
+  return (out && out->status) ? PA_E_NONFINITE : PA_OK;
+}
+
+}  // extern "C"
+

@@ -83,18 +83,3 @@ def test_fast_vs_generic_vs_oracle(shape, bc):
     assert ro["itr"] == rf["itr"]
     assert rel_err(xf, xo) <= tol_o, rel_err(xf, xo)
     assert abs(rf["tol"] - ro["tol"]) <= (1e-6 if dtype == "double" else 1e-4) * abs(ro["tol"]) + 1e-12
-
-
-def test_side_stream_overlap_gives_identical_results(monkeypatch):
-    """PYAPES_HIP_OVERLAP=1 runs the BC fill / shell stop-test term of iteration k on a second stream
-    beside phase A of iteration k+1; results must not change by a bit."""
-    n, dtype = (20, 37, 50), "double"
-    g = torch.Generator().manual_seed(1)
-    rhs0 = torch.randn((1, *n), generator=g, dtype=torch.float64)
-    out = {}
-    for ov in ("0", "1"):
-        monkeypatch.setenv("PYAPES_HIP_OVERLAP", ov)
-        x, rep = _solve(n, dtype, BCS["zper"], rhs0, 9, True)
-        out[ov] = (x, rep)
-    assert torch.equal(out["0"][0], out["1"][0])
-    assert out["0"][1] == out["1"][1]

@@ -1,6 +1,5 @@
-"""-m gpu: the folded launch sequence (scalar steps in the prologue of the next tiled kernel, single-pass
-closed-form BC fill; DESIGN.md §4 "small meshes") against the launch sequence it replaces
-(PYAPES_HIP_FOLD=0, PYAPES_HIP_BC_TWO_PASS=1): same bits in the iterate, same iteration count, same
+"""-m gpu: the folded launch sequence (scalar steps in the prologue of the next tiled kernel, DESIGN.md §4 "small meshes") against the launch sequence it replaces
+(PYAPES_HIP_FOLD=0): same bits in the iterate, same iteration count, same
 tolerance -- for CG, Jacobi and BiCGSTAB, dozens of iterations (so that batches, polls and the flush of a
 pending step all happen), random extents / face types / dtypes, and a stop inside a batch."""
 import os
@@ -25,10 +24,6 @@ def _faces():
 
 def _solve(monkeypatch, folded, n, bcs, dtype, method, rhs, x0, tol, max_it, adv):
     monkeypatch.setenv("PYAPES_HIP_FOLD", "1" if folded else "0")
-    if folded:
-        monkeypatch.delenv("PYAPES_HIP_BC_TWO_PASS", raising=False)
-    else:
-        monkeypatch.setenv("PYAPES_HIP_BC_TWO_PASS", "1")
     nd = len(n)
     mesh = Mesh(Box([0.0] * nd, [1.0 + 0.1 * a for a in range(nd)]), None, list(n), "cuda", dtype)
     cfg = [{"bc_face": _faces()[i], "bc_type": t, "bc_val": v, "bc_val_opt": None} for i, (t, v) in enumerate(bcs)]
