@@ -249,7 +249,24 @@ int pa_report_read(pa_ctx* ctx, pa_report* out);  /* synchronises */
  *   pa_comm_plan        neighbours (-1 = none) and the packed send / receive buffers of one
  *                       iteration, counts in elements of the grid dtype; lower neighbour first
  *   pa_cg_iterate_comm  n x { phase_a, all-reduce sums[0], phase_b, exchange, bc,
- *                             all-reduce sums[1..2], finish_iter } */
+ *                             all-reduce sums[1..2], finish_iter }   (stepwise sequence)
+ *
+ * Folded iterations.  Per iteration the stepwise sequence costs six single-block / per-plane launches
+ * beside the two phases (ghost-direction recurrence, two reductions of per-workgroup partial rows, alpha,
+ * plane packing, beta + stop test).  When every rank runs the tiled kernels, the ranks agree on row
+ * counts (pa_cg_fold_plan on each rank after pa_cg_begin, MAX over the ranks by the host driver,
+ * pa_cg_fold_set) and pa_cg_iterate_comm then all-reduces the partial ROWS (a few KB, the same
+ * latency-bound collective) and lets the prologues of the kernels that follow sum them:
+ *   phase_a (closes the previous iteration in its prologue) -> all-reduce d.Ad rows -> mid kernel
+ *   (alpha; ghost planes of the new direction; the residual / x planes the neighbours need, computed
+ *   ahead of phase B) -> packed exchange on a second communicator + stream, beside: phase_b -> BC fill
+ *   -> all-reduce (r.r, |dx|^2, shell) rows.
+ * Same arithmetic per node; the sums differ from the stepwise sequence only in the order ranks and rows
+ * are added (identical for one rank).  rows[3] = { phase A, phase B, BC shell }; all zero = not applicable
+ * on this rank (then every rank must stay stepwise: pa_cg_fold_set with zeros or not at all). */
+int pa_cg_fold_plan(pa_ctx* ctx, int64_t* rows3);
+int pa_cg_fold_set(pa_ctx* ctx, const int64_t* rows3);
+
 typedef struct {
   int nb_lo, nb_hi;
   const void* send_lo; const void* send_hi;

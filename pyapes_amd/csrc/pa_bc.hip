@@ -781,6 +781,24 @@ int pa_bc_pair_apply(pa_ctx* c, T* x, double* part2, int mode, bool guarded, int
 }
 
 
+// partial rows the BC fill + boundary-shell pass of one solver iteration writes, by the path pa_cg_begin chose
+int pa_bc_shell_rows(const pa_ctx* c) {
+  if (c->bc_fused || !c->bc_pair) return pa_shell_blocks(c);
+  const DevGeom& G = c->G;
+  const int64_t sz[3] = {G.n1 * G.n2, G.n0 * G.n2, G.n0 * G.n1};
+  int rows = 0;
+  for (int a = 0; a < 3; ++a) {
+    if (!G.act[a]) continue;
+    int lo = c->bc[2 * a].type, hi = c->bc[2 * a + 1].type;
+    if (a == 0) {  // slab: only the rank holding the global boundary plane applies the face
+      if (G.off0 != 0) lo = 0;
+      if (G.off0 + G.n0 != G.g0) hi = 0;
+    }
+    if (lo || hi) rows += pa_grid_blocks(sz[a]);
+  }
+  return rows;
+}
+
 // boundary-shell pass on its own (after a face-by-face fill): save the shell, with_delta: + partial sums of
 // (new - old)^2 -> part2 (pa_shell_blocks rows)
 template <typename T>

@@ -14,7 +14,7 @@ int pa_cg3d_phase_a(pa_ctx* c, const DevEq<T>& E, Vec<T> r, Vec<T> d, T* dnew, d
   if (c->fold_b_n > 0) {  // close the previous iteration in this kernel's prologue (next state -> the other slot)
     A.pre_part = c->fold_b_part;
     A.pre_n = c->fold_b_n;
-    A.pre_shell = (const double*)c->scr[SCR_PART2];
+    A.pre_shell = c->fold_b_shell ? c->fold_b_shell : (const double*)c->scr[SCR_PART2];
     A.pre_nsh = c->fold_b_nsh;
     A.sc_w = c->sc_alt;
     A.pre_sums = pa_sums(c);
@@ -24,6 +24,7 @@ int pa_cg3d_phase_a(pa_ctx* c, const DevEq<T>& E, Vec<T> r, Vec<T> d, T* dnew, d
   if (n > 0 && c->fold_b_n > 0) {
     SolverScalars* t = c->sc; c->sc = c->sc_alt; c->sc_alt = t;
     c->fold_b_n = c->fold_b_nsh = 0;
+    c->fold_b_shell = nullptr;
   }
   return n;
 }
@@ -36,7 +37,9 @@ int pa_cg3d_phase_b(pa_ctx* c, const DevEq<T>& E, Vec<T> d, T* x, T* r, double* 
   memset(&A, 0, sizeof(A));
   fill_common<T>(c, E, A);
   A.d = d; A.x = x; A.rw = r; A.partials = partials;
-  A.send_lo = (T*)c->r_send_lo; A.send_hi = (T*)c->r_send_hi;
+  if (!c->slab_fold_live) {   // folded slab iterations: the mid kernel has produced the send planes already
+    A.send_lo = (T*)c->r_send_lo; A.send_hi = (T*)c->r_send_hi;
+  }
   A.reverse = 1;
   if (c->fold_a_n > 0) {  // alpha of this iteration in this kernel's prologue
     A.pre_part = (const double*)c->scr[SCR_PART] + 2 * (size_t)PA_MAX_PARTIALS;
@@ -82,7 +85,7 @@ int pa_tile3d_jacobi(pa_ctx* c, const DevEq<T>& E, Vec<T> x, const T* rhs, T* xn
   if (c->fold_b_n > 0) {  // stop test + iteration count of the previous sweep in this kernel's prologue
     A.pre_part = c->fold_b_part;
     A.pre_n = c->fold_b_n;
-    A.pre_shell = (const double*)c->scr[SCR_PART2];
+    A.pre_shell = c->fold_b_shell ? c->fold_b_shell : (const double*)c->scr[SCR_PART2];
     A.pre_nsh = c->fold_b_nsh;
     A.sc_w = c->sc_alt;
     A.pre_sums = pa_sums(c);
@@ -92,6 +95,7 @@ int pa_tile3d_jacobi(pa_ctx* c, const DevEq<T>& E, Vec<T> x, const T* rhs, T* xn
   if (n > 0 && c->fold_b_n > 0) {
     SolverScalars* t = c->sc; c->sc = c->sc_alt; c->sc_alt = t;
     c->fold_b_n = c->fold_b_nsh = 0;
+    c->fold_b_shell = nullptr;
   }
   return n;
 }

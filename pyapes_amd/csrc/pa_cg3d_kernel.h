@@ -306,20 +306,26 @@ __global__ void __launch_bounds__(256) k_cg3d(Cg3dArgs<T> A) {
       for (int w = 0; w < 4; ++w) { rr += pre_sm[3 * w]; dx2 += pre_sm[3 * w + 1]; sh += pre_sm[3 * w + 2]; }
       // pa_logic_b on registers: a local SolverScalars puts the kernel on scratch memory, and a kernel
       // with a private segment costs ~10 us more to dispatch (measured)
+      // pre_nsh < 0 (folded slab iterations with the BC fill on its own stream): the stop test of the
+      // previous iteration waits for the boundary-shell rows and is evaluated by the mid kernel; here only
+      // beta and the iteration count (the reference updates d before it looks at tol again, linalg.py:141)
+      const bool defer = A.pre_nsh < 0;
       const T rr_new = (T)rr;
       const T tolv = (T)sqrt(dx2 + sh);
-      const bool bad = isnan(tolv) || isinf(tolv);   // linalg.py:334-336 raises before beta / itr
+      const bool bad = !defer && (isnan(tolv) || isinf(tolv));   // linalg.py:334-336 raises before beta / itr
       const T rr_old = (T)rr_in;
       const double bq = bad ? beta_in : (double)(rr_new / rr_old);
       const long long itr = itr_in + (bad ? 0 : 1);
-      const int done = (bad || itr > max_it || !((double)tolv > tol_lim)) ? 1 : 0;
+      const int done = (!defer && (bad || itr > max_it || !((double)tolv > tol_lim))) ? 1 : 0;
       pre_sm[12] = bq;
       pre_sm[13] = done ? 1.0 : 0.0;
       if (blockIdx.x == 0) {
         SolverScalars* so = A.sc_w;
         *so = *si;
-        so->tol = (double)tolv;
-        so->done = done;
+        if (!defer) {
+          so->tol = (double)tolv;
+          so->done = done;
+        }
         if (bad) {
           so->err = 1;
         } else {
@@ -331,7 +337,7 @@ __global__ void __launch_bounds__(256) k_cg3d(Cg3dArgs<T> A) {
           so->itr = itr;
         }
         if (PHASE == 0) A.pre_sums[1] = rr;
-        A.pre_sums[2] = dx2 + sh;
+        if (!defer) A.pre_sums[2] = dx2 + sh;
       }
     }
     __syncthreads();
@@ -1011,6 +1017,7 @@ static int launch_cg3d(pa_ctx* c, Cg3dArgs<T>& A) {
             (char)('A' + PHASE), NARROW ? " (narrow)" : "", A.tiles_j, A.tiles_k, chunks, (long long)(G.n0 / chunks), nblk,
             blocks_per_cu<T, RJ, PHASE, CF, KIND, NARROW>(), cus_of(c));
   }
+  if (c->plan_only) return nblk;   // pa_cg_fold_plan: the grid this launch would use
   hipLaunchKernelGGL((k_cg3d<T, RJ, PHASE, CF, KIND, NARROW>), dim3(nblk), dim3(256), 0, c->stream, A);
   return nblk;
 }

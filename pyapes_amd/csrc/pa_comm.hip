@@ -25,6 +25,7 @@ struct Rccl {
   ncclResult_t (*CommAbort)(ncclComm_t) = nullptr;
   ncclResult_t (*CommCount)(const ncclComm_t, int*) = nullptr;
   ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*Broadcast)(const void*, void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
   ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
   ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
   ncclResult_t (*GroupStart)() = nullptr;
@@ -51,7 +52,7 @@ Rccl* rccl() {
   if (!h) return nullptr;
   bool ok = sym(h, "ncclGetUniqueId", R.GetUniqueId) && sym(h, "ncclCommInitRank", R.CommInitRank) &&
             sym(h, "ncclCommDestroy", R.CommDestroy) && sym(h, "ncclCommAbort", R.CommAbort) && sym(h, "ncclCommCount", R.CommCount) &&
-            sym(h, "ncclAllReduce", R.AllReduce) && sym(h, "ncclSend", R.Send) && sym(h, "ncclRecv", R.Recv) &&
+            sym(h, "ncclAllReduce", R.AllReduce) && sym(h, "ncclBroadcast", R.Broadcast) && sym(h, "ncclSend", R.Send) && sym(h, "ncclRecv", R.Recv) &&
             sym(h, "ncclGroupStart", R.GroupStart) && sym(h, "ncclGroupEnd", R.GroupEnd) &&
             sym(h, "ncclGetErrorString", R.GetErrorString);
   if (!ok) return nullptr;
@@ -82,18 +83,17 @@ bool stream_done_within(hipStream_t s, double timeout_s) {
   }
 }
 
-int exchange(pa_ctx* c, Rccl* R) {
+int exchange(pa_ctx* c, Rccl* R, ncclComm_t comm, hipStream_t st) {
   const pa_exchange& P = c->plan;
   const ncclDataType_t dt = c->dtype == PA_F64 ? ncclDouble : ncclFloat;
-  ncclComm_t comm = (ncclComm_t)c->comm;
   if (P.nb_lo < 0 && P.nb_hi < 0) return PA_OK;
   // order: sends [down, up], receives [from above, from below] -- with P = 2 on a periodic ring both
   // neighbours are the same peer and same-peer operations pair up in program order
   PA_NCCL(c, R, R->GroupStart());
-  if (P.nb_lo >= 0 && P.n_send_lo > 0) PA_NCCL(c, R, R->Send(P.send_lo, (size_t)P.n_send_lo, dt, P.nb_lo, comm, c->stream));
-  if (P.nb_hi >= 0 && P.n_send_hi > 0) PA_NCCL(c, R, R->Send(P.send_hi, (size_t)P.n_send_hi, dt, P.nb_hi, comm, c->stream));
-  if (P.nb_hi >= 0 && P.n_recv_hi > 0) PA_NCCL(c, R, R->Recv(P.recv_hi, (size_t)P.n_recv_hi, dt, P.nb_hi, comm, c->stream));
-  if (P.nb_lo >= 0 && P.n_recv_lo > 0) PA_NCCL(c, R, R->Recv(P.recv_lo, (size_t)P.n_recv_lo, dt, P.nb_lo, comm, c->stream));
+  if (P.nb_lo >= 0 && P.n_send_lo > 0) PA_NCCL(c, R, R->Send(P.send_lo, (size_t)P.n_send_lo, dt, P.nb_lo, comm, st));
+  if (P.nb_hi >= 0 && P.n_send_hi > 0) PA_NCCL(c, R, R->Send(P.send_hi, (size_t)P.n_send_hi, dt, P.nb_hi, comm, st));
+  if (P.nb_hi >= 0 && P.n_recv_hi > 0) PA_NCCL(c, R, R->Recv(P.recv_hi, (size_t)P.n_recv_hi, dt, P.nb_hi, comm, st));
+  if (P.nb_lo >= 0 && P.n_recv_lo > 0) PA_NCCL(c, R, R->Recv(P.recv_lo, (size_t)P.n_recv_lo, dt, P.nb_lo, comm, st));
   PA_NCCL(c, R, R->GroupEnd());
   return PA_OK;
 }
@@ -137,6 +137,49 @@ int pa_comm_init(pa_ctx* c, int rank, int nranks, const void* id128) {
   c->comm_rank = rank;
   c->comm_n = nranks;
   c->plan_set = 0;
+  // Second communicator on its own stream for the plane exchange (PYAPES_HIP_COMM_OVERLAP=0: none).  Its id
+  // travels through the first one; every step that can fail on one rank alone is followed by an agreement
+  // (MIN all-reduce of an ok flag on the first communicator) before any rank depends on the result.
+  // Default: only when there is a peer.  A 1-rank communicator "exchanges" with itself through HBM, and a
+  // copy kernel beside phase B is starved by it (measured: 14.5 us alone, 114 us beside phase B on a
+  // 64 x 512^2 slab): there is no link latency to hide.  PYAPES_HIP_COMM_OVERLAP=1 / 0 forces either.
+  const char* ov = getenv("PYAPES_HIP_COMM_OVERLAP");
+  int want = ov ? (atoi(ov) != 0) : (nranks > 1);
+  struct Box { ncclUniqueId id; int ok; int pad[3]; };
+  Box h;
+  memset(&h, 0, sizeof(h));
+  Box* dev = nullptr;
+  if (hipMalloc((void**)&dev, sizeof(Box)) != hipSuccess) { (void)hipGetLastError(); return PA_OK; }
+  if (rank == 0) {
+    h.ok = (want && R->GetUniqueId(&h.id) == ncclSuccess) ? 1 : 0;
+    (void)hipMemcpyAsync(dev, &h, sizeof(Box), hipMemcpyHostToDevice, c->stream);
+  }
+  ncclResult_t e = R->Broadcast(dev, dev, sizeof(Box), ncclChar, 0, comm, c->stream);
+  if (e == ncclSuccess && hipMemcpyAsync(&h, dev, sizeof(Box), hipMemcpyDeviceToHost, c->stream) == hipSuccess &&
+      hipStreamSynchronize(c->stream) == hipSuccess && h.ok) {
+    ncclComm_t comm2 = nullptr;
+    int prio_lo = 0, prio_hi = 0;   // highest priority: its own hardware queue, and its few workgroups first
+    (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
+    int ok = want && R->CommInitRank(&comm2, nranks, h.id, rank) == ncclSuccess &&
+             hipStreamCreateWithPriority(&c->xstream, hipStreamNonBlocking, prio_hi) == hipSuccess &&
+             hipEventCreateWithFlags(&c->ev_b, hipEventDisableTiming) == hipSuccess &&
+             hipEventCreateWithFlags(&c->ev_x, hipEventDisableTiming) == hipSuccess;
+    h.ok = ok;
+    (void)hipMemcpyAsync(&dev->ok, &h.ok, sizeof(int), hipMemcpyHostToDevice, c->stream);
+    e = R->AllReduce(&dev->ok, &dev->ok, 1, ncclInt, ncclMin, comm, c->stream);
+    int all = 0;
+    if (e == ncclSuccess && hipMemcpyAsync(&all, &dev->ok, sizeof(int), hipMemcpyDeviceToHost, c->stream) == hipSuccess &&
+        hipStreamSynchronize(c->stream) == hipSuccess && all) {
+      c->comm2 = comm2;
+    } else {
+      if (comm2) (void)R->CommDestroy(comm2);
+      if (c->xstream) { (void)hipStreamDestroy(c->xstream); c->xstream = nullptr; }
+      if (c->ev_b) { (void)hipEventDestroy(c->ev_b); c->ev_b = nullptr; }
+      if (c->ev_x) { (void)hipEventDestroy(c->ev_x); c->ev_x = nullptr; }
+    }
+  }
+  (void)hipGetLastError();
+  (void)hipFree(dev);
   return PA_OK;
 }
 
@@ -145,8 +188,14 @@ int pa_comm_destroy(pa_ctx* c) {
   Rccl* R = rccl();
   if (c->comm && R) {
     (void)hipStreamSynchronize(c->stream);
+    if (c->xstream) (void)hipStreamSynchronize(c->xstream);
+    if (c->comm2) (void)R->CommDestroy((ncclComm_t)c->comm2);
     (void)R->CommDestroy((ncclComm_t)c->comm);
   }
+  if (c->xstream) { (void)hipStreamDestroy(c->xstream); c->xstream = nullptr; }
+  if (c->ev_b) { (void)hipEventDestroy(c->ev_b); c->ev_b = nullptr; }
+  if (c->ev_x) { (void)hipEventDestroy(c->ev_x); c->ev_x = nullptr; }
+  c->comm2 = nullptr;
   c->comm = nullptr;
   c->plan_set = 0;
   return PA_OK;
@@ -170,8 +219,20 @@ int pa_comm_selftest(pa_ctx* c, double timeout_s) {
   if (e == ncclSuccess) e = R->Send(dev + 2, 1, ncclDouble, (rk + 1) % n, comm, c->stream);
   if (e == ncclSuccess) e = R->Recv(dev + 3, 1, ncclDouble, (rk + n - 1) % n, comm, c->stream);
   if (e == ncclSuccess) e = R->GroupEnd();
+  if (e == ncclSuccess && c->comm2) {   // the exchange communicator: same ring on its own stream, joined below
+    ncclComm_t c2 = (ncclComm_t)c->comm2;
+    (void)hipEventRecord(c->ev_b, c->stream);
+    (void)hipStreamWaitEvent(c->xstream, c->ev_b, 0);
+    e = R->GroupStart();
+    if (e == ncclSuccess) e = R->Send(dev + 2, 1, ncclDouble, (rk + 1) % n, c2, c->xstream);
+    if (e == ncclSuccess) e = R->Recv(dev + 3, 1, ncclDouble, (rk + n - 1) % n, c2, c->xstream);
+    if (e == ncclSuccess) e = R->GroupEnd();
+    (void)hipEventRecord(c->ev_x, c->xstream);
+    (void)hipStreamWaitEvent(c->stream, c->ev_x, 0);
+  }
   if (e != ncclSuccess) { (void)hipFree(dev); return nccl_fail(c, R, e, "selftest enqueue"); }
   if (!stream_done_within(c->stream, timeout_s)) {
+    if (c->comm2) { (void)R->CommAbort((ncclComm_t)c->comm2); c->comm2 = nullptr; }
     (void)R->CommAbort(comm);
     c->comm = nullptr;
     (void)hipStreamSynchronize(c->stream);
@@ -213,16 +274,91 @@ int pa_cg_iterate_comm(pa_ctx* c, int64_t n) {
   ncclComm_t comm = (ncclComm_t)c->comm;
   double* sums = c->ext_sums;
   int rc;
-  for (int64_t q = 0; q < n; ++q) {
-    if ((rc = pa_cg_phase_a(c))) return rc;
-    PA_NCCL(c, R, R->AllReduce(sums + PA_SUM_DAD, sums + PA_SUM_DAD, 1, ncclDouble, ncclSum, comm, c->stream));
-    if ((rc = pa_cg_phase_b(c))) return rc;
-    if ((rc = exchange(c, R))) return rc;
-    if ((rc = pa_cg_bc(c))) return rc;
-    PA_NCCL(c, R, R->AllReduce(sums + PA_SUM_RR, sums + PA_SUM_RR, 2, ncclDouble, ncclSum, comm, c->stream));
-    if ((rc = pa_cg_finish_iter(c))) return rc;
+  if (!c->slab_fold || c->profile) {
+    // stepwise sequence (also the per-kernel timing loop of pa_profile_set): sums are all-reduced, every
+    // scalar step is its own single-block kernel
+    for (int64_t q = 0; q < n; ++q) {
+      if ((rc = pa_cg_phase_a(c))) return rc;
+      PA_NCCL(c, R, R->AllReduce(sums + PA_SUM_DAD, sums + PA_SUM_DAD, 1, ncclDouble, ncclSum, comm, c->stream));
+      if ((rc = pa_cg_phase_b(c))) return rc;
+      if ((rc = exchange(c, R, comm, c->stream))) return rc;
+      if ((rc = pa_cg_bc(c))) return rc;
+      PA_NCCL(c, R, R->AllReduce(sums + PA_SUM_RR, sums + PA_SUM_RR, 2, ncclDouble, ncclSum, comm, c->stream));
+      if ((rc = pa_cg_finish_iter(c))) return rc;
+    }
+    return PA_OK;
   }
-  return PA_OK;
+  // folded sequence (include/pyapes_hip.h "Folded iterations"): 2 tiled kernels + the mid kernel + 2 row
+  // all-reduces on the ctx stream; beside them the packed exchange on its own communicator + stream and the
+  // BC fill of iteration k on a third stream under the second all-reduce and phase A of iteration k + 1.
+  // Rows: [ A | S | B ]; the first all-reduce carries A (+ S of the previous iteration when its stop test is
+  // deferred to the mid kernel), the second B (+ S when it is not).
+  const size_t mA = (size_t)c->fold_rows[0], mS = (size_t)c->fold_rows[2], mB = 2 * (size_t)c->fold_rows[1];
+  const bool side = c->comm2 && c->xstream;
+  const bool defer = c->bc_defer != 0;
+  // does THIS rank's BC fill read planes that arrive with the exchange (end ranks of a periodic ring)?
+  const bool bc_needs_x = c->bc_far_lo0 || c->bc_far_lo1 || c->bc_far_hi0;
+  const bool any_nb = c->plan.nb_lo >= 0 || c->plan.nb_hi >= 0;
+#define PA_RT(call) if ((call) != hipSuccess) { rc = PA_E_HIP; break; }
+#define PA_NC(call) if ((call) != ncclSuccess) { rc = PA_E_HIP; break; }
+  c->slab_fold_live = 1;
+  rc = PA_OK;
+  for (int64_t q = 0; q < n && !rc; ++q) {
+    if ((rc = pa_cg_phase_a(c))) break;
+    if (c->bc_pending) {   // the BC fill of the previous iteration: its shell rows go out with this all-reduce
+      PA_RT(hipStreamWaitEvent(c->stream, c->ev_bcd, 0));
+      c->bc_pending = 0;
+    }
+    PA_NC(R->AllReduce(c->rows_send, c->rows_recv, c->tol_pending ? mA + mS : mA, ncclDouble, ncclSum, comm, c->stream));
+    if ((rc = pa_cg_slab_mid(c))) break;
+    bool x_pending = false;
+    if (any_nb) {
+      if (side) {
+        PA_RT(hipEventRecord(c->ev_b, c->stream));
+        PA_RT(hipStreamWaitEvent(c->xstream, c->ev_b, 0));
+        if ((rc = exchange(c, R, (ncclComm_t)c->comm2, c->xstream))) break;
+        PA_RT(hipEventRecord(c->ev_x, c->xstream));
+        x_pending = true;
+      } else if ((rc = exchange(c, R, comm, c->stream))) {
+        break;
+      }
+    }
+    if ((rc = pa_cg_phase_b(c))) break;
+    if (defer) {
+      PA_RT(hipEventRecord(c->ev_pb, c->stream));
+      PA_RT(hipStreamWaitEvent(c->bstream, c->ev_pb, 0));
+      if (x_pending && bc_needs_x) PA_RT(hipStreamWaitEvent(c->bstream, c->ev_x, 0));
+      if ((rc = pa_cg_bc_on(c, c->bstream))) break;
+      PA_RT(hipEventRecord(c->ev_bcd, c->bstream));
+      c->bc_pending = 1;
+      PA_NC(R->AllReduce(c->rows_send + mA + mS, c->rows_recv + mA + mS, mB, ncclDouble, ncclSum, comm, c->stream));
+    } else {
+      if (x_pending && bc_needs_x) {
+        PA_RT(hipStreamWaitEvent(c->stream, c->ev_x, 0));
+        x_pending = false;
+      }
+      if ((rc = pa_cg_bc(c))) break;
+      PA_NC(R->AllReduce(c->rows_send + mA, c->rows_recv + mA, mS + mB, ncclDouble, ncclSum, comm, c->stream));
+    }
+    if (x_pending) PA_RT(hipStreamWaitEvent(c->stream, c->ev_x, 0));
+  }
+  // the batch's last scalar step (beta, stop test, iteration count) by the single-block kernel the prologues
+  // would have replaced: pa_report_read / pa_cg_end see the state of n whole iterations
+  while (!rc) {
+    if (c->bc_pending) {
+      PA_RT(hipStreamWaitEvent(c->stream, c->ev_bcd, 0));
+      c->bc_pending = 0;
+    }
+    if (c->tol_pending && mS > 0)
+      PA_NC(R->AllReduce(c->rows_send + mA, c->rows_recv + mA, mS, ncclDouble, ncclSum, comm, c->stream));
+    rc = pa_cg_slab_flush(c);
+    break;
+  }
+#undef PA_RT
+#undef PA_NC
+  c->slab_fold_live = 0;
+  if (rc == PA_E_HIP && !c->err[0]) pa_set_err(c, "pa_cg_iterate_comm: HIP / RCCL call failed in the folded sequence");
+  return rc;
 }
 
 }  // extern "C"

@@ -59,6 +59,28 @@ struct pa_ctx {
   int fold_a_n = 0;                 // rows of d.Ad partials waiting for phase B's prologue
   int fold_b_n = 0, fold_b_nsh = 0; // rows of phase-B (Jacobi: sweep) / shell partials waiting for the next phase A (sweep)
   const double* fold_b_part = nullptr;
+  const double* fold_b_shell = nullptr;  // shell rows of that step (null: SCR_PART2)
+  // slab iterations with the scalar steps folded (pa_cg_iterate_comm): the per-workgroup partial ROWS are
+  // all-reduced instead of their sums -- out of place, rows_send -> rows_recv, so that rows a rank never
+  // writes (its grid is smaller than the agreed row count) stay zero -- and the unchanged prologues of the
+  // mid kernel / the next phase A sum the all-reduced rows in their fixed order.  Layout of both buffers:
+  // [ M_A rows of d.Ad | M_S boundary-shell rows | M_B rows of (r.r, |dx|^2) ], counts = max over ranks.
+  int slab_fold = 0;        // row counts agreed (pa_cg_fold_set) for the live solve
+  int slab_fold_live = 0;   // inside the folded sequence of pa_cg_iterate_comm
+  int fold_rows[3] = {0, 0, 0};
+  double* rows_send = nullptr;     // = rows_buf[0]
+  double* rows_recv = nullptr;     // = rows_buf[1], or rows_buf[0] when this rank reduces in place
+  double* rows_buf[2] = {nullptr, nullptr};
+  size_t rows_cap = 0;
+  int plan_only = 0;        // launch_cg3d returns its grid size without launching (pa_cg_fold_plan)
+  // BC fill + boundary-shell pass of iteration k on their own stream beside the second all-reduce and
+  // phase A of iteration k+1 (phase A touches r and d only); the stop test of iteration k moves into the
+  // mid kernel of iteration k+1, which gets the shell rows with the first all-reduce
+  int bc_defer = 0;
+  hipStream_t bstream = nullptr;
+  hipEvent_t ev_pb = nullptr, ev_bcd = nullptr;
+  int bc_pending = 0;       // ev_bcd recorded, the ctx stream has not waited for it yet
+  int tol_pending = 0;      // the stop test of the last iteration is still to be evaluated
   SolverScalars* h_sc = nullptr;  // pinned host mirror
   // pipelined polls of the done flag: the copy of batch b's scalars is waited for after batch b+1 has
   // been enqueued, so the GPU never idles between batches (the over-enqueued batch is no-ops)
@@ -97,6 +119,11 @@ struct pa_ctx {
   int fastpath = 1;
   // RCCL communicator owned by the library (pa_comm_*): slab iterations without host work
   void* comm = nullptr;          // ncclComm_t
+  // second communicator + stream: the packed plane exchange of an iteration flies beside phase B, the BC
+  // fill and the second all-reduce instead of between them (null: exchange on the ctx stream)
+  void* comm2 = nullptr;
+  hipStream_t xstream = nullptr;
+  hipEvent_t ev_b = nullptr, ev_x = nullptr;
   int comm_rank = 0, comm_n = 0;
   pa_exchange plan;
   int plan_set = 0;
@@ -115,6 +142,10 @@ int pa_scratch(pa_ctx* c, void** slot, size_t* cap, size_t bytes);
 void pa_refresh_geom(pa_ctx* c);
 int pa_bc_apply_any(pa_ctx* c, void* x);
 int pa_check_eq_applicable(pa_ctx* c);   // pa_ops.hip: Grad inside a solver equation is 1-D only
+int pa_cg_slab_mid(pa_ctx* c);                // pa_solver.hip: the step between the phases of a folded slab iteration
+int pa_cg_bc_on(pa_ctx* c, hipStream_t st);   // pa_cg_bc with its launches on stream st
+int pa_cg_slab_flush(pa_ctx* c);              // close the last iteration of a folded batch (single-block kernel)
+int pa_bc_shell_rows(const pa_ctx* c);        // pa_bc.hip: partial rows the BC fill + shell pass of an iteration writes
 void pa_profile_stop(pa_ctx* c, int which);   // pa_solver.hip: close the HIP-event bracket of dominant kernel `which`
 
 // ---- BC fill (pa_bc.hip) ---------------------------------------------------------------------------

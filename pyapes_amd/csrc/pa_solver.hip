@@ -315,6 +315,166 @@ __global__ void __launch_bounds__(PA_BLOCK) k_pack_planes(const SolverScalars* _
   }
 }
 
+// ---- slab, folded iteration: everything between phase A and phase B in ONE launch ------------------
+// (i) alpha = r.r / d'.Ad' from the all-reduced d'.Ad' ROWS: every block sums them in the fixed order of
+// k_cg_post_a / the phase-B prologue (same bits in every block, block 0 stores the state); (ii) the ghost
+// planes of the new direction, d'_g = r_g + beta d_g (k_ghost_dir's recurrence); (iii) the planes the
+// neighbours need from this iteration, computed AHEAD of phase B from the same operands in the same order
+// (pa_apply_terms' Laplacian branch + k_cg_b's update, which the tiled phase B reproduces bit for bit): the
+// new residual on the first / last owned plane and, on the end ranks of a periodic ring, the new x planes
+// the other end's BC fill reads.  The packed exchange can therefore start before phase B and fly beside it.
+// Folded iterations exist only where the tiled kernels run, i.e. for ONE Laplacian term on an xyz mesh, so
+// the stencil is written out with all seven operands loaded up front (one memory round trip per node; the
+// generic per-axis evaluation is a chain of three) -- a 512^2 plane pair: 29 us generic, ~10 us like this.
+template <typename T>
+struct MidArgs {
+  const T* d;            // d' of this iteration
+  const T* r;            // residual before phase B
+  const T* x;            // iterate before phase B
+  const T *r_lo, *r_hi;  // ghost planes of r (null: physical end)
+  const T *d_lo, *d_hi;  // ghost planes of the PREVIOUS direction
+  T *g_lo, *g_hi;        // out: ghost planes of d'
+  T *send_lo, *send_hi;  // out: new residual on plane 0 / n0-1
+  T *xp_lo1, *xp_hi0, *xp_hi1;  // out (periodic ring ends): new x on plane 1 / n0-1 / n0-2, or null
+  // deferred stop test of the PREVIOUS iteration (BC fill on its own stream): all-reduced (r.r, |dx|^2) rows
+  // and boundary-shell rows; n_dx2 = 0: nothing pending
+  const double* rows_b;
+  const double* rows_s;
+  int n_dx2, n_sh;
+  LapCoef<T> lap;
+  T coeff, sign;
+  int has_coeff;
+  const T* coeff_f;
+};
+
+// one axis of the Laplacian row at global index g: ((cP x+ + cC x) + cM x-), fdc.py:190-198 / pa_apply_terms
+template <typename T>
+__device__ __forceinline__ T pa_lap_axis(const DevGeom& G, const LapCoef<T>& L, int a, int64_t g, int64_t N, T xp, T xc,
+                                         T xm) {
+  T cP = L.inv[a], cC = L.m2inv[a], cM = L.inv[a];
+  const T cB = L.c23[a];
+  const int rc = pa_row_case(G, a, g, N, G.treat);
+  if (rc == 1) { cP = cB; cC = -cB; cM = (T)0; }
+  if (rc == 2) { cP = (T)0; cC = -cB; cM = cB; }
+  T s = cP * xp;
+  T m = cC * xc;
+  s = s + m;
+  m = cM * xm;
+  s = s + m;
+  return s;
+}
+
+template <typename T>
+__global__ void __launch_bounds__(PA_BLOCK) k_slab_mid(DevGeom G, SolverScalars* sc, const double* __restrict__ rows,
+                                                        int nrows, double* __restrict__ sums, MidArgs<T> M) {
+  __shared__ double sm[16];
+  const int done_in = sc->done;
+  const double rr_in = sc->rr, tol_lim = sc->tolerance;
+  const long long itr_in = sc->itr, max_it = sc->max_it;
+  const T beta = (T)sc->beta;
+  double v0 = 0.0, v1 = 0.0, v2 = 0.0;
+  for (int b = threadIdx.x; b < nrows; b += PA_BLOCK) v0 += rows[b];
+  for (int b = threadIdx.x; b < M.n_dx2; b += PA_BLOCK) v1 += M.rows_b[2 * (int64_t)b + 1];
+  for (int b = threadIdx.x; b < M.n_sh; b += PA_BLOCK) v2 += M.rows_s[b];
+  if (done_in) return;
+  for (int off = 32; off > 0; off >>= 1) {
+    v0 += __shfl_down(v0, off, 64);
+    v1 += __shfl_down(v1, off, 64);
+    v2 += __shfl_down(v2, off, 64);
+  }
+  if ((threadIdx.x & 63) == 0) {
+    const int w = threadIdx.x >> 6;
+    sm[w] = v0;
+    sm[4 + w] = v1;
+    sm[8 + w] = v2;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double v = 0.0, dx2 = 0.0, sh = 0.0;
+    for (int w = 0; w < PA_BLOCK / 64; ++w) { v += sm[w]; dx2 += sm[4 + w]; sh += sm[8 + w]; }
+    int stop = 0;
+    if (M.n_dx2 > 0) {
+      // stop test of the previous iteration (linalg.py:128-134, 321-338); beta and the iteration count were
+      // advanced by phase A's prologue already (an error therefore reports itr + 1: only tol is raised)
+      const T tolv = (T)sqrt(dx2 + sh);
+      const bool bad = isnan(tolv) || isinf(tolv);
+      stop = (bad || itr_in > max_it || !((double)tolv > tol_lim)) ? 1 : 0;
+      if (blockIdx.x == 0) {
+        sc->tol = (double)tolv;
+        if (bad) sc->err = 1;
+        if (stop) sc->done = 1;
+        sums[2] = dx2 + sh;
+      }
+    }
+    sm[13] = stop ? 1.0 : 0.0;
+    const T dAd = (T)v;                      // linalg.py:118-120
+    const T a = (T)rr_in / dAd;
+    const double al = (isnan(a) || isinf(a)) ? 0.0 : (double)a;
+    sm[12] = al;
+    if (blockIdx.x == 0 && !stop) {
+      sc->dAd = (double)dAd;
+      sc->alpha = al;
+      sums[0] = v;
+    }
+  }
+  __syncthreads();
+  if (sm[13] != 0.0) return;
+  const T alpha = (T)sm[12];
+  // gridDim.x = 5 sections x nb blocks (sections a rank does not have return at once)
+  const int nb = (int)(gridDim.x / 5), sec = (int)(blockIdx.x / nb), bq = (int)(blockIdx.x - sec * nb);
+  if (sec == 0 && !M.r_lo) return;
+  if (sec == 1 && !M.r_hi) return;
+  T* const xout = sec == 2 ? M.xp_lo1 : (sec == 3 ? M.xp_hi0 : M.xp_hi1);
+  if (sec >= 2 && !xout) return;
+  const int64_t ip = sec == 0 ? 0 : (sec == 1 ? G.n0 - 1 : (sec == 2 ? 1 : (sec == 3 ? G.n0 - 1 : G.n0 - 2)));
+  const int64_t gi = ip + G.off0;
+  const bool iS = gi >= G.slo[0] && gi <= G.shi[0];
+  const T* const dpl = M.d + ip * G.s0;
+  for (int64_t q = (int64_t)bq * blockDim.x + threadIdx.x; q < G.s0; q += (int64_t)nb * blockDim.x) {
+    int64_t j, k;
+    if (G.s0 <= 0x7fffffffLL) {
+      const uint32_t qq = (uint32_t)q, s1 = (uint32_t)G.s1, jj = qq / s1;
+      j = jj; k = qq - jj * s1;
+    } else {
+      j = q / G.s1; k = q - j * G.s1;
+    }
+    const bool inS = iS && j >= G.slo[1] && j <= G.shi[1] && k >= G.slo[2] && k <= G.shi[2];
+    const T dc = dpl[q];
+    if (sec >= 2) {   // new x on plane 1 / n0-1 / n0-2 (k_cg_b: x + alpha d' on S, x elsewhere)
+      const T xo = M.x[ip * G.s0 + q];
+      T ad = alpha * dc;
+      T xn = xo + ad;
+      xout[q] = inS ? xn : xo;
+      continue;
+    }
+    // all operands of the node first: ghost pair, the plane inside, the four in-plane neighbours, r, Gamma
+    const T rg = sec == 0 ? M.r_lo[q] : M.r_hi[q];
+    const T dg = sec == 0 ? M.d_lo[q] : M.d_hi[q];
+    const T din = sec == 0 ? M.d[G.s0 + q] : M.d[(G.n0 - 2) * G.s0 + q];
+    const T dj1 = dpl[pa_wrap(j + 1, G.n1) * G.s1 + k], dj0 = dpl[pa_wrap(j - 1, G.n1) * G.s1 + k];
+    const T dk1 = dpl[j * G.s1 + pa_wrap(k + 1, G.n2)], dk0 = dpl[j * G.s1 + pa_wrap(k - 1, G.n2)];
+    const T rc = M.r[ip * G.s0 + q];
+    T cf = M.coeff;
+    if (M.has_coeff && M.coeff_f) cf = M.coeff_f[ip * G.s0 + q];
+    T bg = beta * dg;
+    const T ghost = rg + bg;                 // d'_g = r_g + beta d_g
+    if (sec == 0) M.g_lo[q] = ghost; else M.g_hi[q] = ghost;
+    // A d' at the node: axes 0 -> 1 -> 2 into zero, * Gamma, * sign, + 0 (pa_apply_terms, kind 0)
+    T ax = (T)0;
+    ax = ax + pa_lap_axis<T>(G, M.lap, 0, gi, G.g0, sec == 0 ? din : ghost, dc, sec == 0 ? ghost : din);
+    ax = ax + pa_lap_axis<T>(G, M.lap, 1, j, G.n1, dj1, dc, dj0);
+    ax = ax + pa_lap_axis<T>(G, M.lap, 2, k, G.n2, dk1, dc, dk0);
+    if (M.has_coeff) ax = ax * cf;
+    ax = ax * M.sign;
+    T Ad = (T)0;
+    Ad = Ad + ax;
+    T aAd = alpha * Ad;
+    T rn = rc - aAd;
+    rn = inS ? rn : (T)0;
+    if (sec == 0) M.send_lo[q] = rn; else M.send_hi[q] = rn;
+  }
+}
+
 template <typename T>
 __global__ void k_copy(const T* __restrict__ a, T* __restrict__ b, int64_t n) {
   for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < n;
@@ -686,6 +846,8 @@ static int cg_begin_t(pa_ctx* c, T* x, const T* rhs, double tol, int64_t max_it)
   c->cg_x = x;
   c->cur = 0;
   c->fold_a_n = c->fold_b_n = c->fold_b_nsh = 0;  // nothing of an earlier (possibly failed) solve is pending
+  c->fold_b_shell = nullptr;
+  c->slab_fold = c->slab_fold_live = 0;           // row counts are agreed per solve (pa_cg_fold_plan / _set)
   c->bc_static = pa_bc_is_static(c);
   c->bc_fused = pa_bc_fusable(c);
   c->bc_pair = (!c->bc_fused && pa_bc_pairable(c)) ? 1 : 0;
@@ -774,8 +936,10 @@ static void cg_flush_fold(pa_ctx* c) {
   }
   if (c->fold_b_n > 0) {
     hipLaunchKernelGGL(k_cg_post_b<T>, dim3(1), dim3(PA_BLOCK), 0, c->stream, c->sc, c->fold_b_part,
-                       c->fold_b_n, (const double*)c->scr[SCR_PART2], c->fold_b_nsh, pa_sums(c), 2);
+                       c->fold_b_n, c->fold_b_shell ? c->fold_b_shell : (const double*)c->scr[SCR_PART2],
+                       c->fold_b_nsh, pa_sums(c), 2);
     c->fold_b_n = c->fold_b_nsh = 0;
+    c->fold_b_shell = nullptr;
   }
 }
 
@@ -794,13 +958,15 @@ int pa_cg_phase_a_t(pa_ctx* c, int stage_post) {
   // upper half of SCR_PART, because phase B writes its own rows while its blocks still read these
   const bool foldable = c->fold && c->in_iterate && stage_post == 2 && !c->slab && !c->profile;
   if (foldable) part += 2 * (size_t)PA_MAX_PARTIALS;
+  const bool live = c->slab_fold_live != 0;   // folded slab iteration: rows go out through the all-reduce buffer
+  if (live) part = c->rows_send;
   if (c->pending_init_logic) {  // slab: sum r.r has been all-reduced by the driver
     hipLaunchKernelGGL(k_cg_post_init<T>, dim3(1), dim3(PA_BLOCK), 0, c->stream, c->sc, (const double*)nullptr, 0,
                        pa_sums(c), 1);
     c->pending_init_logic = 0;
   }
   Vec<T> rv = cg_vec<T>(c, r, 0), dv = cg_vec<T>(c, dold, 1);
-  if (c->slab && (c->r_recv_lo || c->r_recv_hi)) {
+  if (c->slab && !live && (c->r_recv_lo || c->r_recv_hi)) {
     hipLaunchKernelGGL(k_ghost_dir<T>, dim3(pa_grid_blocks(G.s0)), dim3(PA_BLOCK), 0, c->stream, c->sc, G.s0,
                        (const T*)c->r_recv_lo, (const T*)c->r_recv_hi, (const T*)c->d_glo[c->cur],
                        (const T*)c->d_ghi[c->cur], (T*)c->d_glo[c->cur ^ 1], (T*)c->d_ghi[c->cur ^ 1]);
@@ -809,6 +975,7 @@ int pa_cg_phase_a_t(pa_ctx* c, int stage_post) {
   int rc = pa_cg3d_phase_a<T>(c, E, rv, dv, dnew, part);
   if (rc < 0) return rc;
   int used_blocks = rc;
+  if (rc == 0 && live) { pa_set_err(c, "folded slab iteration: the tiled phase A declined after the plan"); return PA_E_STATE; }
   if (rc == 0) {
     cg_flush_fold<T>(c);  // the tiled kernel declined: the previous iteration is closed by its own kernel
     hipLaunchKernelGGL(k_cg_a<T>, dim3(nblk), dim3(PA_BLOCK), 0, c->stream, G, E, c->sc, rv, dv, dnew, part);
@@ -816,7 +983,9 @@ int pa_cg_phase_a_t(pa_ctx* c, int stage_post) {
   }
   if (c->profile) pa_profile_stop(c, 0);
   c->cur ^= 1;
-  if (foldable && used_blocks <= PA_MAX_GRID)
+  if (live) {
+    // alpha comes from the mid kernel, after the all-reduce of the rows
+  } else if (foldable && used_blocks <= PA_MAX_GRID)
     c->fold_a_n = used_blocks;  // phase B's prologue (or cg_flush_fold) computes alpha
   else
     hipLaunchKernelGGL(k_cg_post_a<T>, dim3(1), dim3(PA_BLOCK), 0, c->stream, c->sc, part, used_blocks, pa_sums(c),
@@ -837,10 +1006,13 @@ int pa_cg_phase_b_t(pa_ctx* c, int stage_post) {
   double* part = (double*)c->scr[SCR_PART];
   double* part2 = (double*)c->scr[SCR_PART2];
   Vec<T> dv = cg_vec<T>(c, d, 1);
+  const bool live = c->slab_fold_live != 0;
+  if (live) part = c->rows_send + c->fold_rows[0] + c->fold_rows[2];
   if (c->profile) (void)hipEventRecord(c->pev[2], c->stream);
   int rc = pa_cg3d_phase_b<T>(c, E, dv, x, r, part);
   if (rc < 0) return rc;
   int used_blocks = rc;
+  if (rc == 0 && live) { pa_set_err(c, "folded slab iteration: the tiled phase B declined after the plan"); return PA_E_STATE; }
   if (rc == 0) {
     cg_flush_fold<T>(c);  // alpha by its own kernel
     hipLaunchKernelGGL(k_cg_b<T>, dim3(nblk), dim3(PA_BLOCK), 0, c->stream, G, E, c->sc, dv, x, r,
@@ -850,7 +1022,7 @@ int pa_cg_phase_b_t(pa_ctx* c, int stage_post) {
   if (c->profile) pa_profile_stop(c, 1);
   c->b_blocks = used_blocks;
   if (c->slab) {  // BC fill + shell + reduction happen in pa_cg_bc, after the driver's plane exchange
-    if (c->x_pack_lo1 || c->x_pack_hi0 || c->x_pack_hi1) {
+    if (!live && (c->x_pack_lo1 || c->x_pack_hi0 || c->x_pack_hi1)) {
       const T* xr = (const T*)x;
       hipLaunchKernelGGL(k_pack_planes<T>, dim3(pa_grid_blocks(G.s0)), dim3(PA_BLOCK), 0, c->stream, c->sc, G.s0,
                          xr + 1 * G.s0, (T*)c->x_pack_lo1, xr + (G.n0 - 1) * G.s0, (T*)c->x_pack_hi0,
@@ -893,6 +1065,8 @@ int pa_cg_bc_t(pa_ctx* c) {
   T* x = (T*)c->cg_x;
   double* part = (double*)c->scr[SCR_PART];
   double* part2 = (double*)c->scr[SCR_PART2];
+  const bool live = c->slab_fold_live != 0;
+  if (live) part2 = c->rows_send + c->fold_rows[0];
   int nsh = 0, rc;
   if (!c->bc_static) {
     if (c->bc_fused) {
@@ -905,8 +1079,80 @@ int pa_cg_bc_t(pa_ctx* c) {
       pa_shell_launch<T>(c, (const T*)x, (T*)c->scr[SCR_SHELL], part2, 1);
     }
   }
-  hipLaunchKernelGGL(k_cg_post_b<T>, dim3(1), dim3(PA_BLOCK), 0, c->stream, c->sc, part, c->b_blocks, part2, nsh,
+  if (live) {
+    // the all-reduced rows are summed by the next phase A's prologue (or pa_cg_slab_flush)
+    if (nsh > c->fold_rows[2]) { pa_set_err(c, "folded slab iteration: %d shell rows, %d planned", nsh, c->fold_rows[2]); return PA_E_STATE; }
+    c->fold_b_part = c->rows_recv + c->fold_rows[0] + c->fold_rows[2];
+    c->fold_b_n = c->fold_rows[1];
+    c->fold_b_shell = c->rows_recv + c->fold_rows[0];
+    c->fold_b_nsh = c->bc_defer ? -1 : c->fold_rows[2];   // -1: the mid kernel of the next iteration tests
+    if (c->bc_defer) c->tol_pending = 1;
+  } else {
+    hipLaunchKernelGGL(k_cg_post_b<T>, dim3(1), dim3(PA_BLOCK), 0, c->stream, c->sc, part, c->b_blocks, part2, nsh,
                        pa_sums(c), 0);
+  }
+  PA_HIP(c, hipGetLastError());
+  return PA_OK;
+}
+
+// folded slab iteration, between the all-reduce of the d.Ad rows and phase B (k_slab_mid)
+template <typename T>
+static int cg_slab_mid_t(pa_ctx* c) {
+  const DevGeom& G = c->G;
+  DevEq<T> E;
+  pa_build_eq<T>(c, c->nterms, c->terms, E);
+  if (E.nterms != 1 || E.t[0].kind != PA_OP_LAPLACIAN || c->coord != PA_COORD_XYZ || !G.act[0]) {
+    pa_set_err(c, "folded slab iteration: one Laplacian term on a 3-D xyz mesh expected (the tiled kernels' equation)");
+    return PA_E_STATE;
+  }
+  MidArgs<T> M;
+  memset(&M, 0, sizeof(M));
+  M.lap = E.lap;
+  M.coeff = E.t[0].coeff; M.sign = E.t[0].sign; M.has_coeff = E.t[0].has_coeff; M.coeff_f = E.t[0].coeff_f;
+  M.d = (const T*)c->scr[c->cur ? SCR_D1 : SCR_D0];
+  M.r = (const T*)c->scr[SCR_R];
+  M.x = (const T*)c->cg_x;
+  M.r_lo = (const T*)c->r_recv_lo; M.r_hi = (const T*)c->r_recv_hi;
+  M.d_lo = (const T*)c->d_glo[c->cur ^ 1]; M.d_hi = (const T*)c->d_ghi[c->cur ^ 1];
+  M.g_lo = (T*)c->d_glo[c->cur]; M.g_hi = (T*)c->d_ghi[c->cur];
+  M.send_lo = (T*)c->r_send_lo; M.send_hi = (T*)c->r_send_hi;
+  if ((M.r_lo && !M.send_lo) || (M.r_hi && !M.send_hi)) { pa_set_err(c, "slab: a neighbour without a send plane"); return PA_E_STATE; }
+  M.xp_lo1 = (T*)c->x_pack_lo1; M.xp_hi0 = (T*)c->x_pack_hi0; M.xp_hi1 = (T*)c->x_pack_hi1;
+  if (c->tol_pending) {
+    M.rows_b = c->rows_recv + c->fold_rows[0] + c->fold_rows[2];
+    M.n_dx2 = c->fold_rows[1];
+    M.rows_s = c->rows_recv + c->fold_rows[0];
+    M.n_sh = c->fold_rows[2];
+    c->tol_pending = 0;
+  }
+  const bool planes = M.r_lo || M.r_hi || M.xp_lo1 || M.xp_hi0 || M.xp_hi1;
+  // <= 256 blocks per section: with five sections the whole grid is resident at once (a second round of
+  // blocks would pay the prologue's round trip again)
+  const int nbm = planes ? std::min(256, pa_grid_blocks(G.s0)) : 1;
+  hipLaunchKernelGGL(k_slab_mid<T>, dim3(5 * nbm), dim3(PA_BLOCK), 0, c->stream, G, c->sc,
+                     (const double*)c->rows_recv, c->fold_rows[0], pa_sums(c), M);
+  PA_HIP(c, hipGetLastError());
+  return PA_OK;
+}
+
+int pa_cg_slab_mid(pa_ctx* c) {
+  return c->dtype == PA_F64 ? cg_slab_mid_t<double>(c) : cg_slab_mid_t<float>(c);
+}
+
+int pa_cg_bc_on(pa_ctx* c, hipStream_t st) {
+  hipStream_t keep = c->stream;
+  c->stream = st;   // every launch of the BC fill / shell pass goes through c->stream
+  const int rc = c->dtype == PA_F64 ? pa_cg_bc_t<double>(c) : pa_cg_bc_t<float>(c);
+  c->stream = keep;
+  return rc;
+}
+
+int pa_cg_slab_flush(pa_ctx* c) {
+  if (c->fold_b_n > 0 && c->fold_b_nsh < 0) {   // deferred stop test: the caller has all-reduced the shell rows
+    c->fold_b_nsh = c->fold_rows[2];
+    c->tol_pending = 0;
+  }
+  if (c->dtype == PA_F64) cg_flush_fold<double>(c); else cg_flush_fold<float>(c);
   PA_HIP(c, hipGetLastError());
   return PA_OK;
 }
@@ -1230,6 +1476,28 @@ int pa_jacobi(pa_ctx* c, void* x, const void* rhs, double tol, int64_t max_it, d
 // ============================================================================
 //  stepwise CG (bench.py, slab-decomposed driver)
 // ============================================================================
+// rows[0..2] = partial rows this rank's tiled phase A / phase B / BC fill write per iteration (all 0:
+// the folded slab sequence does not apply here -- generic kernels, or too many rows)
+template <typename T>
+static int cg_fold_plan_t(pa_ctx* c, int64_t* rows) {
+  rows[0] = rows[1] = rows[2] = 0;
+  DevEq<T> E;
+  pa_build_eq<T>(c, c->nterms, c->terms, E);
+  T* r = (T*)c->scr[SCR_R];
+  T* d0 = (T*)c->scr[SCR_D0];
+  T* d1 = (T*)c->scr[SCR_D1];
+  double* part = (double*)c->scr[SCR_PART];
+  c->plan_only = 1;
+  const int na = pa_cg3d_phase_a<T>(c, E, cg_vec<T>(c, r, 0), cg_vec<T>(c, d0, 1), d1, part);
+  const int nb = pa_cg3d_phase_b<T>(c, E, cg_vec<T>(c, d1, 1), (T*)c->cg_x, r, part);
+  c->plan_only = 0;
+  (void)hipGetLastError();
+  const int ns = c->bc_static ? 0 : pa_bc_shell_rows(c);
+  if (na <= 0 || nb <= 0 || na > PA_MAX_GRID || nb > PA_MAX_GRID || ns > 3 * PA_MAX_GRID) return PA_OK;
+  rows[0] = na; rows[1] = nb; rows[2] = ns;
+  return PA_OK;
+}
+
 extern "C" {
 
 int pa_cg_begin(pa_ctx* c, void* x, const void* rhs, double tol, int64_t max_it) {
@@ -1248,7 +1516,7 @@ int pa_cg_phase_a(pa_ctx* c) {
 
 int pa_cg_phase_b(pa_ctx* c) {
   if (!c || !c->solver_live) { if (c) pa_set_err(c, "pa_cg_phase_b without pa_cg_begin"); return PA_E_STATE; }
-  if (c->slab) {  // alpha from the all-reduced sum d.Ad
+  if (c->slab && !c->slab_fold_live) {  // alpha from the all-reduced sum d.Ad
     if (c->dtype == PA_F64)
       hipLaunchKernelGGL(k_cg_post_a<double>, dim3(1), dim3(PA_BLOCK), 0, c->stream, c->sc, (const double*)nullptr, 0, pa_sums(c), 1);
     else
@@ -1266,7 +1534,7 @@ int pa_cg_bc(pa_ctx* c) {
 
 int pa_cg_finish_iter(pa_ctx* c) {
   if (!c || !c->solver_live) { if (c) pa_set_err(c, "pa_cg_finish_iter without pa_cg_begin"); return PA_E_STATE; }
-  if (!c->slab) return PA_OK;  // logic already ran inside phase_b
+  if (!c->slab || c->slab_fold_live) return PA_OK;  // logic already ran inside phase_b / runs in the next prologue
   if (c->dtype == PA_F64)
     hipLaunchKernelGGL(k_cg_post_b<double>, dim3(1), dim3(PA_BLOCK), 0, c->stream, c->sc, (const double*)nullptr, 0,
                        (const double*)nullptr, 0, pa_sums(c), 1);
@@ -1274,6 +1542,66 @@ int pa_cg_finish_iter(pa_ctx* c) {
     hipLaunchKernelGGL(k_cg_post_b<float>, dim3(1), dim3(PA_BLOCK), 0, c->stream, c->sc, (const double*)nullptr, 0,
                        (const double*)nullptr, 0, pa_sums(c), 1);
   PA_HIP(c, hipGetLastError());
+  return PA_OK;
+}
+
+int pa_cg_fold_plan(pa_ctx* c, int64_t* rows) {
+  if (!c || !rows) return PA_E_ARG;
+  if (!c->solver_live || !c->slab) { pa_set_err(c, "pa_cg_fold_plan needs a live slab solve (pa_slab_set, pa_cg_begin)"); return PA_E_STATE; }
+  return c->dtype == PA_F64 ? cg_fold_plan_t<double>(c, rows) : cg_fold_plan_t<float>(c, rows);
+}
+
+int pa_cg_fold_set(pa_ctx* c, const int64_t* rows) {
+  if (!c) return PA_E_ARG;
+  if (!c->solver_live || !c->slab) { pa_set_err(c, "pa_cg_fold_set needs a live slab solve"); return PA_E_STATE; }
+  c->slab_fold = 0;
+  if (!rows || rows[0] <= 0 || rows[1] <= 0 || rows[2] < 0) return PA_OK;   // stepwise sequence
+  if (rows[0] > PA_MAX_GRID || rows[1] > PA_MAX_GRID || rows[2] > 3 * PA_MAX_GRID) {
+    pa_set_err(c, "pa_cg_fold_set: row counts beyond one resident wave of workgroups");
+    return PA_E_ARG;
+  }
+  int64_t mine[3];
+  if (int rc = pa_cg_fold_plan(c, mine)) return rc;
+  if (mine[0] <= 0 || mine[0] > rows[0] || mine[1] > rows[1] || mine[2] > rows[2]) {
+    pa_set_err(c, "pa_cg_fold_set: agreed rows (%lld %lld %lld) below this rank's (%lld %lld %lld)", (long long)rows[0],
+               (long long)rows[1], (long long)rows[2], (long long)mine[0], (long long)mine[1], (long long)mine[2]);
+    return PA_E_ARG;
+  }
+  const size_t tot = (size_t)rows[0] + 2 * (size_t)rows[1] + (size_t)rows[2];
+  PA_HIP(c, hipSetDevice(c->device));
+  if (tot > c->rows_cap) {
+    if (c->rows_buf[0]) (void)hipFree(c->rows_buf[0]);
+    if (c->rows_buf[1]) (void)hipFree(c->rows_buf[1]);
+    c->rows_buf[0] = c->rows_buf[1] = nullptr;
+    c->rows_cap = 0;
+    PA_HIP(c, hipMalloc((void**)&c->rows_buf[0], tot * sizeof(double)));
+    PA_HIP(c, hipMalloc((void**)&c->rows_buf[1], tot * sizeof(double)));
+    c->rows_cap = tot;
+  }
+  // Rows beyond this rank's own grids are never written: they must be (and stay) zero in the send buffer,
+  // hence the all-reduce out of place.  A rank whose counts ARE the agreed ones rewrites every row in every
+  // iteration and reduces in place (a local choice: RCCL does not care whether send == recv on a rank).
+  c->rows_send = c->rows_buf[0];
+  c->rows_recv = (mine[0] == rows[0] && mine[1] == rows[1] && mine[2] == rows[2]) ? c->rows_buf[0] : c->rows_buf[1];
+  PA_HIP(c, hipMemsetAsync(c->rows_buf[0], 0, tot * sizeof(double), c->stream));
+  PA_HIP(c, hipMemsetAsync(c->rows_buf[1], 0, tot * sizeof(double), c->stream));
+  for (int q = 0; q < 3; ++q) c->fold_rows[q] = (int)rows[q];
+  c->slab_fold = 1;
+  c->bc_pending = c->tol_pending = 0;
+  const char* df = getenv("PYAPES_HIP_BC_DEFER");
+  c->bc_defer = (!c->bc_static && !(df && atoi(df) == 0)) ? 1 : 0;
+  if (c->bc_defer && !c->bstream) {
+    // highest priority: a stream of the default priority may share its hardware queue with the ctx stream
+    // (seen: the BC kernels then queue up behind the next phase A instead of running beside it)
+    int plo = 0, phi = 0;
+    (void)hipDeviceGetStreamPriorityRange(&plo, &phi);
+    if (hipStreamCreateWithPriority(&c->bstream, hipStreamNonBlocking, phi) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_pb, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_bcd, hipEventDisableTiming) != hipSuccess) {
+      (void)hipGetLastError();
+      c->bc_defer = 0;   // a local choice: the collective sequence is the same either way
+    }
+  }
   return PA_OK;
 }
 

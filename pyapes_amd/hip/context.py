@@ -352,6 +352,15 @@ class HipContext:
         self._keep["plan"] = (p, send_lo, send_hi, recv_lo, recv_hi)
         self._rc(self.lib.pa_comm_plan(self.h, C.byref(p)))
 
+    def cg_fold_plan(self) -> list[int]:
+        rows = (C.c_int64 * 3)()
+        self._rc(self.lib.pa_cg_fold_plan(self.h, rows))
+        return [int(v) for v in rows]
+
+    def cg_fold_set(self, rows: Sequence[int]) -> None:
+        arr = (C.c_int64 * 3)(*[int(v) for v in rows])
+        self._rc(self.lib.pa_cg_fold_set(self.h, arr))
+
     def cg_iterate_comm(self, n: int) -> None:
         self._rc(self.lib.pa_cg_iterate_comm(self.h, int(n)))
 

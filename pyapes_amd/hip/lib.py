@@ -96,6 +96,8 @@ SIGNATURES: dict[str, tuple[Any, list[Any]]] = {
     "pa_cg_bc": (C.c_int, [_VP]),
     "pa_cg_finish_iter": (C.c_int, [_VP]),
     "pa_cg_iterate": (C.c_int, [_VP, C.c_int64]),
+    "pa_cg_fold_plan": (C.c_int, [_VP, _I64P]),
+    "pa_cg_fold_set": (C.c_int, [_VP, _I64P]),
     "pa_cg_end": (C.c_int, [_VP, C.POINTER(PaReport)]),
     "pa_slab_set": (C.c_int, [_VP, C.POINTER(PaSlab)]),
     "pa_comm_available": (C.c_int, []),

@@ -98,6 +98,7 @@ class SlabCG:
         self.terms = list(terms)
         self._stage = None  # pinned CPU staging when the process group cannot move GPU tensors
         self.lib_comm = self._setup_lib_comm()
+        self.folded = False
 
     # -- RCCL inside the library ---------------------------------------------------
     def _setup_lib_comm(self) -> bool:
@@ -229,6 +230,23 @@ class SlabCG:
         self._exchange_planes(self.bufs["r_send_lo"], self.bufs["r_send_hi"],
                               self.bufs["r_recv_lo"], self.bufs["r_recv_hi"])
         self._allreduce(1, 2)
+        self.folded = self._agree_fold()
+
+    def _agree_fold(self) -> bool:
+        """Folded iterations of the library-side loop (include/pyapes_hip.h): every rank plans its partial-row
+        counts, the ranks take the MAX -- or stay stepwise, all of them, if a single rank cannot fold."""
+        import os
+        be, d = self.be, self.dist
+        if not self.lib_comm or not hasattr(be, "cg_fold_plan") or os.environ.get("PYAPES_HIP_SLAB_FOLD", "1") == "0":
+            return False
+        rows = be.cg_fold_plan()
+        t = torch.tensor([*rows, -min(rows[0], rows[1])], dtype=torch.int64, device=self.x.device)
+        d.all_reduce(t, op=d.ReduceOp.MAX, group=self.group)
+        agreed = [int(v) for v in t[:3].tolist()]
+        if -int(t[3].item()) <= 0:          # some rank has no tiled phase kernels here
+            return False
+        be.cg_fold_set(agreed)
+        return True
 
     def iterate(self, n: int) -> None:
         be = self.be

@@ -86,7 +86,7 @@ def test_two_slabs_pair_bc_kernels(name, tmp_path, monkeypatch):
     assert abs(paired["tol"] - plain["tol"]) <= 1e-12 * abs(plain["tol"])
 
 
-def _worker_rccl(rank, world, port, name, n, K, out, lib_comm):
+def _worker_rccl(rank, world, port, name, n, K, out, lib_comm, env=None):
     import sys
     here = os.path.dirname(os.path.abspath(__file__))
     sys.path.insert(0, here)
@@ -95,6 +95,7 @@ def _worker_rccl(rank, world, port, name, n, K, out, lib_comm):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     os.environ["PYAPES_HIP_COMM"] = "1" if lib_comm else "0"
+    os.environ.update(env or {})
     torch.cuda.set_device(0)
     dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", 0))
     try:
@@ -113,6 +114,8 @@ def _worker_rccl(rank, world, port, name, n, K, out, lib_comm):
         drv = SlabCG(mesh, var, rhs_g.cuda(), [{"kind": 0, "sign": -1.0, "coeff": 0.7}], dist)
         assert drv.lib_comm == lib_comm, "library-side RCCL communicator not in use"
         rep = drv.solve(1e-30, K, poll=3)
+        want_fold = lib_comm and os.environ.get("PYAPES_HIP_SLAB_FOLD", "1") != "0"
+        assert drv.folded == want_fold, f"folded={drv.folded}, expected {want_fold}"
         if lib_comm:   # a second solve on the same mesh reuses the communicator (no silent fallback)
             first = var().clone()
             var2 = Field("p", 1, mesh, {"domain": bcs, "obstacle": None})
@@ -125,19 +128,31 @@ def _worker_rccl(rank, world, port, name, n, K, out, lib_comm):
         dist.destroy_process_group()
 
 
+LIB_MODES = {
+    "folded": {},                                                  # default: rows all-reduced, mid kernel; with ONE
+                                                                   # rank the exchange stays on the ctx stream
+    "folded_two_streams": {"PYAPES_HIP_COMM_OVERLAP": "1"},        # what N > 1 ranks run: second communicator + stream
+    "stepwise_in_library": {"PYAPES_HIP_SLAB_FOLD": "0"},                    # the round-1 sequence, still in C
+}
+
+
+@pytest.mark.parametrize("mode", list(LIB_MODES))
 @pytest.mark.parametrize("name", ["per", "xper", "mix"])
-def test_library_side_rccl_one_rank(name, tmp_path):
-    """The C-side iteration loop (pa_cg_iterate_comm: kernels + ncclAllReduce + grouped ncclSend/Recv on
-    one stream) with a 1-rank RCCL communicator -- on a periodic axis 0 the rank is its own ring
-    neighbour, so the packed plane exchange really runs -- against the stepwise torch.distributed
-    driver (bit for bit) and the single-domain oracle."""
+def test_library_side_rccl_one_rank(name, mode, tmp_path):
+    """The C-side iteration loop (pa_cg_iterate_comm) with a 1-rank RCCL communicator -- on a periodic
+    axis 0 the rank is its own ring neighbour, so the packed plane exchange really runs -- against the
+    stepwise torch.distributed driver (bit for bit: with one rank the folded sequence adds the same
+    partial rows in the same order) and the single-domain oracle.  Modes: the folded sequence (row
+    all-reduces, mid kernel), the same with the exchange on the second communicator / stream (the default
+    for N > 1 ranks), and the stepwise sequence inside the library."""
     if name not in CASES:
         pytest.skip(name)
     n, K = (24, 20, 132), 6
     res = {}
     for lib_comm in (True, False):
         out = str(tmp_path / f"x{int(lib_comm)}.pt")
-        mp.spawn(_worker_rccl, args=(1, _free_port(), name, n, K, out, lib_comm), nprocs=1, join=True)
+        mp.spawn(_worker_rccl, args=(1, _free_port(), name, n, K, out, lib_comm, LIB_MODES[mode] if lib_comm else None),
+                 nprocs=1, join=True)
         res[lib_comm] = torch.load(out)
     assert torch.equal(res[True]["x"], res[False]["x"]) and res[True]["itr"] == res[False]["itr"] == K + 1
     assert res[True]["tol"] == res[False]["tol"]
