@@ -1,4 +1,4 @@
-// pa_cg3d.hip -- instantiations of the tiled kernel: CG phases A / B, explicit Euler step, Jacobi sweep
+// pa_cg3d.hip -- instantiations of the tiled kernel: CG phases A / B, Jacobi sweep
 // (kernel and launch helpers: pa_cg3d_kernel.h)
 #include "pa_cg3d_kernel.h"
 
@@ -53,27 +53,7 @@ int pa_cg3d_phase_b(pa_ctx* c, const DevEq<T>& E, Vec<T> d, T* x, T* r, double* 
   return n;
 }
 
-// ---- single-field phases: explicit Euler step, Jacobi sweep -----------------------------------
-template <typename T>
-int pa_tile3d_euler(pa_ctx* c, Vec<T> phi, T* out, int kind, double u, const void* u_field, double nu, double dt) {
-  DevEq<T> E;
-  pa_term t;
-  memset(&t, 0, sizeof(t));
-  t.kind = PA_OP_LAPLACIAN; t.sign = 1.0;
-  pa_build_eq<T>(c, 1, &t, E);
-  const int mode = cg3d_mode<T>(c, E, {phi.p, out, u_field, phi.glo, phi.ghi});
-  if (!mode) return 0;
-  if (kind == PA_OP_DIV_CENTRAL && u_field) return 0;  // needs u at the neighbours: generic kernel
-  Cg3dArgs<T> A;
-  memset(&A, 0, sizeof(A));
-  fill_common<T>(c, E, A);
-  fill_h<T>(c, A);
-  A.d = phi; A.out = out; A.aux = (const T*)u_field; A.u = (T)u; A.p0 = (T)nu; A.p1 = (T)dt; A.kind = kind;
-  int n = launch_any<T, 3>(c, A, mode);
-  if (n > 0 && hipGetLastError() != hipSuccess) { pa_set_err(c, "k_cg3d Euler launch failed"); return PA_E_HIP; }
-  return n;
-}
-
+// ---- Jacobi sweep ---------------------------------------------------------------------------------
 template <typename T>
 int pa_tile3d_jacobi(pa_ctx* c, const DevEq<T>& E, Vec<T> x, const T* rhs, T* xnew, double omega, double* partials) {
   const int mode = cg3d_mode<T>(c, E, {x.p, rhs, xnew, x.glo, x.ghi});
@@ -100,8 +80,6 @@ int pa_tile3d_jacobi(pa_ctx* c, const DevEq<T>& E, Vec<T> x, const T* rhs, T* xn
   return n;
 }
 
-template int pa_tile3d_euler<float>(pa_ctx*, Vec<float>, float*, int, double, const void*, double, double);
-template int pa_tile3d_euler<double>(pa_ctx*, Vec<double>, double*, int, double, const void*, double, double);
 template int pa_tile3d_jacobi<float>(pa_ctx*, const DevEq<float>&, Vec<float>, const float*, float*, double, double*);
 template int pa_tile3d_jacobi<double>(pa_ctx*, const DevEq<double>&, Vec<double>, const double*, double*, double, double*);
 template int pa_cg3d_phase_a<float>(pa_ctx*, const DevEq<float>&, Vec<float>, Vec<float>, float*, double*);

@@ -1,41 +1,6 @@
-// pa_cg3d_b.hip -- instantiations of the tiled kernel: A x (Laplacian, or Laplacian + Div) and the two
-// BiCGSTAB phases (kernel and launch helpers: pa_cg3d_kernel.h)
+// pa_cg3d_b.hip -- instantiations of the tiled kernel: the two BiCGSTAB phases (kernel and launch helpers:
+// pa_cg3d_kernel.h)
 #include "pa_cg3d_kernel.h"
-
-template <typename T>
-int pa_tile3d_aop(pa_ctx* c, const DevEq<T>& E, Vec<T> x, T* y, int interior_only) {
-  const int mode = cg3d_mode<T>(c, E, {x.p, y, x.glo, x.ghi}, true, true);
-  if (!mode) return 0;
-  Cg3dArgs<T> A;
-  memset(&A, 0, sizeof(A));
-  fill_common<T>(c, E, A);
-  A.d = x; A.out = y; A.interior_only = interior_only;
-  if (A.lap_off) A.aux = E.t[0].u_f;  // explicit upwind Div with a speed field (null: scalar speed)
-  int n = launch_any<T, 2>(c, A, mode);
-  if (n > 0 && hipGetLastError() != hipSuccess) { pa_set_err(c, "k_cg3d A x launch failed"); return PA_E_HIP; }
-  return n;
-}
-
-// explicit gradient, nd components of ncell each (k_grad): geometry / mode check as for a Laplacian
-template <typename T>
-int pa_tile3d_grad(pa_ctx* c, Vec<T> x, T* y, int nd) {
-  DevEq<T> E;
-  pa_term t;
-  memset(&t, 0, sizeof(t));
-  t.kind = PA_OP_LAPLACIAN; t.sign = 1.0;
-  pa_build_eq<T>(c, 1, &t, E);
-  const int mode = cg3d_mode<T>(c, E, {x.p, y, x.glo, x.ghi});
-  if (!mode || nd != c->ndim) return 0;
-  Cg3dArgs<T> A;
-  memset(&A, 0, sizeof(A));
-  fill_common<T>(c, E, A);
-  A.grd = E.grd;
-  A.gnd = nd;
-  A.d = x; A.out = y;
-  int n = launch_any<T, 7>(c, A, mode);
-  if (n > 0 && hipGetLastError() != hipSuccess) { pa_set_err(c, "k_cg3d grad launch failed"); return PA_E_HIP; }
-  return n;
-}
 
 template <typename T>
 int pa_tile3d_bicg_pv(pa_ctx* c, const DevEq<T>& E, Vec<T> r, Vec<T> p, Vec<T> v, const T* r0, T* pnew, T* vnew,
@@ -83,7 +48,3 @@ template int pa_tile3d_bicg_pv<float>(pa_ctx*, const DevEq<float>&, Vec<float>, 
 template int pa_tile3d_bicg_pv<double>(pa_ctx*, const DevEq<double>&, Vec<double>, Vec<double>, Vec<double>, const double*, double*, double*, double*);
 template int pa_tile3d_bicg_st<float>(pa_ctx*, const DevEq<float>&, Vec<float>, Vec<float>, const float*, float*, float*, double*);
 template int pa_tile3d_bicg_st<double>(pa_ctx*, const DevEq<double>&, Vec<double>, Vec<double>, const double*, double*, double*, double*);
-template int pa_tile3d_grad<float>(pa_ctx*, Vec<float>, float*, int);
-template int pa_tile3d_grad<double>(pa_ctx*, Vec<double>, double*, int);
-template int pa_tile3d_aop<float>(pa_ctx*, const DevEq<float>&, Vec<float>, float*, int);
-template int pa_tile3d_aop<double>(pa_ctx*, const DevEq<double>&, Vec<double>, double*, int);

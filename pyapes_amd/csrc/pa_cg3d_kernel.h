@@ -68,6 +68,8 @@ struct Cg3dArgs {
   GradCoef<T> grd;      // phase 7 (explicit gradient): the row coefficients of k_grad
   int gnd;              // phase 7: mesh dimension (components written: gnd, one field of ncell each)
   int interior_only;    // A x: zero outside the interior set
+  int out_all;          // Euler step (k_sf): the caller overwrites every node outside the interior set (its BC
+                        // fill covers all 2 * ndim faces), so the step need not preserve phi there
   // folded scalar step (pre_n > 0; single GPU inside pa_cg_iterate): EVERY block first reduces the partial
   // rows the previous kernel left (same fixed order as k_cg_post_a / k_cg_post_b -> the same bits in
   // every block, no fence, no atomics: the kernel boundary made the rows visible) and runs the scalar

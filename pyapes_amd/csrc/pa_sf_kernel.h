@@ -1,0 +1,481 @@
+// pa_sf_kernel.h -- k_sf, the marching kernel of the SINGLE-FIELD operations: A x (explicit Laplacian,
+// Div, Laplacian + Div), the explicit Euler step, the explicit gradient.  These move 8-24 bytes per cell,
+// a third of a CG phase, so what bounds them is not HBM but how well instruction issue overlaps the loads:
+// k_cg3d (pa_cg3d_kernel.h) stages every plane in LDS behind a workgroup barrier and needs ~250 VGPRs at
+// four rows per thread, i.e. two waves per SIMD that advance in lock step -- its explicit Euler step sits at
+// 0.5 of the HBM roofline whatever the tile height or the number of workgroups per CU.
+//
+// Here every WAVE marches on its own: no LDS, no barrier.
+//   * A wave owns RJ rows x 64 lanes x VEC cells (VEC = 16 B / sizeof(T): one 16-byte lane access per row,
+//     1 KiB per wave and row) and keeps four planes of them in registers -- behind / current / ahead / the
+//     one being loaded -- addressed by compile-time slot numbers (the plane loop is unrolled by four, so
+//     nothing is ever rotated).
+//   * j +- 1 across the wave's row block: the two rows above / below are loaded by the wave itself.  They
+//     are the neighbour wave's own rows, at the same time on the same XCD (blockIdx -> tile is XCD-aware):
+//     L2 hits, no HBM traffic.
+//   * k +- 1 across lanes: one DPP move per row and side (v_mov_b32 wave_shr:1 / wave_shl:1); lane 0 / 63
+//     keep the cell left / right of the tile, which every lane loads with one (uniform-address) access.
+//   * loads run two planes ahead of the arithmetic; ~120 VGPRs -> four waves per SIMD that drift freely, so
+//     one wave's stencil covers another's wait.
+// Arithmetic: the row expressions of k_cg3d's VROW path, operation for operation (every product and sum
+// rounded separately, -ffp-contract=off), so results are bit-identical to it, to the generic kernels and to
+// the oracle (tests/test_gpu_tiled_ops.py, test_gpu_parity_golden.py).
+#pragma once
+#include "pa_cg3d_kernel.h"
+
+#include <type_traits>
+
+template <typename T> struct SfBits;
+template <> struct SfBits<float> {
+  static __device__ __forceinline__ float prev(float x, float edge) {   // value of lane - 1; lane 0 keeps `edge`
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(edge), __float_as_int(x), 0x138, 0xf, 0xf, false));
+  }
+  static __device__ __forceinline__ float next(float x, float edge) {   // value of lane + 1; lane 63 keeps `edge`
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(edge), __float_as_int(x), 0x130, 0xf, 0xf, false));
+  }
+};
+template <> struct SfBits<double> {
+  static __device__ __forceinline__ double mv(double x, double edge, bool up) {
+    const long long xb = __double_as_longlong(x), eb = __double_as_longlong(edge);
+    int lo, hi;
+    if (up) {
+      lo = __builtin_amdgcn_update_dpp((int)eb, (int)xb, 0x138, 0xf, 0xf, false);
+      hi = __builtin_amdgcn_update_dpp((int)(eb >> 32), (int)(xb >> 32), 0x138, 0xf, 0xf, false);
+    } else {
+      lo = __builtin_amdgcn_update_dpp((int)eb, (int)xb, 0x130, 0xf, 0xf, false);
+      hi = __builtin_amdgcn_update_dpp((int)(eb >> 32), (int)(xb >> 32), 0x130, 0xf, 0xf, false);
+    }
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+  }
+  static __device__ __forceinline__ double prev(double x, double edge) { return mv(x, edge, true); }
+  static __device__ __forceinline__ double next(double x, double edge) { return mv(x, edge, false); }
+};
+
+// PHASE 2: A x (KIND 0: Laplacian; else Laplacian + Div, or the Div term alone when lap_off)
+// PHASE 3: explicit Euler step (KIND = PA_OP_DIV_* of the advection term)
+// PHASE 7: explicit gradient
+// HASU: the advection speed is a field (read at the cell)
+//
+// Instruction economy is the point of this kernel (a wave64 VALU instruction occupies its SIMD for four
+// cycles whatever it does, and the first version spent 3/4 of them on bookkeeping): in-plane positions are
+// 32-bit byte offsets added to a uniform plane pointer (scalar-base addressing, no 64-bit per-lane
+// arithmetic), everything that does not change from plane to plane -- row / column coefficients, masks,
+// u+ / u- of a scalar speed -- is formed once in front of the loop, and the interior-set select of the
+// output disappears where the caller overwrites the nodes outside it anyway (out_all).
+template <typename T, int RJ, int PHASE, int KIND, bool HASU>
+__global__ void __launch_bounds__(256) k_sf(Cg3dArgs<T> A) {
+  constexpr int VEC = VecOf<T>::N;
+  typedef T V __attribute__((ext_vector_type(VEC)));
+  constexpr int TJ = 4 * RJ, TK = 64 * VEC;
+  static_assert(PHASE == 2 || PHASE == 3 || PHASE == 7, "single-field phases");   // 7 and KIND 0 are not
+  // instantiated: the gradient and the Laplacian alone run at copy speed on k_cg3d (pa_sf.hip)
+  constexpr bool DIV = (PHASE == 3) || (PHASE == 2 && KIND != 0);
+  const DevGeom& G = A.G;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int vb = pa_xcd_remap(blockIdx.x, gridDim.x);
+  const int tiles = A.tiles_j * A.tiles_k;
+  const int chunk = vb / tiles, tl = vb - chunk * tiles;
+  const int tjb = tl / A.tiles_k, tkb = tl - tjb * A.tiles_k;
+  const int n0 = (int)G.n0, n1 = (int)G.n1, n2 = (int)G.n2;
+  const int i0 = (int)((int64_t)chunk * n0 / A.chunks), i1 = (int)((int64_t)(chunk + 1) * n0 / A.chunks);
+  const int CI = i1 - i0;
+  const int j0 = tjb * TJ + wv * RJ, k0 = tkb * TK;
+  auto wrap = [](int v, int n) { v %= n; return v < 0 ? v + n : v; };
+
+  // ---- per-thread geometry: RJ rows x VEC columns, as 32-bit byte offsets inside a plane ------------
+  const int kg = k0 + lane * VEC;
+  const int kc = wrap(kg, n2);
+  const bool kvalid = kg < n2;
+  unsigned off[RJ], offe[RJ];
+  const int ecol = lane == 63 ? wrap(k0 + TK, n2) : wrap(k0 - 1, n2);   // lane 0: cell left of the tile, 63: right
+  bool rowOk[RJ], rowS[RJ];
+  T cPj[RJ], cCj[RJ], cMj[RJ];     // Laplacian rows along j (uniform per row)
+  T gPj[RJ], gCj[RJ], gMj[RJ];     // gradient rows along j
+  bool rPLo[RJ], rPHi[RJ];
+#pragma unroll
+  for (int jj = 0; jj < RJ; ++jj) {
+    const int jg = j0 + jj;
+    const unsigned ro = (unsigned)wrap(jg, n1) * (unsigned)n2;
+    off[jj] = (ro + (unsigned)kc) * (unsigned)sizeof(T);
+    offe[jj] = (ro + (unsigned)ecol) * (unsigned)sizeof(T);
+    rowOk[jj] = kvalid && jg < n1;
+    rowS[jj] = jg < n1 && jg >= G.slo[1] && jg <= G.shi[1];
+    const int rc = pa_row_case(G, 1, jg, G.n1, G.treat);
+    cPj[jj] = A.lap.inv[1]; cCj[jj] = A.lap.m2inv[1]; cMj[jj] = A.lap.inv[1];
+    if (rc == 1) { cPj[jj] = A.lap.c23[1]; cCj[jj] = -A.lap.c23[1]; cMj[jj] = (T)0; }
+    if (rc == 2) { cPj[jj] = (T)0; cCj[jj] = -A.lap.c23[1]; cMj[jj] = A.lap.c23[1]; }
+    rPLo[jj] = G.bct[2] == 4 && jg == 1;
+    rPHi[jj] = G.bct[3] == 4 && jg == n1 - 2;
+    if (PHASE == 7) {
+      gPj[jj] = A.grd.g[1]; gCj[jj] = (T)0; gMj[jj] = A.grd.mg[1];
+      if (rc == 1) { gPj[jj] = A.grd.lo_p[1]; gCj[jj] = A.grd.lo_c[1]; gMj[jj] = (T)0; }
+      if (rc == 2) { gPj[jj] = (T)0; gCj[jj] = A.grd.hi_c[1]; gMj[jj] = A.grd.hi_m[1]; }
+      if (rPLo[jj]) gMj[jj] = (T)0;
+      if (rPHi[jj]) gPj[jj] = (T)0;
+    }
+  }
+  const unsigned offu = ((unsigned)wrap(j0 - 1, n1) * (unsigned)n2 + (unsigned)kc) * (unsigned)sizeof(T);
+  const unsigned offd = ((unsigned)wrap(j0 + RJ, n1) * (unsigned)n2 + (unsigned)kc) * (unsigned)sizeof(T);
+  bool colS[VEC], cPLo[VEC], cPHi[VEC];
+  V cPkV, cCkV, cMkV, gPkV, gCkV, gMkV;
+#pragma unroll
+  for (int v = 0; v < VEC; ++v) {
+    const int kk = kg + v;
+    colS[v] = kvalid && kk >= G.slo[2] && kk <= G.shi[2];
+    const int rc = pa_row_case(G, 2, kk, G.n2, G.treat);
+    T p = A.lap.inv[2], c0 = A.lap.m2inv[2], mq = A.lap.inv[2];
+    if (rc == 1) { p = A.lap.c23[2]; c0 = -A.lap.c23[2]; mq = (T)0; }
+    if (rc == 2) { p = (T)0; c0 = -A.lap.c23[2]; mq = A.lap.c23[2]; }
+    cPkV[v] = p; cCkV[v] = c0; cMkV[v] = mq;
+    cPLo[v] = G.bct[4] == 4 && kk == 1;
+    cPHi[v] = G.bct[5] == 4 && kk == n2 - 2;
+    if (PHASE == 7) {
+      T gp = A.grd.g[2], gc = (T)0, gm = A.grd.mg[2];
+      if (rc == 1) { gp = A.grd.lo_p[2]; gc = A.grd.lo_c[2]; gm = (T)0; }
+      if (rc == 2) { gp = (T)0; gc = A.grd.hi_c[2]; gm = A.grd.hi_m[2]; }
+      if (cPLo[v]) gm = (T)0;
+      if (cPHi[v]) gp = (T)0;
+      gPkV[v] = gp; gCkV[v] = gc; gMkV[v] = gm;
+    }
+  }
+  const size_t pstride = (size_t)G.s0 * sizeof(T);
+  auto plane = [&](int ii) -> const char* {   // uniform
+    return ii < 0 ? (const char*)A.d.glo : (ii >= n0 ? (const char*)A.d.ghi : (const char*)A.d.p + (size_t)ii * pstride);
+  };
+
+  // scalar speed: u+ / u- (upwind) or the three rows (literal upwind) once
+  V uplC = (V)(T)0, umiC = (V)(T)0;
+  if (DIV && !HASU) {
+    const T u = A.u;
+    uplC = (V)(u > (T)0 ? u : (T)0);
+    umiC = (V)(u < (T)0 ? u : (T)0);
+  }
+
+  // ---- register planes -----------------------------------------------------------------------------
+  V P[4][RJ];          // own rows of four planes: slot of chunk-relative plane q is (q + 1) & 3
+  V Hu[4], Hd[4];      // rows above / below: slot q & 3 (loaded two planes ahead, like the own rows)
+  T He[4][RJ];         // edge cells of those planes
+  V U[4][HASU ? RJ : 1];   // advection speed field of those planes
+
+  auto load_own = [&](auto SLOT, int ii) {
+    constexpr int s = decltype(SLOT)::value;
+    const char* p = plane(ii);
+#pragma unroll
+    for (int jj = 0; jj < RJ; ++jj) P[s][jj] = *reinterpret_cast<const V*>(p + off[jj]);
+  };
+  auto load_halo = [&](auto SLOT, int ii) {
+    constexpr int s = decltype(SLOT)::value;
+    const char* p = plane(ii);
+    Hu[s] = *reinterpret_cast<const V*>(p + offu);
+    Hd[s] = *reinterpret_cast<const V*>(p + offd);
+#pragma unroll
+    for (int jj = 0; jj < RJ; ++jj) He[s][jj] = *reinterpret_cast<const T*>(p + offe[jj]);
+    if constexpr (HASU) {
+      const char* pu = (const char*)A.aux + (size_t)ii * pstride;
+#pragma unroll
+      for (int jj = 0; jj < RJ; ++jj) U[s][jj] = *reinterpret_cast<const V*>(pu + off[jj]);
+    }
+  };
+  using I0 = std::integral_constant<int, 0>;
+  using I1 = std::integral_constant<int, 1>;
+  using I2 = std::integral_constant<int, 2>;
+  using I3 = std::integral_constant<int, 3>;
+
+  // prologue: planes -1, 0, 1 of the chunk and the halo of plane 0
+  load_own(I0{}, i0 - 1);
+  load_own(I1{}, i0);
+  load_halo(I0{}, i0);
+  load_own(I2{}, i0 + 1);   // also for a chunk of one plane: the next chunk's first plane / the ghost
+  if (CI > 1) load_halo(I1{}, i0 + 1);
+
+  const T sgn = A.sign;
+  const T cf = A.has_coeff ? A.coeff : (T)1;   // x * 1 is x: no select in the loop
+  const bool out_all = PHASE == 3 ? A.out_all != 0 : (PHASE == 2 ? A.interior_only == 0 : true);
+  const int gcomp0 = A.gnd - 3;
+
+  // one plane: C = q & 3 (q = chunk-relative plane index); slots behind C, current C+1, ahead C+2, loading C+3
+  auto step = [&](auto CC, int q) {
+    constexpr int C = decltype(CC)::value;
+    constexpr int SB = C & 3, SC = (C + 1) & 3, SA = (C + 2) & 3, SL = (C + 3) & 3, HC = C & 3, HN = (C + 2) & 3;
+    const int ii = i0 + q;
+    // loads for later planes first: they fly during this plane's arithmetic
+    if (q + 2 <= CI) load_own(std::integral_constant<int, SL>{}, ii + 2);
+    if (q + 2 < CI) load_halo(std::integral_constant<int, HN>{}, ii + 2);
+
+    // the planes next to an axis-0 face carry other coefficients (and the first / last plane may lie outside
+    // the interior set): they take the same code with the values selected; every other plane takes it with
+    // the plain constants, free of selects
+    const int64_t gi = ii + G.off0;
+    const int rci = pa_row_case(G, 0, gi, G.g0, G.treat);
+    const bool iPLo_ = G.bct[0] == 4 && gi == 1;
+    const bool iPHi_ = G.bct[1] == 4 && gi == G.g0 - 2;
+    const bool iS_ = gi >= G.slo[0] && gi <= G.shi[0];
+    char* const po = (char*)A.out + (size_t)ii * pstride;
+    auto body = [&](auto PLAINC) {
+    constexpr bool PLAIN = decltype(PLAINC)::value;
+    const bool iS = PLAIN ? true : iS_;
+    const bool iPLo = PLAIN ? false : iPLo_, iPHi = PLAIN ? false : iPHi_;
+    T cPi = A.lap.inv[0], cCi = A.lap.m2inv[0], cMi = A.lap.inv[0];
+    T gP0 = A.grd.g[0], gC0 = (T)0, gM0 = A.grd.mg[0];
+    if (!PLAIN) {
+      if (rci == 1) { cPi = A.lap.c23[0]; cCi = -A.lap.c23[0]; cMi = (T)0; }
+      if (rci == 2) { cPi = (T)0; cCi = -A.lap.c23[0]; cMi = A.lap.c23[0]; }
+      if (PHASE == 7) {
+        if (rci == 1) { gP0 = A.grd.lo_p[0]; gC0 = A.grd.lo_c[0]; gM0 = (T)0; }
+        if (rci == 2) { gP0 = (T)0; gC0 = A.grd.hi_c[0]; gM0 = A.grd.hi_m[0]; }
+        if (iPLo) gM0 = (T)0;
+        if (iPHi) gP0 = (T)0;
+      }
+    }
+#pragma unroll
+    for (int jj = 0; jj < RJ; ++jj) {
+      const V xc = P[SC][jj];
+      const V xpi = P[SA][jj], xmi = P[SB][jj];
+      V up, dn;   // rows j-1 / j+1
+      if (jj > 0) up = P[SC][jj - 1]; else up = Hu[HC];
+      if (jj < RJ - 1) dn = P[SC][jj + 1]; else dn = Hd[HC];
+      // k-1 / k+1: inside the lane's vector, across lanes by DPP (lane 0 / 63 keep the tile's edge cell)
+      V xpk, xmk;
+      const T edge = He[HC][jj];
+      const T fromPrev = SfBits<T>::prev(xc[VEC - 1], edge);
+      const T fromNext = SfBits<T>::next(xc[0], edge);
+#pragma unroll
+      for (int v = 0; v < VEC; ++v) {
+        xpk[v] = (v < VEC - 1) ? xc[v + 1 < VEC ? v + 1 : v] : fromNext;
+        xmk[v] = (v > 0) ? xc[v > 0 ? v - 1 : 0] : fromPrev;
+      }
+      if constexpr (PHASE == 7) {
+        V s = gP0 * xpi;
+        V mm = gC0 * xc;
+        s = s + mm;
+        mm = gM0 * xmi;
+        const V g0 = s + mm;
+        s = gPj[jj] * dn;
+        mm = gCj[jj] * xc;
+        s = s + mm;
+        mm = gMj[jj] * up;
+        const V g1 = s + mm;
+        s = gPkV * xpk;
+        mm = gCkV * xc;
+        s = s + mm;
+        mm = gMkV * xmk;
+        const V g2 = s + mm;
+        if (rowOk[jj]) {
+          const size_t cs = (size_t)G.ncell * sizeof(T);
+          *reinterpret_cast<V*>(po + (size_t)gcomp0 * cs + off[jj]) = g0;
+          *reinterpret_cast<V*>(po + (size_t)(gcomp0 + 1) * cs + off[jj]) = g1;
+          *reinterpret_cast<V*>(po + (size_t)(gcomp0 + 2) * cs + off[jj]) = g2;
+        }
+      } else {
+        V axv;
+        {
+          V s = cPi * xpi;
+          V mm = cCi * xc;
+          s = s + mm;
+          mm = cMi * xmi;
+          s = s + mm;
+          axv = s;
+          s = cPj[jj] * dn;
+          mm = cCj[jj] * xc;
+          s = s + mm;
+          mm = cMj[jj] * up;
+          s = s + mm;
+          axv = axv + s;
+          s = cPkV * xpk;
+          mm = cCkV * xc;
+          s = s + mm;
+          mm = cMkV * xmk;
+          s = s + mm;
+          axv = axv + s;
+          axv = axv * cf;
+          axv = axv * sgn;
+        }
+        V adv = (V)(T)0;
+        if constexpr (DIV) {
+          // Div(u phi) of this row, scheme KIND (fdc.py:708-772; 4 = upwind as tests/test_fdm.py:239 states it)
+          const V xp3[3] = {xpi, dn, xpk}, xm3[3] = {xmi, up, xmk};
+          if (KIND == 4) {
+            V upl = uplC, umi = umiC;
+            if constexpr (HASU) {
+              const V uc = U[HC][jj];
+#pragma unroll
+              for (int v = 0; v < VEC; ++v) {
+                upl[v] = uc[v] > (T)0 ? uc[v] : (T)0;
+                umi[v] = uc[v] < (T)0 ? uc[v] : (T)0;
+              }
+            }
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+              V bwd = xc - xm3[a];
+              V fwd = xp3[a] - xc;
+              V t = upl * bwd;
+              V m2 = umi * fwd;
+              t = t + m2;
+              t = t * A.ih[a];
+              adv = adv + t;
+            }
+          } else if (KIND == 3) {
+            V uc;
+            if constexpr (HASU) uc = U[HC][jj]; else uc = (V)A.u;
+            V cP, cC, cM;
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) {
+              cP[v] = (T)2 * (uc[v] < (T)0 ? uc[v] : (T)0);
+              cC[v] = (T)0 * ((T)2 * uc[v]);
+              cM[v] = (T)2 * (uc[v] > (T)0 ? uc[v] : (T)0);
+            }
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+              V t = cP * xp3[a];
+              V m2 = cC * xc;
+              t = t + m2;
+              m2 = cM * xm3[a];
+              t = t + m2;
+              adv = adv + t;
+            }
+          } else {
+            V uc;
+            if constexpr (HASU) uc = U[HC][jj]; else uc = (V)A.u;
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+              V cP = uc, cC = (T)0 * uc, cM = -uc;
+#pragma unroll
+              for (int v = 0; v < VEC; ++v) {
+                const bool lo = a == 0 ? iPLo : (a == 1 ? rPLo[jj] : cPLo[v]);
+                const bool hi = a == 0 ? iPHi : (a == 1 ? rPHi[jj] : cPHi[v]);
+                if (lo) cM[v] = (T)0;
+                if (hi) cP[v] = (T)0;
+              }
+              cP = cP / A.h2[a];
+              cC = cC / A.h2[a];
+              cM = cM / A.h2[a];
+              V t = cP * xp3[a];
+              V m2 = cC * xc;
+              t = t + m2;
+              m2 = cM * xm3[a];
+              t = t + m2;
+              adv = adv + t;
+            }
+          }
+        }
+        V res;
+        if constexpr (PHASE == 3) {
+          V qv = A.p0 * axv;
+          qv = qv - adv;
+          qv = A.p1 * qv;
+          res = xc + qv;
+        } else if constexpr (KIND != 0) {
+          // sum_k sign_k Aop_k (ops.py:122-154) of {Laplacian, Div}: p0 = sign of the Div term, p1 != 0: Div first
+          V dv = adv * A.p0;
+          if (A.lap_off) axv = (V)(T)0;
+          if (A.p1 != (T)0) res = dv + axv; else res = axv + dv;
+        } else {
+          res = axv;
+        }
+        if (!out_all) {   // nodes outside the interior set: phi itself (Euler) / zero (A x on S only)
+          const bool rs = iS && rowS[jj];
+#pragma unroll
+          for (int v = 0; v < VEC; ++v) {
+            const bool inS = rs && colS[v];
+            res[v] = inS ? res[v] : (PHASE == 3 ? xc[v] : (T)0);
+          }
+        }
+        if (rowOk[jj]) *reinterpret_cast<V*>(po + off[jj]) = res;
+      }
+    }
+    };   // body
+    if (rci != 0 || iPLo_ || iPHi_ || !iS_) body(std::false_type{}); else body(std::true_type{});
+  };
+
+  for (int q = 0; q < CI; q += 4) {
+    step(I0{}, q);
+    if (q + 1 < CI) step(I1{}, q + 1);
+    if (q + 2 < CI) step(I2{}, q + 2);
+    if (q + 3 < CI) step(I3{}, q + 3);
+  }
+}
+
+// ---- host side ---------------------------------------------------------------------------------------
+template <typename T, int RJ, int PHASE, int KIND, bool HASU>
+static int sf_blocks_per_cu() {
+  static int cached = 0;
+  if (!cached) {
+    const char* e = getenv("PYAPES_HIP_BPC_SF");
+    int n = e ? atoi(e) : 0;
+    if (n <= 0 &&
+        (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_sf<T, RJ, PHASE, KIND, HASU>, 256, 0) != hipSuccess || n <= 0))
+      n = 4;
+    cached = n;
+  }
+  return cached;
+}
+
+template <typename T, int RJ, int PHASE, int KIND, bool HASU>
+static int launch_sf(pa_ctx* c, Cg3dArgs<T>& A) {
+  constexpr int VEC = VecOf<T>::N;
+  constexpr int TJ = 4 * RJ, TK = 64 * VEC;
+  const DevGeom& G = c->G;
+  A.tiles_j = (int)((G.n1 + TJ - 1) / TJ);
+  A.tiles_k = (int)((G.n2 + TK - 1) / TK);
+  const int tiles = A.tiles_j * A.tiles_k;
+  const int capacity = cus_of(c) * sf_blocks_per_cu<T, RJ, PHASE, KIND, HASU>();
+  int chunks = capacity / tiles;
+  if (chunks < 1) chunks = 1;
+  if (chunks > G.n0) chunks = (int)G.n0;
+  A.chunks = chunks;
+  const int nblk = tiles * chunks;
+  if (nblk > PA_MAX_PARTIALS) return 0;
+  static int dbg = -1;
+  if (dbg < 0) dbg = getenv("PYAPES_HIP_DEBUG") ? 8 : 0;
+  if (dbg > 0) {
+    --dbg;
+    fprintf(stderr, "[pyapes_hip] k_sf phase %d kind %d RJ %d: tiles %dx%d chunks %d (CI ~%lld) blocks %d, %d blocks/CU\n",
+            PHASE, KIND, RJ, A.tiles_j, A.tiles_k, chunks, (long long)(G.n0 / chunks), nblk,
+            sf_blocks_per_cu<T, RJ, PHASE, KIND, HASU>());
+  }
+  hipLaunchKernelGGL((k_sf<T, RJ, PHASE, KIND, HASU>), dim3(nblk), dim3(256), 0, c->stream, A);
+  return nblk;
+}
+
+// Rows per wave (measured, MI355X, us per launch at 1 / 2 / 4 rows; k_cg3d for comparison):
+//   Euler step fp32 512^3: 240 / 311 / 273 (k_cg3d 277)     256^3: 30.2 / 33.4 / 35.4 (38.4)
+//   upwind Div fp32 512^3: 230 / 289 / 243 (274)
+//   upwind Div fp64 512^3: 838 / 555 / 483 (493)            256^3: 52.0 / 51.3 / 50.2 (64.8)
+// fp32: one row (most waves in flight, ~160 VGPRs); fp64: four (one row re-reads its two neighbour rows from
+// L2 for every row it owns, which at 8-byte cells costs more than the occupancy buys).
+template <typename T, int PHASE, int KIND>
+static int launch_sf_any(pa_ctx* c, Cg3dArgs<T>& A) {
+  int rj = sizeof(T) == 4 ? 1 : 4;
+  if (const char* e = getenv("PYAPES_HIP_RJ_SF")) {
+    const int v = atoi(e);
+    if (v == 1 || v == 2 || v == 4) rj = v;
+  } else if (c->G.n1 <= 4) {
+    rj = 1;
+  } else if (c->G.n1 <= 8 && rj > 2) {
+    rj = 2;
+  }
+  constexpr bool CAN_U = (PHASE == 3 || (PHASE == 2 && KIND != 0));
+  if constexpr (CAN_U) {
+    if (A.aux) {
+      switch (rj) {
+        case 1: return launch_sf<T, 1, PHASE, KIND, true>(c, A);
+        case 2: return launch_sf<T, 2, PHASE, KIND, true>(c, A);
+        default: return launch_sf<T, 4, PHASE, KIND, true>(c, A);
+      }
+    }
+  }
+  switch (rj) {
+    case 1: return launch_sf<T, 1, PHASE, KIND, false>(c, A);
+    case 2: return launch_sf<T, 2, PHASE, KIND, false>(c, A);
+    default: return launch_sf<T, 4, PHASE, KIND, false>(c, A);
+  }
+}
+
+// can k_sf take this launch?  Full 16-byte vectors only (mode 1 of cg3d_mode), scalar coefficient.
+template <typename T>
+static bool sf_applies(const pa_ctx* c, const Cg3dArgs<T>& A, int mode) {
+  static int on = -1;
+  if (on < 0) { const char* e = getenv("PYAPES_HIP_SF"); on = (e && atoi(e) == 0) ? 0 : 1; }
+  // 32-bit byte offsets inside a plane
+  return on && mode == 1 && !A.coeff_f && c->G.act[0] && (size_t)c->G.s0 * sizeof(T) < ((size_t)1 << 31);
+}
