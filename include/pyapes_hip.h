@@ -167,6 +167,10 @@ int pa_rfp_diffusion(pa_ctx* ctx, const void* Drr, const void* Drz, const void* 
 int pa_limiter(pa_ctx* ctx, int which, const void* a, const void* b, void* out, int64_t n);
 
 /* ---- solvers (linalg.solve -> cg | bicgstab, linalg.py:33-279) --------- */
+/* replaces: var.save_old() at the top of every solver iteration (linalg.py:110, 210; fields.py:129-131):
+ * x_old = device field the solvers below keep equal to the iterate BEFORE the last executed iteration
+ * (what Field.VARo holds after linalg.solve); NULL (default) = not kept, no extra pass. */
+int pa_solver_keep_old(pa_ctx* ctx, void* x_old);
 int pa_cg(pa_ctx* ctx, void* x, const void* rhs, double tol, int64_t max_it, pa_report* out);
 int pa_bicgstab(pa_ctx* ctx, void* x, const void* rhs, double tol, int64_t max_it, pa_report* out);
 /* new: weighted Jacobi with the CG's BC fill / interior set / stop test */

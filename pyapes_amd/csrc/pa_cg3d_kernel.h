@@ -308,26 +308,20 @@ __global__ void __launch_bounds__(256) k_cg3d(Cg3dArgs<T> A) {
       for (int w = 0; w < 4; ++w) { rr += pre_sm[3 * w]; dx2 += pre_sm[3 * w + 1]; sh += pre_sm[3 * w + 2]; }
       // pa_logic_b on registers: a local SolverScalars puts the kernel on scratch memory, and a kernel
       // with a private segment costs ~10 us more to dispatch (measured)
-      // pre_nsh < 0 (folded slab iterations with the BC fill on its own stream): the stop test of the
-      // previous iteration waits for the boundary-shell rows and is evaluated by the mid kernel; here only
-      // beta and the iteration count (the reference updates d before it looks at tol again, linalg.py:141)
-      const bool defer = A.pre_nsh < 0;
       const T rr_new = (T)rr;
       const T tolv = (T)sqrt(dx2 + sh);
-      const bool bad = !defer && (isnan(tolv) || isinf(tolv));   // linalg.py:334-336 raises before beta / itr
+      const bool bad = isnan(tolv) || isinf(tolv);   // linalg.py:334-336 raises before beta / itr
       const T rr_old = (T)rr_in;
       const double bq = bad ? beta_in : (double)(rr_new / rr_old);
       const long long itr = itr_in + (bad ? 0 : 1);
-      const int done = (!defer && (bad || itr > max_it || !((double)tolv > tol_lim))) ? 1 : 0;
+      const int done = (bad || itr > max_it || !((double)tolv > tol_lim)) ? 1 : 0;
       pre_sm[12] = bq;
       pre_sm[13] = done ? 1.0 : 0.0;
       if (blockIdx.x == 0) {
         SolverScalars* so = A.sc_w;
         *so = *si;
-        if (!defer) {
-          so->tol = (double)tolv;
-          so->done = done;
-        }
+        so->tol = (double)tolv;
+        so->done = done;
         if (bad) {
           so->err = 1;
         } else {
@@ -339,7 +333,7 @@ __global__ void __launch_bounds__(256) k_cg3d(Cg3dArgs<T> A) {
           so->itr = itr;
         }
         if (PHASE == 0) A.pre_sums[1] = rr;
-        if (!defer) A.pre_sums[2] = dx2 + sh;
+        A.pre_sums[2] = dx2 + sh;
       }
     }
     __syncthreads();

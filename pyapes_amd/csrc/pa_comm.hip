@@ -288,14 +288,11 @@ int pa_cg_iterate_comm(pa_ctx* c, int64_t n) {
     }
     return PA_OK;
   }
-  // folded sequence (include/pyapes_hip.h "Folded iterations"): 2 tiled kernels + the mid kernel + 2 row
-  // all-reduces on the ctx stream; beside them the packed exchange on its own communicator + stream and the
-  // BC fill of iteration k on a third stream under the second all-reduce and phase A of iteration k + 1.
-  // Rows: [ A | S | B ]; the first all-reduce carries A (+ S of the previous iteration when its stop test is
-  // deferred to the mid kernel), the second B (+ S when it is not).
-  const size_t mA = (size_t)c->fold_rows[0], mS = (size_t)c->fold_rows[2], mB = 2 * (size_t)c->fold_rows[1];
+  // folded sequence (include/pyapes_hip.h "Folded iterations"): 2 tiled kernels + the mid kernel + the BC
+  // fill + 2 row all-reduces on the ctx stream, the packed exchange beside them on its own communicator +
+  // stream.  Rows: [ A | S | B ]; the first all-reduce carries A, the second S + B.
+  const size_t mA = (size_t)c->fold_rows[0], mSB = (size_t)c->fold_rows[2] + 2 * (size_t)c->fold_rows[1];
   const bool side = c->comm2 && c->xstream;
-  const bool defer = c->bc_defer != 0;
   // does THIS rank's BC fill read planes that arrive with the exchange (end ranks of a periodic ring)?
   const bool bc_needs_x = c->bc_far_lo0 || c->bc_far_lo1 || c->bc_far_hi0;
   const bool any_nb = c->plan.nb_lo >= 0 || c->plan.nb_hi >= 0;
@@ -305,11 +302,7 @@ int pa_cg_iterate_comm(pa_ctx* c, int64_t n) {
   rc = PA_OK;
   for (int64_t q = 0; q < n && !rc; ++q) {
     if ((rc = pa_cg_phase_a(c))) break;
-    if (c->bc_pending) {   // the BC fill of the previous iteration: its shell rows go out with this all-reduce
-      PA_RT(hipStreamWaitEvent(c->stream, c->ev_bcd, 0));
-      c->bc_pending = 0;
-    }
-    PA_NC(R->AllReduce(c->rows_send, c->rows_recv, c->tol_pending ? mA + mS : mA, ncclDouble, ncclSum, comm, c->stream));
+    PA_NC(R->AllReduce(c->rows_send, c->rows_recv, mA, ncclDouble, ncclSum, comm, c->stream));
     if ((rc = pa_cg_slab_mid(c))) break;
     bool x_pending = false;
     if (any_nb) {
@@ -324,38 +317,19 @@ int pa_cg_iterate_comm(pa_ctx* c, int64_t n) {
       }
     }
     if ((rc = pa_cg_phase_b(c))) break;
-    if (defer) {
-      PA_RT(hipEventRecord(c->ev_pb, c->stream));
-      PA_RT(hipStreamWaitEvent(c->bstream, c->ev_pb, 0));
-      if (x_pending && bc_needs_x) PA_RT(hipStreamWaitEvent(c->bstream, c->ev_x, 0));
-      if ((rc = pa_cg_bc_on(c, c->bstream))) break;
-      PA_RT(hipEventRecord(c->ev_bcd, c->bstream));
-      c->bc_pending = 1;
-      PA_NC(R->AllReduce(c->rows_send + mA + mS, c->rows_recv + mA + mS, mB, ncclDouble, ncclSum, comm, c->stream));
-    } else {
-      if (x_pending && bc_needs_x) {
-        PA_RT(hipStreamWaitEvent(c->stream, c->ev_x, 0));
-        x_pending = false;
-      }
-      if ((rc = pa_cg_bc(c))) break;
-      PA_NC(R->AllReduce(c->rows_send + mA, c->rows_recv + mA, mS + mB, ncclDouble, ncclSum, comm, c->stream));
+    if (x_pending && bc_needs_x) {
+      PA_RT(hipStreamWaitEvent(c->stream, c->ev_x, 0));
+      x_pending = false;
     }
+    if ((rc = pa_cg_bc(c))) break;
+    PA_NC(R->AllReduce(c->rows_send + mA, c->rows_recv + mA, mSB, ncclDouble, ncclSum, comm, c->stream));
     if (x_pending) PA_RT(hipStreamWaitEvent(c->stream, c->ev_x, 0));
-  }
-  // the batch's last scalar step (beta, stop test, iteration count) by the single-block kernel the prologues
-  // would have replaced: pa_report_read / pa_cg_end see the state of n whole iterations
-  while (!rc) {
-    if (c->bc_pending) {
-      PA_RT(hipStreamWaitEvent(c->stream, c->ev_bcd, 0));
-      c->bc_pending = 0;
-    }
-    if (c->tol_pending && mS > 0)
-      PA_NC(R->AllReduce(c->rows_send + mA, c->rows_recv + mA, mS, ncclDouble, ncclSum, comm, c->stream));
-    rc = pa_cg_slab_flush(c);
-    break;
   }
 #undef PA_RT
 #undef PA_NC
+  // the batch's last scalar step (beta, stop test, iteration count) by the single-block kernel the prologue
+  // of a next phase A would have replaced: pa_report_read / pa_cg_end see the state of n whole iterations
+  if (!rc) rc = pa_cg_slab_flush(c);
   c->slab_fold_live = 0;
   if (rc == PA_E_HIP && !c->err[0]) pa_set_err(c, "pa_cg_iterate_comm: HIP / RCCL call failed in the folded sequence");
   return rc;

@@ -234,9 +234,6 @@ int pa_ctx_destroy(pa_ctx* c) {
     if (c->scr_base[q]) (void)hipFree(c->scr_base[q]);
   if (c->sc_base) (void)hipFree(c->sc_base);
   if (c->sums) (void)hipFree(c->sums);
-  if (c->bstream) { (void)hipStreamSynchronize(c->bstream); (void)hipStreamDestroy(c->bstream); }
-  if (c->ev_pb) (void)hipEventDestroy(c->ev_pb);
-  if (c->ev_bcd) (void)hipEventDestroy(c->ev_bcd);
   if (c->rows_buf[0]) (void)hipFree(c->rows_buf[0]);
   if (c->rows_buf[1]) (void)hipFree(c->rows_buf[1]);
   if (c->h_sc) (void)hipHostFree(c->h_sc);

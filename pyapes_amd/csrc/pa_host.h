@@ -73,14 +73,6 @@ struct pa_ctx {
   double* rows_buf[2] = {nullptr, nullptr};
   size_t rows_cap = 0;
   int plan_only = 0;        // launch_cg3d returns its grid size without launching (pa_cg_fold_plan)
-  // BC fill + boundary-shell pass of iteration k on their own stream beside the second all-reduce and
-  // phase A of iteration k+1 (phase A touches r and d only); the stop test of iteration k moves into the
-  // mid kernel of iteration k+1, which gets the shell rows with the first all-reduce
-  int bc_defer = 0;
-  hipStream_t bstream = nullptr;
-  hipEvent_t ev_pb = nullptr, ev_bcd = nullptr;
-  int bc_pending = 0;       // ev_bcd recorded, the ctx stream has not waited for it yet
-  int tol_pending = 0;      // the stop test of the last iteration is still to be evaluated
   SolverScalars* h_sc = nullptr;  // pinned host mirror
   // pipelined polls of the done flag: the copy of batch b's scalars is waited for after batch b+1 has
   // been enqueued, so the GPU never idles between batches (the over-enqueued batch is no-ops)
@@ -94,6 +86,10 @@ struct pa_ctx {
   int bc_pair = 0;  // per-axis pair kernels (lower + upper face + shell stop-test term in one launch)
   int bc_fused = 0, shell_cur = 0;  // fused BC fill: which half of SCR_SHELL holds x_old on the shell
   void* cg_x = nullptr;
+  // Field.VARo (var.save_old() at the top of every solver iteration, linalg.py:110 / 210): when the caller
+  // hands a buffer (pa_solver_keep_old) the loops copy the iterate into it before each update -- one extra
+  // pass per iteration, paid only on request
+  void* x_old_out = nullptr;
   // slab decomposition (P > 1): externally owned exchange buffers
   int slab = 0;
   const void* x_glo = nullptr;   // ghost planes of the field handed to pa_aop / begin
@@ -143,7 +139,6 @@ void pa_refresh_geom(pa_ctx* c);
 int pa_bc_apply_any(pa_ctx* c, void* x);
 int pa_check_eq_applicable(pa_ctx* c);   // pa_ops.hip: Grad inside a solver equation is 1-D only
 int pa_cg_slab_mid(pa_ctx* c);                // pa_solver.hip: the step between the phases of a folded slab iteration
-int pa_cg_bc_on(pa_ctx* c, hipStream_t st);   // pa_cg_bc with its launches on stream st
 int pa_cg_slab_flush(pa_ctx* c);              // close the last iteration of a folded batch (single-block kernel)
 int pa_bc_shell_rows(const pa_ctx* c);        // pa_bc.hip: partial rows the BC fill + shell pass of an iteration writes
 void pa_profile_stop(pa_ctx* c, int which);   // pa_solver.hip: close the HIP-event bracket of dominant kernel `which`

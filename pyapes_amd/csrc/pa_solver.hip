@@ -336,11 +336,6 @@ struct MidArgs {
   T *g_lo, *g_hi;        // out: ghost planes of d'
   T *send_lo, *send_hi;  // out: new residual on plane 0 / n0-1
   T *xp_lo1, *xp_hi0, *xp_hi1;  // out (periodic ring ends): new x on plane 1 / n0-1 / n0-2, or null
-  // deferred stop test of the PREVIOUS iteration (BC fill on its own stream): all-reduced (r.r, |dx|^2) rows
-  // and boundary-shell rows; n_dx2 = 0: nothing pending
-  const double* rows_b;
-  const double* rows_s;
-  int n_dx2, n_sh;
   LapCoef<T> lap;
   T coeff, sign;
   int has_coeff;
@@ -367,59 +362,31 @@ __device__ __forceinline__ T pa_lap_axis(const DevGeom& G, const LapCoef<T>& L, 
 template <typename T>
 __global__ void __launch_bounds__(PA_BLOCK) k_slab_mid(DevGeom G, SolverScalars* sc, const double* __restrict__ rows,
                                                         int nrows, double* __restrict__ sums, MidArgs<T> M) {
-  __shared__ double sm[16];
+  __shared__ double sm[8];
   const int done_in = sc->done;
-  const double rr_in = sc->rr, tol_lim = sc->tolerance;
-  const long long itr_in = sc->itr, max_it = sc->max_it;
+  const double rr_in = sc->rr;
   const T beta = (T)sc->beta;
-  double v0 = 0.0, v1 = 0.0, v2 = 0.0;
+  double v0 = 0.0;
   for (int b = threadIdx.x; b < nrows; b += PA_BLOCK) v0 += rows[b];
-  for (int b = threadIdx.x; b < M.n_dx2; b += PA_BLOCK) v1 += M.rows_b[2 * (int64_t)b + 1];
-  for (int b = threadIdx.x; b < M.n_sh; b += PA_BLOCK) v2 += M.rows_s[b];
   if (done_in) return;
-  for (int off = 32; off > 0; off >>= 1) {
-    v0 += __shfl_down(v0, off, 64);
-    v1 += __shfl_down(v1, off, 64);
-    v2 += __shfl_down(v2, off, 64);
-  }
-  if ((threadIdx.x & 63) == 0) {
-    const int w = threadIdx.x >> 6;
-    sm[w] = v0;
-    sm[4 + w] = v1;
-    sm[8 + w] = v2;
-  }
+  for (int off = 32; off > 0; off >>= 1) v0 += __shfl_down(v0, off, 64);
+  if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = v0;
   __syncthreads();
   if (threadIdx.x == 0) {
-    double v = 0.0, dx2 = 0.0, sh = 0.0;
-    for (int w = 0; w < PA_BLOCK / 64; ++w) { v += sm[w]; dx2 += sm[4 + w]; sh += sm[8 + w]; }
-    int stop = 0;
-    if (M.n_dx2 > 0) {
-      // stop test of the previous iteration (linalg.py:128-134, 321-338); beta and the iteration count were
-      // advanced by phase A's prologue already (an error therefore reports itr + 1: only tol is raised)
-      const T tolv = (T)sqrt(dx2 + sh);
-      const bool bad = isnan(tolv) || isinf(tolv);
-      stop = (bad || itr_in > max_it || !((double)tolv > tol_lim)) ? 1 : 0;
-      if (blockIdx.x == 0) {
-        sc->tol = (double)tolv;
-        if (bad) sc->err = 1;
-        if (stop) sc->done = 1;
-        sums[2] = dx2 + sh;
-      }
-    }
-    sm[13] = stop ? 1.0 : 0.0;
+    double v = 0.0;
+    for (int w = 0; w < PA_BLOCK / 64; ++w) v += sm[w];
     const T dAd = (T)v;                      // linalg.py:118-120
     const T a = (T)rr_in / dAd;
     const double al = (isnan(a) || isinf(a)) ? 0.0 : (double)a;
-    sm[12] = al;
-    if (blockIdx.x == 0 && !stop) {
+    sm[4] = al;
+    if (blockIdx.x == 0) {
       sc->dAd = (double)dAd;
       sc->alpha = al;
       sums[0] = v;
     }
   }
   __syncthreads();
-  if (sm[13] != 0.0) return;
-  const T alpha = (T)sm[12];
+  const T alpha = (T)sm[4];
   // gridDim.x = 5 sections x nb blocks (sections a rank does not have return at once)
   const int nb = (int)(gridDim.x / 5), sec = (int)(blockIdx.x / nb), bq = (int)(blockIdx.x - sec * nb);
   if (sec == 0 && !M.r_lo) return;
@@ -473,6 +440,21 @@ __global__ void __launch_bounds__(PA_BLOCK) k_slab_mid(DevGeom G, SolverScalars*
     rn = inS ? rn : (T)0;
     if (sec == 0) M.send_lo[q] = rn; else M.send_hi[q] = rn;
   }
+}
+
+// x_old of the iteration that is about to update x (skipped, like the update, once the solve is over)
+template <typename T>
+__global__ void __launch_bounds__(PA_BLOCK) k_copy_guarded(const SolverScalars* __restrict__ sc, const T* __restrict__ a,
+                                                            T* __restrict__ b, int64_t n) {
+  if (sc->done) return;
+  typedef T V __attribute__((ext_vector_type(16 / sizeof(T))));
+  constexpr int VEC = 16 / sizeof(T);
+  const bool vec = (((uintptr_t)a | (uintptr_t)b) & 15) == 0;
+  const int64_t nv = vec ? n / VEC : 0;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nv; i += (int64_t)gridDim.x * blockDim.x)
+    reinterpret_cast<V*>(b)[i] = reinterpret_cast<const V*>(a)[i];
+  for (int64_t i = nv * VEC + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    b[i] = a[i];
 }
 
 template <typename T>
@@ -1085,8 +1067,7 @@ int pa_cg_bc_t(pa_ctx* c) {
     c->fold_b_part = c->rows_recv + c->fold_rows[0] + c->fold_rows[2];
     c->fold_b_n = c->fold_rows[1];
     c->fold_b_shell = c->rows_recv + c->fold_rows[0];
-    c->fold_b_nsh = c->bc_defer ? -1 : c->fold_rows[2];   // -1: the mid kernel of the next iteration tests
-    if (c->bc_defer) c->tol_pending = 1;
+    c->fold_b_nsh = c->fold_rows[2];
   } else {
     hipLaunchKernelGGL(k_cg_post_b<T>, dim3(1), dim3(PA_BLOCK), 0, c->stream, c->sc, part, c->b_blocks, part2, nsh,
                        pa_sums(c), 0);
@@ -1118,13 +1099,6 @@ static int cg_slab_mid_t(pa_ctx* c) {
   M.send_lo = (T*)c->r_send_lo; M.send_hi = (T*)c->r_send_hi;
   if ((M.r_lo && !M.send_lo) || (M.r_hi && !M.send_hi)) { pa_set_err(c, "slab: a neighbour without a send plane"); return PA_E_STATE; }
   M.xp_lo1 = (T*)c->x_pack_lo1; M.xp_hi0 = (T*)c->x_pack_hi0; M.xp_hi1 = (T*)c->x_pack_hi1;
-  if (c->tol_pending) {
-    M.rows_b = c->rows_recv + c->fold_rows[0] + c->fold_rows[2];
-    M.n_dx2 = c->fold_rows[1];
-    M.rows_s = c->rows_recv + c->fold_rows[0];
-    M.n_sh = c->fold_rows[2];
-    c->tol_pending = 0;
-  }
   const bool planes = M.r_lo || M.r_hi || M.xp_lo1 || M.xp_hi0 || M.xp_hi1;
   // <= 256 blocks per section: with five sections the whole grid is resident at once (a second round of
   // blocks would pay the prologue's round trip again)
@@ -1139,19 +1113,7 @@ int pa_cg_slab_mid(pa_ctx* c) {
   return c->dtype == PA_F64 ? cg_slab_mid_t<double>(c) : cg_slab_mid_t<float>(c);
 }
 
-int pa_cg_bc_on(pa_ctx* c, hipStream_t st) {
-  hipStream_t keep = c->stream;
-  c->stream = st;   // every launch of the BC fill / shell pass goes through c->stream
-  const int rc = c->dtype == PA_F64 ? pa_cg_bc_t<double>(c) : pa_cg_bc_t<float>(c);
-  c->stream = keep;
-  return rc;
-}
-
 int pa_cg_slab_flush(pa_ctx* c) {
-  if (c->fold_b_n > 0 && c->fold_b_nsh < 0) {   // deferred stop test: the caller has all-reduced the shell rows
-    c->fold_b_nsh = c->fold_rows[2];
-    c->tol_pending = 0;
-  }
   if (c->dtype == PA_F64) cg_flush_fold<double>(c); else cg_flush_fold<float>(c);
   PA_HIP(c, hipGetLastError());
   return PA_OK;
@@ -1177,6 +1139,9 @@ static int cg_run_t(pa_ctx* c, T* x, const T* rhs, double tol, int64_t max_it, p
     }
     for (int64_t q = 0; q < nb && !rc; ++q) {
       if ((rc = pa_cg_phase_a_t<T>(c, 2))) break;
+      if (c->x_old_out)   // after phase A: its prologue has decided whether this iteration still runs
+        hipLaunchKernelGGL(k_copy_guarded<T>, dim3(pa_grid_blocks(c->G.ncell)), dim3(PA_BLOCK), 0, c->stream, c->sc,
+                           (const T*)x, (T*)c->x_old_out, c->G.ncell);
       rc = pa_cg_phase_b_t<T>(c, 2);
       ++enq;
     }
@@ -1299,7 +1264,10 @@ static int jacobi_run_t(pa_ctx* c, T* x, const T* rhs, double tol, int64_t max_i
     batch = std::min<int64_t>(2 * poll, std::max<int64_t>(2, enq));
   }
   if ((rc = read_scalars(c))) return rc;
-  // the final iterate lives in buf[itr & 1]
+  // the final iterate lives in buf[itr & 1], the one before it (Field.VARo) in the other buffer
+  if (c->x_old_out && c->h_sc->itr >= 1)
+    hipLaunchKernelGGL(k_copy<T>, dim3(nblk), dim3(PA_BLOCK), 0, c->stream, (const T*)buf[(c->h_sc->itr & 1) ^ 1],
+                       (T*)c->x_old_out, G.ncell);
   if (c->h_sc->itr & 1) {
     hipLaunchKernelGGL(k_copy<T>, dim3(nblk), dim3(PA_BLOCK), 0, c->stream, (const T*)buf[1], x, G.ncell);
   }
@@ -1398,6 +1366,9 @@ static int bicg_run_t(pa_ctx* c, T* x, const T* rhs, double tol, int64_t max_it,
                          p[cur ^ 1], v[cur ^ 1], reg0);
       used = nblk;
     }
+    if (c->x_old_out)   // after the p / v phase: its prologue has decided whether this iteration still runs
+      hipLaunchKernelGGL(k_copy_guarded<T>, dim3(nblk), dim3(PA_BLOCK), 0, c->stream, c->sc, (const T*)x,
+                         (T*)c->x_old_out, G.ncell);
     int pend0 = (fold && used <= PA_MAX_GRID) ? used : 0;
     if (!pend0) hipLaunchKernelGGL(k_bicg_post<T>, dim3(1), dim3(PA_BLOCK), 0, c->stream, c->sc, reg0, used, 0);
     Vec<T> vnv = pa_vec_self<T>(c, v[cur ^ 1]);
@@ -1442,6 +1413,13 @@ static int bicg_run_t(pa_ctx* c, T* x, const T* rhs, double tol, int64_t max_it,
 }
 
 extern "C" {
+
+int pa_solver_keep_old(pa_ctx* c, void* x_old) {
+  if (!c) return PA_E_ARG;
+  if (x_old && c->solver_live) { pa_set_err(c, "pa_solver_keep_old during a solve"); return PA_E_STATE; }
+  c->x_old_out = x_old;
+  return PA_OK;
+}
 
 int pa_cg(pa_ctx* c, void* x, const void* rhs, double tol, int64_t max_it, pa_report* out) {
   if (!c || !c->grid_set || !c->eq_set) { if (c) pa_set_err(c, "pa_cg: grid/equation not set"); return PA_E_STATE; }
@@ -1587,21 +1565,6 @@ int pa_cg_fold_set(pa_ctx* c, const int64_t* rows) {
   PA_HIP(c, hipMemsetAsync(c->rows_buf[1], 0, tot * sizeof(double), c->stream));
   for (int q = 0; q < 3; ++q) c->fold_rows[q] = (int)rows[q];
   c->slab_fold = 1;
-  c->bc_pending = c->tol_pending = 0;
-  const char* df = getenv("PYAPES_HIP_BC_DEFER");
-  c->bc_defer = (!c->bc_static && !(df && atoi(df) == 0)) ? 1 : 0;
-  if (c->bc_defer && !c->bstream) {
-    // highest priority: a stream of the default priority may share its hardware queue with the ctx stream
-    // (seen: the BC kernels then queue up behind the next phase A instead of running beside it)
-    int plo = 0, phi = 0;
-    (void)hipDeviceGetStreamPriorityRange(&plo, &phi);
-    if (hipStreamCreateWithPriority(&c->bstream, hipStreamNonBlocking, phi) != hipSuccess ||
-        hipEventCreateWithFlags(&c->ev_pb, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&c->ev_bcd, hipEventDisableTiming) != hipSuccess) {
-      (void)hipGetLastError();
-      c->bc_defer = 0;   // a local choice: the collective sequence is the same either way
-    }
-  }
   return PA_OK;
 }
 

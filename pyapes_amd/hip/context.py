@@ -250,6 +250,11 @@ class HipContext:
                                         float(nu), float(dt)))
 
     # -- solvers --------------------------------------------------------------------------
+    def keep_old(self, x_old: Tensor | None) -> None:
+        """Buffer that receives the iterate before the last executed solver iteration (Field.VARo), or None."""
+        self._keep["x_old"] = x_old
+        self._rc(self.lib.pa_solver_keep_old(self.h, self._ptr(None if x_old is None else self._field(x_old, "x_old"))))
+
     def solve(self, method: str, x: Tensor, rhs: Tensor, tol: float, max_it: int,
               omega: float = 1.0) -> L.PaReport:
         x = self._field(x, "solve")

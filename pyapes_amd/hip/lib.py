@@ -85,6 +85,7 @@ SIGNATURES: dict[str, tuple[Any, list[Any]]] = {
     "pa_rfp_friction": (C.c_int, [_VP, _VP, _VP, _VP, _VP]),
     "pa_rfp_diffusion": (C.c_int, [_VP, _VP, _VP, _VP, _VP, _VP]),
     "pa_limiter": (C.c_int, [_VP, C.c_int, _VP, _VP, _VP, C.c_int64]),
+    "pa_solver_keep_old": (C.c_int, [_VP, _VP]),
     "pa_cg": (C.c_int, [_VP, _VP, _VP, C.c_double, C.c_int64, C.POINTER(PaReport)]),
     "pa_bicgstab": (C.c_int, [_VP, _VP, _VP, C.c_double, C.c_int64, C.POINTER(PaReport)]),
     "pa_jacobi": (C.c_int, [_VP, _VP, _VP, C.c_double, C.c_int64, C.c_double, C.POINTER(PaReport)]),

@@ -10,6 +10,7 @@ from __future__ import annotations
 import warnings
 from typing import Any, Callable, TypedDict
 
+import torch
 from torch import Tensor
 
 from ..backend import require_gpu
@@ -96,10 +97,31 @@ def _run(method: str, var: Field, rhs: Tensor, eqs: dict[int, OPStype], config: 
     boundary_slicer(mesh.dim, var.bcs)
     ctx = context_for(mesh)
     terms, _ = terms_of(eqs)
+    # a callable BC value is evaluated ONCE per solve (the loops run on the device); the reference
+    # re-evaluates it with the current iterate inside every BC fill (bcs.py:203, 245).  The two agree
+    # unless the callable reads the iterate -- which is detected here and refused, not silently frozen.
+    for bc in var.bcs:
+        if bc.depends_on_var(var()):
+            raise NotImplementedError(
+                f"pyapes_amd: the callable bc_val of face '{bc.bc_face}' depends on the field it is given; the "
+                "device solvers evaluate BC callables once per solve (the reference calls them in every BC "
+                "fill, bcs.py:200-213). Use a callable of (grid, mask) only, or a tensor.")
     ctx.bind_bcs(var(), var.bcs, 0)          # the BC fill uses the solved field's own list
     ctx.set_terms(terms)
-    rep = ctx.solve(method, var()[0], rhs[0] if rhs.dim() == mesh.dim + 1 else rhs, tol, max_it,
-                    omega=float(config.get("omega", 1.0)))
+    # Field.VARo: the reference's loops call var.save_old() at the top of every iteration (linalg.py:110, 210).
+    # The device loops do that copy only on request ({"save_old": True}); otherwise VARo is marked stale and
+    # reading it raises instead of returning something the reference would not have there.
+    x_old = torch.empty_like(var()) if config.get("save_old", False) else None
+    ctx.keep_old(None if x_old is None else x_old[0])
+    try:
+        rep = ctx.solve(method, var()[0], rhs[0] if rhs.dim() == mesh.dim + 1 else rhs, tol, max_it,
+                        omega=float(config.get("omega", 1.0)))
+    finally:
+        ctx.keep_old(None)
+    if x_old is not None and rep.itr >= 1:
+        var.VARo = x_old
+    elif x_old is None:
+        var.mark_old_stale('solved on the device without {"fdm": {"save_old": True}}')
     hit_max = (rep.itr > max_it) if method != "bicgstab" else (rep.itr >= max_it and rep.tol > tol)
     if hit_max:
         warnings.warn(f"Maximum iteration reached! max_it: {max_it}", RuntimeWarning)

@@ -12,6 +12,8 @@ class FDMSolverConfig(TypedDict, total=False):
     max_it: int
     report: bool
     omega: float   # jacobi relaxation (new, default 1.0)
+    save_old: bool  # keep Field.VARo = the iterate before the last iteration, as var.save_old() in the
+                    # reference's loops does (linalg.py:110, 210); costs one extra pass per iteration
 
 
 class SolverConfig(TypedDict):

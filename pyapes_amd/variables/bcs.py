@@ -121,6 +121,8 @@ class BC:
         if isinstance(v, list):
             v = v[comp]
         if v is None:
+            # bcs.py:200, 224: Dirichlet / Neumann assert a value; Symmetry / Periodic have none
+            assert self._bc_type not in ("dirichlet", "neumann"), "BC: bc_val is not specified!"
             return 0.0, None
         if isinstance(v, (int, float)):
             return float(v), None
@@ -130,6 +132,19 @@ class BC:
             arr = v.to(device=self.device, dtype=self.dtype.float).contiguous().reshape(-1)
             return 0.0, arr
         raise TypeError(f"{self._bc_type}: bc_val must be float, int, callable, list or Tensor!")
+
+    def depends_on_var(self, var: Tensor) -> bool:
+        """Does a callable ``bc_val`` read the field it is given?  The reference calls it inside EVERY BC fill
+        with the current iterate (bcs.py:203, 245 from linalg.py:125); the device solvers evaluate it once
+        per solve, which is the same thing only if the result does not depend on ``var``.  Probed by calling
+        it on the field and on a shifted, scaled copy."""
+        v = self.bc_val
+        if not callable(v):
+            return False
+        a = v(self.mesh.grid, self.bc_mask, var, self.bc_val_opt)
+        b = v(self.mesh.grid, self.bc_mask, var * 1.5 + 0.25, self.bc_val_opt)
+        a, b = torch.as_tensor(a), torch.as_tensor(b)
+        return a.shape != b.shape or not torch.equal(a.to(b.device), b)
 
     def apply(self, var: Tensor, grid: Any, var_dim: int) -> None:
         """Fill this ONE face of component ``var_dim`` in place (bcs.py:186-194)."""

@@ -68,14 +68,24 @@ class Field(FieldArithmetic):
 
     def save_old(self) -> None:
         self._VARo = self._VAR.clone()
+        self._VARo_stale = None
 
     @property
     def VARo(self) -> Tensor:
+        """fields.py:129-136.  After a device solve without ``save_old`` the reference would hold the
+        iterate before the last iteration here; rather than hand out something else, reading it raises."""
+        why = getattr(self, "_VARo_stale", None)
+        if why:
+            raise RuntimeError(f"pyapes_amd: Field.VARo of '{self.name}' is not available: {why}")
         return self._VARo
 
     @VARo.setter
     def VARo(self, other: Tensor) -> None:
         self._VARo = other
+        self._VARo_stale = None
+
+    def mark_old_stale(self, why: str) -> None:
+        self._VARo_stale = why
 
     # -- container -------------------------------------------------------------
     @property

@@ -238,3 +238,87 @@ def test_callable_bc_with_bc_val_opt():
     assert torch.allclose(v[1:-1, -1], mesh.grid[0][1:-1, -1] * 25.0)
     assert torch.allclose(v[0, 1:-1], 4 / 3 * v[1, 1:-1] - 1 / 3 * v[2, 1:-1])
     assert torch.allclose(v[1:-1, 0], 4 / 3 * v[1:-1, 1] - 1 / 3 * v[1:-1, 2] + 2 / 3 * 1.3 * mesh.dx[1])
+
+
+# ---- Field.VARo and BC callables that read the field (round 2: the two API deviations of round 1) ----------
+def _solve_k(method, n, bcs, rhs0, K, save_old):
+    prod, _ = _cfgs(bcs)
+    mesh = Mesh(Box([0.0] * len(n), [1.0] * len(n)), None, list(n), "cuda", "double")
+    var = Field("p", 1, mesh, {"domain": prod, "obstacle": None})
+    s = Solver({"fdm": {"method": method, "tol": 1e-30, "max_it": K, "report": False, "save_old": save_old}})
+    s.set_eq(FDM().laplacian(1.0, var) == rhs0.cuda().clone())
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        rep = s.solve()
+    return var, rep
+
+
+@pytest.mark.parametrize("n", [(12, 10, 132), (9, 11, 13), (33, 40)], ids=["tiled", "generic", "2d"])
+@pytest.mark.parametrize("method", ["cg", "bicgstab", "jacobi"])
+def test_varo_is_the_iterate_before_the_last_iteration(method, n):
+    """var.save_old() opens every iteration of the reference's loops (linalg.py:110, 210), so after
+    solve() Field.VARo holds the iterate before the last executed iteration.  With {"save_old": True} the
+    device loops keep it: it must be, bit for bit, what a solve that stops one iteration earlier returns
+    (and that one is pinned to the oracle elsewhere)."""
+    bcs = [("dirichlet", 0.2), ("neumann", 0.1), ("dirichlet", 0.0), ("symmetry", None), ("dirichlet", 1.0),
+           ("neumann", 0.0)][:2 * len(n)]
+    g = torch.Generator().manual_seed(5)
+    rhs0 = torch.randn((1, *n), generator=g, dtype=torch.float64)
+    K = 7
+    var, rep = _solve_k(method, n, bcs, rhs0, K, True)
+    prev, rep_prev = _solve_k(method, n, bcs, rhs0, K - 1, False)
+    assert rep["itr"] == rep_prev["itr"] + 1
+    assert bit_equal(var.VARo, prev()), method
+    assert not bit_equal(var.VARo, var())
+    # the solve without the flag gives the same answer and a VARo that refuses to be read
+    plain, rep_plain = _solve_k(method, n, bcs, rhs0, K, False)
+    assert bit_equal(plain(), var()) and rep_plain == rep
+    with pytest.raises(RuntimeError, match="VARo"):
+        plain.VARo
+    plain.save_old()                      # the user's own save_old() makes it readable again
+    assert bit_equal(plain.VARo, plain())
+
+
+def test_bc_callable_that_reads_the_field_is_refused_by_the_solvers():
+    """The reference calls a callable bc_val inside every BC fill with the current iterate (bcs.py:203,
+    245); the device solvers evaluate it once per solve.  A callable of (grid, mask) alone -- all the
+    reference's own tests use -- is the same thing either way; one that reads ``var`` is detected and
+    raises instead of being silently frozen.  Outside the solvers (BC fill of a field) it is evaluated
+    with the field at hand, like the reference."""
+    n = [12, 14]
+    mesh = Mesh(Box[0:1, 0:1], None, n, "cuda", "double")
+    robin = lambda grid, mask, var, opt: 0.5 * var[0][torch.roll(mask, 1, 0)]   # noqa: E731  reads the field
+    bcs = [{"bc_face": f, "bc_type": "dirichlet", "bc_val": (robin if f == "xl" else 0.0), "bc_val_opt": None}
+           for f in ("xl", "xu", "yl", "yu")]
+    var = Field("p", 1, mesh, {"domain": bcs, "obstacle": None}, init_val="random")
+    assert var.bcs[0].depends_on_var(var()) and not var.bcs[1].depends_on_var(var())
+    s = Solver({"fdm": {"method": "cg", "tol": 1e-8, "max_it": 10, "report": False}})
+    s.set_eq(FDM().laplacian(1.0, var) == torch.ones_like(var()))
+    with pytest.raises(NotImplementedError, match="depends on the field"):
+        s.solve()
+    # the explicit BC fill evaluates it with the current field (oracle: literal sequential fill)
+    x0 = var().clone()
+    var.apply_bcs()
+    om = O.OMesh([0, 0], [1, 1], n, "double")
+    orc = [{"bc_face": f, "bc_type": "dirichlet",
+            "bc_val": ((lambda grid, mask, v, opt: 0.5 * v[0][torch.roll(mask, 1, 0)]) if f == "xl" else 0.0)}
+           for f in ("xl", "xu", "yl", "yu")]
+    xo = x0.cpu().clone()
+    O.bc_fill(xo, O.make_bcs(om, orc))
+    assert bit_equal(var(), xo)
+    # a callable of (grid, mask) only is accepted by the solvers
+    ok = Field("q", 1, mesh, {"domain": poisson_bcs(2), "obstacle": None})
+    s2 = Solver({"fdm": {"method": "cg", "tol": 1e-8, "max_it": 50, "report": False}})
+    s2.set_eq(FDM().laplacian(1.0, ok) == poisson_rhs_nd(mesh, ok))
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        assert s2.solve()["itr"] > 1
+
+
+def test_dirichlet_and_neumann_need_a_value_like_the_reference():
+    mesh = Mesh(Box[0:1, 0:1], None, [8, 8], "cuda", "double")
+    bcs = [{"bc_face": f, "bc_type": "dirichlet", "bc_val": (None if f == "yu" else 0.0), "bc_val_opt": None}
+           for f in ("xl", "xu", "yl", "yu")]
+    var = Field("p", 1, mesh, {"domain": bcs, "obstacle": None})
+    with pytest.raises(AssertionError, match="bc_val is not specified"):   # bcs.py:200
+        var.apply_bcs()
