@@ -79,6 +79,11 @@ typedef struct {
 /* replaces: device/dtype gate Mesh(..., device, dtype) pyapes/mesh/_mesh.py:30-44, backend.py:7-94 */
 int pa_ctx_create(int device, void* hip_stream, pa_ctx** out);
 int pa_ctx_destroy(pa_ctx* ctx);
+/* Kernel-path switches of one ctx (tests and A/B measurements; defaults from PYAPES_HIP_FASTPATH / _SF /
+ * _FOLD at pa_ctx_create): "fastpath" 0 = generic kernels only, "sf" 0 = k_cg3d instead of k_sf for the
+ * Div-carrying single-field operations, "fold" 0 = scalar steps as single-block kernels.  Results do not
+ * depend on them (bit-identical paths; tests/test_gpu_properties.py, test_gpu_fold.py). */
+int pa_ctx_set_option(pa_ctx* ctx, const char* name, int value);
 const char* pa_last_error(const pa_ctx* ctx); /* ctx may be NULL: error of the failed create */
 const char* pa_version(void);
 

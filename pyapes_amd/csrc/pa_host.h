@@ -113,6 +113,7 @@ struct pa_ctx {
   int64_t prof_n[2] = {0, 0};
   // 3-D fast path switch (PYAPES_HIP_FASTPATH=0 disables; tests compare both)
   int fastpath = 1;
+  int sf = 1;                    // k_sf for the Div-carrying single-field operations (else k_cg3d's phases)
   // RCCL communicator owned by the library (pa_comm_*): slab iterations without host work
   void* comm = nullptr;          // ncclComm_t
   // second communicator + stream: the packed plane exchange of an iteration flies beside phase B, the BC

@@ -474,8 +474,6 @@ static int launch_sf_any(pa_ctx* c, Cg3dArgs<T>& A) {
 // can k_sf take this launch?  Full 16-byte vectors only (mode 1 of cg3d_mode), scalar coefficient.
 template <typename T>
 static bool sf_applies(const pa_ctx* c, const Cg3dArgs<T>& A, int mode) {
-  static int on = -1;
-  if (on < 0) { const char* e = getenv("PYAPES_HIP_SF"); on = (e && atoi(e) == 0) ? 0 : 1; }
   // 32-bit byte offsets inside a plane
-  return on && mode == 1 && !A.coeff_f && c->G.act[0] && (size_t)c->G.s0 * sizeof(T) < ((size_t)1 << 31);
+  return c->sf && mode == 1 && !A.coeff_f && c->G.act[0] && (size_t)c->G.s0 * sizeof(T) < ((size_t)1 << 31);
 }

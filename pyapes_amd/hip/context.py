@@ -58,6 +58,10 @@ class HipContext:
         except Exception:
             pass
 
+    def set_option(self, name: str, value: bool | int) -> None:
+        """Kernel-path switch of this context ("fastpath", "sf", "fold"); results do not depend on them."""
+        self._rc(self.lib.pa_ctx_set_option(self.h, name.encode(), int(value)))
+
     def _rc(self, rc: int) -> None:
         _check(self, self.lib, rc, self.h)
 

@@ -1,7 +1,9 @@
-"""-m gpu: the reference's three demo notebooks (demos/poisson_equations/pure_dirichlet.ipynb,
-axisymmetric.ipynb, demos/advection_diffusion/ss_advection_diffusion.ipynb) with their own import
-lines (``pyapes.core.*``), made to resolve to this package by ``pyapes_amd.install_as_pyapes()`` -- the
-only edit a user makes is the device string.  Runs in a child process so the aliases do not leak."""
+"""-m gpu: the computational cells of the reference's three demo notebooks (demos/poisson_equations/
+pure_dirichlet.ipynb, axisymmetric.ipynb, demos/advection_diffusion/ss_advection_diffusion.ipynb),
+CONDENSED: their own import lines (``pyapes.core.*``) and call sequences, plotting dropped, the BC
+lambdas inlined, asserts on the numbers the notebooks print added.  The imports resolve to this package
+through ``pyapes_amd.install_as_pyapes()``; the one edit a user makes is the device string.  Runs in a
+child process so the aliases do not leak.  (Not the .ipynb files themselves: those cannot travel.)"""
 import os
 import subprocess
 import sys

@@ -21,16 +21,18 @@ from pyapes_amd.variables.bcs import homogeneous_bcs, mixed_bcs
 
 
 def _fixed_cg(mesh, bcs, rhs, K, fast=True):
-    os.environ["PYAPES_HIP_FASTPATH"] = "1" if fast else "0"
-    mesh._hip = None                                   # fresh ctx picks the switch up
-    var = Field("p", 1, mesh, {"domain": bcs, "obstacle": None})
-    solver = Solver({"fdm": {"method": "cg", "tol": -1.0, "max_it": K - 1, "report": False}})
-    solver.set_eq(FDM().laplacian(1.0, var) == rhs.clone())
-    with warnings.catch_warnings():
-        warnings.simplefilter("ignore")
-        rep = solver.solve()
-    os.environ.pop("PYAPES_HIP_FASTPATH", None)
-    mesh._hip = None
+    from pyapes_amd.hip.context import context_for
+    ctx = context_for(mesh)
+    ctx.set_option("fastpath", fast)                   # tiled kernels, or the generic ones
+    try:
+        var = Field("p", 1, mesh, {"domain": bcs, "obstacle": None})
+        solver = Solver({"fdm": {"method": "cg", "tol": -1.0, "max_it": K - 1, "report": False}})
+        solver.set_eq(FDM().laplacian(1.0, var) == rhs.clone())
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            rep = solver.solve()
+    finally:
+        ctx.set_option("fastpath", True)
     return var(), rep
 
 
@@ -96,7 +98,7 @@ def test_full_size_fast_equals_generic_and_is_deterministic(workload):
     rhs = torch.randn((1, *n), generator=g, dtype=mesh.dtype.float, device="cuda")
     if workload.startswith("c3"):
         rhs -= rhs.mean()
-    K = 4
+    K = 12
     xf, rf = _fixed_cg(mesh, bcs, rhs, K, True)
     xf2, rf2 = _fixed_cg(mesh, bcs, rhs, K, True)
     assert torch.equal(xf, xf2) and rf["tol"] == rf2["tol"], "fused CG is not run-to-run deterministic"
@@ -106,3 +108,48 @@ def test_full_size_fast_equals_generic_and_is_deterministic(workload):
     rel = float(torch.linalg.norm((xf - xg).double()) / torch.linalg.norm(xg.double()))
     assert rel <= (1e-12 if dtype == "double" else 1e-5), rel
     assert abs(rf["tol"] - rg["tol"]) <= (1e-10 if dtype == "double" else 1e-4) * abs(rg["tol"])
+
+
+@pytest.mark.parametrize("speed", ["scalar", "tensor"])
+def test_c4_256_f32_euler_march_full_size(speed):
+    """BASELINE config 4 at its full size: 256^3 fp32, Div(upwind) + Laplacian explicit Euler march,
+    Neumann (x) / Symmetry (y, z).  The three kernel paths -- k_sf, k_cg3d's Euler phase, the generic kernel --
+    must give the same bits after 30 steps; and the scheme's own properties hold: with u >= 0, nu dt /dx^2
+    and u dt / dx inside the monotone range the update is a convex combination of neighbours (discrete
+    maximum principle: no new extrema), a constant state stays constant."""
+    from pyapes_amd.hip.context import context_for
+    from pyapes_amd.solver.march import euler_march
+    n = 256
+    mesh = Mesh(Box[0:1, 0:1, 0:1], None, [n, n, n], "cuda", "single")
+    bcs = mixed_bcs([0.0, 0.0, None, None, None, None], ["neumann", "neumann", "symmetry", "symmetry", "symmetry", "symmetry"])
+    phi0 = torch.exp(-((mesh.X - 0.5) ** 2 + (mesh.Y - 0.5) ** 2 + (mesh.Z - 0.5) ** 2) / 0.02).unsqueeze(0).contiguous()
+    u = 1.0 if speed == "scalar" else (0.25 + 0.75 * torch.rand((1, n, n, n), device="cuda", dtype=torch.float32,
+                                                                generator=torch.Generator(device="cuda").manual_seed(1)))
+    nu, dx = 1e-3, mesh.dx_list[0]
+    dt = 0.2 * min(dx * dx / (6 * nu), dx / 1.0)
+    cfg = {"div": {"limiter": "upwind"}}
+    ctx = context_for(mesh)
+    out = {}
+    for path, (fast, sf) in {"k_sf": (True, True), "k_cg3d": (True, False), "generic": (False, False)}.items():
+        ctx.set_option("fastpath", fast)
+        ctx.set_option("sf", sf)
+        try:
+            phi = Field("phi", 1, mesh, {"domain": bcs, "obstacle": None})
+            phi.set_var_tensor(phi0.clone())
+            phi.apply_bcs()
+            euler_march(phi, u, nu, dt, 30, cfg)
+            out[path] = phi().clone()
+        finally:
+            ctx.set_option("fastpath", True)
+            ctx.set_option("sf", True)
+    assert torch.equal(out["k_sf"], out["k_cg3d"]) and torch.equal(out["k_sf"], out["generic"])
+    x = out["k_sf"]
+    assert bool(torch.isfinite(x).all())
+    assert float(x.max()) <= float(phi0.max()) * (1 + 1e-6) and float(x.min()) >= -1e-6, (float(x.max()), float(x.min()))
+    assert float(x.max()) < float(phi0.max())          # it did diffuse / move
+    const = Field("c", 1, mesh, {"domain": bcs, "obstacle": None})
+    const.set_var_tensor(torch.full_like(phi0, 0.7))
+    const.apply_bcs()
+    euler_march(const, u, nu, dt, 10, cfg)
+    # (not to the last bit: the Neumann fill 4/3 p - 1/3 p rounds, bcs.py:246-253)
+    assert float((const() - 0.7).abs().max()) <= 2e-6
