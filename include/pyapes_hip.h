@@ -84,6 +84,10 @@ int pa_ctx_destroy(pa_ctx* ctx);
  * Div-carrying single-field operations, "fold" 0 = scalar steps as single-block kernels.  Results do not
  * depend on them (bit-identical paths; tests/test_gpu_properties.py, test_gpu_fold.py). */
 int pa_ctx_set_option(pa_ctx* ctx, const char* name, int value);
+/* The stream every later call enqueues on (the binding passes torch's CURRENT stream before each call, so
+ * that work the caller queued on it -- tensor allocation, input preparation -- is ordered before the
+ * kernels).  Refused while a stepwise solve is live on another stream. */
+int pa_ctx_set_stream(pa_ctx* ctx, void* hip_stream);
 const char* pa_last_error(const pa_ctx* ctx); /* ctx may be NULL: error of the failed create */
 const char* pa_version(void);
 
@@ -241,6 +245,9 @@ int pa_cg_finish_iter(pa_ctx* ctx);
  * returns, so pa_report_read / pa_cg_end see the same state as after n x { phase_a, phase_b }. */
 int pa_cg_iterate(pa_ctx* ctx, int64_t n);
 int pa_cg_end(pa_ctx* ctx, pa_report* out);       /* synchronises */
+int pa_cg_abort(pa_ctx* ctx);                     /* drop the live stepwise solve (no read-back) */
+/* While a stepwise solve is live (pa_cg_begin ... pa_cg_end / pa_cg_abort) pa_bc_clear, pa_bc_set and
+ * pa_eq_set return PA_E_STATE: every phase re-reads that state. */
 int pa_report_read(pa_ctx* ctx, pa_report* out);  /* synchronises */
 
 /* ---- RCCL inside the library (slab mode, SURVEY 8e: "pa_comm_init(ctx, rank, nranks, rccl_unique_id)") --

@@ -270,6 +270,7 @@ int pa_cg_iterate_comm(pa_ctx* c, int64_t n) {
   if (!c || !c->solver_live) { if (c) pa_set_err(c, "pa_cg_iterate_comm without pa_cg_begin"); return PA_E_STATE; }
   if (!c->slab || !c->ext_sums) { pa_set_err(c, "pa_cg_iterate_comm needs slab mode (pa_slab_set)"); return PA_E_STATE; }
   if (!c->comm || !c->plan_set) { pa_set_err(c, "pa_cg_iterate_comm needs pa_comm_init + pa_comm_plan"); return PA_E_STATE; }
+  PA_HIP(c, hipSetDevice(c->device));
   Rccl* R = rccl();
   ncclComm_t comm = (ncclComm_t)c->comm;
   double* sums = c->ext_sums;

@@ -226,6 +226,16 @@ int pa_ctx_create(int device, void* hip_stream, pa_ctx** out) {
   return PA_OK;
 }
 
+int pa_ctx_set_stream(pa_ctx* c, void* hip_stream) {
+  if (!c) return PA_E_ARG;
+  if (c->solver_live && (hipStream_t)hip_stream != c->stream) {
+    pa_set_err(c, "pa_ctx_set_stream during a stepwise solve");
+    return PA_E_STATE;
+  }
+  c->stream = (hipStream_t)hip_stream;
+  return PA_OK;
+}
+
 int pa_ctx_set_option(pa_ctx* c, const char* name, int value) {
   if (!c || !name) return PA_E_ARG;
   if (c->solver_live) { pa_set_err(c, "pa_ctx_set_option during a solve"); return PA_E_STATE; }
@@ -324,8 +334,17 @@ int pa_coord_set(pa_ctx* c, int coord_sys, const void* r_nodes) {
   return PA_OK;
 }
 
+// The BC list and the equation are read again by every phase of a live stepwise solve (pa_cg_begin ...
+// pa_cg_end): changing them in between would silently change the fill and the stencil of the running solve.
+static int pa_refuse_live(pa_ctx* c, const char* what) {
+  if (!c->solver_live) return PA_OK;
+  pa_set_err(c, "%s during a stepwise solve (pa_cg_begin ... pa_cg_end); end or abort it first", what);
+  return PA_E_STATE;
+}
+
 int pa_bc_clear(pa_ctx* c) {
   if (!c || !c->grid_set) return PA_E_STATE;
+  if (int rl = pa_refuse_live(c, "pa_bc_clear")) return rl;
   for (int f = 0; f < 6; ++f) c->bc[f] = HostBC();
   c->nbc = 0;
   pa_refresh_geom(c);
@@ -334,6 +353,7 @@ int pa_bc_clear(pa_ctx* c) {
 
 int pa_bc_set(pa_ctx* c, int face, int order_pos, int type, double value, const void* face_vals, double dxf) {
   if (!c || !c->grid_set) { if (c) pa_set_err(c, "pa_bc_set before pa_grid_set"); return PA_E_STATE; }
+  if (int rl = pa_refuse_live(c, "pa_bc_set")) return rl;
   if (face < 0 || face >= 2 * c->ndim) { pa_set_err(c, "pa_bc_set: face %d outside a %d-D mesh", face, c->ndim); return PA_E_ARG; }
   if (order_pos < 0 || order_pos >= 6) { pa_set_err(c, "pa_bc_set: bad order_pos"); return PA_E_ARG; }
   if (type < PA_BC_NONE || type > PA_BC_PERIODIC) { pa_set_err(c, "pa_bc_set: bad type"); return PA_E_ARG; }
@@ -348,6 +368,7 @@ int pa_bc_set(pa_ctx* c, int face, int order_pos, int type, double value, const 
 
 int pa_eq_set(pa_ctx* c, int nterms, const pa_term* terms) {
   if (!c || !c->grid_set) { if (c) pa_set_err(c, "pa_eq_set before pa_grid_set"); return PA_E_STATE; }
+  if (int rl = pa_refuse_live(c, "pa_eq_set")) return rl;
   if (nterms < 1 || nterms > PA_MAX_TERMS) { pa_set_err(c, "pa_eq_set: 1..%d terms", PA_MAX_TERMS); return PA_E_ARG; }
   for (int q = 0; q < nterms; ++q) {
     int k = terms[q].kind;

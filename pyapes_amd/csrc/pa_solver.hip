@@ -1427,8 +1427,10 @@ int pa_cg(pa_ctx* c, void* x, const void* rhs, double tol, int64_t max_it, pa_re
   if (!out) return PA_E_ARG;
   if (c->slab) { pa_set_err(c, "pa_cg is the single-GPU loop; use the stepwise API on a slab"); return PA_E_STATE; }
   PA_HIP(c, hipSetDevice(c->device));
-  return c->dtype == PA_F64 ? cg_run_t<double>(c, (double*)x, (const double*)rhs, tol, max_it, out)
-                            : cg_run_t<float>(c, (float*)x, (const float*)rhs, tol, max_it, out);
+  const int rc = c->dtype == PA_F64 ? cg_run_t<double>(c, (double*)x, (const double*)rhs, tol, max_it, out)
+                                    : cg_run_t<float>(c, (float*)x, (const float*)rhs, tol, max_it, out);
+  c->solver_live = 0;   // also on the error paths: a failed one-shot solve must not lock the BC / equation state
+  return rc;
 }
 
 int pa_bicgstab(pa_ctx* c, void* x, const void* rhs, double tol, int64_t max_it, pa_report* out) {
@@ -1488,12 +1490,14 @@ int pa_cg_begin(pa_ctx* c, void* x, const void* rhs, double tol, int64_t max_it)
 
 int pa_cg_phase_a(pa_ctx* c) {
   if (!c || !c->solver_live) { if (c) pa_set_err(c, "pa_cg_phase_a without pa_cg_begin"); return PA_E_STATE; }
+  PA_HIP(c, hipSetDevice(c->device));
   const int st = c->slab ? 0 : 2;
   return c->dtype == PA_F64 ? pa_cg_phase_a_t<double>(c, st) : pa_cg_phase_a_t<float>(c, st);
 }
 
 int pa_cg_phase_b(pa_ctx* c) {
   if (!c || !c->solver_live) { if (c) pa_set_err(c, "pa_cg_phase_b without pa_cg_begin"); return PA_E_STATE; }
+  PA_HIP(c, hipSetDevice(c->device));
   if (c->slab && !c->slab_fold_live) {  // alpha from the all-reduced sum d.Ad
     if (c->dtype == PA_F64)
       hipLaunchKernelGGL(k_cg_post_a<double>, dim3(1), dim3(PA_BLOCK), 0, c->stream, c->sc, (const double*)nullptr, 0, pa_sums(c), 1);
@@ -1506,12 +1510,14 @@ int pa_cg_phase_b(pa_ctx* c) {
 
 int pa_cg_bc(pa_ctx* c) {
   if (!c || !c->solver_live) { if (c) pa_set_err(c, "pa_cg_bc without pa_cg_begin"); return PA_E_STATE; }
+  PA_HIP(c, hipSetDevice(c->device));
   if (!c->slab) return PA_OK;  // done inside phase_b
   return c->dtype == PA_F64 ? pa_cg_bc_t<double>(c) : pa_cg_bc_t<float>(c);
 }
 
 int pa_cg_finish_iter(pa_ctx* c) {
   if (!c || !c->solver_live) { if (c) pa_set_err(c, "pa_cg_finish_iter without pa_cg_begin"); return PA_E_STATE; }
+  PA_HIP(c, hipSetDevice(c->device));
   if (!c->slab || c->slab_fold_live) return PA_OK;  // logic already ran inside phase_b / runs in the next prologue
   if (c->dtype == PA_F64)
     hipLaunchKernelGGL(k_cg_post_b<double>, dim3(1), dim3(PA_BLOCK), 0, c->stream, c->sc, (const double*)nullptr, 0,
@@ -1570,6 +1576,7 @@ int pa_cg_fold_set(pa_ctx* c, const int64_t* rows) {
 
 int pa_cg_iterate(pa_ctx* c, int64_t n) {
   if (!c || !c->solver_live) { if (c) pa_set_err(c, "pa_cg_iterate without pa_cg_begin"); return PA_E_STATE; }
+  PA_HIP(c, hipSetDevice(c->device));
   if (c->slab) { pa_set_err(c, "pa_cg_iterate is single-rank; drive the phases on a slab"); return PA_E_STATE; }
   c->in_iterate = 1;
   int rc = PA_OK;
@@ -1609,8 +1616,18 @@ int pa_report_read(pa_ctx* c, pa_report* out) {
   return PA_OK;
 }
 
+int pa_cg_abort(pa_ctx* c) {   // drop a stepwise solve without reading it back (error paths of a host driver)
+  if (!c) return PA_E_ARG;
+  c->solver_live = 0;
+  c->in_iterate = c->slab_fold_live = 0;
+  c->fold_a_n = c->fold_b_n = c->fold_b_nsh = 0;
+  c->fold_b_shell = nullptr;
+  return PA_OK;
+}
+
 int pa_cg_end(pa_ctx* c, pa_report* out) {
   if (!c || !c->solver_live) { if (c) pa_set_err(c, "pa_cg_end without pa_cg_begin"); return PA_E_STATE; }
+  PA_HIP(c, hipSetDevice(c->device));
   int rc = out ? pa_report_read(c, out) : PA_OK;
   c->solver_live = 0;
   if (rc) return rc;

@@ -65,11 +65,20 @@ class HipContext:
     def _rc(self, rc: int) -> None:
         _check(self, self.lib, rc, self.h)
 
+    def use_current_stream(self) -> None:
+        """Enqueue on torch's CURRENT stream of the mesh device (called at the top of the public entry points:
+        tensors the caller just made on that stream are then ordered before the kernels that read them)."""
+        cur = torch.cuda.current_stream(self.device)
+        if cur.cuda_stream != self.stream.cuda_stream:
+            self._rc(self.lib.pa_ctx_set_stream(self.h, C.c_void_p(cur.cuda_stream)))
+            self.stream = cur
+
     def _ptr(self, t: Tensor | None) -> C.c_void_p:
         return C.c_void_p(0 if t is None else t.data_ptr())
 
     def _field(self, t: Tensor, what: str) -> Tensor:
         """a contiguous scalar field view ``(*nx)`` of the mesh dtype on the GPU"""
+        self.use_current_stream()
         require_gpu(t, what)
         if t.dtype != self.dtype:
             raise TypeError(f"pyapes_amd: {what}: tensor dtype {t.dtype} != mesh dtype {self.dtype}")
@@ -82,6 +91,7 @@ class HipContext:
     # -- boundary conditions -----------------------------------------------------
     def bind_bcs(self, var: Tensor, bcs: Sequence[Any], comp: int = 0, for_rhs: bool = False) -> None:
         """(Re)load the ordered BC list for component ``comp`` of ``var`` ((dim,*nx) tensor)."""
+        self.use_current_stream()
         self._rc(self.lib.pa_bc_clear(self.h))
         keep = []
         for pos, bc in enumerate(bcs):
@@ -107,6 +117,7 @@ class HipContext:
     # -- equation -------------------------------------------------------------------
     def set_terms(self, terms: Sequence[dict]) -> None:
         """terms: dicts with kind, sign, coeff (None|float|Tensor), u (float|Tensor)."""
+        self.use_current_stream()
         arr = (L.PaTerm * len(terms))()
         keep = []
         for q, t in enumerate(terms):
@@ -299,6 +310,10 @@ class HipContext:
 
     def cg_finish_iter(self) -> None:
         self._rc(self.lib.pa_cg_finish_iter(self.h))
+
+    def cg_abort(self) -> None:
+        self._rc(self.lib.pa_cg_abort(self.h))
+        self._keep.pop("cg", None)
 
     def cg_end(self) -> L.PaReport:
         rep = L.PaReport()
