@@ -27,7 +27,7 @@ int pa_tile3d_euler(pa_ctx* c, Vec<T> phi, T* out, int kind, double u, const voi
     A.out_all = faces == 2 * c->ndim ? 1 : 0;
   }
   int n = 0;
-  if (sf_applies<T>(c, A, mode)) {
+  if (sf_applies<T, 3>(c, A, mode)) {
     switch (kind) {
       case PA_OP_DIV_CENTRAL: n = launch_sf_any<T, 3, PA_OP_DIV_CENTRAL>(c, A); break;
       case PA_OP_DIV_UPWIND_COMPAT: n = launch_sf_any<T, 3, PA_OP_DIV_UPWIND_COMPAT>(c, A); break;
@@ -51,7 +51,9 @@ int pa_tile3d_aop(pa_ctx* c, const DevEq<T>& E, Vec<T> x, T* y, int interior_onl
   A.d = x; A.out = y; A.interior_only = interior_only;
   if (A.lap_off) A.aux = E.t[0].u_f;  // explicit upwind Div with a speed field (null: scalar speed)
   int n = 0;
-  if (A.kind != 0 && sf_applies<T>(c, A, mode)) {   // the Laplacian alone: k_cg3d sits at copy speed already
+  // the Laplacian alone stays on k_cg3d: both kernels move it at the speed of a device copy (512^3 fp64
+  // 0.416 vs 0.423 ms, fp32 0.192 vs 0.200; a copy: 0.414 / 0.200), as they do the gradient
+  if (A.kind != 0 && sf_applies<T, 2>(c, A, mode)) {
     switch (A.kind) {   // Laplacian + Div, or the Div term alone (lap_off)
       case PA_OP_DIV_CENTRAL: n = launch_sf_any<T, 2, PA_OP_DIV_CENTRAL>(c, A); break;
       case PA_OP_DIV_UPWIND_COMPAT: n = launch_sf_any<T, 2, PA_OP_DIV_UPWIND_COMPAT>(c, A); break;

@@ -1,9 +1,10 @@
-// pa_sf_kernel.h -- k_sf, the marching kernel of the SINGLE-FIELD operations: A x (explicit Laplacian,
-// Div, Laplacian + Div), the explicit Euler step, the explicit gradient.  These move 8-24 bytes per cell,
-// a third of a CG phase, so what bounds them is not HBM but how well instruction issue overlaps the loads:
-// k_cg3d (pa_cg3d_kernel.h) stages every plane in LDS behind a workgroup barrier and needs ~250 VGPRs at
-// four rows per thread, i.e. two waves per SIMD that advance in lock step -- its explicit Euler step sits at
-// 0.5 of the HBM roofline whatever the tile height or the number of workgroups per CU.
+// pa_sf_kernel.h -- k_sf, the marching kernel of the instruction-heavy SINGLE-FIELD operations: everything
+// with a Div term -- the explicit Euler step, Div, Laplacian + Div.  These move 8-24 bytes per cell, a third of
+// a CG phase, and carry 2-3 times its arithmetic (no FMA: every product and sum is rounded separately), so
+// what bounds them is instruction issue and how well it overlaps the loads.  k_cg3d (pa_cg3d_kernel.h) stages
+// every plane in LDS behind a workgroup barrier and needs ~250 VGPRs at four rows per thread -- two waves per
+// SIMD advancing in lock step; its Euler step ran at 0.49 of the HBM roofline whatever the tile height or the
+// number of workgroups per CU, 46 VALU instructions per cell.
 //
 // Here every WAVE marches on its own: no LDS, no barrier.
 //   * A wave owns RJ rows x 64 lanes x VEC cells (VEC = 16 B / sizeof(T): one 16-byte lane access per row,
@@ -12,14 +13,16 @@
 //     nothing is ever rotated).
 //   * j +- 1 across the wave's row block: the two rows above / below are loaded by the wave itself.  They
 //     are the neighbour wave's own rows, at the same time on the same XCD (blockIdx -> tile is XCD-aware):
-//     L2 hits, no HBM traffic.
+//     L2 hits, 8.2 B of HBM traffic per cell measured against 8 algorithmic.
 //   * k +- 1 across lanes: one DPP move per row and side (v_mov_b32 wave_shr:1 / wave_shl:1); lane 0 / 63
 //     keep the cell left / right of the tile, which every lane loads with one (uniform-address) access.
-//   * loads run two planes ahead of the arithmetic; ~120 VGPRs -> four waves per SIMD that drift freely, so
-//     one wave's stencil covers another's wait.
-// Arithmetic: the row expressions of k_cg3d's VROW path, operation for operation (every product and sum
-// rounded separately, -ffp-contract=off), so results are bit-identical to it, to the generic kernels and to
-// the oracle (tests/test_gpu_tiled_ops.py, test_gpu_parity_golden.py).
+//   * loads run two planes ahead of the arithmetic, and the code between their issue and their use is free
+//     of branches (see `plane`): that is what lets the compiler wait with vmcnt(N > 0).
+// Result (MI355X): explicit Euler step 512^3 fp32 273 -> 209 us (0.64 of the 8 TB/s roofline; a plain device
+// copy of the array: 0.66), 256^3 (BASELINE config 4) 38.7 -> 28.3 us; upwind Div fp64 512^3 553 -> 428 us.
+// Arithmetic: the row expressions of k_cg3d's VROW path, operation for operation (-ffp-contract=off), so
+// results are bit-identical to it, to the generic kernels and to the oracle (tests/test_gpu_tiled_ops.py,
+// test_gpu_parity_golden.py, test_gpu_properties.py).
 #pragma once
 #include "pa_cg3d_kernel.h"
 
@@ -56,12 +59,12 @@ template <> struct SfBits<double> {
 // PHASE 7: explicit gradient
 // HASU: the advection speed is a field (read at the cell)
 //
-// Instruction economy is the point of this kernel (a wave64 VALU instruction occupies its SIMD for four
-// cycles whatever it does, and the first version spent 3/4 of them on bookkeeping): in-plane positions are
-// 32-bit byte offsets added to a uniform plane pointer (scalar-base addressing, no 64-bit per-lane
-// arithmetic), everything that does not change from plane to plane -- row / column coefficients, masks,
-// u+ / u- of a scalar speed -- is formed once in front of the loop, and the interior-set select of the
-// output disappears where the caller overwrites the nodes outside it anyway (out_all).
+// Instruction economy (a wave64 VALU instruction occupies its SIMD for four cycles whatever it does): in-plane
+// positions are 32-bit byte offsets added to a uniform plane pointer, everything that does not change from
+// plane to plane -- row / column coefficients, masks, u+ / u- of a scalar speed -- is formed once in front of
+// the loop, planes beside an axis-0 face take a second copy of the body so that the common one has no
+// coefficient selects, and there is no interior-set select: k_sf only takes launches whose output is wanted
+// at every node (sf_applies).
 template <typename T, int RJ, int PHASE, int KIND, bool HASU>
 __global__ void __launch_bounds__(256) k_sf(Cg3dArgs<T> A) {
   constexpr int VEC = VecOf<T>::N;
@@ -88,7 +91,7 @@ __global__ void __launch_bounds__(256) k_sf(Cg3dArgs<T> A) {
   const bool kvalid = kg < n2;
   unsigned off[RJ], offe[RJ];
   const int ecol = lane == 63 ? wrap(k0 + TK, n2) : wrap(k0 - 1, n2);   // lane 0: cell left of the tile, 63: right
-  bool rowOk[RJ], rowS[RJ];
+  bool rowOk[RJ];
   T cPj[RJ], cCj[RJ], cMj[RJ];     // Laplacian rows along j (uniform per row)
   T gPj[RJ], gCj[RJ], gMj[RJ];     // gradient rows along j
   bool rPLo[RJ], rPHi[RJ];
@@ -99,7 +102,6 @@ __global__ void __launch_bounds__(256) k_sf(Cg3dArgs<T> A) {
     off[jj] = (ro + (unsigned)kc) * (unsigned)sizeof(T);
     offe[jj] = (ro + (unsigned)ecol) * (unsigned)sizeof(T);
     rowOk[jj] = kvalid && jg < n1;
-    rowS[jj] = jg < n1 && jg >= G.slo[1] && jg <= G.shi[1];
     const int rc = pa_row_case(G, 1, jg, G.n1, G.treat);
     cPj[jj] = A.lap.inv[1]; cCj[jj] = A.lap.m2inv[1]; cMj[jj] = A.lap.inv[1];
     if (rc == 1) { cPj[jj] = A.lap.c23[1]; cCj[jj] = -A.lap.c23[1]; cMj[jj] = (T)0; }
@@ -116,12 +118,11 @@ __global__ void __launch_bounds__(256) k_sf(Cg3dArgs<T> A) {
   }
   const unsigned offu = ((unsigned)wrap(j0 - 1, n1) * (unsigned)n2 + (unsigned)kc) * (unsigned)sizeof(T);
   const unsigned offd = ((unsigned)wrap(j0 + RJ, n1) * (unsigned)n2 + (unsigned)kc) * (unsigned)sizeof(T);
-  bool colS[VEC], cPLo[VEC], cPHi[VEC];
+  bool cPLo[VEC], cPHi[VEC];
   V cPkV, cCkV, cMkV, gPkV, gCkV, gMkV;
 #pragma unroll
   for (int v = 0; v < VEC; ++v) {
     const int kk = kg + v;
-    colS[v] = kvalid && kk >= G.slo[2] && kk <= G.shi[2];
     const int rc = pa_row_case(G, 2, kk, G.n2, G.treat);
     T p = A.lap.inv[2], c0 = A.lap.m2inv[2], mq = A.lap.inv[2];
     if (rc == 1) { p = A.lap.c23[2]; c0 = -A.lap.c23[2]; mq = (T)0; }
@@ -139,8 +140,20 @@ __global__ void __launch_bounds__(256) k_sf(Cg3dArgs<T> A) {
     }
   }
   const size_t pstride = (size_t)G.s0 * sizeof(T);
-  auto plane = [&](int ii) -> const char* {   // uniform
-    return ii < 0 ? (const char*)A.d.glo : (ii >= n0 ? (const char*)A.d.ghi : (const char*)A.d.p + (size_t)ii * pstride);
+  // Uniform and BRANCH-FREE: with a branch between the issue of a load and its use the compiler's waitcnt
+  // pass loses count of what is outstanding and falls back to s_waitcnt vmcnt(0) right behind the loads --
+  // the two-plane software pipeline is then gone without a word (seen: 240 -> 279 us at 512^3 fp32).  For
+  // the same reason every load below is unconditional, on a clamped plane index.
+  // (integer selects lose the address space: the result is cast back to a GLOBAL pointer explicitly, or the
+  // loads become flat_load, which also count on lgkmcnt)
+  typedef const char __attribute__((address_space(1))) * gcptr;
+  auto plane = [&](int ii) -> gcptr {
+    const int ic = ii < 0 ? 0 : (ii >= n0 ? n0 - 1 : ii);
+    uintptr_t u = (uintptr_t)A.d.p + (size_t)(unsigned)ic * pstride;
+    const uintptr_t mlo = (uintptr_t)0 - (uintptr_t)(ii < 0), mhi = (uintptr_t)0 - (uintptr_t)(ii >= n0);
+    u = (u & ~mlo) | ((uintptr_t)A.d.glo & mlo);
+    u = (u & ~mhi) | ((uintptr_t)A.d.ghi & mhi);
+    return (gcptr)u;
   };
 
   // scalar speed: u+ / u- (upwind) or the three rows (literal upwind) once
@@ -159,17 +172,17 @@ __global__ void __launch_bounds__(256) k_sf(Cg3dArgs<T> A) {
 
   auto load_own = [&](auto SLOT, int ii) {
     constexpr int s = decltype(SLOT)::value;
-    const char* p = plane(ii);
+    gcptr p = plane(ii);
 #pragma unroll
-    for (int jj = 0; jj < RJ; ++jj) P[s][jj] = *reinterpret_cast<const V*>(p + off[jj]);
+    for (int jj = 0; jj < RJ; ++jj) P[s][jj] = *reinterpret_cast<const V __attribute__((address_space(1)))*>(p + off[jj]);
   };
   auto load_halo = [&](auto SLOT, int ii) {
     constexpr int s = decltype(SLOT)::value;
-    const char* p = plane(ii);
-    Hu[s] = *reinterpret_cast<const V*>(p + offu);
-    Hd[s] = *reinterpret_cast<const V*>(p + offd);
+    gcptr p = plane(ii);
+    Hu[s] = *reinterpret_cast<const V __attribute__((address_space(1)))*>(p + offu);
+    Hd[s] = *reinterpret_cast<const V __attribute__((address_space(1)))*>(p + offd);
 #pragma unroll
-    for (int jj = 0; jj < RJ; ++jj) He[s][jj] = *reinterpret_cast<const T*>(p + offe[jj]);
+    for (int jj = 0; jj < RJ; ++jj) He[s][jj] = *reinterpret_cast<const T __attribute__((address_space(1)))*>(p + offe[jj]);
     if constexpr (HASU) {
       const char* pu = (const char*)A.aux + (size_t)ii * pstride;
 #pragma unroll
@@ -186,11 +199,13 @@ __global__ void __launch_bounds__(256) k_sf(Cg3dArgs<T> A) {
   load_own(I1{}, i0);
   load_halo(I0{}, i0);
   load_own(I2{}, i0 + 1);   // also for a chunk of one plane: the next chunk's first plane / the ghost
-  if (CI > 1) load_halo(I1{}, i0 + 1);
+  load_halo(I1{}, i0 + 1 < i1 ? i0 + 1 : i1 - 1);
 
   const T sgn = A.sign;
   const T cf = A.has_coeff ? A.coeff : (T)1;   // x * 1 is x: no select in the loop
-  const bool out_all = PHASE == 3 ? A.out_all != 0 : (PHASE == 2 ? A.interior_only == 0 : true);
+  // k_sf writes the operator's value at EVERY node: the Euler step where the caller's BC fill rewrites all
+  // nodes outside the interior set (out_all), A x without interior_only.  The masked forms stay on k_cg3d
+  // (sf_applies), so the loop carries no interior-set select at all.
   const int gcomp0 = A.gnd - 3;
 
   // one plane: C = q & 3 (q = chunk-relative plane index); slots behind C, current C+1, ahead C+2, loading C+3
@@ -199,8 +214,11 @@ __global__ void __launch_bounds__(256) k_sf(Cg3dArgs<T> A) {
     constexpr int SB = C & 3, SC = (C + 1) & 3, SA = (C + 2) & 3, SL = (C + 3) & 3, HC = C & 3, HN = (C + 2) & 3;
     const int ii = i0 + q;
     // loads for later planes first: they fly during this plane's arithmetic
-    if (q + 2 <= CI) load_own(std::integral_constant<int, SL>{}, ii + 2);
-    if (q + 2 < CI) load_halo(std::integral_constant<int, HN>{}, ii + 2);
+    load_own(std::integral_constant<int, SL>{}, ii + 2 <= i1 ? ii + 2 : i1);          // plane q + 2 (<= the one behind the chunk)
+    load_halo(std::integral_constant<int, HN>{}, ii + 2 < i1 ? ii + 2 : i1 - 1);
+    // keep them HERE: left to itself the scheduler sinks these loads to just above their first use two planes
+    // later (shorter live ranges, 163 -> 116 VGPRs) and the software pipeline is gone (512^3 fp32: 240 -> 279 us)
+    __builtin_amdgcn_sched_barrier(0);
 
     // the planes next to an axis-0 face carry other coefficients (and the first / last plane may lie outside
     // the interior set): they take the same code with the values selected; every other plane takes it with
@@ -209,11 +227,9 @@ __global__ void __launch_bounds__(256) k_sf(Cg3dArgs<T> A) {
     const int rci = pa_row_case(G, 0, gi, G.g0, G.treat);
     const bool iPLo_ = G.bct[0] == 4 && gi == 1;
     const bool iPHi_ = G.bct[1] == 4 && gi == G.g0 - 2;
-    const bool iS_ = gi >= G.slo[0] && gi <= G.shi[0];
     char* const po = (char*)A.out + (size_t)ii * pstride;
     auto body = [&](auto PLAINC) {
     constexpr bool PLAIN = decltype(PLAINC)::value;
-    const bool iS = PLAIN ? true : iS_;
     const bool iPLo = PLAIN ? false : iPLo_, iPHi = PLAIN ? false : iPHi_;
     T cPi = A.lap.inv[0], cCi = A.lap.m2inv[0], cMi = A.lap.inv[0];
     T gP0 = A.grd.g[0], gC0 = (T)0, gM0 = A.grd.mg[0];
@@ -287,8 +303,10 @@ __global__ void __launch_bounds__(256) k_sf(Cg3dArgs<T> A) {
           mm = cMkV * xmk;
           s = s + mm;
           axv = axv + s;
-          axv = axv * cf;
-          axv = axv * sgn;
+          if (PHASE != 3) {   // the Euler step's Laplacian: no coefficient, sign +1 (pa_tile3d_euler); x * 1 is x
+            axv = axv * cf;
+            axv = axv * sgn;
+          }
         }
         V adv = (V)(T)0;
         if constexpr (DIV) {
@@ -372,19 +390,11 @@ __global__ void __launch_bounds__(256) k_sf(Cg3dArgs<T> A) {
         } else {
           res = axv;
         }
-        if (!out_all) {   // nodes outside the interior set: phi itself (Euler) / zero (A x on S only)
-          const bool rs = iS && rowS[jj];
-#pragma unroll
-          for (int v = 0; v < VEC; ++v) {
-            const bool inS = rs && colS[v];
-            res[v] = inS ? res[v] : (PHASE == 3 ? xc[v] : (T)0);
-          }
-        }
         if (rowOk[jj]) *reinterpret_cast<V*>(po + off[jj]) = res;
       }
     }
     };   // body
-    if (rci != 0 || iPLo_ || iPHi_ || !iS_) body(std::false_type{}); else body(std::true_type{});
+    if (rci != 0 || iPLo_ || iPHi_) body(std::false_type{}); else body(std::true_type{});
   };
 
   for (int q = 0; q < CI; q += 4) {
@@ -437,22 +447,26 @@ static int launch_sf(pa_ctx* c, Cg3dArgs<T>& A) {
   return nblk;
 }
 
-// Rows per wave (measured, MI355X, us per launch at 1 / 2 / 4 rows; k_cg3d for comparison):
-//   Euler step fp32 512^3: 240 / 311 / 273 (k_cg3d 277)     256^3: 30.2 / 33.4 / 35.4 (38.4)
-//   upwind Div fp32 512^3: 230 / 289 / 243 (274)
-//   upwind Div fp64 512^3: 838 / 555 / 483 (493)            256^3: 52.0 / 51.3 / 50.2 (64.8)
-// fp32: one row (most waves in flight, ~160 VGPRs); fp64: four (one row re-reads its two neighbour rows from
-// L2 for every row it owns, which at 8-byte cells costs more than the occupancy buys).
+// Rows per wave (measured, MI355X, us per launch of the upwind Div at 1 / 2 / 4 rows; k_cg3d for comparison):
+//   fp32 512^3: 260 / 231 / 207 (284)   256^3: 26.4 / 25.5 / 27.3 (39.4)   128^3: 14.8 / 11.8 / 11.9 (14.7)
+//   fp64 512^3: 493 / 442 / 447 (553)   256^3: 45.3 / 45.2 / 45.5 (65.3)   128^3: 14.0 / 11.4 / 12.9 (15.1)
+// Four rows (least re-read of the rows above / below, ~230 VGPRs, two waves per SIMD) where a workgroup still
+// marches >= 32 planes, else two (the three planes of prologue weigh less on short chunks).
 template <typename T, int PHASE, int KIND>
 static int launch_sf_any(pa_ctx* c, Cg3dArgs<T>& A) {
-  int rj = sizeof(T) == 4 ? 1 : 4;
-  if (const char* e = getenv("PYAPES_HIP_RJ_SF")) {
-    const int v = atoi(e);
-    if (v == 1 || v == 2 || v == 4) rj = v;
-  } else if (c->G.n1 <= 4) {
+  constexpr int VEC = VecOf<T>::N;
+  const DevGeom& G = c->G;
+  int rj;
+  if (const char* e = getenv("PYAPES_HIP_RJ_SF"); e && (atoi(e) == 1 || atoi(e) == 2 || atoi(e) == 4)) {
+    rj = atoi(e);
+  } else if (G.n1 <= 4) {
     rj = 1;
-  } else if (c->G.n1 <= 8 && rj > 2) {
+  } else if (G.n1 <= 8) {
     rj = 2;
+  } else {
+    const int64_t tiles4 = ((G.n1 + 15) / 16) * ((G.n2 + 64 * VEC - 1) / (64 * VEC));
+    const int64_t chunks4 = std::max<int64_t>(1, (int64_t)cus_of(c) * 2 / tiles4);
+    rj = G.n0 / chunks4 >= 32 ? 4 : 2;
   }
   constexpr bool CAN_U = (PHASE == 3 || (PHASE == 2 && KIND != 0));
   if constexpr (CAN_U) {
@@ -472,8 +486,9 @@ static int launch_sf_any(pa_ctx* c, Cg3dArgs<T>& A) {
 }
 
 // can k_sf take this launch?  Full 16-byte vectors only (mode 1 of cg3d_mode), scalar coefficient.
-template <typename T>
+template <typename T, int PHASE>
 static bool sf_applies(const pa_ctx* c, const Cg3dArgs<T>& A, int mode) {
   // 32-bit byte offsets inside a plane
-  return c->sf && mode == 1 && !A.coeff_f && c->G.act[0] && (size_t)c->G.s0 * sizeof(T) < ((size_t)1 << 31);
+  return c->sf && mode == 1 && !A.coeff_f && c->G.act[0] && (size_t)c->G.s0 * sizeof(T) < ((size_t)1 << 31) &&
+         (PHASE == 3 ? A.out_all != 0 : (PHASE == 2 ? A.interior_only == 0 : true));
 }
