@@ -298,18 +298,28 @@ __device__ __forceinline__ bool pa_shell_node(const DevGeom& G, int64_t q, const
     if (G.act[w >> 1] && q >= start[w]) f = w;
   const int a = f >> 1, side = f & 1;
   const int64_t local = q - start[f];
+  // local = u * n + v: a 32-bit division where the mesh allows it (a quarter of the 64-bit one; the shell
+  // kernels are instruction-bound: one short thread per node)
+  const int64_t dn = a == 2 ? G.n1 : G.n2;
+  int64_t u, v;
+  if (G.ncell <= 0x7fffffffLL) {
+    const uint32_t lu = (uint32_t)local, du = (uint32_t)dn, uu = lu / du;
+    u = uu; v = lu - uu * du;
+  } else {
+    u = local / dn; v = local - u * dn;
+  }
   if (a == 0) {
     int64_t gi = side == 0 ? 0 : G.g0 - 1;
     i = gi - G.off0;
     if (i < 0 || i >= G.n0) return false;
-    j = local / G.n2; k = local - j * G.n2;
+    j = u; k = v;
   } else if (a == 1) {
-    i = local / G.n2; k = local - i * G.n2;
+    i = u; k = v;
     j = side == 0 ? 0 : G.n1 - 1;
     int64_t gi = i + G.off0;
     if (G.act[0] && (gi == 0 || gi == G.g0 - 1)) return false;
   } else {
-    i = local / G.n1; j = local - i * G.n1;
+    i = u; j = v;
     k = side == 0 ? 0 : G.n2 - 1;
     int64_t gi = i + G.off0;
     if (G.act[0] && (gi == 0 || gi == G.g0 - 1)) return false;
@@ -592,7 +602,14 @@ bool pa_bc_fusable(const pa_ctx* c) {
   // Against the per-axis pair kernels (explicit Euler step, fp32, us / step fused : pair : faces):
   // 64^3 17 : 20 : 25, 128^3 27.9 : 28.5 : 33, 192^3 44 : 40 : 45, 256^3 65 : 55 : 59 -- the crossover
   // sits between 98 k and 221 k shell nodes.  PYAPES_HIP_BC_FUSED=1 forces the closed form (tests do).
-  const int64_t limit = pa_bc_pairable(c) ? 150000 : 400000;
+  // Round 2: without a periodic face (and off a slab) the closed form is ONE launch writing straight into the
+  // field (pa_bc_shell_fused), and the explicit Euler step in front of it got faster, so the crossover moved:
+  // Euler step fp32, us / step fused : pair -- 128^3 17.2 : 23.6, 256^3 35.6 : 40.4, 384^3 134 : 140,
+  // 512^3 253 : 258; CG fp32 mixed faces 128^3 43.7 : 48.2, 256^3 132 : 133, 384^3 417 : 417.
+  bool one_pass = !c->slab;
+  for (int f = 0; f < 6; ++f)
+    if (c->bc[f].type == PA_BC_PERIODIC) one_pass = false;
+  const int64_t limit = pa_bc_pairable(c) ? (one_pass ? 2000000 : 150000) : 400000;
   if (!getenv("PYAPES_HIP_BC_FUSED") &&
       2 * (c->G.n1 * c->G.n2 + c->G.n0 * c->G.n2 + c->G.n0 * c->G.n1) > limit)
     return false;

@@ -154,9 +154,24 @@ int pa_comm_init(pa_ctx* c, int rank, int nranks, const void* id128) {
     h.ok = (want && R->GetUniqueId(&h.id) == ncclSuccess) ? 1 : 0;
     (void)hipMemcpyAsync(dev, &h, sizeof(Box), hipMemcpyHostToDevice, c->stream);
   }
+  // every wait on a collective is bounded (a rank that never arrives must not hang the others for good): on
+  // expiry the first communicator is aborted too and the caller falls back to the stepwise driver
+  const char* to = getenv("PYAPES_HIP_COMM_TIMEOUT");
+  const double tmo = to ? atof(to) : 60.0;
+  auto give_up = [&]() {
+    (void)R->CommAbort(comm);
+    c->comm = nullptr;
+    (void)hipFree(dev);
+    pa_set_err(c, "pa_comm_init: no completion of the second communicator's set-up within %.0f s", tmo);
+    return PA_E_STATE;
+  };
   ncclResult_t e = R->Broadcast(dev, dev, sizeof(Box), ncclChar, 0, comm, c->stream);
-  if (e == ncclSuccess && hipMemcpyAsync(&h, dev, sizeof(Box), hipMemcpyDeviceToHost, c->stream) == hipSuccess &&
-      hipStreamSynchronize(c->stream) == hipSuccess && h.ok) {
+  if (e == ncclSuccess && hipMemcpyAsync(&h, dev, sizeof(Box), hipMemcpyDeviceToHost, c->stream) == hipSuccess) {
+    if (!stream_done_within(c->stream, tmo)) return give_up();
+  } else {
+    h.ok = 0;
+  }
+  if (e == ncclSuccess && h.ok) {
     ncclComm_t comm2 = nullptr;
     int prio_lo = 0, prio_hi = 0;   // highest priority: its own hardware queue, and its few workgroups first
     (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
@@ -168,8 +183,12 @@ int pa_comm_init(pa_ctx* c, int rank, int nranks, const void* id128) {
     (void)hipMemcpyAsync(&dev->ok, &h.ok, sizeof(int), hipMemcpyHostToDevice, c->stream);
     e = R->AllReduce(&dev->ok, &dev->ok, 1, ncclInt, ncclMin, comm, c->stream);
     int all = 0;
-    if (e == ncclSuccess && hipMemcpyAsync(&all, &dev->ok, sizeof(int), hipMemcpyDeviceToHost, c->stream) == hipSuccess &&
-        hipStreamSynchronize(c->stream) == hipSuccess && all) {
+    bool copied = e == ncclSuccess && hipMemcpyAsync(&all, &dev->ok, sizeof(int), hipMemcpyDeviceToHost, c->stream) == hipSuccess;
+    if (copied && !stream_done_within(c->stream, tmo)) {
+      if (comm2) (void)R->CommAbort(comm2);
+      return give_up();
+    }
+    if (copied && all) {
       c->comm2 = comm2;
     } else {
       if (comm2) (void)R->CommDestroy(comm2);
