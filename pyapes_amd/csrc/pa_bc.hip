@@ -190,7 +190,10 @@ __device__ __forceinline__ T pa_bc_const(const BCAll<T>& B, int f, int64_t q) {
 
 // Closed-form evaluation, one stage per axis.  stage<A>(i,j,k) = value of the node after the
 // faces of axes 0..A have been applied, expressed through stage<A-1> of the nodes that face reads.
-template <typename T>
+// PER = false: no periodic face anywhere (the one-pass form of pa_bc_shell_fused): the periodic branches of the
+// three stages -- three more recursive evaluations each -- are compiled out (18,000 -> a third of the
+// instructions; the kernel is one short thread per shell node and instruction-bound)
+template <typename T, bool PER = true>
 struct BCEval {
   const DevGeom& G;
   const BCAll<T>& B;
@@ -202,7 +205,7 @@ struct BCEval {
     // one pointer select, one load (an if/return ladder here was miscompiled by hipcc 7.2 when fully
     // inlined: tests/test_gpu_bc_fused.py is the regression test)
     const T* p = x + (g - G.off0) * G.s0;
-    if (B.slab_periodic0 && B.f[f].type == 4) {
+    if (PER && B.slab_periodic0 && B.f[f].type == 4) {
       if (f == 0) {
         p = (g == G.g0 - 1) ? B.far_lo0 : ((g == G.g0 - 2) ? B.far_lo1 : p);
       } else {
@@ -233,7 +236,7 @@ struct BCEval {
       t1 = t1 - t2;
       return t1 + pa_bc_const<T>(B, f, base);
     }
-    if (type == 3) return raw0(f, lower ? 1 : N - 2, base);
+    if (type == 3 || !PER) return raw0(f, lower ? 1 : N - 2, base);
     T t1 = raw0(f, 1, base) - raw0(f, N - 1, base);
     return t1 + raw0(f, N - 2, base);
   }
@@ -255,7 +258,7 @@ struct BCEval {
       t1 = t1 - t2;
       return t1 + pa_bc_const<T>(B, f, q);
     }
-    if (type == 3) return stage0(i, lower ? 1 : N - 2, k);
+    if (type == 3 || !PER) return stage0(i, lower ? 1 : N - 2, k);
     T t1 = stage0(i, 1, k) - stage0(i, N - 1, k);
     return t1 + stage0(i, N - 2, k);
   }
@@ -277,16 +280,16 @@ struct BCEval {
       t1 = t1 - t2;
       return t1 + pa_bc_const<T>(B, f, q);
     }
-    if (type == 3) return stage1(i, j, lower ? 1 : N - 2);
+    if (type == 3 || !PER) return stage1(i, j, lower ? 1 : N - 2);
     T t1 = stage1(i, j, 1) - stage1(i, j, N - 1);
     return t1 + stage1(i, j, N - 2);
   }
 };
 
-template <typename T>
+template <typename T, bool PER>
 __device__ __forceinline__ T pa_bc_v3(const DevGeom& G, const BCAll<T>& B, const T* __restrict__ x, int64_t i,
                                       int64_t j, int64_t k) {
-  BCEval<T> ev{G, B, x};
+  BCEval<T, PER> ev{G, B, x};
   return ev.stage2(i, j, k);
 }
 
@@ -328,7 +331,7 @@ __device__ __forceinline__ bool pa_shell_node(const DevGeom& G, int64_t q, const
   return true;
 }
 
-template <typename T>
+template <typename T, bool PER>
 __global__ void __launch_bounds__(PA_BLOCK) k_bc_compute(DevGeom G, BCAll<T> B_, const int* __restrict__ done,
                                                           const T* x, const T* __restrict__ shell_old,
                                                           T* __restrict__ shell_new, double* __restrict__ partials,
@@ -343,10 +346,10 @@ __global__ void __launch_bounds__(PA_BLOCK) k_bc_compute(DevGeom G, BCAll<T> B_,
        q += (int64_t)gridDim.x * blockDim.x) {
     int64_t i, j, k;
     if (!pa_shell_node(G, q, start, i, j, k)) continue;
-    T v = pa_bc_v3<T>(G, B, x, i, j, k);
+    T v = pa_bc_v3<T, PER>(G, B, x, i, j, k);
 #ifdef PA_DEBUG_BC
     if (i == 0 && j == 1 && k == G.n2 - 1) {
-      BCEval<T> ev{G, B, x};
+      BCEval<T, PER> ev{G, B, x};
       printf("DBG node(0,1,%lld) v=%g stage1(0,1,n2-2)=%g stage0=%g types %d %d %d %d %d %d slabp %d far %p %p %p raw1 %g rawN1 %g rawN2 %g\n",
              (long long)k, (double)v, (double)ev.stage1(0, 1, G.n2 - 2), (double)ev.stage0(0, 1, G.n2 - 2),
              B.f[0].type, B.f[1].type, B.f[2].type, B.f[3].type, B.f[4].type, B.f[5].type, B.slab_periodic0,
@@ -697,8 +700,15 @@ int pa_bc_shell_fused(pa_ctx* c, T* x, double* part2, int with_delta, bool guard
   bool direct = !c->slab;
   for (int f = 0; f < 6; ++f)
     if (c->bc[f].type == PA_BC_PERIODIC) direct = false;
-  hipLaunchKernelGGL(k_bc_compute<T>, dim3(nb), dim3(PA_BLOCK), 0, c->stream, c->G, B, done, (const T*)x,
-                     (const T*)so, sn, part2, with_delta, direct ? x : (T*)nullptr);
+  bool any_per = false;
+  for (int f = 0; f < 6; ++f)
+    if (c->bc[f].type == PA_BC_PERIODIC) any_per = true;
+  if (any_per)
+    hipLaunchKernelGGL((k_bc_compute<T, true>), dim3(nb), dim3(PA_BLOCK), 0, c->stream, c->G, B, done, (const T*)x,
+                       (const T*)so, sn, part2, with_delta, direct ? x : (T*)nullptr);
+  else
+    hipLaunchKernelGGL((k_bc_compute<T, false>), dim3(nb), dim3(PA_BLOCK), 0, c->stream, c->G, B, done, (const T*)x,
+                       (const T*)so, sn, part2, with_delta, direct ? x : (T*)nullptr);
   if (!direct)
     hipLaunchKernelGGL(k_bc_scatter<T>, dim3(nb), dim3(PA_BLOCK), 0, c->stream, c->G, done, x, (const T*)sn);
   if (!standalone) c->shell_cur ^= 1;
