@@ -66,32 +66,59 @@ def _free_port() -> int:
         return s.getsockname()[1]
 
 
+def _run_ranks(n: int, argv: list[str], extra_env: dict, timeout_s: float):
+    """One attempt: (return code or None on timeout, JSON line or None)."""
+    import signal
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env["BENCH_SELF_LAUNCHED"] = "1"
+    env.update(extra_env)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + argv
+    log(f"starting {n} ranks: {' '.join(cmd[1:])}" + (f"  [{extra_env}]" if extra_env else ""))
+    p = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env, text=True, start_new_session=True)
+    try:
+        out, _ = p.communicate(timeout=timeout_s)
+    except subprocess.TimeoutExpired:
+        log(f"no result within {timeout_s:.0f} s: stopping the ranks (process group {p.pid})")
+        try:
+            os.killpg(p.pid, signal.SIGTERM)     # exactly the group this call started
+            p.communicate(timeout=20)
+        except Exception:
+            try:
+                os.killpg(p.pid, signal.SIGKILL)
+            except Exception:
+                pass
+            p.communicate()
+        return None, None
+    line = None
+    for ln in out.splitlines():
+        st = ln.strip()
+        if st.startswith("{") and '"metric"' in st:
+            line = st
+        elif st:
+            print(st, file=sys.stderr)
+    return p.returncode, line
+
+
 def launch_ranks(n: int, argv: list[str]) -> int:
     """Start ``python -m torch.distributed.run --nproc-per-node n bench.py <argv>`` as a CHILD process,
     pass its stderr through, print the one JSON line rank 0 wrote, return the child's exit code.
     Nothing here imports torch.cuda or calls HIP: a process that has initialised the GPU must not be
-    replaced or forked into ranks."""
-    env = dict(os.environ)
-    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    env["BENCH_SELF_LAUNCHED"] = "1"
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
-           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + argv
-    log(f"starting {n} ranks: {' '.join(cmd[1:])}")
-    p = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env, text=True)
-    out, _ = p.communicate()
-    line = None
-    for ln in out.splitlines():
-        s = ln.strip()
-        if s.startswith("{") and '"metric"' in s:
-            line = s
-        elif s:
-            print(s, file=sys.stderr)
+    replaced or forked into ranks.  Watchdog: if the ranks give no result within BENCH_RANKS_TIMEOUT seconds
+    (default 900) or fail, ONE more attempt runs with the stepwise torch.distributed slab driver
+    (PYAPES_HIP_COMM=0) instead of the library-side RCCL loop -- its record says so in config.parallelism."""
+    tmo = float(os.environ.get("BENCH_RANKS_TIMEOUT", "900"))
+    rc, line = _run_ranks(n, argv, {}, tmo)
+    if (rc != 0 or line is None) and os.environ.get("PYAPES_HIP_COMM", "1") != "0":
+        log(f"first attempt {'timed out' if rc is None else f'ended with rc {rc}'}; retrying with PYAPES_HIP_COMM=0")
+        rc, line = _run_ranks(n, argv, {"PYAPES_HIP_COMM": "0"}, tmo)
     if line is not None:
         print(line, flush=True)
-    elif p.returncode == 0:
+    elif rc == 0:
         log("the ranks exited 0 but printed no JSON line")
         return 1
-    return p.returncode
+    return 1 if rc is None else rc
 
 
 # ------------------------------------------------------------------------------------------------
