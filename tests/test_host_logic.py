@@ -280,3 +280,32 @@ def test_div_operand_resolution_mirrors_the_reference_indexing():
     for adv in (1.5, torch.rand(1, 4, 5), sc.copy()):            # scalar target + edge: the reference indexes [1] of a size-1 axis
         with pytest.raises(IndexError):
             _div_plan(adv, sc, True)
+
+
+def test_bc_callable_probe_and_varo_flag_host_side():
+    """Round 2 host logic (no GPU): a callable bc_val that reads the field is told apart from one of
+    (grid, mask) only -- the device solvers refuse the former (linalg._run) --, Dirichlet / Neumann without a
+    value assert like the reference (bcs.py:200, 224), and Field.VARo raises once marked stale and comes
+    back with save_old() (fields.py:129-136)."""
+    mesh = Mesh(Box[0:1, 0:1], None, [6, 7], "cpu", "double")
+    reads = lambda grid, mask, var, opt: 0.5 * var[0][torch.roll(mask, 1, 0)]   # noqa: E731
+    plain = lambda grid, mask, var, opt: grid[1][mask] * 2.0                     # noqa: E731
+    cfg = [{"bc_face": f, "bc_type": "dirichlet", "bc_val": v, "bc_val_opt": None}
+           for f, v in zip(("xl", "xu", "yl", "yu"), (reads, plain, 0.25, torch.ones(6)))]
+    var = Field("p", 1, mesh, {"domain": cfg, "obstacle": None}, init_val="random")
+    assert [bc.depends_on_var(var()) for bc in var.bcs] == [True, False, False, False]
+    s, arr = var.bcs[1].resolve(var(), 0)
+    assert arr is not None and torch.equal(arr, mesh.grid[1][var.bcs[1].bc_mask] * 2.0)
+    none_cfg = [{"bc_face": f, "bc_type": t, "bc_val": None, "bc_val_opt": None}
+                for f, t in zip(("xl", "xu", "yl", "yu"), ("neumann", "symmetry", "periodic", "periodic"))]
+    v2 = Field("q", 1, mesh, {"domain": none_cfg, "obstacle": None})
+    with pytest.raises(AssertionError, match="bc_val is not specified"):
+        v2.bcs[0].resolve(v2(), 0)
+    assert v2.bcs[1].resolve(v2(), 0) == (0.0, None)
+    var.save_old()
+    assert torch.equal(var.VARo, var())
+    var.mark_old_stale("test")
+    with pytest.raises(RuntimeError, match="VARo"):
+        var.VARo
+    var.save_old()
+    assert torch.equal(var.VARo, var())
