@@ -263,16 +263,22 @@ def cpu_baseline(solver, kind, dtype, gn):
 # ------------------------------------------------------------------------------------------------
 #  roofline record
 # ------------------------------------------------------------------------------------------------
-def source_hash() -> str:
-    """Hash of the kernel sources the built library comes from: profiles/traffic.json entries carry it
-    and are ignored once the kernels have changed."""
+def source_hash(csrc_dir: str | None = None) -> str:
+    """Hash of the kernel sources the built library comes from -- comments and white space stripped, so that
+    only a change of CODE invalidates what was measured on them: profiles/traffic.json entries carry it and
+    are ignored once the kernels have changed."""
+    import re
     h = hashlib.sha256()
-    d = os.path.join(ROOT, "pyapes_amd", "csrc")
+    d = csrc_dir or os.path.join(ROOT, "pyapes_amd", "csrc")
     for name in sorted(os.listdir(d)):
         if name.endswith((".hip", ".h")):
-            with open(os.path.join(d, name), "rb") as f:
-                h.update(name.encode())
-                h.update(f.read())
+            with open(os.path.join(d, name)) as f:
+                txt = f.read()
+            txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+            txt = re.sub(r"//[^\n]*", "", txt)
+            txt = re.sub(r"\s+", " ", txt)
+            h.update(name.encode())
+            h.update(txt.encode())
     return h.hexdigest()[:16]
 
 

@@ -6,7 +6,7 @@
 //
 // Equation covered: one Laplacian term (scalar or no coefficient), any BC mix, fp64 / fp32,
 // single GPU or slab (ghost planes through Vec<T>).  Anything else returns 0 and the caller
-// launches the generic kernels of pa_core.hip.
+// launches the generic kernels of pa_solver.hip / pa_ops.hip.
 //
 // Data movement (both phases are HBM-bound; no MFMA):
 //   phase A  reads r, d      writes d' = r + beta d          + sum d'.(A d')      3 array passes
@@ -489,7 +489,7 @@ __global__ void __launch_bounds__(256) k_cg3d(Cg3dArgs<T> A) {
       cPkV[v] = p; cCkV[v] = c0; cMkV[v] = mq;
     }
   }
-  V gPkV, gCkV, gMkV;   // phase 7: k-axis rows of the gradient (k_grad, pa_core.hip)
+  V gPkV, gCkV, gMkV;   // phase 7: k-axis rows of the gradient (k_grad, pa_ops.hip)
   if (PHASE == 7) {
 #pragma unroll
     for (int v = 0; v < VEC; ++v) {
@@ -725,7 +725,7 @@ __global__ void __launch_bounds__(256) k_cg3d(Cg3dArgs<T> A) {
           T ax = axv[v];
           T cCk = cCkV[v];
           if (PHASE == 4) {
-            // Jacobi:  x + omega (b - A x) / diag(A)   (k_jacobi, pa_core.hip)
+            // Jacobi:  x + omega (b - A x) / diag(A)   (k_jacobi, pa_solver.hip)
             T dg = act0 ? cCi : (T)0;
             dg = dg + cCj;
             dg = dg + cCk;
@@ -770,7 +770,7 @@ __global__ void __launch_bounds__(256) k_cg3d(Cg3dArgs<T> A) {
           if (hasc) ax = ax * (CF ? cv[jj][v] : cf);
           ax = ax * sgn;
           if (PHASE == 4) {
-            // Jacobi:  x + omega (b - A x) / diag(A)   (k_jacobi, pa_core.hip)
+            // Jacobi:  x + omega (b - A x) / diag(A)   (k_jacobi, pa_solver.hip)
             T dg = act0 ? cCi : (T)0;
             dg = dg + cCj;
             dg = dg + cCk;

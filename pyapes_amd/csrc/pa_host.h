@@ -1,4 +1,4 @@
-// pa_host.h -- host-side context of libpyapes_hip (shared by pa_core.hip / pa_cg3d.hip / pa_slab.hip)
+// pa_host.h -- host-side context of libpyapes_hip (shared by every translation unit)
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdarg.h>

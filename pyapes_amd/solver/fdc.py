@@ -3,7 +3,7 @@
 ``FDC(config).laplacian(var)``, ``.grad(var)``, ``.div(var_j, var_i)`` evaluate the
 2nd-order stencils on the current field and return a tensor; ``build_A_coeffs`` /
 ``adjust_rhs`` / ``apply`` keep their meaning.  All arithmetic is done by
-``k_aop`` / ``k_grad`` / ``k_edge`` / ``k_rhs_adjust`` in ``csrc/pa_core.hip`` and, for the general
+``k_aop`` / ``k_grad`` / ``k_edge`` / ``k_rhs_adjust`` in ``csrc/pa_ops.hip`` and, for the general
 Div (Jac advection, vector targets, edge=True in n-D) and ``DiffFlux``, ``csrc/pa_rfp.hip``.
 """
 from __future__ import annotations

@@ -1,7 +1,7 @@
 """Boundary conditions (mirrors ``pyapes/variables/bcs.py``).
 
 A BC object here is a small record (face, type, value); the ghost / boundary-node
-fill itself is ``k_bc_face`` in ``csrc/pa_core.hip`` and is reached through
+fill itself is ``k_bc_face`` in ``csrc/pa_bc.hip`` and is reached through
 ``BC.apply`` (one face) or ``HipContext.apply_bcs`` (all faces in list order, what
 ``linalg._apply_bc_otf`` does).  The shifted boolean masks of the reference
 (bcs.py:84-95) exist as lazy properties for API compatibility only.
