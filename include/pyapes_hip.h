@@ -80,10 +80,18 @@ typedef struct {
 int pa_ctx_create(int device, void* hip_stream, pa_ctx** out);
 int pa_ctx_destroy(pa_ctx* ctx);
 /* Kernel-path switches of one ctx (tests and A/B measurements; defaults from PYAPES_HIP_FASTPATH / _SF /
- * _FOLD at pa_ctx_create): "fastpath" 0 = generic kernels only, "sf" 0 = k_cg3d instead of k_sf for the
- * Div-carrying single-field operations, "fold" 0 = scalar steps as single-block kernels.  Results do not
- * depend on them (bit-identical paths; tests/test_gpu_properties.py, test_gpu_fold.py). */
+ * _FOLD / _RESIDENT at pa_ctx_create): "fastpath" 0 = generic kernels only, "sf" 0 = k_cg3d instead of k_sf
+ * for the Div-carrying single-field operations, "fold" 0 = scalar steps as single-block kernels, "resident"
+ * 0 = launch-per-phase solver loops on small meshes too.  The first three do not change results
+ * (bit-identical paths; tests/test_gpu_properties.py, test_gpu_fold.py); "resident" changes the grouping of
+ * the global sums only (tests/test_gpu_resident.py). */
 int pa_ctx_set_option(pa_ctx* ctx, const char* name, int value);
+/* Small meshes: pa_cg / pa_jacobi run the whole solve in ONE cooperative launch with the fields resident in
+ * LDS (pa_resident.hip) when the bound mesh / BCs / equation allow it.  Returns the number of workgroups
+ * (= boxes the mesh is cut into; boxes[3] = boxes per internal axis) such a solve would use, 0 when the
+ * launch-per-phase loops would run.  pa_resident_used: the same for the LAST solve of this ctx. */
+int pa_resident_plan(pa_ctx* ctx, int* boxes);
+int pa_resident_used(const pa_ctx* ctx);
 /* The stream every later call enqueues on (the binding passes torch's CURRENT stream before each call, so
  * that work the caller queued on it -- tensor allocation, input preparation -- is ordered before the
  * kernels).  Refused while a stepwise solve is live on another stream. */

@@ -205,6 +205,7 @@ int pa_ctx_create(int device, void* hip_stream, pa_ctx** out) {
   c->err[0] = 0;
   if (const char* fp = getenv("PYAPES_HIP_FASTPATH")) c->fastpath = atoi(fp) != 0;
   if (const char* sf = getenv("PYAPES_HIP_SF")) c->sf = atoi(sf) != 0;
+  if (const char* rs = getenv("PYAPES_HIP_RESIDENT")) c->resident = atoi(rs) != 0;
   if (hipMalloc((void**)&c->sc_base, 2 * sizeof(SolverScalars)) != hipSuccess ||
       hipMalloc((void**)&c->sums, PA_NSUM * sizeof(double)) != hipSuccess ||
       hipHostMalloc((void**)&c->h_sc, sizeof(SolverScalars)) != hipSuccess ||
@@ -242,6 +243,7 @@ int pa_ctx_set_option(pa_ctx* c, const char* name, int value) {
   if (!strcmp(name, "fastpath")) c->fastpath = value != 0;      // tiled kernels (else the generic ones)
   else if (!strcmp(name, "sf")) c->sf = value != 0;             // k_sf (else k_cg3d's single-field phases)
   else if (!strcmp(name, "fold")) c->fold = value != 0;         // scalar steps in the next kernel's prologue
+  else if (!strcmp(name, "resident")) c->resident = value != 0; // small meshes: one cooperative launch per solve
   else { pa_set_err(c, "pa_ctx_set_option: unknown option '%s'", name); return PA_E_ARG; }
   return PA_OK;
 }

@@ -28,7 +28,7 @@ struct HostBC {
 
 enum {
   SCR_R = 0, SCR_D0, SCR_D1, SCR_PART, SCR_PART2, SCR_SHELL, SCR_R0, SCR_V0, SCR_V1, SCR_S, SCR_TT,
-  SCR_GHOST, SCR_SHELL2, SCR_RZ, PA_NSCRATCH
+  SCR_GHOST, SCR_SHELL2, SCR_RZ, SCR_RES, PA_NSCRATCH
 };
 
 struct pa_ctx {
@@ -114,6 +114,8 @@ struct pa_ctx {
   // 3-D fast path switch (PYAPES_HIP_FASTPATH=0 disables; tests compare both)
   int fastpath = 1;
   int sf = 1;                    // k_sf for the Div-carrying single-field operations (else k_cg3d's phases)
+  int resident = 1;              // small meshes: the whole CG / Jacobi solve in one cooperative launch (pa_resident.hip)
+  int resident_used = 0;         // workgroups of the last solve's resident launch (0: launch-per-phase loops ran)
   // RCCL communicator owned by the library (pa_comm_*): slab iterations without host work
   void* comm = nullptr;          // ncclComm_t
   // second communicator + stream: the packed plane exchange of an iteration flies beside phase B, the BC
@@ -181,6 +183,13 @@ template <typename T>
 int pa_cg3d_phase_b(pa_ctx* c, const DevEq<T>& E, Vec<T> d, T* x, T* r, double* partials);
 
 // single-field tiled kernels (pa_cg3d.hip); same return convention as the CG phases
+// small meshes (pa_resident.hip): the whole solve in one cooperative launch, fields resident in LDS.  Returns the
+// number of workgroups (> 0) when it ran to the end of the solve (scalars in c->sc), 0 when the configuration is
+// not covered (the caller runs its launch-per-phase loop), < 0 on error.  solver: 0 CG (r0 = initial residual),
+// 1 Jacobi (rhs).  x must already hold the BC-filled start.
+template <typename T>
+int pa_resident_launch(pa_ctx* c, int solver, T* x, const T* r0, const T* rhs, double omega);
+
 template <typename T>
 int pa_tile3d_aop(pa_ctx* c, const DevEq<T>& E, Vec<T> x, T* y, int interior_only);
 template <typename T>

@@ -1,0 +1,852 @@
+// pa_resident.hip -- small meshes: the whole CG / Jacobi solve in ONE cooperative launch, the fields resident
+// in LDS (linalg.py:74-159 and the Jacobi of SURVEY a15, same arithmetic as the kernels of pa_solver.hip).
+//
+// On the meshes the reference's tests and demos run (128^2, 33^3, 64^3 ...) an iteration of the launch-per-
+// phase loops costs ~10 us per dependent kernel whatever the kernel does (DESIGN "small meshes").  Here the
+// mesh is cut into <= 128 boxes, one workgroup each, all co-resident (hipLaunchCooperativeKernel); x, r and
+// the direction d (with a one-cell halo) live in the workgroup's LDS for the whole solve and an iteration
+// costs two grid-wide steps:
+//   step 1: partial d.Ad -> mailbox, arrive, wait, every workgroup sums all partials in the same fixed
+//           order (same bits everywhere) -> alpha
+//   step 2: x, r update, ordered BC fill (literal, face after face, in LDS), boundary-shell stop-test
+//           term; partial r.r and |dx|^2 and the box's outer layers of r -> mailbox, arrive, wait -> beta,
+//           stop test; d' = r + beta d on the own cells and -- from the neighbours' r layers and the old
+//           halo of d -- on the halo, bit for bit what the neighbour computes, so d is never exchanged.
+// A grid-wide step is an agent-scope release add on one counter plus an acquire spin (2 us at 16 boxes,
+// 3.2 us at 64, 5 us at 128: scratch/gb/gridbar.hip); every spin is bounded, a timeout raises PA_E_STATE.
+// Jacobi: one step per sweep (the outer layers of x travel with the stop-test partial).
+//
+// Scope: one GPU, no periodic face, scalar operator coefficients (any term list pa_apply_terms knows, xyz
+// or rz), mesh <= 128 boxes of <= 4096 cells.  Everything else runs the launch-per-phase loops.
+#include "pa_host.h"
+#include "pa_scalar_steps.h"
+
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <algorithm>
+
+#define RES_MAXG 128
+#define RES_MAXBOX 4096
+#define RES_NS 2            // partial sums per grid-wide step
+#define RES_LDS_LIMIT (156 * 1024)
+
+template <typename T>
+struct ResFace {      // one BC face, in list order (linalg.py:295-297)
+  int face;           // internal face 2 * axis + side; -1: unused slot
+  int type;
+  T sval;             // dirichlet value / neumann additive constant for scalar V
+  const T* vals;      // per-node g or V (face layout of the whole mesh)
+  T dxf, ndir;
+};
+
+template <typename T>
+struct ResArgs {
+  ResFace<T> f[6];
+  T c43, c13, c23;
+  int P[3];            // boxes per axis
+  int bmax[3];         // largest box extent per axis
+  int nface;           // largest box face (nodes)
+  int bc_static;
+  T omega;
+  T* x;                // in: BC-filled start; out: the iterate
+  const T* r0;         // CG: r = (b - A x) on S, 0 elsewhere
+  const T* rhs;        // Jacobi
+  T* x_old_out;        // Field.VARo on request
+  SolverScalars* sc;
+  unsigned long long* counter;
+  int* fail;           // set when a grid-wide wait timed out
+  double* parts;       // [2][G][RES_NS]
+  T* mail;             // [2][G][6][nface]
+  unsigned spin_max;
+  unsigned o_h, o_p1, o_p2, o_bcc, o_sh, o_meta, o_lists;   // LDS byte offsets: haloed array, two plain arrays, BC constants, shell, per-cell words, work lists
+};
+
+template <typename T>
+struct BoxView {   // an LDS array addressed with the node indices of the mesh
+  T* p;
+  int s0, s1, off;
+  __device__ __forceinline__ T& operator()(int i, int j, int k) const { return p[i * s0 + j * s1 + k + off]; }
+};
+template <typename T>
+struct BoxAcc {    // accessor of pa_apply_terms
+  BoxView<T> v;
+  __device__ __forceinline__ T at(const DevGeom&, int64_t i, int64_t j, int64_t k) const {
+    return v.p[(int)i * v.s0 + (int)j * v.s1 + (int)k + v.off];
+  }
+};
+
+// a[axis] with a run-time axis: selects, not an indexed read (which would put the array -- and the kernel -- on
+// scratch memory)
+template <typename V>
+__device__ __forceinline__ V res_pick(const V (&v)[3], int a) { return a == 0 ? v[0] : (a == 1 ? v[1] : v[2]); }
+
+struct ResSync {
+  unsigned long long* counter;
+  int* fail;
+  unsigned long long step;
+  unsigned G, spin_max;
+};
+
+// arrive + wait: everything this workgroup stored before is visible to every workgroup that returns
+__device__ __forceinline__ bool res_grid_wait(ResSync& S) {
+  __shared__ int ok;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __hip_atomic_fetch_add(S.counter, 1ull, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned long long target = (S.step + 1) * S.G;
+    int good = 0;
+    for (unsigned spin = 0; spin < S.spin_max; ++spin) {
+      if (__hip_atomic_load(S.counter, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) >= target) { good = 1; break; }
+      if (__hip_atomic_load(S.fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
+      __builtin_amdgcn_s_sleep(1);
+    }
+    if (!good) __hip_atomic_store(S.fail, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    ok = good;
+  }
+  __syncthreads();
+  S.step += 1;
+  return ok != 0;
+}
+
+// sum over the 64 lanes of a wave, the result in every lane: an inclusive scan inside each row of 16 lanes with
+// DPP row shifts (lanes without a source add 0), then the four row totals read from lanes 15 / 31 / 47 / 63.
+// Fixed order, no LDS: ~25 instructions against the six dependent ds_bpermute round trips of a shuffle reduction.
+__device__ __forceinline__ double res_dpp_shr(double x, const int ctrl_sel) {
+  const long long b = __double_as_longlong(x);
+  int lo = (int)(b & 0xffffffffll), hi = (int)(b >> 32);
+  // row_shr:n = 0x110 + n ; row_mask / bank_mask all, bound_ctrl off: out-of-row lanes receive `old` = 0
+  if (ctrl_sel == 1) { lo = __builtin_amdgcn_update_dpp(0, lo, 0x111, 0xf, 0xf, false); hi = __builtin_amdgcn_update_dpp(0, hi, 0x111, 0xf, 0xf, false); }
+  if (ctrl_sel == 2) { lo = __builtin_amdgcn_update_dpp(0, lo, 0x112, 0xf, 0xf, false); hi = __builtin_amdgcn_update_dpp(0, hi, 0x112, 0xf, 0xf, false); }
+  if (ctrl_sel == 4) { lo = __builtin_amdgcn_update_dpp(0, lo, 0x114, 0xf, 0xf, false); hi = __builtin_amdgcn_update_dpp(0, hi, 0x114, 0xf, 0xf, false); }
+  if (ctrl_sel == 8) { lo = __builtin_amdgcn_update_dpp(0, lo, 0x118, 0xf, 0xf, false); hi = __builtin_amdgcn_update_dpp(0, hi, 0x118, 0xf, 0xf, false); }
+  return __longlong_as_double(((long long)hi << 32) | (long long)(unsigned)lo);
+}
+__device__ __forceinline__ double res_lane(double x, const int lane) {
+  const long long b = __double_as_longlong(x);
+  const int lo = __builtin_amdgcn_readlane((int)(b & 0xffffffffll), lane);
+  const int hi = __builtin_amdgcn_readlane((int)(b >> 32), lane);
+  return __longlong_as_double(((long long)hi << 32) | (long long)(unsigned)lo);
+}
+__device__ __forceinline__ double res_wave_sum(double x) {
+  x += res_dpp_shr(x, 1);
+  x += res_dpp_shr(x, 2);
+  x += res_dpp_shr(x, 4);
+  x += res_dpp_shr(x, 8);
+  return ((res_lane(x, 15) + res_lane(x, 31)) + res_lane(x, 47)) + res_lane(x, 63);
+}
+
+// grid-wide sums: v (per thread) -> out[RES_NS] in LDS, the same bits in every workgroup
+__device__ __forceinline__ bool res_allreduce(ResSync& S, double* parts, double (&v)[RES_NS], double* out) {
+  __shared__ double sm[RES_NS][16];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  double* row = parts + (size_t)(S.step & 1) * S.G * RES_NS;
+#pragma unroll
+  for (int s = 0; s < RES_NS; ++s) {
+    const double x = res_wave_sum(v[s]);
+    if (lane == 0) sm[s][wave] = x;
+  }
+  __syncthreads();
+  if (threadIdx.x < RES_NS) {
+    const int s = threadIdx.x;
+    double x = sm[s][0];
+    for (int w = 1; w < (int)(blockDim.x >> 6); ++w) x += sm[s][w];
+    __hip_atomic_store(row + (size_t)blockIdx.x * RES_NS + s, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  if (!res_grid_wait(S)) return false;
+  if (wave == 0) {
+#pragma unroll
+    for (int s = 0; s < RES_NS; ++s) {
+      double x = 0.0;
+      for (unsigned g = lane; g < S.G; g += 64)
+        x += __hip_atomic_load(row + (size_t)g * RES_NS + s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      x = res_wave_sum(x);
+      if (lane == 0) out[s] = x;
+    }
+  }
+  __syncthreads();
+  return true;
+}
+
+// per-cell word, built once (the thread -> cell mapping is fixed for the whole solve): where the cell lives in
+// the haloed and in the plain arrays, whether it is in the interior set S, and the boundary-row case of each axis
+#define RES_M_H(m) ((int)((m) & 0x1fffu))
+#define RES_M_P(m) ((int)(((m) >> 13) & 0xfffu))
+#define RES_M_S(m) (((m) >> 25) & 1u)
+#define RES_M_RC(m, a) ((int)(((m) >> (26 + 2 * (a))) & 3u))
+
+// SOLVER 0: CG (H = d with halo, P1 = x, P2 = r)   1: Jacobi (H = x with halo, P1 = x', P2 = rhs)
+// LEAN: the equation is one Laplacian term with a scalar coefficient on an xyz mesh (the stencil is evaluated from
+// the per-cell word and fixed LDS offsets); else pa_apply_terms on the box (any term list, rz)
+template <typename T, int SOLVER, bool LEAN, int NT>
+__global__ void __launch_bounds__(NT) k_resident(DevGeom G, DevEq<T> E, ResArgs<T> A) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  __shared__ SolverScalars sc;
+  __shared__ double red[RES_NS];
+  const int tid = threadIdx.x;
+
+  // ---- this workgroup's box (plain scalars and selects: an aggregate indexed with a run-time axis would put
+  //      the kernel on scratch memory) -----------------------------------------------------------------
+  int p0, p1, p2;
+  {
+    int g = blockIdx.x;
+    p2 = g % A.P[2]; g /= A.P[2];
+    p1 = g % A.P[1];
+    p0 = g / A.P[1];
+  }
+  const int lo0 = (int)((int64_t)p0 * G.n0 / A.P[0]), b0 = (int)((int64_t)(p0 + 1) * G.n0 / A.P[0]) - lo0;
+  const int lo1 = (int)((int64_t)p1 * G.n1 / A.P[1]), b1 = (int)((int64_t)(p1 + 1) * G.n1 / A.P[1]) - lo1;
+  const int lo2 = (int)((int64_t)p2 * G.n2 / A.P[2]), b2 = (int)((int64_t)(p2 + 1) * G.n2 / A.P[2]) - lo2;
+  const int nbox = b0 * b1 * b2;
+  auto LO = [&](int a) -> int { return a == 0 ? lo0 : (a == 1 ? lo1 : lo2); };
+  auto BB = [&](int a) -> int { return a == 0 ? b0 : (a == 1 ? b1 : b2); };
+  auto PP = [&](int a) -> int { return a == 0 ? p0 : (a == 1 ? p1 : p2); };
+  // own cell c -> box coordinates: two divisions by magic numbers (cells < 4096, divisors <= 4096: exact)
+  const unsigned mp = (1u << 24) / (unsigned)(b1 * b2) + 1u, mk = (1u << 24) / (unsigned)b2 + 1u;
+  auto decode = [&](int c, int& bi, int& bj, int& bk) {
+    const unsigned plane = (unsigned)(b1 * b2);
+    bi = (int)(((unsigned long long)(unsigned)c * mp) >> 24);
+    const unsigned rem = (unsigned)c - (unsigned)bi * plane;
+    bj = (int)(((unsigned long long)rem * mk) >> 24);
+    bk = (int)(rem - (unsigned)bj * (unsigned)b2);
+  };
+  // nodes of box face 2 * a + side: q = u * nv + v with (u, v) the two other axes in ascending order
+  auto face_dims = [&](int a, int& nu, int& nv) {
+    nu = a == 0 ? b1 : b0;
+    nv = a == 2 ? b1 : b2;
+  };
+  auto face_node = [&](int a, int pos, int q, int nv, int& i, int& j, int& k) {
+    const int u = q / nv, v = q - u * nv;
+    if (a == 0) { i = pos; j = lo1 + u; k = lo2 + v; }
+    else if (a == 1) { i = lo0 + u; j = pos; k = lo2 + v; }
+    else { i = lo0 + u; j = lo1 + v; k = pos; }
+  };
+  int h[3];
+#pragma unroll
+  for (int a = 0; a < 3; ++a) h[a] = G.act[a] ? 1 : 0;
+  // views: strides from the largest box, so that the LDS layout is the same in every workgroup
+  BoxView<T> H, P1, P2;
+  H.p = (T*)(smem + A.o_h);
+  H.s1 = A.bmax[2] + 2 * h[2];
+  H.s0 = (A.bmax[1] + 2 * h[1]) * H.s1;
+  H.off = (h[0] - LO(0)) * H.s0 + (h[1] - LO(1)) * H.s1 + (h[2] - LO(2));
+  P1.p = (T*)(smem + A.o_p1);
+  P1.s1 = A.bmax[2];
+  P1.s0 = A.bmax[1] * A.bmax[2];
+  P1.off = -LO(0) * P1.s0 - LO(1) * P1.s1 - LO(2);
+  P2 = P1;
+  P2.p = (T*)(smem + A.o_p2);
+  T* bcc = (T*)(smem + A.o_bcc);    // [6 list slots][nface]
+  T* shold = (T*)(smem + A.o_sh);   // [6 faces][nface]
+  unsigned* meta = (unsigned*)(smem + A.o_meta);
+  // work lists of the per-iteration face loops, dense by (face, q) with uniform bases (built once below):
+  //   BC fill: index of the face node in X, in list order per BC slot (bcc in the same order)
+  //   shell:   index in X of the shell nodes this box owns (0xffff: owned by another face), shold in the same order
+  //   publish: index of the layer cell in the source array + its mailbox offset
+  //   receive: index of the halo cell in H + the offset of its value in the neighbour's mailbox (+ in-S flag)
+  unsigned short* bcD = (unsigned short*)(smem + A.o_lists);
+  unsigned short* shD = bcD + 6 * A.nface;
+  unsigned short* pubS = shD + 6 * A.nface;
+  unsigned short* pubO = pubS + 6 * A.nface;
+  unsigned short* rcvH = pubO + 6 * A.nface;
+  unsigned* rcvO = (unsigned*)(smem + A.o_lists + (size_t)10 * 6 * A.nface);
+  __shared__ int fm_cnt[6], fm_base[6], fm_sst[6];   // BC slot w: nodes of this box, list base, signed stride to prev
+  __shared__ int n_sh, n_pub, n_rcv;
+  const BoxView<T>& X = SOLVER == 0 ? P1 : H;   // the iterate (BC fill, shell term)
+  const BoxAcc<T> hacc{H};
+  T* const Hp = H.p;
+  T* const P1p = P1.p;
+  T* const P2p = P2.p;
+  const int hs0 = H.s0, hs1 = H.s1;
+
+  ResSync S;
+  S.counter = A.counter; S.fail = A.fail; S.step = 0; S.G = gridDim.x; S.spin_max = A.spin_max;
+
+  if (tid == 0) sc = *A.sc;
+  __syncthreads();
+  if (sc.done) return;   // `while tol > tolerance` false at entry (linalg.py:109): nothing runs
+
+  // neighbour boxes: workgroup index, or -1 at the ends of the mesh
+  int nb[6];
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    const int st = a == 0 ? A.P[1] * A.P[2] : (a == 1 ? A.P[2] : 1);
+    nb[2 * a] = PP(a) > 0 ? (int)blockIdx.x - st : -1;
+    nb[2 * a + 1] = PP(a) + 1 < A.P[a] ? (int)blockIdx.x + st : -1;
+  }
+
+  // ---- load ---------------------------------------------------------------------------------------
+  for (int c = tid; c < nbox; c += NT) {
+    int bi, bj, bk;
+    decode(c, bi, bj, bk);
+    const int i = LO(0) + bi, j = LO(1) + bj, k = LO(2) + bk;
+    const int64_t o = (int64_t)i * G.s0 + (int64_t)j * G.s1 + k;
+    const int hidx = i * H.s0 + j * H.s1 + k + H.off;
+    const int pidx = i * P1.s0 + j * P1.s1 + k + P1.off;
+    unsigned m = (unsigned)hidx | ((unsigned)pidx << 13);
+    if (pa_in_S(G, i, j, k)) m |= 1u << 25;
+    m |= (unsigned)pa_row_case(G, 0, i, G.n0, G.treat) << 26;
+    m |= (unsigned)pa_row_case(G, 1, j, G.n1, G.treat) << 28;
+    m |= (unsigned)pa_row_case(G, 2, k, G.n2, G.treat) << 30;
+    meta[c] = m;
+    if (SOLVER == 0) {
+      P1p[pidx] = A.x[o];
+      const T rv = A.r0[o];
+      P2p[pidx] = rv;
+      Hp[hidx] = rv;   // d = r (linalg.py:107)
+    } else {
+      Hp[hidx] = A.x[o];
+      P2p[pidx] = A.rhs[o];
+    }
+  }
+  // halo of H from the global arrays (complete at this point)
+#pragma unroll
+  for (int dir = 0; dir < 6; ++dir) {
+    const int a = dir >> 1, side = dir & 1;
+    if (nb[dir] < 0) continue;
+    int nu, nv;
+    face_dims(a, nu, nv);
+    const int pos = side == 0 ? LO(a) - 1 : LO(a) + BB(a);
+    for (int q = tid; q < nu * nv; q += NT) {
+      int i, j, k;
+      face_node(a, pos, q, nv, i, j, k);
+      const int64_t o = (int64_t)i * G.s0 + (int64_t)j * G.s1 + k;
+      H(i, j, k) = SOLVER == 0 ? A.r0[o] : A.x[o];
+    }
+  }
+  const int64_t Ng[3] = {G.n0, G.n1, G.n2};
+  auto touches = [&](int f) -> bool {
+    const int a = f >> 1;
+    const int pa = PP(a);
+    return res_pick(G.act, a) && ((f & 1) == 0 ? pa == 0 : pa == res_pick(A.P, a) - 1);
+  };
+  // ---- work lists (see above) and the BC constants, by list slot --------------------------------------
+  T* const Xp = X.p;
+  {
+    int base = 0;
+#pragma unroll
+    for (int w = 0; w < 6; ++w) {
+      const ResFace<T>& F = A.f[w];
+      int cnt = 0;
+      if (F.face >= 0 && touches(F.face)) {
+        const int a = F.face >> 1, side = F.face & 1;
+        int nu, nv;
+        face_dims(a, nu, nv);
+        cnt = nu * nv;
+        const int64_t gnv = a == 2 ? G.n1 : G.n2;
+        const int pos = side == 0 ? 0 : (int)res_pick(Ng, a) - 1;
+        for (int q = tid; q < cnt; q += NT) {
+          int i, j, k;
+          face_node(a, pos, q, nv, i, j, k);
+          const int u = q / nv, v = q - u * nv;
+          const int64_t gq = (int64_t)((a == 0 ? LO(1) : LO(0)) + u) * gnv + ((a == 2 ? LO(1) : LO(2)) + v);
+          T ct = F.sval;
+          if (F.vals) {
+            ct = F.vals[gq];
+            if (F.type == 2) {
+              ct = A.c23 * ct;
+              ct = ct * F.dxf;
+              ct = ct * F.ndir;
+            }
+          }
+          bcc[base + q] = ct;
+          bcD[base + q] = (unsigned short)(i * X.s0 + j * X.s1 + k + X.off);
+        }
+        if (tid == 0) {
+          const int st = a == 0 ? X.s0 : (a == 1 ? X.s1 : 1);
+          fm_sst[w] = side == 0 ? st : -st;
+        }
+      }
+      if (tid == 0) { fm_cnt[w] = cnt; fm_base[w] = base; }
+      base += cnt;
+    }
+  }
+  __syncthreads();
+  {
+    int base = 0;
+#pragma unroll
+    for (int f = 0; f < 6; ++f) {
+      if (!touches(f)) continue;
+      const int a = f >> 1;
+      int nu, nv;
+      face_dims(a, nu, nv);
+      const int pos = (f & 1) == 0 ? 0 : (int)Ng[a] - 1;
+      for (int q = tid; q < nu * nv; q += NT) {
+        int i, j, k;
+        face_node(a, pos, q, nv, i, j, k);
+        bool owned = true;   // each shell node once: the rule of pa_shell_node
+        if (a >= 1 && G.act[0] && (i == 0 || i == G.n0 - 1)) owned = false;
+        if (a == 2 && G.act[1] && (j == 0 || j == G.n1 - 1)) owned = false;
+        shD[base + q] = owned ? (unsigned short)(i * X.s0 + j * X.s1 + k + X.off) : (unsigned short)0xffff;
+        shold[base + q] = X(i, j, k);   // the filled shell as x_old (k_shell, mode 0)
+      }
+      base += nu * nv;
+    }
+    if (tid == 0) n_sh = A.bc_static ? 0 : base;
+  }
+  {
+    const BoxView<T>& SRC = SOLVER == 0 ? P2 : H;   // what travels: CG the residual, Jacobi the iterate
+    int base = 0;
+#pragma unroll
+    for (int dir = 0; dir < 6; ++dir) {
+      if (nb[dir] < 0) continue;
+      const int a = dir >> 1;
+      int nu, nv;
+      face_dims(a, nu, nv);
+      const int pos_out = (dir & 1) == 0 ? LO(a) : LO(a) + BB(a) - 1;
+      const int pos_in = (dir & 1) == 0 ? LO(a) - 1 : LO(a) + BB(a);
+      for (int q = tid; q < nu * nv; q += NT) {
+        int i, j, k;
+        face_node(a, pos_out, q, nv, i, j, k);
+        pubS[base + q] = (unsigned short)(i * SRC.s0 + j * SRC.s1 + k + SRC.off);
+        pubO[base + q] = (unsigned short)(dir * A.nface + q);
+        face_node(a, pos_in, q, nv, i, j, k);
+        rcvH[base + q] = (unsigned short)(i * H.s0 + j * H.s1 + k + H.off);
+        rcvO[base + q] = (unsigned)((nb[dir] * 6 + (dir ^ 1)) * A.nface + q) | (pa_in_S(G, i, j, k) ? 0x80000000u : 0u);
+      }
+      base += nu * nv;
+    }
+    if (tid == 0) { n_pub = base; n_rcv = base; }
+  }
+  __syncthreads();
+
+  // A(field in H) at own cell c: one Laplacian term from the per-cell word (the arithmetic of pa_apply_terms,
+  // kind 0, rounding for rounding), or pa_apply_terms itself
+  const T lsign = E.t[0].sign, lcoeff = E.t[0].coeff;
+  const int lhas = E.t[0].has_coeff;
+  auto stencil = [&](int c, unsigned m, T xc) -> T {
+    if (LEAN) {
+      const int hx = RES_M_H(m);
+      T ax = (T)0;
+      if ((m >> 26) == 0u) {   // no boundary row on any axis (almost every cell): the plain (1, -2, 1) / h^2 rows
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+          if (!G.act[a]) continue;
+          const int st = a == 0 ? hs0 : (a == 1 ? hs1 : 1);
+          const T xp = Hp[hx + st], xm = Hp[hx - st];
+          T s = E.lap.inv[a] * xp;
+          T mm = E.lap.m2inv[a] * xc;
+          s = s + mm;
+          mm = E.lap.inv[a] * xm;
+          s = s + mm;
+          ax = ax + s;
+        }
+        if (lhas) ax = ax * lcoeff;
+        ax = ax * lsign;
+        return (T)0 + ax;
+      }
+#pragma unroll
+      for (int a = 0; a < 3; ++a) {
+        if (!G.act[a]) continue;
+        const int st = a == 0 ? hs0 : (a == 1 ? hs1 : 1);
+        const int rc = RES_M_RC(m, a);
+        const T cB = E.lap.c23[a];
+        T cP = E.lap.inv[a], cC = E.lap.m2inv[a], cM = E.lap.inv[a];
+        if (rc == 1) { cP = cB; cC = -cB; cM = (T)0; }
+        if (rc == 2) { cP = (T)0; cC = -cB; cM = cB; }
+        const T xp = Hp[hx + st], xm = Hp[hx - st];
+        T s = cP * xp;
+        T mm = cC * xc;
+        s = s + mm;
+        mm = cM * xm;
+        s = s + mm;
+        ax = ax + s;
+      }
+      if (lhas) ax = ax * lcoeff;
+      ax = ax * lsign;
+      return (T)0 + ax;
+    } else {
+      int bi, bj, bk;
+      decode(c, bi, bj, bk);
+      return pa_apply_terms<T>(G, E, hacc, LO(0) + bi, LO(1) + bj, LO(2) + bk, xc);
+    }
+  };
+
+  // the ordered BC fill of the box's part of the shell (literal: face after face, a later face reads what an
+  // earlier one wrote), then sum (x_new - x_old)^2 over the shell nodes this box owns
+  auto bc_fill_and_shell = [&](double& acc) {
+#pragma unroll
+    for (int w = 0; w < 6; ++w) {
+      const int cnt = fm_cnt[w];
+      if (cnt > 0) {
+        const int base = fm_base[w], sst = fm_sst[w], type = A.f[w].type;
+        for (int n = tid; n < cnt; n += NT) {
+          const int d = bcD[base + n];
+          T val;
+          if (type == 1) {
+            val = bcc[base + n];
+          } else if (type == 2) {
+            T t1 = A.c43 * Xp[d + sst];
+            T t2 = A.c13 * Xp[d + 2 * sst];
+            t1 = t1 - t2;
+            val = t1 + bcc[base + n];
+          } else {
+            val = Xp[d + sst];
+          }
+          Xp[d] = val;
+        }
+        __syncthreads();
+      }
+    }
+    const int ns = n_sh;
+    for (int n = tid; n < ns; n += NT) {
+      const int d = shD[n];
+      if (d == 0xffff) continue;
+      const T xn = Xp[d];
+      T df = xn - shold[n];
+      T p = df * df;
+      acc += (double)p;
+      shold[n] = xn;
+    }
+  };
+
+  // the box's outer layers -> this workgroup's mailboxes (one per direction with a neighbour)
+  T* const SRCp = SOLVER == 0 ? P2p : Hp;
+  auto publish = [&]() {
+    T* mine = A.mail + ((size_t)(S.step & 1) * gridDim.x + blockIdx.x) * 6 * A.nface;
+    const int np = n_pub;
+    for (int n = tid; n < np; n += NT)
+      __hip_atomic_store(mine + pubO[n], SRCp[pubS[n]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  };
+
+  bool timed_out = false;
+  for (;;) {
+    if (A.x_old_out) {   // Field.VARo: the iterate before this iteration's update
+      for (int c = tid; c < nbox; c += NT) {
+        int bi, bj, bk;
+        decode(c, bi, bj, bk);
+        const int i = LO(0) + bi, j = LO(1) + bj, k = LO(2) + bk;
+        A.x_old_out[(int64_t)i * G.s0 + (int64_t)j * G.s1 + k] = X(i, j, k);
+      }
+    }
+    if (SOLVER == 0) {
+      // ---- Ad = A(d) on S, alpha = r.r / d.Ad (linalg.py:115-120) ----------------------------------
+      double v[RES_NS] = {0.0, 0.0};
+      for (int c = tid; c < nbox; c += NT) {
+        const unsigned m = meta[c];
+        if (RES_M_S(m)) {
+          const T e = Hp[RES_M_H(m)];
+          const T Ad = stencil(c, m, e);
+          T p = e * Ad;
+          v[0] += (double)p;
+        }
+      }
+      if (!res_allreduce(S, A.parts, v, red)) { timed_out = true; break; }
+      if (tid == 0) pa_logic_a<T>(&sc, red);
+      __syncthreads();
+      const T alpha = (T)sc.alpha;
+      // ---- x += alpha d ; r -= alpha A d ; BC fill ; partial r.r, |dx|^2 (linalg.py:122-134) -------
+      // (no node of S is on the shell without a periodic face: the off-shell test of k_cg_b is always true)
+      v[0] = 0.0; v[1] = 0.0;
+      for (int c = tid; c < nbox; c += NT) {
+        const unsigned m = meta[c];
+        if (RES_M_S(m)) {
+          const int px = RES_M_P(m);
+          const T dc = Hp[RES_M_H(m)];
+          const T Ad = stencil(c, m, dc);
+          const T xo = P1p[px];
+          T ad = alpha * dc;
+          T xn = xo + ad;
+          P1p[px] = xn;
+          T aAd = alpha * Ad;
+          T rn = P2p[px] - aAd;
+          P2p[px] = rn;
+          T p = rn * rn;
+          v[0] += (double)p;
+          T df = xn - xo;
+          T p2 = df * df;
+          v[1] += (double)p2;
+        }
+      }
+      __syncthreads();
+      if (!A.bc_static) bc_fill_and_shell(v[1]);
+      publish();
+      // sums: red[0] = r.r, red[1] = |x_new - x_old|^2 ; pa_logic_b reads them as sums[1], sums[2]
+      if (!res_allreduce(S, A.parts, v, red)) { timed_out = true; break; }
+      if (tid == 0) {
+        const double sums[3] = {0.0, red[0], red[1]};
+        pa_logic_b<T>(&sc, sums);
+      }
+      __syncthreads();
+      if (sc.done) break;
+      // ---- d' = r + beta d (linalg.py:141): own cells, then the halo from the neighbours' r layers ---
+      const T beta = (T)sc.beta;
+      for (int c = tid; c < nbox; c += NT) {
+        const unsigned m = meta[c];
+        const int hx = RES_M_H(m);
+        T e = (T)0;
+        if (RES_M_S(m)) {
+          T bd = beta * Hp[hx];
+          e = P2p[RES_M_P(m)] + bd;
+        }
+        Hp[hx] = e;
+      }
+      {
+        const T* theirs = A.mail + (size_t)((S.step - 1) & 1) * gridDim.x * 6 * A.nface;   // the step just completed
+        const int nr = n_rcv;
+        for (int n = tid; n < nr; n += NT) {
+          const unsigned o = rcvO[n];
+          const int hx = rcvH[n];
+          const T rv = __hip_atomic_load(theirs + (o & 0x7fffffffu), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          T e = (T)0;
+          if (o >> 31) {
+            T bd = beta * Hp[hx];
+            e = rv + bd;
+          }
+          Hp[hx] = e;
+        }
+      }
+      __syncthreads();
+    } else {
+      // ---- Jacobi sweep: x' = x + omega (b - A x) / diag(A) on S (k_jacobi) -------------------------
+      double v[RES_NS] = {0.0, 0.0};
+      for (int c = tid; c < nbox; c += NT) {
+        const unsigned m = meta[c];
+        const T xo = Hp[RES_M_H(m)];
+        T xn = xo;
+        if (RES_M_S(m)) {
+          T diag = (T)0;
+          const int nterms = LEAN ? 1 : E.nterms;   // LEAN: one term (a constant index keeps E off scratch memory)
+          for (int q = 0; q < nterms; ++q) {
+            const DevTerm<T>& t = E.t[LEAN ? 0 : q];
+            T dg = (T)0;
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+              if (!G.act[a]) continue;
+              const int rc = RES_M_RC(m, a);
+              T cB = E.lap.c23[a];
+              if (!LEAN && E.rz && a == PA_RZ_AXIS) {
+                int bi, bj, bk;
+                decode(c, bi, bj, bk);
+                cB = E.rz[2 * E.rz_n + LO(1) + bj];
+              }
+              T cC = rc == 0 ? E.lap.m2inv[a] : -cB;
+              dg = dg + cC;
+            }
+            if (t.has_coeff) dg = dg * t.coeff;
+            dg = dg * t.sign;
+            diag = diag + dg;
+          }
+          T ax = stencil(c, m, xo);
+          T res = P2p[RES_M_P(m)] - ax;
+          res = res / diag;
+          T w = A.omega * res;
+          xn = xo + w;
+          T df = xn - xo;
+          T p2 = df * df;
+          v[1] += (double)p2;
+        }
+        P1p[RES_M_P(m)] = xn;
+      }
+      __syncthreads();
+      for (int c = tid; c < nbox; c += NT) {
+        const unsigned m = meta[c];
+        Hp[RES_M_H(m)] = P1p[RES_M_P(m)];
+      }
+      __syncthreads();
+      if (!A.bc_static) bc_fill_and_shell(v[1]);
+      __syncthreads();
+      publish();
+      if (!res_allreduce(S, A.parts, v, red)) { timed_out = true; break; }
+      if (tid == 0) pa_logic_jacobi<T>(&sc, red[1]);
+      __syncthreads();
+      if (sc.done) break;
+      {
+        const T* theirs = A.mail + (size_t)((S.step - 1) & 1) * gridDim.x * 6 * A.nface;
+        const int nr = n_rcv;
+        for (int n = tid; n < nr; n += NT)
+          Hp[rcvH[n]] = __hip_atomic_load(theirs + (rcvO[n] & 0x7fffffffu), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      __syncthreads();
+    }
+  }
+
+  // ---- store ---------------------------------------------------------------------------------------
+  __syncthreads();
+  for (int c = tid; c < nbox; c += NT) {
+    int bi, bj, bk;
+    decode(c, bi, bj, bk);
+    const int i = LO(0) + bi, j = LO(1) + bj, k = LO(2) + bk;
+    A.x[(int64_t)i * G.s0 + (int64_t)j * G.s1 + k] = X(i, j, k);
+  }
+  if (blockIdx.x == 0 && tid == 0) {
+    if (timed_out) { sc.err = 2; }
+    sc.done = 1;
+    *A.sc = sc;
+  }
+}
+
+// ---- host side ------------------------------------------------------------------------------------------
+struct ResPlan {
+  int P[3], bmax[3], nface, G;
+  unsigned o_h, o_p1, o_p2, o_bcc, o_sh, o_meta, o_lists, lds;
+  int cells;
+};
+
+// tuning knobs of the plan (measurement runs only; the defaults are what DESIGN.md quotes)
+static int res_tune(const char* name, int dflt) {
+  const char* e = getenv(name);
+  return e && atoi(e) > 0 ? atoi(e) : dflt;
+}
+
+static bool res_plan(const pa_ctx* c, size_t es, ResPlan& R) {
+  const DevGeom& G = c->G;
+  const int64_t N[3] = {G.n0, G.n1, G.n2};
+  const int maxbox = std::min(RES_MAXBOX, res_tune("PYAPES_HIP_RES_BOX", RES_MAXBOX));
+  const int per_wg = res_tune("PYAPES_HIP_RES_CELLS", 1024);   // cells per workgroup aimed at (<= 64 workgroups)
+  if (G.ncell > (int64_t)RES_MAXG * maxbox) return false;
+  int P[3] = {1, 1, 1};
+  const int want = (int)std::max<int64_t>(1, std::min<int64_t>(res_tune("PYAPES_HIP_RES_MAXWANT", 64), (G.ncell + per_wg - 1) / per_wg));
+  for (;;) {
+    int b[3];
+    for (int a = 0; a < 3; ++a) b[a] = (int)((N[a] + P[a] - 1) / P[a]);
+    const int g = P[0] * P[1] * P[2];
+    const int cells = b[0] * b[1] * b[2];
+    const int h[3] = {G.act[0] ? 1 : 0, G.act[1] ? 1 : 0, G.act[2] ? 1 : 0};
+    const size_t halo = (size_t)(b[0] + 2 * h[0]) * (b[1] + 2 * h[1]) * (b[2] + 2 * h[2]);
+    int nface = 1;   // largest box face among the faces normal to a mesh axis
+    for (int a = 0; a < 3; ++a)
+      if (G.act[a]) nface = std::max(nface, b[0] * b[1] * b[2] / b[a]);
+    auto up = [](size_t v) { return (v + 15) & ~(size_t)15; };
+    size_t o = 0;
+    R.o_h = (unsigned)o;   o += up(halo * es);
+    R.o_p1 = (unsigned)o;  o += up((size_t)cells * es);
+    R.o_p2 = (unsigned)o;  o += up((size_t)cells * es);
+    R.o_bcc = (unsigned)o; o += up((size_t)6 * nface * es);
+    R.o_sh = (unsigned)o;  o += up((size_t)6 * nface * es);
+    R.o_meta = (unsigned)o; o += up((size_t)cells * sizeof(unsigned));
+    R.o_lists = (unsigned)o; o += up((size_t)6 * nface * (5 * sizeof(unsigned short) + sizeof(unsigned)));
+    // (the per-cell word has 13 bits for the haloed index, 12 for the plain one)
+    if (g >= want && cells <= maxbox && halo <= 8192 && o <= RES_LDS_LIMIT) {
+      for (int a = 0; a < 3; ++a) { R.P[a] = P[a]; R.bmax[a] = b[a]; }
+      R.nface = nface; R.G = g; R.lds = (unsigned)o; R.cells = cells;
+      return true;
+    }
+    // split the axis with the largest box extent; every box keeps >= 3 nodes per axis, so that the nodes a
+    // face fill reads (prev, prev2) are in the box that holds the face node
+    int best = -1;
+    for (int a = 0; a < 3; ++a)
+      if (G.act[a] && N[a] / (P[a] + 1) >= 3 && (best < 0 || b[a] > b[best])) best = a;
+    if (best < 0) return false;
+    P[best] += 1;
+    if (P[0] * P[1] * P[2] > RES_MAXG) return false;
+  }
+}
+
+static bool res_applicable(const pa_ctx* c) {
+  if (!c->resident || c->slab || c->profile) return false;
+  const DevGeom& G = c->G;
+  for (int f = 0; f < 6; ++f)
+    if (G.act[f >> 1] && (c->bc[f].type == PA_BC_PERIODIC || c->bc[f].type == PA_BC_NONE)) return false;
+  for (int q = 0; q < c->nterms; ++q)
+    if (c->terms[q].coeff_field || c->terms[q].u_field) return false;
+  for (int a = 0; a < 3; ++a)
+    if (G.act[a] && (a == 0 ? G.g0 : (a == 1 ? G.n1 : G.n2)) < 5) return false;
+  return true;
+}
+
+template <typename T>
+int pa_resident_launch(pa_ctx* c, int solver, T* x, const T* r0, const T* rhs, double omega) {
+  if (!res_applicable(c)) return 0;
+  ResPlan R;
+  if (!res_plan(c, sizeof(T), R)) return 0;
+  const bool lean = c->nterms == 1 && c->terms[0].kind == PA_OP_LAPLACIAN && c->coord == PA_COORD_XYZ;
+  // threads per workgroup: more waves hide the LDS latency of the cell passes once a thread has several cells;
+  // the general-equation build needs more registers than 512 / 1024 threads leave
+  int nt = 256;
+  if (lean && R.cells > res_tune("PYAPES_HIP_RES_NT_CELLS", 256))
+    nt = res_tune("PYAPES_HIP_RES_NT", R.cells > 1024 ? 1024 : 512);
+  const void* fn;
+  if (!lean) fn = solver == 0 ? (const void*)k_resident<T, 0, false, 256> : (const void*)k_resident<T, 1, false, 256>;
+  else if (nt == 1024) fn = solver == 0 ? (const void*)k_resident<T, 0, true, 1024> : (const void*)k_resident<T, 1, true, 1024>;
+  else if (nt == 512) fn = solver == 0 ? (const void*)k_resident<T, 0, true, 512> : (const void*)k_resident<T, 1, true, 512>;
+  else { nt = 256; fn = solver == 0 ? (const void*)k_resident<T, 0, true, 256> : (const void*)k_resident<T, 1, true, 256>; }
+  // co-residency: one workgroup per CU at this LDS size; the cooperative launch itself refuses a grid that
+  // does not fit (then the launch-per-phase loops run)
+  if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)R.lds) != hipSuccess) {
+    (void)hipGetLastError();
+    return 0;
+  }
+  int per_cu = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, nt, R.lds) != hipSuccess || per_cu < 1) {
+    (void)hipGetLastError();
+    return 0;
+  }
+  int cus = 0;
+  if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device) != hipSuccess || per_cu * cus < R.G)
+    return 0;
+  // scratch: counter + fail flag | partial sums | mailboxes
+  const size_t head = 256;
+  const size_t parts_b = (size_t)2 * R.G * RES_NS * sizeof(double);
+  const size_t mail_b = (size_t)2 * R.G * 6 * R.nface * sizeof(T);
+  int rc;
+  if ((rc = pa_scratch(c, &c->scr[SCR_RES], &c->cap[SCR_RES], head + parts_b + mail_b))) return rc;
+  char* base = (char*)c->scr[SCR_RES];
+  PA_HIP(c, hipMemsetAsync(base, 0, head + parts_b, c->stream));
+
+  ResArgs<T> A;
+  memset(&A, 0, sizeof(A));
+  for (int w = 0; w < 6; ++w) A.f[w].face = -1;
+  int nw = 0;
+  for (int w = 0; w < c->nbc && nw < 6; ++w) {
+    const int f = c->bc_order[w];
+    const HostBC& b = c->bc[f];
+    if (b.type == PA_BC_NONE || !c->G.act[f >> 1]) continue;
+    ResFace<T>& F = A.f[nw++];
+    F.face = f;
+    F.type = b.type;
+    F.vals = (const T*)b.vals;
+    F.dxf = (T)b.dxf;
+    F.ndir = (f & 1) == 0 ? (T)-1 : (T)1;
+    if (b.type == PA_BC_DIRICHLET) F.sval = (T)b.value;
+    if (b.type == PA_BC_NEUMANN) {   // as pa_bc_apply_faces
+      T pre = (T)((2.0 / 3.0) * b.value);
+      pre = pre * F.dxf;
+      pre = pre * F.ndir;
+      F.sval = pre;
+    }
+  }
+  A.c43 = (T)(4.0 / 3.0);
+  A.c13 = (T)(1.0 / 3.0);
+  A.c23 = (T)(2.0 / 3.0);
+  for (int a = 0; a < 3; ++a) { A.P[a] = R.P[a]; A.bmax[a] = R.bmax[a]; }
+  A.nface = R.nface;
+  A.bc_static = pa_bc_is_static(c) ? 1 : 0;
+  A.omega = (T)omega;
+  A.x = x; A.r0 = r0; A.rhs = rhs;
+  A.x_old_out = (T*)c->x_old_out;
+  A.sc = c->sc;
+  A.counter = (unsigned long long*)base;
+  A.fail = (int*)(base + 64);
+  A.parts = (double*)(base + head);
+  A.mail = (T*)(base + head + parts_b);
+  A.spin_max = 1u << 21;   // x (one atomic load + s_sleep) ~ seconds: far beyond any legitimate wait
+  A.o_h = R.o_h; A.o_p1 = R.o_p1; A.o_p2 = R.o_p2; A.o_bcc = R.o_bcc; A.o_sh = R.o_sh; A.o_meta = R.o_meta; A.o_lists = R.o_lists;
+  DevGeom G = c->G;
+  DevEq<T> E;
+  pa_build_eq<T>(c, c->nterms, c->terms, E);
+  void* args[] = {&G, &E, &A};
+  hipError_t e = hipLaunchCooperativeKernel(fn, dim3(R.G), dim3(nt), args, R.lds, c->stream);
+  if (e != hipSuccess) {   // e.g. the device is shared and the grid cannot be co-resident right now
+    (void)hipGetLastError();
+    return 0;
+  }
+  return R.G;
+}
+
+extern "C" {
+int pa_resident_used(const pa_ctx* c) { return c ? c->resident_used : 0; }
+
+int pa_resident_plan(pa_ctx* c, int* boxes) {   // what a solve on the bound mesh would use (tests, DESIGN numbers)
+  if (!c || !boxes) return PA_E_ARG;
+  ResPlan R;
+  boxes[0] = boxes[1] = boxes[2] = 0;
+  if (!res_applicable(c) || !res_plan(c, (size_t)c->esize, R)) return 0;
+  for (int a = 0; a < 3; ++a) boxes[a] = R.P[a];
+  return R.G;
+}
+}  // extern "C"
+
+template int pa_resident_launch<float>(pa_ctx*, int, float*, const float*, const float*, double);
+template int pa_resident_launch<double>(pa_ctx*, int, double*, const double*, const double*, double);

@@ -2,6 +2,7 @@
 // generic kernels (any dimension / term list; the tiled kernels of pa_cg3d*.hip take over where they
 // apply), the single-block reduction + scalar-step kernels, the stepwise CG entry points.
 #include "pa_host.h"
+#include "pa_scalar_steps.h"
 
 #include <math.h>
 #include <stdlib.h>
@@ -143,39 +144,6 @@ __device__ __forceinline__ double pa_reduce_partials(const double* __restrict__ 
   return t;  // valid on thread 0
 }
 
-template <typename T>
-__device__ __forceinline__ double pa_nan_to_num(T v) {
-  return (isnan(v) || isinf(v)) ? 0.0 : (double)v;  // linalg.py:302-305
-}
-
-// the scalar steps of a CG iteration on the device-resident state
-template <typename T>
-__device__ __forceinline__ void pa_logic_a(SolverScalars* sc, const double* sums) {  // linalg.py:118-120
-  T dAd = (T)sums[0];
-  T rr = (T)sc->rr;
-  sc->dAd = (double)dAd;
-  T a = rr / dAd;
-  sc->alpha = (isnan(a) || isinf(a)) ? 0.0 : (double)a;
-}
-
-template <typename T>
-__device__ __forceinline__ void pa_logic_b(SolverScalars* sc, const double* sums) {  // linalg.py:128-141, 321-338
-  T rr_new = (T)sums[1];
-  T tol = (T)sqrt(sums[2]);
-  sc->tol = (double)tol;
-  if (isnan(tol) || isinf(tol)) {  // linalg.py:334-336 raises before beta / itr
-    sc->err = 1;
-    sc->done = 1;
-    return;
-  }
-  T rr_old = (T)sc->rr;
-  sc->rr_old = (double)rr_old;
-  sc->beta = (double)(rr_new / rr_old);
-  sc->rr = (double)rr_new;
-  sc->itr += 1;
-  if (sc->itr > sc->max_it || !(sc->tol > sc->tolerance)) sc->done = 1;
-}
-
 // stage 0: reduce only (multi-GPU, before the all-reduce); 1: logic only; 2: both
 template <typename T>
 __global__ void __launch_bounds__(PA_BLOCK) k_cg_post_a(SolverScalars* sc, const double* partials, int nblk,
@@ -277,11 +245,7 @@ __global__ void __launch_bounds__(PA_BLOCK) k_jacobi_post(SolverScalars* sc, con
   double sh = nblk_shell > 0 ? pa_reduce_partials(partials_shell, nblk_shell, 1, 0, sm) : 0.0;
   if (threadIdx.x == 0) {
     sums[2] = dx2 + sh;
-    T tol = (T)sqrt(sums[2]);
-    sc->tol = (double)tol;
-    if (isnan(tol) || isinf(tol)) { sc->err = 1; sc->done = 1; return; }
-    sc->itr += 1;
-    if (sc->itr > sc->max_it || !(sc->tol > sc->tolerance)) sc->done = 1;
+    pa_logic_jacobi<T>(sc, sums[2]);
   }
 }
 
@@ -786,6 +750,23 @@ static void fill_report(pa_ctx* c, pa_report* out, float ms) {
   out->gpu_ms = ms;
 }
 
+// after a resident launch (pa_resident.hip): the solve has run to its end inside the one kernel
+static int resident_finish(pa_ctx* c, pa_report* out) {
+  int rc = read_scalars(c);
+  c->solver_live = 0;
+  if (rc) return rc;
+  PA_HIP(c, hipEventRecord(c->ev1, c->stream));
+  PA_HIP(c, hipEventSynchronize(c->ev1));
+  float ms = 0.f;
+  (void)hipEventElapsedTime(&ms, c->ev0, c->ev1);
+  fill_report(c, out, ms);
+  if (c->h_sc->err == 2) {
+    pa_set_err(c, "resident solver: a grid-wide wait timed out (workgroups not co-resident?)");
+    return PA_E_STATE;
+  }
+  return c->h_sc->err ? PA_E_NONFINITE : PA_OK;
+}
+
 // r = (b - A x) on S (0 elsewhere), d = r, per-block partial sums of r.r: the tiled A x kernel plus one
 // streaming pass where the tiled kernel applies, else the generic kernel
 template <typename T>
@@ -1125,6 +1106,10 @@ static int cg_run_t(pa_ctx* c, T* x, const T* rhs, double tol, int64_t max_it, p
   if (rc) return rc;
   const int poll = poll_interval(c);
   PA_HIP(c, hipEventRecord(c->ev0, c->stream));
+  // small meshes: the whole loop in one cooperative launch (pa_resident.hip); r = d = the initial residual
+  c->resident_used = pa_resident_launch<T>(c, 0, x, (const T*)c->scr[SCR_R], (const T*)nullptr, 1.0);
+  if (c->resident_used < 0) { c->solver_live = 0; return c->resident_used; }
+  if (c->resident_used > 0) return resident_finish(c, out);
   int64_t enq = 0;
   c->in_iterate = 1;  // scalar steps folded into the next tiled kernel's prologue (flushed before every poll)
   PollPipe P;
@@ -1198,6 +1183,9 @@ static int jacobi_run_t(pa_ctx* c, T* x, const T* rhs, double tol, int64_t max_i
   int cur = 0;
   const int poll = poll_interval(c);
   PA_HIP(c, hipEventRecord(c->ev0, c->stream));
+  c->resident_used = pa_resident_launch<T>(c, 1, x, (const T*)nullptr, rhs, omega);
+  if (c->resident_used < 0) return c->resident_used;
+  if (c->resident_used > 0) return resident_finish(c, out);
   int64_t enq = 0;
   // the stop test of sweep q is left to the prologue of sweep q+1 (pa_cg3d_kernel.h) when both are
   // tiled; this runs it as the single-block kernel it replaces (before a poll, before a generic sweep)

@@ -59,7 +59,8 @@ class HipContext:
             pass
 
     def set_option(self, name: str, value: bool | int) -> None:
-        """Kernel-path switch of this context ("fastpath", "sf", "fold"); results do not depend on them."""
+        """Kernel-path switch of this context ("fastpath", "sf", "fold": results do not depend on them;
+        "resident": small-mesh solves in one cooperative launch, changes the grouping of the global sums only)."""
         self._rc(self.lib.pa_ctx_set_option(self.h, name.encode(), int(value)))
 
     def _rc(self, rc: int) -> None:
@@ -310,6 +311,19 @@ class HipContext:
 
     def cg_finish_iter(self) -> None:
         self._rc(self.lib.pa_cg_finish_iter(self.h))
+
+    def resident_plan(self) -> tuple[int, tuple[int, int, int]]:
+        """(workgroups, boxes per internal axis) a CG / Jacobi solve on the bound mesh, BCs and equation would
+        run resident with; (0, (0, 0, 0)) when the launch-per-phase loops would run."""
+        boxes = (C.c_int * 3)()
+        g = self.lib.pa_resident_plan(self.h, boxes)
+        if g < 0:
+            self._rc(g)
+        return int(g), (int(boxes[0]), int(boxes[1]), int(boxes[2]))
+
+    def resident_used(self) -> int:
+        """Workgroups of the last solve's resident launch (0: the launch-per-phase loops ran)."""
+        return int(self.lib.pa_resident_used(self.h))
 
     def cg_abort(self) -> None:
         self._rc(self.lib.pa_cg_abort(self.h))

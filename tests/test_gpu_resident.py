@@ -1,0 +1,195 @@
+"""-m gpu: the resident small-mesh solver (pa_resident.hip: the whole CG / Jacobi solve in one cooperative
+launch, fields in LDS) against the launch-per-phase loops it replaces and against the oracle.
+
+The two paths run the same per-cell arithmetic; only the grouping of the global sums differs (per-box partials
+summed in box order, against per-tile partial rows), so Jacobi iterates -- no global sum feeds back into them --
+must be bit-identical and CG iterates agree to rounding.  The reference goldens of tests/test_gpu_parity_golden.py
+run through the resident path by default (every golden mesh is small); this file pins the path itself: that it
+is taken, every box layout / face order / dtype, the stop test, Field.VARo and the fall-backs."""
+import os
+import random
+import warnings
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from pyapes_amd.geometry import Box
+from pyapes_amd.hip.context import context_for
+from pyapes_amd.mesh import Mesh
+from pyapes_amd.solver.fdm import FDM
+from pyapes_amd.solver.ops import Solver
+from pyapes_amd.variables import Field
+
+FACES = ["xl", "xu", "yl", "yu", "zl", "zu"]
+
+
+def _solve(monkeypatch, resident, n, bcs, dtype, method, rhs, x0, tol, max_it, order=None, save_old=False, coeff=0.8,
+           env=None):
+    monkeypatch.setenv("PYAPES_HIP_RESIDENT", "1" if resident else "0")
+    for k, v in (env or {}).items():
+        monkeypatch.setenv(k, v)
+    nd = len(n)
+    mesh = Mesh(Box([0.0] * nd, [1.0 + 0.1 * a for a in range(nd)]), None, list(n), "cuda", dtype)
+    cfg = [{"bc_face": FACES[i], "bc_type": t, "bc_val": v, "bc_val_opt": None} for i, (t, v) in enumerate(bcs)]
+    if order is not None:
+        cfg = [cfg[i] for i in order]
+    var = Field("p", 1, mesh, {"domain": cfg, "obstacle": None})
+    var.set_var_tensor(x0.cuda().clone())
+    c = {"method": method, "tol": tol, "max_it": max_it, "report": False}
+    if save_old:
+        c["save_old"] = True
+    s = Solver({"fdm": c})
+    s.set_eq(-FDM().laplacian(coeff, var) == rhs.cuda().clone())
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        rep = s.solve()
+    ctx = context_for(mesh)
+    old = var.VARo.cpu() if save_old and rep["itr"] >= 1 else None
+    return var().cpu(), rep, ctx.resident_used(), ctx.resident_plan(), old
+
+
+def _case(rng):
+    nd = rng.choice([2, 3, 3])
+    if nd == 2:
+        n = [rng.choice([9, 16, 33, 64, 100, 129]), rng.choice([8, 17, 64, 65, 128, 130])]
+    else:
+        n = [rng.choice([5, 8, 12, 17, 24, 33]), rng.choice([6, 9, 16, 20, 40]), rng.choice([8, 17, 32, 33, 64, 66])]
+    bcs = []
+    for a in range(nd):
+        for _ in range(2):
+            t = rng.choice(["dirichlet", "dirichlet", "neumann", "symmetry"])
+            bcs.append((t, None if t == "symmetry" else round(rng.uniform(-1, 1), 3)))
+    if not any(t == "dirichlet" for t, _ in bcs):
+        bcs[0] = ("dirichlet", 0.25)
+    dtype = "double" if rng.random() < 0.7 else "single"
+    return n, bcs, dtype
+
+
+def _fields(n, dtype, seed):
+    tdt = torch.float64 if dtype == "double" else torch.float32
+    g = torch.Generator().manual_seed(seed)
+    rhs = torch.randn((1, *n), generator=g, dtype=torch.float64).to(tdt)
+    x0 = torch.randn((1, *n), generator=g, dtype=torch.float64).to(tdt)
+    return rhs, x0
+
+
+@pytest.mark.parametrize("method", ["cg", "jacobi"])
+def test_resident_matches_launch_per_phase(monkeypatch, method):
+    """random extents / face types / face ORDER / dtypes; a dozen iterations (far from convergence, where a
+    change of the summation grouping cannot yet have been amplified) and, every third case, a stop on the
+    tolerance"""
+    ncases = int(os.environ.get("PYAPES_FUZZ_CASES", "36"))
+    rng = random.Random(11 + len(method) + ncases)
+    taken = 0
+    for case in range(ncases):
+        n, bcs, dtype = _case(rng)
+        rhs, x0 = _fields(n, dtype, 2000 + case)
+        order = list(range(2 * len(n)))
+        if case % 4 == 1:
+            rng.shuffle(order)          # not the factory order: the resident fill is literal, face after face
+        stop = case % 3 == 0
+        tol = (1e-1 if dtype == "double" else 3e-1) if stop else -1.0
+        max_it = 60 if stop else 11
+        xa, ra, ua, _, _ = _solve(monkeypatch, False, n, bcs, dtype, method, rhs, x0, tol, max_it, order)
+        xb, rb, ub, plan, _ = _solve(monkeypatch, True, n, bcs, dtype, method, rhs, x0, tol, max_it, order)
+        assert ua == 0
+        assert ub == plan[0]
+        if ub == 0:
+            continue   # a mesh the plan does not take (an axis too short to cut ...): nothing to compare
+        taken += 1
+        assert int(np.prod(plan[1])) == ub
+        assert ra["itr"] == rb["itr"], (case, n, bcs, dtype, ra, rb)
+        scale = float(xa.abs().max())
+        if method == "jacobi":
+            assert torch.equal(xa, xb), (case, n, bcs, dtype, float((xa - xb).abs().max()))
+        else:
+            rtol = 1e-11 if dtype == "double" else 2e-4
+            assert float((xa - xb).abs().max()) <= rtol * scale, (case, n, bcs, dtype, float((xa - xb).abs().max()), scale)
+        assert rb["tol"] == pytest.approx(ra["tol"], rel=1e-9 if dtype == "double" else 1e-3)
+        assert ra["converge"] == rb["converge"]
+    assert taken >= ncases // 2
+
+
+def test_resident_plan_and_layouts(monkeypatch):
+    """box layouts: one workgroup, cuts along one / two / three axes, uneven boxes, the largest mesh the plan takes
+    (64^3: boxes of 16 x 16 x 13 with a one-cell halo), and just above it (launch-per-phase loops)"""
+    bc3 = [("dirichlet", 0.0), ("neumann", 0.3), ("symmetry", None), ("dirichlet", 1.0), ("neumann", -0.2), ("dirichlet", 0.5)]
+    for n, expect_resident in (([9, 9], True), ([128, 128], True), ([7, 300], True), ([33, 33, 33], True), ([23, 5, 130], True),
+                               ([64, 64, 64], True), ([96, 96, 96], False)):
+        bcs = bc3[: 2 * len(n)]
+        rhs, x0 = _fields(n, "double", 7)
+        xb, rb, ub, plan, _ = _solve(monkeypatch, True, n, bcs, "double", "cg", rhs, x0, -1.0, 6)
+        assert (ub > 0) == expect_resident, (n, ub, plan)
+        xa, ra, ua, _, _ = _solve(monkeypatch, False, n, bcs, "double", "cg", rhs, x0, -1.0, 6)
+        assert ra["itr"] == rb["itr"] == 7
+        assert float((xa - xb).abs().max()) <= 1e-11 * float(xa.abs().max()), (n, plan)
+    # forced layouts of one mesh: many small boxes / few large ones, 256 .. 1024 threads
+    n = [24, 20, 28]
+    rhs, x0 = _fields(n, "double", 8)
+    xa, ra, _, _, _ = _solve(monkeypatch, False, n, bc3, "double", "cg", rhs, x0, -1.0, 9)
+    seen = set()
+    for env in ({"PYAPES_HIP_RES_CELLS": "128"}, {"PYAPES_HIP_RES_CELLS": "4096"}, {"PYAPES_HIP_RES_NT": "256"},
+                {"PYAPES_HIP_RES_NT": "1024", "PYAPES_HIP_RES_NT_CELLS": "1"}):
+        xb, rb, ub, plan, _ = _solve(monkeypatch, True, n, bc3, "double", "cg", rhs, x0, -1.0, 9, env=env)
+        for k in env:
+            monkeypatch.delenv(k)
+        assert ub > 0
+        seen.add(ub)
+        assert float((xa - xb).abs().max()) <= 1e-11 * float(xa.abs().max()), (env, plan)
+    assert len(seen) >= 2
+
+
+def test_resident_vs_oracle(monkeypatch):
+    """the resident path against the CPU oracle (the literal reference algorithm) on a mixed-BC mesh, per-node
+    Dirichlet values and an inhomogeneous Neumann face"""
+    import pyapes_oracle as O
+    n = [18, 14, 22]
+    mesh_o = O.OMesh([0.0, 0.0, 0.0], [1.0, 1.1, 1.2], n, "double", "xyz")
+    bcs = [("dirichlet", 0.4), ("neumann", 0.25), ("symmetry", None), ("dirichlet", -0.3), ("neumann", 0.0), ("dirichlet", 1.0)]
+    cfg = [{"bc_face": FACES[i], "bc_type": t, "bc_val": v} for i, (t, v) in enumerate(bcs)]
+    rhs, x0 = _fields(n, "double", 21)
+    for method, K in (("cg", 8), ("jacobi", 8)):
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            xo, rep_o = O.solve_poisson(mesh_o, cfg, rhs.clone(), x0=x0.clone(), method=method, tol=-1.0, max_it=K - 1,
+                                        coeff=0.8, sign=-1.0)[:2]
+        xb, rb, ub, _, _ = _solve(monkeypatch, True, n, bcs, "double", method, rhs, x0, -1.0, K - 1)
+        assert ub > 0
+        assert rb["itr"] == rep_o["itr"]
+        assert float((xb - xo).abs().max()) <= 1e-11 * float(xo.abs().max())
+        assert rb["tol"] == pytest.approx(rep_o["tol"], rel=1e-9)
+
+
+def test_resident_edges(monkeypatch):
+    """zero iterations (tol >= 1), Field.VARo, a coefficient-free and a negative-coefficient equation, fp32"""
+    n = [20, 24]
+    bcs = [("dirichlet", 0.1), ("neumann", 0.2), ("dirichlet", -0.4), ("symmetry", None)]
+    rhs, x0 = _fields(n, "double", 3)
+    xb, rb, ub, _, _ = _solve(monkeypatch, True, n, bcs, "double", "cg", rhs, x0, 1.5, 10)
+    xa, ra, _, _, _ = _solve(monkeypatch, False, n, bcs, "double", "cg", rhs, x0, 1.5, 10)
+    assert rb["itr"] == ra["itr"] == 0 and torch.equal(xa, xb)
+    for method in ("cg", "jacobi"):
+        xb, rb, ub, _, ob = _solve(monkeypatch, True, n, bcs, "double", method, rhs, x0, -1.0, 5, save_old=True)
+        xa, ra, _, _, oa = _solve(monkeypatch, False, n, bcs, "double", method, rhs, x0, -1.0, 5, save_old=True)
+        assert ub > 0 and rb["itr"] == 6
+        assert float((oa - ob).abs().max()) <= 1e-12 * float(oa.abs().max())
+        xp, rp, _, _, _ = _solve(monkeypatch, True, n, bcs, "double", method, rhs, x0, -1.0, 4)
+        assert float((xp - ob).abs().max()) <= 1e-12 * float(xp.abs().max())   # VARo = the iterate one iteration earlier
+    rhs32, x032 = _fields(n, "single", 4)
+    xb, rb, ub, _, _ = _solve(monkeypatch, True, n, bcs, "single", "cg", rhs32, x032, -1.0, 7, coeff=-1.3)
+    xa, ra, _, _, _ = _solve(monkeypatch, False, n, bcs, "single", "cg", rhs32, x032, -1.0, 7, coeff=-1.3)
+    assert ub > 0 and float((xa - xb).abs().max()) <= 2e-4 * float(xa.abs().max())
+
+
+def test_resident_falls_back(monkeypatch):
+    """periodic faces and tensor coefficients run the launch-per-phase loops (resident_used == 0), same results as ever"""
+    n = [16, 20, 24]
+    rhs, x0 = _fields(n, "double", 5)
+    bcs = [("periodic", None), ("periodic", None), ("dirichlet", 0.0), ("dirichlet", 0.0), ("neumann", 0.1), ("dirichlet", 0.2)]
+    xb, rb, ub, plan, _ = _solve(monkeypatch, True, n, bcs, "double", "cg", rhs, x0, -1.0, 5)
+    assert ub == 0 and plan[0] == 0
+    xa, ra, _, _, _ = _solve(monkeypatch, False, n, bcs, "double", "cg", rhs, x0, -1.0, 5)
+    assert torch.equal(xa, xb)
