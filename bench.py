@@ -517,7 +517,16 @@ def main():
         assert rep.itr == K and rep.status == 0, f"work was skipped: itr={rep.itr}"
         assert bool(torch.isfinite(var()).all())
         passes = 3
-        if not args.no_roofline_probe:
+        res_wg = ctx.resident_used()
+        if res_wg > 0:
+            # small mesh: the whole solve ran as ONE cooperative launch with the fields in LDS (pa_resident.hip);
+            # there is no per-sweep kernel to bracket, a sweep costs stream time / sweeps
+            roof = roofline("k_resident (Jacobi, whole solve in one launch)", ev_ms / K, passes * esize * mesh.N, args.workload,
+                            bool(args.n), {"remark": f"128^2 fp64 = 128 KiB per array, resident in the LDS of {res_wg} workgroups: "
+                                                     "bound by the grid-wide step of a sweep (one agent-scope arrive + wait), "
+                                                     "not by HBM; kernel_ms = stream time of the solve / sweeps",
+                                           "resident_workgroups": res_wg})
+        elif not args.no_roofline_probe:
             ctx.profile(True)
             with warnings.catch_warnings():
                 warnings.simplefilter("ignore")

@@ -86,11 +86,12 @@ int pa_ctx_destroy(pa_ctx* ctx);
  * (bit-identical paths; tests/test_gpu_properties.py, test_gpu_fold.py); "resident" changes the grouping of
  * the global sums only (tests/test_gpu_resident.py). */
 int pa_ctx_set_option(pa_ctx* ctx, const char* name, int value);
-/* Small meshes: pa_cg / pa_jacobi run the whole solve in ONE cooperative launch with the fields resident in
- * LDS (pa_resident.hip) when the bound mesh / BCs / equation allow it.  Returns the number of workgroups
- * (= boxes the mesh is cut into; boxes[3] = boxes per internal axis) such a solve would use, 0 when the
- * launch-per-phase loops would run.  pa_resident_used: the same for the LAST solve of this ctx. */
-int pa_resident_plan(pa_ctx* ctx, int* boxes);
+/* Small meshes: pa_cg / pa_jacobi / pa_bicgstab run the whole solve in ONE cooperative launch with the fields
+ * resident in LDS (pa_resident.hip) when the bound mesh / BCs / equation allow it.  Returns the number of
+ * workgroups (= boxes the mesh is cut into; boxes[3] = boxes per internal axis) such a solve would use
+ * (solver: 0 CG, 1 Jacobi, 2 BiCGSTAB), 0 when the launch-per-phase loops would run.  pa_resident_used: the
+ * same for the LAST solve of this ctx. */
+int pa_resident_plan(pa_ctx* ctx, int solver, int* boxes);
 int pa_resident_used(const pa_ctx* ctx);
 /* The stream every later call enqueues on (the binding passes torch's CURRENT stream before each call, so
  * that work the caller queued on it -- tensor allocation, input preparation -- is ordered before the

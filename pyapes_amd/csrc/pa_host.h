@@ -186,7 +186,8 @@ int pa_cg3d_phase_b(pa_ctx* c, const DevEq<T>& E, Vec<T> d, T* x, T* r, double* 
 // small meshes (pa_resident.hip): the whole solve in one cooperative launch, fields resident in LDS.  Returns the
 // number of workgroups (> 0) when it ran to the end of the solve (scalars in c->sc), 0 when the configuration is
 // not covered (the caller runs its launch-per-phase loop), < 0 on error.  solver: 0 CG (r0 = initial residual),
-// 1 Jacobi (rhs).  x must already hold the BC-filled start.
+// 1 Jacobi (rhs), 2 BiCGSTAB (r0 = initial residual, rhs = the shadow residual: a second copy of it).  x must
+// already hold the BC-filled start, c->sc the scalars the launch-per-phase loop would start from.
 template <typename T>
 int pa_resident_launch(pa_ctx* c, int solver, T* x, const T* r0, const T* rhs, double omega);
 

@@ -29,7 +29,7 @@
 
 #define RES_MAXG 128
 #define RES_MAXBOX 4096
-#define RES_NS 2            // partial sums per grid-wide step
+#define RES_NS 4            // partial sums per grid-wide step (row width of the mailbox; CG / Jacobi use 2)
 #define RES_LDS_LIMIT (156 * 1024)
 
 template <typename T>
@@ -61,6 +61,8 @@ struct ResArgs {
   T* mail;             // [2][G][6][nface]
   unsigned spin_max;
   unsigned o_h, o_p1, o_p2, o_bcc, o_sh, o_meta, o_lists;   // LDS byte offsets: haloed array, two plain arrays, BC constants, shell, per-cell words, work lists
+  unsigned o_h2, o_h3, o_p3;   // BiCGSTAB: two more haloed arrays, one more plain one
+  const T* rb0;        // BiCGSTAB: the shadow residual r0 (global, read once)
 };
 
 template <typename T>
@@ -138,17 +140,18 @@ __device__ __forceinline__ double res_wave_sum(double x) {
 }
 
 // grid-wide sums: v (per thread) -> out[RES_NS] in LDS, the same bits in every workgroup
-__device__ __forceinline__ bool res_allreduce(ResSync& S, double* parts, double (&v)[RES_NS], double* out) {
+template <int NU>
+__device__ __forceinline__ bool res_allreduce(ResSync& S, double* parts, double (&v)[NU], double* out) {
   __shared__ double sm[RES_NS][16];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   double* row = parts + (size_t)(S.step & 1) * S.G * RES_NS;
 #pragma unroll
-  for (int s = 0; s < RES_NS; ++s) {
+  for (int s = 0; s < NU; ++s) {
     const double x = res_wave_sum(v[s]);
     if (lane == 0) sm[s][wave] = x;
   }
   __syncthreads();
-  if (threadIdx.x < RES_NS) {
+  if (threadIdx.x < NU) {
     const int s = threadIdx.x;
     double x = sm[s][0];
     for (int w = 1; w < (int)(blockDim.x >> 6); ++w) x += sm[s][w];
@@ -157,7 +160,7 @@ __device__ __forceinline__ bool res_allreduce(ResSync& S, double* parts, double 
   if (!res_grid_wait(S)) return false;
   if (wave == 0) {
 #pragma unroll
-    for (int s = 0; s < RES_NS; ++s) {
+    for (int s = 0; s < NU; ++s) {
       double x = 0.0;
       for (unsigned g = lane; g < S.G; g += 64)
         x += __hip_atomic_load(row + (size_t)g * RES_NS + s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -177,6 +180,7 @@ __device__ __forceinline__ bool res_allreduce(ResSync& S, double* parts, double 
 #define RES_M_RC(m, a) ((int)(((m) >> (26 + 2 * (a))) & 3u))
 
 // SOLVER 0: CG (H = d with halo, P1 = x, P2 = r)   1: Jacobi (H = x with halo, P1 = x', P2 = rhs)
+//        2: BiCGSTAB (H = r, then s, then the new r -- with halo; H2 = p, H3 = v with halo; P1 = x, P2 = r0, P3 = t)
 // LEAN: the equation is one Laplacian term with a scalar coefficient on an xyz mesh (the stencil is evaluated from
 // the per-cell word and fixed LDS offsets); else pa_apply_terms on the box (any term list, rz)
 template <typename T, int SOLVER, bool LEAN, int NT>
@@ -253,8 +257,16 @@ __global__ void __launch_bounds__(NT) k_resident(DevGeom G, DevEq<T> E, ResArgs<
   unsigned* rcvO = (unsigned*)(smem + A.o_lists + (size_t)10 * 6 * A.nface);
   __shared__ int fm_cnt[6], fm_base[6], fm_sst[6];   // BC slot w: nodes of this box, list base, signed stride to prev
   __shared__ int n_sh, n_pub, n_rcv;
-  const BoxView<T>& X = SOLVER == 0 ? P1 : H;   // the iterate (BC fill, shell term)
-  const BoxAcc<T> hacc{H};
+  const BoxView<T>& X = SOLVER == 1 ? H : P1;   // the iterate (BC fill, shell term)
+  BoxView<T> H2 = H, H3 = H, P3 = P1;
+  if (SOLVER == 2) {
+    H2.p = (T*)(smem + A.o_h2);
+    H3.p = (T*)(smem + A.o_h3);
+    P3.p = (T*)(smem + A.o_p3);
+  }
+  T* const H2p = H2.p;
+  T* const H3p = H3.p;
+  T* const P3p = P3.p;
   T* const Hp = H.p;
   T* const P1p = P1.p;
   T* const P2p = P2.p;
@@ -295,6 +307,12 @@ __global__ void __launch_bounds__(NT) k_resident(DevGeom G, DevEq<T> E, ResArgs<
       const T rv = A.r0[o];
       P2p[pidx] = rv;
       Hp[hidx] = rv;   // d = r (linalg.py:107)
+    } else if (SOLVER == 2) {
+      P1p[pidx] = A.x[o];
+      Hp[hidx] = A.r0[o];     // r (linalg.py:196-199)
+      P2p[pidx] = A.rb0[o];   // r0
+      H2p[hidx] = (T)0;       // p = v = 0 (linalg.py:203-204)
+      H3p[hidx] = (T)0;
     } else {
       Hp[hidx] = A.x[o];
       P2p[pidx] = A.rhs[o];
@@ -312,7 +330,11 @@ __global__ void __launch_bounds__(NT) k_resident(DevGeom G, DevEq<T> E, ResArgs<
       int i, j, k;
       face_node(a, pos, q, nv, i, j, k);
       const int64_t o = (int64_t)i * G.s0 + (int64_t)j * G.s1 + k;
-      H(i, j, k) = SOLVER == 0 ? A.r0[o] : A.x[o];
+      H(i, j, k) = SOLVER == 1 ? A.x[o] : A.r0[o];
+      if (SOLVER == 2) {
+        H2(i, j, k) = (T)0;
+        H3(i, j, k) = (T)0;
+      }
     }
   }
   const int64_t Ng[3] = {G.n0, G.n1, G.n2};
@@ -383,10 +405,10 @@ __global__ void __launch_bounds__(NT) k_resident(DevGeom G, DevEq<T> E, ResArgs<
       }
       base += nu * nv;
     }
-    if (tid == 0) n_sh = A.bc_static ? 0 : base;
+    if (tid == 0) n_sh = (A.bc_static || SOLVER == 2) ? 0 : base;   // (BiCGSTAB stops on the residual: no shell term)
   }
   {
-    const BoxView<T>& SRC = SOLVER == 0 ? P2 : H;   // what travels: CG the residual, Jacobi the iterate
+    const BoxView<T>& SRC = SOLVER == 0 ? P2 : H;   // what travels: CG the residual, Jacobi the iterate (BiCGSTAB: haloed arrays)
     int base = 0;
 #pragma unroll
     for (int dir = 0; dir < 6; ++dir) {
@@ -415,7 +437,8 @@ __global__ void __launch_bounds__(NT) k_resident(DevGeom G, DevEq<T> E, ResArgs<
   // kind 0, rounding for rounding), or pa_apply_terms itself
   const T lsign = E.t[0].sign, lcoeff = E.t[0].coeff;
   const int lhas = E.t[0].has_coeff;
-  auto stencil = [&](int c, unsigned m, T xc) -> T {
+  auto stencil = [&](const BoxView<T>& SV, int c, unsigned m, T xc) -> T {
+    T* const Hp = SV.p;   // (the source array of this evaluation)
     if (LEAN) {
       const int hx = RES_M_H(m);
       T ax = (T)0;
@@ -459,7 +482,8 @@ __global__ void __launch_bounds__(NT) k_resident(DevGeom G, DevEq<T> E, ResArgs<
     } else {
       int bi, bj, bk;
       decode(c, bi, bj, bk);
-      return pa_apply_terms<T>(G, E, hacc, LO(0) + bi, LO(1) + bj, LO(2) + bk, xc);
+      const BoxAcc<T> acc{SV};
+      return pa_apply_terms<T>(G, E, acc, LO(0) + bi, LO(1) + bj, LO(2) + bk, xc);
     }
   };
 
@@ -502,12 +526,18 @@ __global__ void __launch_bounds__(NT) k_resident(DevGeom G, DevEq<T> E, ResArgs<
   };
 
   // the box's outer layers -> this workgroup's mailboxes (one per direction with a neighbour)
-  T* const SRCp = SOLVER == 0 ? P2p : Hp;
-  auto publish = [&]() {
+  auto publish = [&](const T* SRCp) {
     T* mine = A.mail + ((size_t)(S.step & 1) * gridDim.x + blockIdx.x) * 6 * A.nface;
     const int np = n_pub;
     for (int n = tid; n < np; n += NT)
       __hip_atomic_store(mine + pubO[n], SRCp[pubS[n]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  };
+  // the neighbours' layers of the step just completed -> the halo of DST
+  auto receive = [&](T* DSTp) {
+    const T* theirs = A.mail + (size_t)((S.step - 1) & 1) * gridDim.x * 6 * A.nface;
+    const int nr = n_rcv;
+    for (int n = tid; n < nr; n += NT)
+      DSTp[rcvH[n]] = __hip_atomic_load(theirs + (rcvO[n] & 0x7fffffffu), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   };
 
   bool timed_out = false;
@@ -522,12 +552,12 @@ __global__ void __launch_bounds__(NT) k_resident(DevGeom G, DevEq<T> E, ResArgs<
     }
     if (SOLVER == 0) {
       // ---- Ad = A(d) on S, alpha = r.r / d.Ad (linalg.py:115-120) ----------------------------------
-      double v[RES_NS] = {0.0, 0.0};
+      double v[2] = {0.0, 0.0};
       for (int c = tid; c < nbox; c += NT) {
         const unsigned m = meta[c];
         if (RES_M_S(m)) {
           const T e = Hp[RES_M_H(m)];
-          const T Ad = stencil(c, m, e);
+          const T Ad = stencil(H, c, m, e);
           T p = e * Ad;
           v[0] += (double)p;
         }
@@ -544,7 +574,7 @@ __global__ void __launch_bounds__(NT) k_resident(DevGeom G, DevEq<T> E, ResArgs<
         if (RES_M_S(m)) {
           const int px = RES_M_P(m);
           const T dc = Hp[RES_M_H(m)];
-          const T Ad = stencil(c, m, dc);
+          const T Ad = stencil(H, c, m, dc);
           const T xo = P1p[px];
           T ad = alpha * dc;
           T xn = xo + ad;
@@ -561,7 +591,7 @@ __global__ void __launch_bounds__(NT) k_resident(DevGeom G, DevEq<T> E, ResArgs<
       }
       __syncthreads();
       if (!A.bc_static) bc_fill_and_shell(v[1]);
-      publish();
+      publish(P2p);
       // sums: red[0] = r.r, red[1] = |x_new - x_old|^2 ; pa_logic_b reads them as sums[1], sums[2]
       if (!res_allreduce(S, A.parts, v, red)) { timed_out = true; break; }
       if (tid == 0) {
@@ -598,9 +628,159 @@ __global__ void __launch_bounds__(NT) k_resident(DevGeom G, DevEq<T> E, ResArgs<
         }
       }
       __syncthreads();
+    } else if (SOLVER == 2) {
+      // ---- BiCGSTAB (linalg.py:162-279; the arithmetic of k_bicg_pv / _s / _t / _x and k_bicg_post) --------
+      // p' = r + beta (p - omega v) on every cell, own and halo (the halos hold r, p and v of the neighbours)
+      {
+        const T beta = (T)sc.beta, omega = (T)sc.omega;
+        auto pnew = [&](int hx) {
+          T t = omega * H3p[hx];
+          t = H2p[hx] - t;
+          t = beta * t;
+          H2p[hx] = Hp[hx] + t;
+        };
+        for (int c = tid; c < nbox; c += NT) pnew(RES_M_H(meta[c]));
+        const int nr = n_rcv;
+        for (int n = tid; n < nr; n += NT) pnew(rcvH[n]);
+      }
+      __syncthreads();
+      // v' = A p' on S ; r0 . v' -> alpha (k_bicg_post stage 0)
+      double v1[1] = {0.0};
+      for (int c = tid; c < nbox; c += NT) {
+        const unsigned m = meta[c];
+        const int hx = RES_M_H(m);
+        T vn = (T)0;
+        if (RES_M_S(m)) {
+          vn = stencil(H2, c, m, H2p[hx]);
+          T p = P2p[RES_M_P(m)] * vn;
+          v1[0] += (double)p;
+        }
+        H3p[hx] = vn;
+      }
+      __syncthreads();
+      publish(H3p);
+      if (!res_allreduce(S, A.parts, v1, red)) { timed_out = true; break; }
+      if (tid == 0) {
+        sc.itr += 1;
+        T r0v = (T)red[0];
+        T rho = (T)sc.rho;
+        sc.alpha = pa_nan_to_num<T>(rho / r0v);
+      }
+      receive(H3p);
+      __syncthreads();
+      // s = r - alpha v' on every cell, own and halo, in place of r ; |s|^2
+      const T alpha = (T)sc.alpha;
+      double v4[4] = {0.0, 0.0, 0.0, 0.0};
+      for (int c = tid; c < nbox; c += NT) {
+        const int hx = RES_M_H(meta[c]);
+        T av = alpha * H3p[hx];
+        T sv = Hp[hx] - av;
+        Hp[hx] = sv;
+        T p = sv * sv;
+        v4[0] += (double)p;
+      }
+      {
+        const int nr = n_rcv;
+        for (int n = tid; n < nr; n += NT) {
+          const int hx = rcvH[n];
+          T av = alpha * H3p[hx];
+          Hp[hx] = Hp[hx] - av;
+        }
+      }
+      __syncthreads();
+      // t = A s on S ; t.s, t.t, r0.t -> stop test 1, omega, rho' (k_bicg_post stage 12)
+      for (int c = tid; c < nbox; c += NT) {
+        const unsigned m = meta[c];
+        T tv = (T)0;
+        if (RES_M_S(m)) {
+          const T sc_ = Hp[RES_M_H(m)];
+          tv = stencil(H, c, m, sc_);
+          T a = tv * sc_;
+          T b = tv * tv;
+          T c3 = P2p[RES_M_P(m)] * tv;
+          v4[1] += (double)a;
+          v4[2] += (double)b;
+          v4[3] += (double)c3;
+        }
+        P3p[RES_M_P(m)] = tv;
+      }
+      if (!res_allreduce(S, A.parts, v4, red)) { timed_out = true; break; }
+      if (tid == 0) {
+        T tol = (T)sqrt(red[0]);
+        sc.tol = (double)tol;
+        if (isnan(tol) || isinf(tol)) {
+          sc.err = 1;
+          sc.done = 1;
+        } else {
+          sc.finished_early = (sc.tol <= sc.tolerance) ? 1 : 0;
+          if (!sc.finished_early) {
+            T om = (T)pa_nan_to_num<T>((T)red[1] / (T)red[2]);
+            sc.omega = (double)om;
+            T rn = -om;
+            rn = rn * (T)red[3];
+            sc.rho_next = (double)rn;
+          }
+        }
+      }
+      __syncthreads();
+      if (sc.err) break;
+      // x += alpha p' (+ s omega) ; r = s - omega t ; |r|^2 ; BC fill (k_bicg_x, linalg.py:236-262)
+      {
+        const T omega = (T)sc.omega;
+        const int early = sc.finished_early;
+        v1[0] = 0.0;
+        for (int c = tid; c < nbox; c += NT) {
+          const unsigned m = meta[c];
+          const int hx = RES_M_H(m), px = RES_M_P(m);
+          T ap = alpha * H2p[hx];
+          T xn = P1p[px] + ap;
+          if (!early) {
+            const T sv = Hp[hx];
+            T so = sv * omega;
+            xn = xn + so;
+            T ot = omega * P3p[px];
+            T rn = sv - ot;
+            Hp[hx] = rn;
+            T q = rn * rn;
+            v1[0] += (double)q;
+          }
+          P1p[px] = xn;
+        }
+      }
+      __syncthreads();
+      if (!A.bc_static) {
+        double unused = 0.0;
+        bc_fill_and_shell(unused);
+      }
+      publish(Hp);
+      if (!res_allreduce(S, A.parts, v1, red)) { timed_out = true; break; }
+      if (tid == 0) {   // k_bicg_post stage 3
+        if (sc.finished_early) {
+          sc.done = 1;
+        } else {
+          T tol = (T)sqrt(red[0]);
+          sc.tol = (double)tol;
+          if (isnan(tol) || isinf(tol)) {
+            sc.err = 1;
+            sc.done = 1;
+          } else {
+            if (sc.tol <= sc.tolerance) sc.done = 1;
+            if (sc.itr >= sc.max_it) sc.done = 1;
+            T b = (T)sc.rho_next / (T)sc.rho;
+            b = b * (T)sc.alpha;
+            b = b / (T)sc.omega;
+            sc.beta = (double)b;
+            sc.rho = sc.rho_next;
+          }
+        }
+      }
+      __syncthreads();
+      if (sc.done) break;
+      receive(Hp);
+      __syncthreads();
     } else {
       // ---- Jacobi sweep: x' = x + omega (b - A x) / diag(A) on S (k_jacobi) -------------------------
-      double v[RES_NS] = {0.0, 0.0};
+      double v[2] = {0.0, 0.0};
       for (int c = tid; c < nbox; c += NT) {
         const unsigned m = meta[c];
         const T xo = Hp[RES_M_H(m)];
@@ -628,7 +808,7 @@ __global__ void __launch_bounds__(NT) k_resident(DevGeom G, DevEq<T> E, ResArgs<
             dg = dg * t.sign;
             diag = diag + dg;
           }
-          T ax = stencil(c, m, xo);
+          T ax = stencil(H, c, m, xo);
           T res = P2p[RES_M_P(m)] - ax;
           res = res / diag;
           T w = A.omega * res;
@@ -647,17 +827,12 @@ __global__ void __launch_bounds__(NT) k_resident(DevGeom G, DevEq<T> E, ResArgs<
       __syncthreads();
       if (!A.bc_static) bc_fill_and_shell(v[1]);
       __syncthreads();
-      publish();
+      publish(Hp);
       if (!res_allreduce(S, A.parts, v, red)) { timed_out = true; break; }
       if (tid == 0) pa_logic_jacobi<T>(&sc, red[1]);
       __syncthreads();
       if (sc.done) break;
-      {
-        const T* theirs = A.mail + (size_t)((S.step - 1) & 1) * gridDim.x * 6 * A.nface;
-        const int nr = n_rcv;
-        for (int n = tid; n < nr; n += NT)
-          Hp[rcvH[n]] = __hip_atomic_load(theirs + (rcvO[n] & 0x7fffffffu), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      }
+      receive(Hp);
       __syncthreads();
     }
   }
@@ -680,7 +855,7 @@ __global__ void __launch_bounds__(NT) k_resident(DevGeom G, DevEq<T> E, ResArgs<
 // ---- host side ------------------------------------------------------------------------------------------
 struct ResPlan {
   int P[3], bmax[3], nface, G;
-  unsigned o_h, o_p1, o_p2, o_bcc, o_sh, o_meta, o_lists, lds;
+  unsigned o_h, o_p1, o_p2, o_bcc, o_sh, o_meta, o_lists, o_h2, o_h3, o_p3, lds;
   int cells;
 };
 
@@ -690,7 +865,7 @@ static int res_tune(const char* name, int dflt) {
   return e && atoi(e) > 0 ? atoi(e) : dflt;
 }
 
-static bool res_plan(const pa_ctx* c, size_t es, ResPlan& R) {
+static bool res_plan(const pa_ctx* c, size_t es, int solver, ResPlan& R) {
   const DevGeom& G = c->G;
   const int64_t N[3] = {G.n0, G.n1, G.n2};
   const int maxbox = std::min(RES_MAXBOX, res_tune("PYAPES_HIP_RES_BOX", RES_MAXBOX));
@@ -713,6 +888,12 @@ static bool res_plan(const pa_ctx* c, size_t es, ResPlan& R) {
     R.o_h = (unsigned)o;   o += up(halo * es);
     R.o_p1 = (unsigned)o;  o += up((size_t)cells * es);
     R.o_p2 = (unsigned)o;  o += up((size_t)cells * es);
+    R.o_h2 = R.o_h3 = R.o_p3 = 0;
+    if (solver == 2) {   // BiCGSTAB: r / s, p and v with halo ; x, r0, t without
+      R.o_h2 = (unsigned)o; o += up(halo * es);
+      R.o_h3 = (unsigned)o; o += up(halo * es);
+      R.o_p3 = (unsigned)o; o += up((size_t)cells * es);
+    }
     R.o_bcc = (unsigned)o; o += up((size_t)6 * nface * es);
     R.o_sh = (unsigned)o;  o += up((size_t)6 * nface * es);
     R.o_meta = (unsigned)o; o += up((size_t)cells * sizeof(unsigned));
@@ -750,7 +931,7 @@ template <typename T>
 int pa_resident_launch(pa_ctx* c, int solver, T* x, const T* r0, const T* rhs, double omega) {
   if (!res_applicable(c)) return 0;
   ResPlan R;
-  if (!res_plan(c, sizeof(T), R)) return 0;
+  if (!res_plan(c, sizeof(T), solver, R)) return 0;
   const bool lean = c->nterms == 1 && c->terms[0].kind == PA_OP_LAPLACIAN && c->coord == PA_COORD_XYZ;
   // threads per workgroup: more waves hide the LDS latency of the cell passes once a thread has several cells;
   // the general-equation build needs more registers than 512 / 1024 threads leave
@@ -758,10 +939,11 @@ int pa_resident_launch(pa_ctx* c, int solver, T* x, const T* r0, const T* rhs, d
   if (lean && R.cells > res_tune("PYAPES_HIP_RES_NT_CELLS", 256))
     nt = res_tune("PYAPES_HIP_RES_NT", R.cells > 1024 ? 1024 : 512);
   const void* fn;
-  if (!lean) fn = solver == 0 ? (const void*)k_resident<T, 0, false, 256> : (const void*)k_resident<T, 1, false, 256>;
-  else if (nt == 1024) fn = solver == 0 ? (const void*)k_resident<T, 0, true, 1024> : (const void*)k_resident<T, 1, true, 1024>;
-  else if (nt == 512) fn = solver == 0 ? (const void*)k_resident<T, 0, true, 512> : (const void*)k_resident<T, 1, true, 512>;
-  else { nt = 256; fn = solver == 0 ? (const void*)k_resident<T, 0, true, 256> : (const void*)k_resident<T, 1, true, 256>; }
+  auto pick = [&](const void* f0, const void* f1, const void* f2) { return solver == 0 ? f0 : (solver == 1 ? f1 : f2); };
+  if (!lean) fn = pick((const void*)k_resident<T, 0, false, 256>, (const void*)k_resident<T, 1, false, 256>, (const void*)k_resident<T, 2, false, 256>);
+  else if (nt == 1024) fn = pick((const void*)k_resident<T, 0, true, 1024>, (const void*)k_resident<T, 1, true, 1024>, (const void*)k_resident<T, 2, true, 1024>);
+  else if (nt == 512) fn = pick((const void*)k_resident<T, 0, true, 512>, (const void*)k_resident<T, 1, true, 512>, (const void*)k_resident<T, 2, true, 512>);
+  else { nt = 256; fn = pick((const void*)k_resident<T, 0, true, 256>, (const void*)k_resident<T, 1, true, 256>, (const void*)k_resident<T, 2, true, 256>); }
   // co-residency: one workgroup per CU at this LDS size; the cooperative launch itself refuses a grid that
   // does not fit (then the launch-per-phase loops run)
   if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)R.lds) != hipSuccess) {
@@ -815,6 +997,7 @@ int pa_resident_launch(pa_ctx* c, int solver, T* x, const T* r0, const T* rhs, d
   A.bc_static = pa_bc_is_static(c) ? 1 : 0;
   A.omega = (T)omega;
   A.x = x; A.r0 = r0; A.rhs = rhs;
+  A.rb0 = solver == 2 ? rhs : nullptr;   // BiCGSTAB: the `rhs` argument carries the shadow residual r0
   A.x_old_out = (T*)c->x_old_out;
   A.sc = c->sc;
   A.counter = (unsigned long long*)base;
@@ -823,6 +1006,7 @@ int pa_resident_launch(pa_ctx* c, int solver, T* x, const T* r0, const T* rhs, d
   A.mail = (T*)(base + head + parts_b);
   A.spin_max = 1u << 21;   // x (one atomic load + s_sleep) ~ seconds: far beyond any legitimate wait
   A.o_h = R.o_h; A.o_p1 = R.o_p1; A.o_p2 = R.o_p2; A.o_bcc = R.o_bcc; A.o_sh = R.o_sh; A.o_meta = R.o_meta; A.o_lists = R.o_lists;
+  A.o_h2 = R.o_h2; A.o_h3 = R.o_h3; A.o_p3 = R.o_p3;
   DevGeom G = c->G;
   DevEq<T> E;
   pa_build_eq<T>(c, c->nterms, c->terms, E);
@@ -838,11 +1022,11 @@ int pa_resident_launch(pa_ctx* c, int solver, T* x, const T* r0, const T* rhs, d
 extern "C" {
 int pa_resident_used(const pa_ctx* c) { return c ? c->resident_used : 0; }
 
-int pa_resident_plan(pa_ctx* c, int* boxes) {   // what a solve on the bound mesh would use (tests, DESIGN numbers)
-  if (!c || !boxes) return PA_E_ARG;
+int pa_resident_plan(pa_ctx* c, int solver, int* boxes) {   // what a solve on the bound mesh would use (tests, DESIGN numbers)
+  if (!c || !boxes || solver < 0 || solver > 2) return PA_E_ARG;
   ResPlan R;
   boxes[0] = boxes[1] = boxes[2] = 0;
-  if (!res_applicable(c) || !res_plan(c, (size_t)c->esize, R)) return 0;
+  if (!res_applicable(c) || !res_plan(c, (size_t)c->esize, solver, R)) return 0;
   for (int a = 0; a < 3; ++a) boxes[a] = R.P[a];
   return R.G;
 }

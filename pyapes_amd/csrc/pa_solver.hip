@@ -1313,6 +1313,10 @@ static int bicg_run_t(pa_ctx* c, T* x, const T* rhs, double tol, int64_t max_it,
   int cur = 0;
   const int poll = poll_interval(c);
   PA_HIP(c, hipEventRecord(c->ev0, c->stream));
+  // small meshes: the whole loop in one cooperative launch (pa_resident.hip); r and r0 hold the initial residual
+  c->resident_used = pa_resident_launch<T>(c, 2, x, (const T*)r, (const T*)r0, 1.0);
+  if (c->resident_used < 0) return c->resident_used;
+  if (c->resident_used > 0) return resident_finish(c, out);
   int64_t enq = 0;
   // The three single-block scalar kernels of an iteration are folded into the prologue of the kernel
   // that follows each (pa_cg3d_kernel.h phases 5 / 6, k_bicg_x) when that kernel is a tiled one / the

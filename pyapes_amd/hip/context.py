@@ -312,11 +312,11 @@ class HipContext:
     def cg_finish_iter(self) -> None:
         self._rc(self.lib.pa_cg_finish_iter(self.h))
 
-    def resident_plan(self) -> tuple[int, tuple[int, int, int]]:
-        """(workgroups, boxes per internal axis) a CG / Jacobi solve on the bound mesh, BCs and equation would
+    def resident_plan(self, method: str = "cg") -> tuple[int, tuple[int, int, int]]:
+        """(workgroups, boxes per internal axis) a solve with `method` on the bound mesh, BCs and equation would
         run resident with; (0, (0, 0, 0)) when the launch-per-phase loops would run."""
         boxes = (C.c_int * 3)()
-        g = self.lib.pa_resident_plan(self.h, boxes)
+        g = self.lib.pa_resident_plan(self.h, {"cg": 0, "jacobi": 1, "bicgstab": 2}[method.lower()], boxes)
         if g < 0:
             self._rc(g)
         return int(g), (int(boxes[0]), int(boxes[1]), int(boxes[2]))

@@ -69,7 +69,7 @@ SIGNATURES: dict[str, tuple[Any, list[Any]]] = {
     "pa_ctx_set_option": (C.c_int, [_VP, C.c_char_p, C.c_int]),
     "pa_ctx_set_stream": (C.c_int, [_VP, _VP]),
     "pa_cg_abort": (C.c_int, [_VP]),
-    "pa_resident_plan": (C.c_int, [_VP, C.POINTER(C.c_int)]),
+    "pa_resident_plan": (C.c_int, [_VP, C.c_int, C.POINTER(C.c_int)]),
     "pa_resident_used": (C.c_int, [_VP]),
     "pa_last_error": (C.c_char_p, [_VP]),
     "pa_version": (C.c_char_p, []),

@@ -27,7 +27,7 @@ FACES = ["xl", "xu", "yl", "yu", "zl", "zu"]
 
 
 def _solve(monkeypatch, resident, n, bcs, dtype, method, rhs, x0, tol, max_it, order=None, save_old=False, coeff=0.8,
-           env=None):
+           env=None, adv=False):
     monkeypatch.setenv("PYAPES_HIP_RESIDENT", "1" if resident else "0")
     for k, v in (env or {}).items():
         monkeypatch.setenv(k, v)
@@ -42,13 +42,17 @@ def _solve(monkeypatch, resident, n, bcs, dtype, method, rhs, x0, tol, max_it, o
     if save_old:
         c["save_old"] = True
     s = Solver({"fdm": c})
-    s.set_eq(-FDM().laplacian(coeff, var) == rhs.cuda().clone())
+    if adv:   # a term list the lean (one Laplacian) build does not cover: pa_apply_terms on the box
+        fdm = FDM({"div": {"limiter": "upwind", "edge": False}})
+        s.set_eq(fdm.div(0.6, var) - fdm.laplacian(0.05, var) == rhs.cuda().clone())
+    else:
+        s.set_eq(-FDM().laplacian(coeff, var) == rhs.cuda().clone())
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
         rep = s.solve()
     ctx = context_for(mesh)
     old = var.VARo.cpu() if save_old and rep["itr"] >= 1 else None
-    return var().cpu(), rep, ctx.resident_used(), ctx.resident_plan(), old
+    return var().cpu(), rep, ctx.resident_used(), ctx.resident_plan(method), old
 
 
 def _case(rng):
@@ -76,7 +80,7 @@ def _fields(n, dtype, seed):
     return rhs, x0
 
 
-@pytest.mark.parametrize("method", ["cg", "jacobi"])
+@pytest.mark.parametrize("method", ["cg", "jacobi", "bicgstab"])
 def test_resident_matches_launch_per_phase(monkeypatch, method):
     """random extents / face types / face ORDER / dtypes; a dozen iterations (far from convergence, where a
     change of the summation grouping cannot yet have been amplified) and, every third case, a stop on the
@@ -93,8 +97,14 @@ def test_resident_matches_launch_per_phase(monkeypatch, method):
         stop = case % 3 == 0
         tol = (1e-1 if dtype == "double" else 3e-1) if stop else -1.0
         max_it = 60 if stop else 11
-        xa, ra, ua, _, _ = _solve(monkeypatch, False, n, bcs, dtype, method, rhs, x0, tol, max_it, order)
-        xb, rb, ub, plan, _ = _solve(monkeypatch, True, n, bcs, dtype, method, rhs, x0, tol, max_it, order)
+        adv = method == "bicgstab" and case % 2 == 0
+        if method == "bicgstab":
+            # BiCGSTAB amplifies a change of the summation grouping within tens of iterations on the nearly singular
+            # operators this fuzz draws (one dirichlet face): tests/test_gpu_parity_golden.py grades such runs against
+            # the reference's own summation-order hull; here every case is a short fixed run
+            tol, max_it = -1.0, 7
+        xa, ra, ua, _, _ = _solve(monkeypatch, False, n, bcs, dtype, method, rhs, x0, tol, max_it, order, adv=adv)
+        xb, rb, ub, plan, _ = _solve(monkeypatch, True, n, bcs, dtype, method, rhs, x0, tol, max_it, order, adv=adv)
         assert ua == 0
         assert ub == plan[0]
         if ub == 0:
@@ -106,9 +116,9 @@ def test_resident_matches_launch_per_phase(monkeypatch, method):
         if method == "jacobi":
             assert torch.equal(xa, xb), (case, n, bcs, dtype, float((xa - xb).abs().max()))
         else:
-            rtol = 1e-11 if dtype == "double" else 2e-4
+            rtol = (1e-11 if dtype == "double" else 2e-4) * (50.0 if method == "bicgstab" else 1.0)
             assert float((xa - xb).abs().max()) <= rtol * scale, (case, n, bcs, dtype, float((xa - xb).abs().max()), scale)
-        assert rb["tol"] == pytest.approx(ra["tol"], rel=1e-9 if dtype == "double" else 1e-3)
+        assert rb["tol"] == pytest.approx(ra["tol"], rel=(1e-9 if dtype == "double" else 1e-3) * (100.0 if method == "bicgstab" else 1.0))
         assert ra["converge"] == rb["converge"]
     assert taken >= ncases // 2
 
@@ -151,7 +161,7 @@ def test_resident_vs_oracle(monkeypatch):
     bcs = [("dirichlet", 0.4), ("neumann", 0.25), ("symmetry", None), ("dirichlet", -0.3), ("neumann", 0.0), ("dirichlet", 1.0)]
     cfg = [{"bc_face": FACES[i], "bc_type": t, "bc_val": v} for i, (t, v) in enumerate(bcs)]
     rhs, x0 = _fields(n, "double", 21)
-    for method, K in (("cg", 8), ("jacobi", 8)):
+    for method, K in (("cg", 8), ("jacobi", 8), ("bicgstab", 6)):
         with warnings.catch_warnings():
             warnings.simplefilter("ignore")
             xo, rep_o = O.solve_poisson(mesh_o, cfg, rhs.clone(), x0=x0.clone(), method=method, tol=-1.0, max_it=K - 1,
@@ -159,7 +169,7 @@ def test_resident_vs_oracle(monkeypatch):
         xb, rb, ub, _, _ = _solve(monkeypatch, True, n, bcs, "double", method, rhs, x0, -1.0, K - 1)
         assert ub > 0
         assert rb["itr"] == rep_o["itr"]
-        assert float((xb - xo).abs().max()) <= 1e-11 * float(xo.abs().max())
+        assert float((xb - xo).abs().max()) <= (1e-9 if method == "bicgstab" else 1e-11) * float(xo.abs().max())
         assert rb["tol"] == pytest.approx(rep_o["tol"], rel=1e-9)
 
 
@@ -171,13 +181,13 @@ def test_resident_edges(monkeypatch):
     xb, rb, ub, _, _ = _solve(monkeypatch, True, n, bcs, "double", "cg", rhs, x0, 1.5, 10)
     xa, ra, _, _, _ = _solve(monkeypatch, False, n, bcs, "double", "cg", rhs, x0, 1.5, 10)
     assert rb["itr"] == ra["itr"] == 0 and torch.equal(xa, xb)
-    for method in ("cg", "jacobi"):
+    for method in ("cg", "jacobi", "bicgstab"):
         xb, rb, ub, _, ob = _solve(monkeypatch, True, n, bcs, "double", method, rhs, x0, -1.0, 5, save_old=True)
         xa, ra, _, _, oa = _solve(monkeypatch, False, n, bcs, "double", method, rhs, x0, -1.0, 5, save_old=True)
-        assert ub > 0 and rb["itr"] == 6
-        assert float((oa - ob).abs().max()) <= 1e-12 * float(oa.abs().max())
+        assert ub > 0 and rb["itr"] == ra["itr"] == (5 if method == "bicgstab" else 6)
+        assert float((oa - ob).abs().max()) <= 1e-10 * float(oa.abs().max())
         xp, rp, _, _, _ = _solve(monkeypatch, True, n, bcs, "double", method, rhs, x0, -1.0, 4)
-        assert float((xp - ob).abs().max()) <= 1e-12 * float(xp.abs().max())   # VARo = the iterate one iteration earlier
+        assert float((xp - ob).abs().max()) <= 1e-10 * float(xp.abs().max())   # VARo = the iterate one iteration earlier
     rhs32, x032 = _fields(n, "single", 4)
     xb, rb, ub, _, _ = _solve(monkeypatch, True, n, bcs, "single", "cg", rhs32, x032, -1.0, 7, coeff=-1.3)
     xa, ra, _, _, _ = _solve(monkeypatch, False, n, bcs, "single", "cg", rhs32, x032, -1.0, 7, coeff=-1.3)
