@@ -68,6 +68,11 @@ def short(name):
     if m:
         t = "f64" if m.group(1) == "double" else "f32"
         return f"k_sf_{PHASES.get(int(m.group(3)), m.group(3))}_{t}_RJ{m.group(2)}_kind{m.group(4)}" + ("_ufield" if m.group(5) == "true" else "")
+    m = re.search(r"k_resident<(\w+), (\d+), (\w+), (\d+)>", name)
+    if m:
+        t = "f64" if m.group(1) == "double" else "f32"
+        sv = {"0": "cg", "1": "jacobi", "2": "bicgstab"}.get(m.group(2), m.group(2))
+        return f"k_resident_{sv}_{t}" + ("_lean" if m.group(3) == "true" else "_general") + f"_NT{m.group(4)}"
     m = re.search(r"(k_\w+)<(\w+)>", name)
     if m:
         return f"{m.group(1)}_{'f64' if m.group(2) == 'double' else 'f32'}"

@@ -838,6 +838,16 @@ __global__ void __launch_bounds__(NT) k_resident(DevGeom G, DevEq<T> E, ResArgs<
   }
 
   // ---- store ---------------------------------------------------------------------------------------
+  // a grid-wide wait that timed out (workgroups descheduled for seconds ...): nothing is stored -- x, r and the
+  // scalars in device memory are what they were before the launch, the `fail` flag tells the host to run the
+  // launch-per-phase loop from there
+  if (timed_out) return;
+  {   // ... also when another workgroup gave up in the very step that ended the solve here
+    __shared__ int any_fail;
+    if (tid == 0) any_fail = __hip_atomic_load(A.fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    if (any_fail) return;
+  }
   __syncthreads();
   for (int c = tid; c < nbox; c += NT) {
     int bi, bj, bk;
@@ -846,7 +856,6 @@ __global__ void __launch_bounds__(NT) k_resident(DevGeom G, DevEq<T> E, ResArgs<
     A.x[(int64_t)i * G.s0 + (int64_t)j * G.s1 + k] = X(i, j, k);
   }
   if (blockIdx.x == 0 && tid == 0) {
-    if (timed_out) { sc.err = 2; }
     sc.done = 1;
     *A.sc = sc;
   }
@@ -1005,6 +1014,7 @@ int pa_resident_launch(pa_ctx* c, int solver, T* x, const T* r0, const T* rhs, d
   A.parts = (double*)(base + head);
   A.mail = (T*)(base + head + parts_b);
   A.spin_max = 1u << 21;   // x (one atomic load + s_sleep) ~ seconds: far beyond any legitimate wait
+  if (const char* e = getenv("PYAPES_HIP_RES_SPIN")) A.spin_max = (unsigned)atoi(e);   // tests: 0 = every wait gives up
   A.o_h = R.o_h; A.o_p1 = R.o_p1; A.o_p2 = R.o_p2; A.o_bcc = R.o_bcc; A.o_sh = R.o_sh; A.o_meta = R.o_meta; A.o_lists = R.o_lists;
   A.o_h2 = R.o_h2; A.o_h3 = R.o_h3; A.o_p3 = R.o_p3;
   DevGeom G = c->G;

@@ -750,21 +750,29 @@ static void fill_report(pa_ctx* c, pa_report* out, float ms) {
   out->gpu_ms = ms;
 }
 
-// after a resident launch (pa_resident.hip): the solve has run to its end inside the one kernel
-static int resident_finish(pa_ctx* c, pa_report* out) {
-  int rc = read_scalars(c);
+// after a resident launch (pa_resident.hip): the solve has run to its end inside the one kernel -- returns 1 --
+// or one of its bounded grid-wide waits timed out and the kernel left x, r and the scalars untouched -- returns 0:
+// the caller goes on into its launch-per-phase loop as if the launch had not happened
+static int resident_finish(pa_ctx* c, pa_report* out, int* rc_out) {
+  int* h_fail = (int*)&c->h_poll[0]->rr;   // pinned scratch (the poll slots are idle here)
+  *h_fail = 0;
+  hipError_t e = hipMemcpyAsync(h_fail, (const char*)c->scr[SCR_RES] + 64, sizeof(int), hipMemcpyDeviceToHost, c->stream);
+  if (e != hipSuccess) { *rc_out = pa_hip_fail(c, e, "resident fail flag"); return 1; }
+  int rc = read_scalars(c);   // synchronises the stream
+  if (rc) { c->solver_live = 0; *rc_out = rc; return 1; }
+  if (*h_fail) {
+    c->resident_used = 0;
+    return 0;
+  }
   c->solver_live = 0;
-  if (rc) return rc;
-  PA_HIP(c, hipEventRecord(c->ev1, c->stream));
-  PA_HIP(c, hipEventSynchronize(c->ev1));
+  e = hipEventRecord(c->ev1, c->stream);
+  if (e == hipSuccess) e = hipEventSynchronize(c->ev1);
+  if (e != hipSuccess) { *rc_out = pa_hip_fail(c, e, "resident finish"); return 1; }
   float ms = 0.f;
   (void)hipEventElapsedTime(&ms, c->ev0, c->ev1);
   fill_report(c, out, ms);
-  if (c->h_sc->err == 2) {
-    pa_set_err(c, "resident solver: a grid-wide wait timed out (workgroups not co-resident?)");
-    return PA_E_STATE;
-  }
-  return c->h_sc->err ? PA_E_NONFINITE : PA_OK;
+  *rc_out = c->h_sc->err ? PA_E_NONFINITE : PA_OK;
+  return 1;
 }
 
 // r = (b - A x) on S (0 elsewhere), d = r, per-block partial sums of r.r: the tiled A x kernel plus one
@@ -1109,7 +1117,10 @@ static int cg_run_t(pa_ctx* c, T* x, const T* rhs, double tol, int64_t max_it, p
   // small meshes: the whole loop in one cooperative launch (pa_resident.hip); r = d = the initial residual
   c->resident_used = pa_resident_launch<T>(c, 0, x, (const T*)c->scr[SCR_R], (const T*)nullptr, 1.0);
   if (c->resident_used < 0) { c->solver_live = 0; return c->resident_used; }
-  if (c->resident_used > 0) return resident_finish(c, out);
+  if (c->resident_used > 0) {
+    int rrc = PA_OK;
+    if (resident_finish(c, out, &rrc)) return rrc;
+  }
   int64_t enq = 0;
   c->in_iterate = 1;  // scalar steps folded into the next tiled kernel's prologue (flushed before every poll)
   PollPipe P;
@@ -1185,7 +1196,10 @@ static int jacobi_run_t(pa_ctx* c, T* x, const T* rhs, double tol, int64_t max_i
   PA_HIP(c, hipEventRecord(c->ev0, c->stream));
   c->resident_used = pa_resident_launch<T>(c, 1, x, (const T*)nullptr, rhs, omega);
   if (c->resident_used < 0) return c->resident_used;
-  if (c->resident_used > 0) return resident_finish(c, out);
+  if (c->resident_used > 0) {
+    int rrc = PA_OK;
+    if (resident_finish(c, out, &rrc)) return rrc;
+  }
   int64_t enq = 0;
   // the stop test of sweep q is left to the prologue of sweep q+1 (pa_cg3d_kernel.h) when both are
   // tiled; this runs it as the single-block kernel it replaces (before a poll, before a generic sweep)
@@ -1316,7 +1330,10 @@ static int bicg_run_t(pa_ctx* c, T* x, const T* rhs, double tol, int64_t max_it,
   // small meshes: the whole loop in one cooperative launch (pa_resident.hip); r and r0 hold the initial residual
   c->resident_used = pa_resident_launch<T>(c, 2, x, (const T*)r, (const T*)r0, 1.0);
   if (c->resident_used < 0) return c->resident_used;
-  if (c->resident_used > 0) return resident_finish(c, out);
+  if (c->resident_used > 0) {
+    int rrc = PA_OK;
+    if (resident_finish(c, out, &rrc)) return rrc;
+  }
   int64_t enq = 0;
   // The three single-block scalar kernels of an iteration are folded into the prologue of the kernel
   // that follows each (pa_cg3d_kernel.h phases 5 / 6, k_bicg_x) when that kernel is a tiled one / the

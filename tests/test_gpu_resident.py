@@ -203,3 +203,18 @@ def test_resident_falls_back(monkeypatch):
     assert ub == 0 and plan[0] == 0
     xa, ra, _, _, _ = _solve(monkeypatch, False, n, bcs, "double", "cg", rhs, x0, -1.0, 5)
     assert torch.equal(xa, xb)
+
+
+@pytest.mark.parametrize("method", ["cg", "jacobi", "bicgstab"])
+def test_resident_wait_timeout_falls_back(monkeypatch, method):
+    """a grid-wide wait that gives up (forced: spin bound 0) stores nothing; the host runs the launch-per-phase loop
+    from the untouched state: same bits as with the resident path switched off"""
+    n = [20, 18, 22]
+    bcs = [("dirichlet", 0.0), ("neumann", 0.3), ("symmetry", None), ("dirichlet", 1.0), ("neumann", -0.2), ("dirichlet", 0.5)]
+    rhs, x0 = _fields(n, "double", 31)
+    xa, ra, ua, _, _ = _solve(monkeypatch, False, n, bcs, "double", method, rhs, x0, -1.0, 6)
+    xb, rb, ub, plan, _ = _solve(monkeypatch, True, n, bcs, "double", method, rhs, x0, -1.0, 6, env={"PYAPES_HIP_RES_SPIN": "0"})
+    monkeypatch.delenv("PYAPES_HIP_RES_SPIN")
+    assert plan[0] > 1 and ub == 0
+    assert ra["itr"] == rb["itr"] and ra["tol"] == rb["tol"]
+    assert torch.equal(xa, xb)
