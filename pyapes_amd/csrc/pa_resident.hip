@@ -1,11 +1,11 @@
-// pa_resident.hip -- small meshes: the whole CG / Jacobi solve in ONE cooperative launch, the fields resident
-// in LDS (linalg.py:74-159 and the Jacobi of SURVEY a15, same arithmetic as the kernels of pa_solver.hip).
+// pa_resident.hip -- small meshes: the whole CG / Jacobi / BiCGSTAB solve in ONE cooperative launch, the fields
+// resident in LDS (linalg.py:74-279 and the Jacobi of SURVEY a15, same arithmetic as the kernels of pa_solver.hip).
 //
 // On the meshes the reference's tests and demos run (128^2, 33^3, 64^3 ...) an iteration of the launch-per-
 // phase loops costs ~10 us per dependent kernel whatever the kernel does (DESIGN "small meshes").  Here the
-// mesh is cut into <= 128 boxes, one workgroup each, all co-resident (hipLaunchCooperativeKernel); x, r and
-// the direction d (with a one-cell halo) live in the workgroup's LDS for the whole solve and an iteration
-// costs two grid-wide steps:
+// mesh is cut into <= 128 boxes, one workgroup each, all co-resident (hipLaunchCooperativeKernel); the fields
+// (CG: x, r and the direction d with a one-cell halo) live in the workgroup's LDS for the whole solve and an
+// iteration costs two grid-wide steps:
 //   step 1: partial d.Ad -> mailbox, arrive, wait, every workgroup sums all partials in the same fixed
 //           order (same bits everywhere) -> alpha
 //   step 2: x, r update, ordered BC fill (literal, face after face, in LDS), boundary-shell stop-test
@@ -13,11 +13,13 @@
 //           stop test; d' = r + beta d on the own cells and -- from the neighbours' r layers and the old
 //           halo of d -- on the halo, bit for bit what the neighbour computes, so d is never exchanged.
 // A grid-wide step is an agent-scope release add on one counter plus an acquire spin (2 us at 16 boxes,
-// 3.2 us at 64, 5 us at 128: scratch/gb/gridbar.hip); every spin is bounded, a timeout raises PA_E_STATE.
-// Jacobi: one step per sweep (the outer layers of x travel with the stop-test partial).
+// 3.2 us at 64, 5 us at 128: profiles/tools/gridbar.hip).  Every spin is bounded; a wait that gives up makes
+// every workgroup return without storing anything, and the host runs the launch-per-phase loop instead.
+// Jacobi: one step per sweep (the outer layers of x travel with the stop-test partial).  BiCGSTAB: three.
 //
 // Scope: one GPU, no periodic face, scalar operator coefficients (any term list pa_apply_terms knows, xyz
-// or rz), mesh <= 128 boxes of <= 4096 cells.  Everything else runs the launch-per-phase loops.
+// or rz), mesh <= 128 boxes of <= 4096 cells (and what fits the LDS: BiCGSTAB keeps six arrays).  Everything
+// else runs the launch-per-phase loops.
 #include "pa_host.h"
 #include "pa_scalar_steps.h"
 
