@@ -17,9 +17,10 @@
 // every workgroup return without storing anything, and the host runs the launch-per-phase loop instead.
 // Jacobi: one step per sweep (the outer layers of x travel with the stop-test partial).  BiCGSTAB: three.
 //
-// Scope: one GPU, no periodic face, scalar operator coefficients (any term list pa_apply_terms knows, xyz
-// or rz), mesh <= 128 boxes of <= 4096 cells (and what fits the LDS: BiCGSTAB keeps six arrays).  Everything
-// else runs the launch-per-phase loops.
+// Scope: one GPU, scalar operator coefficients (any term list pa_apply_terms knows, xyz or rz), mesh <= 128
+// boxes of <= 4096 cells (and what fits the LDS: BiCGSTAB keeps six arrays); a periodic axis is never cut (the
+// fill of its faces reads the far end of the axis), the box is its own neighbour there.  Everything else runs
+// the launch-per-phase loops.
 #include "pa_host.h"
 #include "pa_scalar_steps.h"
 
@@ -180,6 +181,7 @@ __device__ __forceinline__ bool res_allreduce(ResSync& S, double* parts, double 
 #define RES_M_P(m) ((int)(((m) >> 13) & 0xfffu))
 #define RES_M_S(m) (((m) >> 25) & 1u)
 #define RES_M_RC(m, a) ((int)(((m) >> (26 + 2 * (a))) & 3u))
+#define RES_M_SHELL(m) (((((m) >> 26) & ((m) >> 27)) & 0x15u) != 0u)   // some axis has row case 3
 
 // SOLVER 0: CG (H = d with halo, P1 = x, P2 = r)   1: Jacobi (H = x with halo, P1 = x', P2 = rhs)
 //        2: BiCGSTAB (H = r, then s, then the new r -- with halo; H2 = p, H3 = v with halo; P1 = x, P2 = r0, P3 = t)
@@ -257,7 +259,7 @@ __global__ void __launch_bounds__(NT) k_resident(DevGeom G, DevEq<T> E, ResArgs<
   unsigned short* pubO = pubS + 6 * A.nface;
   unsigned short* rcvH = pubO + 6 * A.nface;
   unsigned* rcvO = (unsigned*)(smem + A.o_lists + (size_t)10 * 6 * A.nface);
-  __shared__ int fm_cnt[6], fm_base[6], fm_sst[6];   // BC slot w: nodes of this box, list base, signed stride to prev
+  __shared__ int fm_cnt[6], fm_base[6], fm_sst[6], fm_n[6];   // BC slot w: nodes of this box, list base, signed stride to prev, axis length
   __shared__ int n_sh, n_pub, n_rcv;
   const BoxView<T>& X = SOLVER == 1 ? H : P1;   // the iterate (BC fill, shell term)
   BoxView<T> H2 = H, H3 = H, P3 = P1;
@@ -288,6 +290,9 @@ __global__ void __launch_bounds__(NT) k_resident(DevGeom G, DevEq<T> E, ResArgs<
     const int st = a == 0 ? A.P[1] * A.P[2] : (a == 1 ? A.P[2] : 1);
     nb[2 * a] = PP(a) > 0 ? (int)blockIdx.x - st : -1;
     nb[2 * a + 1] = PP(a) + 1 < A.P[a] ? (int)blockIdx.x + st : -1;
+    // a periodic axis is never cut (the fill of its faces reads the far end of the axis): the box is its own
+    // neighbour there, the wrap-around layers travel through its own mailbox like any other layer
+    if (G.act[a] && G.bct[2 * a] == 4) nb[2 * a] = nb[2 * a + 1] = (int)blockIdx.x;
   }
 
   // ---- load ---------------------------------------------------------------------------------------
@@ -300,9 +305,15 @@ __global__ void __launch_bounds__(NT) k_resident(DevGeom G, DevEq<T> E, ResArgs<
     const int pidx = i * P1.s0 + j * P1.s1 + k + P1.off;
     unsigned m = (unsigned)hidx | ((unsigned)pidx << 13);
     if (pa_in_S(G, i, j, k)) m |= 1u << 25;
-    m |= (unsigned)pa_row_case(G, 0, i, G.n0, G.treat) << 26;
-    m |= (unsigned)pa_row_case(G, 1, j, G.n1, G.treat) << 28;
-    m |= (unsigned)pa_row_case(G, 2, k, G.n2, G.treat) << 30;
+    // row case per axis: 0 plain, 1 / 2 the lower / upper neumann | symmetry row, 3 = the node is a boundary node
+    // of the axis (a plain row; only a periodic face puts such a node into S, and its |dx|^2 is the shell term's)
+    auto rowc = [&](int a, int g, int64_t N) -> unsigned {
+      const int rc = pa_row_case(G, a, g, N, G.treat);
+      return (rc == 0 && G.act[a] && (g == 0 || g == N - 1)) ? 3u : (unsigned)rc;
+    };
+    m |= rowc(0, i, G.n0) << 26;
+    m |= rowc(1, j, G.n1) << 28;
+    m |= rowc(2, k, G.n2) << 30;
     meta[c] = m;
     if (SOLVER == 0) {
       P1p[pidx] = A.x[o];
@@ -331,8 +342,9 @@ __global__ void __launch_bounds__(NT) k_resident(DevGeom G, DevEq<T> E, ResArgs<
     for (int q = tid; q < nu * nv; q += NT) {
       int i, j, k;
       face_node(a, pos, q, nv, i, j, k);
-      const int64_t o = (int64_t)i * G.s0 + (int64_t)j * G.s1 + k;
-      H(i, j, k) = SOLVER == 1 ? A.x[o] : A.r0[o];
+      // (beyond a periodic end: the node at the other end of the axis)
+      const int64_t ow = pa_wrap(i, G.n0) * G.s0 + pa_wrap(j, G.n1) * G.s1 + pa_wrap(k, G.n2);
+      H(i, j, k) = SOLVER == 1 ? A.x[ow] : A.r0[ow];
       if (SOLVER == 2) {
         H2(i, j, k) = (T)0;
         H3(i, j, k) = (T)0;
@@ -380,6 +392,7 @@ __global__ void __launch_bounds__(NT) k_resident(DevGeom G, DevEq<T> E, ResArgs<
         if (tid == 0) {
           const int st = a == 0 ? X.s0 : (a == 1 ? X.s1 : 1);
           fm_sst[w] = side == 0 ? st : -st;
+          fm_n[w] = (int)res_pick(Ng, a);
         }
       }
       if (tid == 0) { fm_cnt[w] = cnt; fm_base[w] = base; }
@@ -427,7 +440,7 @@ __global__ void __launch_bounds__(NT) k_resident(DevGeom G, DevEq<T> E, ResArgs<
         pubO[base + q] = (unsigned short)(dir * A.nface + q);
         face_node(a, pos_in, q, nv, i, j, k);
         rcvH[base + q] = (unsigned short)(i * H.s0 + j * H.s1 + k + H.off);
-        rcvO[base + q] = (unsigned)((nb[dir] * 6 + (dir ^ 1)) * A.nface + q) | (pa_in_S(G, i, j, k) ? 0x80000000u : 0u);
+        rcvO[base + q] = (unsigned)((nb[dir] * 6 + (dir ^ 1)) * A.nface + q) | (pa_in_S(G, pa_wrap(i, G.n0), pa_wrap(j, G.n1), pa_wrap(k, G.n2)) ? 0x80000000u : 0u);
       }
       base += nu * nv;
     }
@@ -507,8 +520,14 @@ __global__ void __launch_bounds__(NT) k_resident(DevGeom G, DevEq<T> E, ResArgs<
             T t2 = A.c13 * Xp[d + 2 * sst];
             t1 = t1 - t2;
             val = t1 + bcc[base + n];
-          } else {
+          } else if (type == 3) {
             val = Xp[d + sst];
+          } else if (sst > 0) {   // periodic lower: x[0] = x[1] - x[N-1] + x[N-2] (bcs.py:245-262)
+            const int N = fm_n[w];
+            T t1 = Xp[d + sst] - Xp[d + (N - 1) * sst];
+            val = t1 + Xp[d + (N - 2) * sst];
+          } else {                // periodic upper: x[N-1] = x[0], which the lower face (earlier in the list or not) has set
+            val = Xp[d + (fm_n[w] - 1) * sst];
           }
           Xp[d] = val;
         }
@@ -569,7 +588,6 @@ __global__ void __launch_bounds__(NT) k_resident(DevGeom G, DevEq<T> E, ResArgs<
       __syncthreads();
       const T alpha = (T)sc.alpha;
       // ---- x += alpha d ; r -= alpha A d ; BC fill ; partial r.r, |dx|^2 (linalg.py:122-134) -------
-      // (no node of S is on the shell without a periodic face: the off-shell test of k_cg_b is always true)
       v[0] = 0.0; v[1] = 0.0;
       for (int c = tid; c < nbox; c += NT) {
         const unsigned m = meta[c];
@@ -586,9 +604,11 @@ __global__ void __launch_bounds__(NT) k_resident(DevGeom G, DevEq<T> E, ResArgs<
           P2p[px] = rn;
           T p = rn * rn;
           v[0] += (double)p;
-          T df = xn - xo;
-          T p2 = df * df;
-          v[1] += (double)p2;
+          if (!RES_M_SHELL(m)) {
+            T df = xn - xo;
+            T p2 = df * df;
+            v[1] += (double)p2;
+          }
         }
       }
       __syncthreads();
@@ -803,7 +823,7 @@ __global__ void __launch_bounds__(NT) k_resident(DevGeom G, DevEq<T> E, ResArgs<
                 decode(c, bi, bj, bk);
                 cB = E.rz[2 * E.rz_n + LO(1) + bj];
               }
-              T cC = rc == 0 ? E.lap.m2inv[a] : -cB;
+              T cC = (rc == 1 || rc == 2) ? -cB : E.lap.m2inv[a];
               dg = dg + cC;
             }
             if (t.has_coeff) dg = dg * t.coeff;
@@ -815,9 +835,11 @@ __global__ void __launch_bounds__(NT) k_resident(DevGeom G, DevEq<T> E, ResArgs<
           res = res / diag;
           T w = A.omega * res;
           xn = xo + w;
-          T df = xn - xo;
-          T p2 = df * df;
-          v[1] += (double)p2;
+          if (!RES_M_SHELL(m)) {
+            T df = xn - xo;
+            T p2 = df * df;
+            v[1] += (double)p2;
+          }
         }
         P1p[RES_M_P(m)] = xn;
       }
@@ -910,17 +932,19 @@ static bool res_plan(const pa_ctx* c, size_t es, int solver, ResPlan& R) {
     R.o_meta = (unsigned)o; o += up((size_t)cells * sizeof(unsigned));
     R.o_lists = (unsigned)o; o += up((size_t)6 * nface * (5 * sizeof(unsigned short) + sizeof(unsigned)));
     // (the per-cell word has 13 bits for the haloed index, 12 for the plain one)
-    if (g >= want && cells <= maxbox && halo <= 8192 && o <= RES_LDS_LIMIT) {
+    const bool fits = cells <= maxbox && halo <= 8192 && o <= RES_LDS_LIMIT;
+    auto accept = [&]() {
       for (int a = 0; a < 3; ++a) { R.P[a] = P[a]; R.bmax[a] = b[a]; }
       R.nface = nface; R.G = g; R.lds = (unsigned)o; R.cells = cells;
       return true;
-    }
+    };
+    if (fits && g >= want) return accept();
     // split the axis with the largest box extent; every box keeps >= 3 nodes per axis, so that the nodes a
     // face fill reads (prev, prev2) are in the box that holds the face node
     int best = -1;
     for (int a = 0; a < 3; ++a)
-      if (G.act[a] && N[a] / (P[a] + 1) >= 3 && (best < 0 || b[a] > b[best])) best = a;
-    if (best < 0) return false;
+      if (G.act[a] && c->bc[2 * a].type != PA_BC_PERIODIC && N[a] / (P[a] + 1) >= 3 && (best < 0 || b[a] > b[best])) best = a;
+    if (best < 0) return fits ? accept() : false;   // nothing left to cut (periodic / short axes): fewer, larger boxes
     P[best] += 1;
     if (P[0] * P[1] * P[2] > RES_MAXG) return false;
   }
@@ -929,8 +953,12 @@ static bool res_plan(const pa_ctx* c, size_t es, int solver, ResPlan& R) {
 static bool res_applicable(const pa_ctx* c) {
   if (!c->resident || c->slab || c->profile) return false;
   const DevGeom& G = c->G;
-  for (int f = 0; f < 6; ++f)
-    if (G.act[f >> 1] && (c->bc[f].type == PA_BC_PERIODIC || c->bc[f].type == PA_BC_NONE)) return false;
+  for (int a = 0; a < 3; ++a) {   // every face has a BC; a periodic axis is periodic at both ends
+    if (!G.act[a]) continue;
+    const int lo = c->bc[2 * a].type, hi = c->bc[2 * a + 1].type;
+    if (lo == PA_BC_NONE || hi == PA_BC_NONE) return false;
+    if ((lo == PA_BC_PERIODIC) != (hi == PA_BC_PERIODIC)) return false;
+  }
   for (int q = 0; q < c->nterms; ++q)
     if (c->terms[q].coeff_field || c->terms[q].u_field) return false;
   for (int a = 0; a < 3; ++a)

@@ -1,11 +1,11 @@
-"""-m gpu: the resident small-mesh solver (pa_resident.hip: the whole CG / Jacobi solve in one cooperative
-launch, fields in LDS) against the launch-per-phase loops it replaces and against the oracle.
+"""-m gpu: the resident small-mesh solver (pa_resident.hip: the whole CG / Jacobi / BiCGSTAB solve in one
+cooperative launch, fields in LDS) against the launch-per-phase loops it replaces and against the oracle.
 
 The two paths run the same per-cell arithmetic; only the grouping of the global sums differs (per-box partials
 summed in box order, against per-tile partial rows), so Jacobi iterates -- no global sum feeds back into them --
-must be bit-identical and CG iterates agree to rounding.  The reference goldens of tests/test_gpu_parity_golden.py
-run through the resident path by default (every golden mesh is small); this file pins the path itself: that it
-is taken, every box layout / face order / dtype, the stop test, Field.VARo and the fall-backs."""
+must be bit-identical and CG / BiCGSTAB iterates agree to rounding.  tests/test_gpu_parity_golden.py runs the
+reference goldens through BOTH loops; this file pins the path itself: that it is taken, every box layout / face
+order / dtype, periodic axes, the stop test, Field.VARo, a wait that gives up, and the fall-backs."""
 import os
 import random
 import warnings
@@ -63,11 +63,19 @@ def _case(rng):
         n = [rng.choice([5, 8, 12, 17, 24, 33]), rng.choice([6, 9, 16, 20, 40]), rng.choice([8, 17, 32, 33, 64, 66])]
     bcs = []
     for a in range(nd):
+        if rng.random() < 0.25:   # a periodic axis: never cut, the box is its own neighbour there
+            bcs += [("periodic", None), ("periodic", None)]
+            continue
         for _ in range(2):
             t = rng.choice(["dirichlet", "dirichlet", "neumann", "symmetry"])
             bcs.append((t, None if t == "symmetry" else round(rng.uniform(-1, 1), 3)))
     if not any(t == "dirichlet" for t, _ in bcs):
-        bcs[0] = ("dirichlet", 0.25)
+        for a in range(nd):
+            if bcs[2 * a][0] != "periodic":
+                bcs[2 * a] = ("dirichlet", 0.25)
+                break
+        else:
+            bcs[0], bcs[1] = ("dirichlet", 0.25), ("dirichlet", -0.5)
     dtype = "double" if rng.random() < 0.7 else "single"
     return n, bcs, dtype
 
@@ -194,11 +202,35 @@ def test_resident_edges(monkeypatch):
     assert ub > 0 and float((xa - xb).abs().max()) <= 2e-4 * float(xa.abs().max())
 
 
+def test_resident_periodic_axes(monkeypatch):
+    """a periodic axis is never cut (its fill reads the far end): taken when the uncut boxes still fit (x-periodic
+    16 x 20 x 24: boxes 16 x b x b; fully periodic 12^3: one box), launch-per-phase loops otherwise (fully periodic
+    32^3) -- same results either way; non-factory order of the two periodic faces included"""
+    per = ("periodic", None)
+    for n, bcs, order, expect in (
+            ([16, 20, 24], [per, per, ("dirichlet", 0.0), ("dirichlet", 0.0), ("neumann", 0.1), ("dirichlet", 0.2)], None, True),
+            ([16, 20, 24], [per, per, ("dirichlet", 0.0), ("dirichlet", 0.0), ("neumann", 0.1), ("dirichlet", 0.2)], [1, 0, 2, 3, 4, 5], True),
+            ([24, 40], [("dirichlet", 0.3), ("symmetry", None), per, per], None, True),
+            ([12, 12, 12], [per] * 6, None, True),
+            ([32, 32, 32], [per] * 6, None, False)):
+        rhs, x0 = _fields(n, "double", 5)
+        rhs = rhs - rhs.mean()
+        for method in ("cg", "jacobi", "bicgstab"):
+            xb, rb, ub, plan, _ = _solve(monkeypatch, True, n, bcs, "double", method, rhs, x0, -1.0, 5, order)
+            assert (ub > 0) == expect and ub == plan[0], (n, method, ub, plan)
+            xa, ra, _, _, _ = _solve(monkeypatch, False, n, bcs, "double", method, rhs, x0, -1.0, 5, order)
+            assert ra["itr"] == rb["itr"]
+            if ub == 0 or method == "jacobi":
+                assert torch.equal(xa, xb), (n, method)
+            else:
+                assert float((xa - xb).abs().max()) <= 1e-9 * float(xa.abs().max()), (n, method, float((xa - xb).abs().max()))
+
+
 def test_resident_falls_back(monkeypatch):
-    """periodic faces and tensor coefficients run the launch-per-phase loops (resident_used == 0), same results as ever"""
+    """a one-sided periodic axis and meshes too large for 128 boxes run the launch-per-phase loops (resident_used == 0)"""
     n = [16, 20, 24]
     rhs, x0 = _fields(n, "double", 5)
-    bcs = [("periodic", None), ("periodic", None), ("dirichlet", 0.0), ("dirichlet", 0.0), ("neumann", 0.1), ("dirichlet", 0.2)]
+    bcs = [("periodic", None), ("dirichlet", 0.3), ("dirichlet", 0.0), ("dirichlet", 0.0), ("neumann", 0.1), ("dirichlet", 0.2)]
     xb, rb, ub, plan, _ = _solve(monkeypatch, True, n, bcs, "double", "cg", rhs, x0, -1.0, 5)
     assert ub == 0 and plan[0] == 0
     xa, ra, _, _, _ = _solve(monkeypatch, False, n, bcs, "double", "cg", rhs, x0, -1.0, 5)
