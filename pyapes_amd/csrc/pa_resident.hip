@@ -102,11 +102,14 @@ __device__ __forceinline__ bool res_grid_wait(ResSync& S) {
     __hip_atomic_fetch_add(S.counter, 1ull, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
     const unsigned long long target = (S.step + 1) * S.G;
     int good = 0;
+    // relaxed polls, ONE acquire fence after the last: an acquire load per poll would invalidate the caches of
+    // the XCD on every round, under the feet of the workgroups that are still working
     for (unsigned spin = 0; spin < S.spin_max; ++spin) {
-      if (__hip_atomic_load(S.counter, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) >= target) { good = 1; break; }
-      if (__hip_atomic_load(S.fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
+      if (__hip_atomic_load(S.counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= target) { good = 1; break; }
+      if ((spin & 63u) == 63u && __hip_atomic_load(S.fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
       __builtin_amdgcn_s_sleep(1);
     }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     if (!good) __hip_atomic_store(S.fail, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     ok = good;
   }
@@ -561,6 +564,13 @@ __global__ void __launch_bounds__(NT) k_resident(DevGeom G, DevEq<T> E, ResArgs<
       DSTp[rcvH[n]] = __hip_atomic_load(theirs + (rcvO[n] & 0x7fffffffu), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   };
 
+#ifdef PA_RES_TIMING   // measurement build (PA_EXTRA_FLAGS=-DPA_RES_TIMING): where an iteration's time goes, workgroup 0
+  unsigned long long tt[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tl = wall_clock64();
+  long long tn = 0;
+#define RES_T(q) do { const unsigned long long t_ = wall_clock64(); tt[q] += t_ - tl; tl = t_; } while (0)
+#else
+#define RES_T(q) do { } while (0)
+#endif
   bool timed_out = false;
   for (;;) {
     if (A.x_old_out) {   // Field.VARo: the iterate before this iteration's update
@@ -583,9 +593,12 @@ __global__ void __launch_bounds__(NT) k_resident(DevGeom G, DevEq<T> E, ResArgs<
           v[0] += (double)p;
         }
       }
+      RES_T(0);   // pass A
       if (!res_allreduce(S, A.parts, v, red)) { timed_out = true; break; }
+      RES_T(1);   // step 1
       if (tid == 0) pa_logic_a<T>(&sc, red);
       __syncthreads();
+      RES_T(2);   // alpha
       const T alpha = (T)sc.alpha;
       // ---- x += alpha d ; r -= alpha A d ; BC fill ; partial r.r, |dx|^2 (linalg.py:122-134) -------
       v[0] = 0.0; v[1] = 0.0;
@@ -612,15 +625,20 @@ __global__ void __launch_bounds__(NT) k_resident(DevGeom G, DevEq<T> E, ResArgs<
         }
       }
       __syncthreads();
+      RES_T(3);   // pass B
       if (!A.bc_static) bc_fill_and_shell(v[1]);
+      RES_T(4);   // BC fill + shell
       publish(P2p);
+      RES_T(5);   // publish
       // sums: red[0] = r.r, red[1] = |x_new - x_old|^2 ; pa_logic_b reads them as sums[1], sums[2]
       if (!res_allreduce(S, A.parts, v, red)) { timed_out = true; break; }
+      RES_T(6);   // step 2
       if (tid == 0) {
         const double sums[3] = {0.0, red[0], red[1]};
         pa_logic_b<T>(&sc, sums);
       }
       __syncthreads();
+      RES_T(7);   // beta, stop test
       if (sc.done) break;
       // ---- d' = r + beta d (linalg.py:141): own cells, then the halo from the neighbours' r layers ---
       const T beta = (T)sc.beta;
@@ -650,6 +668,10 @@ __global__ void __launch_bounds__(NT) k_resident(DevGeom G, DevEq<T> E, ResArgs<
         }
       }
       __syncthreads();
+      RES_T(8);   // d' own + halo
+#ifdef PA_RES_TIMING
+      ++tn;
+#endif
     } else if (SOLVER == 2) {
       // ---- BiCGSTAB (linalg.py:162-279; the arithmetic of k_bicg_pv / _s / _t / _x and k_bicg_post) --------
       // p' = r + beta (p - omega v) on every cell, own and halo (the halos hold r, p and v of the neighbours)
@@ -865,6 +887,12 @@ __global__ void __launch_bounds__(NT) k_resident(DevGeom G, DevEq<T> E, ResArgs<
   // a grid-wide wait that timed out (workgroups descheduled for seconds ...): nothing is stored -- x, r and the
   // scalars in device memory are what they were before the launch, the `fail` flag tells the host to run the
   // launch-per-phase loop from there
+#ifdef PA_RES_TIMING
+  if (SOLVER == 0 && blockIdx.x == 0 && tid == 0 && tn > 0)
+    printf("k_resident CG timing, ns per iteration over %lld iterations (100 MHz clock): passA %.0f step1 %.0f alpha %.0f passB %.0f "
+           "bc %.0f publish %.0f step2 %.0f beta %.0f dnew %.0f\n", tn, 10.0 * tt[0] / tn, 10.0 * tt[1] / tn, 10.0 * tt[2] / tn,
+           10.0 * tt[3] / tn, 10.0 * tt[4] / tn, 10.0 * tt[5] / tn, 10.0 * tt[6] / tn, 10.0 * tt[7] / tn, 10.0 * tt[8] / tn);
+#endif
   if (timed_out) return;
   {   // ... also when another workgroup gave up in the very step that ended the solve here
     __shared__ int any_fail;
