@@ -182,7 +182,7 @@ template Vec<double> pa_vec_self<double>(const pa_ctx*, const double*);
 // ---------------------------------------------------------------------------------------
 extern "C" {
 
-const char* pa_version(void) { return "pyapes_hip 0.1 (gfx950)"; }
+const char* pa_version(void) { return "pyapes_hip 0.2 (gfx950)"; }
 
 const char* pa_last_error(const pa_ctx* c) { return c ? c->err : g_create_err; }
 

@@ -1092,6 +1092,7 @@ int pa_resident_used(const pa_ctx* c) { return c ? c->resident_used : 0; }
 
 int pa_resident_plan(pa_ctx* c, int solver, int* boxes) {   // what a solve on the bound mesh would use (tests, DESIGN numbers)
   if (!c || !boxes || solver < 0 || solver > 2) return PA_E_ARG;
+  if (!c->grid_set || !c->eq_set) { pa_set_err(c, "pa_resident_plan: grid / equation not set"); return PA_E_STATE; }
   ResPlan R;
   boxes[0] = boxes[1] = boxes[2] = 0;
   if (!res_applicable(c) || !res_plan(c, (size_t)c->esize, solver, R)) return 0;
