@@ -183,13 +183,13 @@ template <typename T>
 int pa_cg3d_phase_b(pa_ctx* c, const DevEq<T>& E, Vec<T> d, T* x, T* r, double* partials);
 
 // single-field tiled kernels (pa_cg3d.hip); same return convention as the CG phases
-// small meshes (pa_resident.hip): the whole solve in one cooperative launch, fields resident in LDS.  Returns the
-// number of workgroups (> 0) when it ran to the end of the solve (scalars in c->sc), 0 when the configuration is
-// not covered (the caller runs its launch-per-phase loop), < 0 on error.  solver: 0 CG (r0 = initial residual),
-// 1 Jacobi (rhs), 2 BiCGSTAB (r0 = initial residual, rhs = the shadow residual: a second copy of it).  x must
-// already hold the BC-filled start, c->sc the scalars the launch-per-phase loop would start from.
+// small meshes (pa_resident.hip): the WHOLE solve -- BC fill of the start, first residual, the loop -- in one
+// cooperative launch, fields resident in LDS.  Returns the number of workgroups (> 0) when the kernel was launched
+// (it then runs to the end of the solve and leaves the scalars in c->sc), 0 when the configuration is not covered
+// (the caller runs its launch-per-phase path), < 0 on error.  solver: 0 CG, 1 Jacobi, 2 BiCGSTAB.  x: the start as
+// the caller hands it over (BCs not filled), rhs: after pa_rhs_adjust.
 template <typename T>
-int pa_resident_launch(pa_ctx* c, int solver, T* x, const T* r0, const T* rhs, double omega);
+int pa_resident_launch(pa_ctx* c, int solver, T* x, const T* rhs, double tol, int64_t max_it, double omega);
 
 template <typename T>
 int pa_tile3d_aop(pa_ctx* c, const DevEq<T>& E, Vec<T> x, T* y, int interior_only);

@@ -29,6 +29,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <mutex>
 
 #define RES_MAXG 128
 #define RES_MAXBOX 4096
@@ -53,9 +54,10 @@ struct ResArgs {
   int nface;           // largest box face (nodes)
   int bc_static;
   T omega;
-  T* x;                // in: BC-filled start; out: the iterate
-  const T* r0;         // CG: r = (b - A x) on S, 0 elsewhere
-  const T* rhs;        // Jacobi
+  T* x;                // in: the start (BCs not yet filled); out: the iterate
+  const T* rhs;        // the right-hand side (after pa_rhs_adjust)
+  double tol;          // FDMSolverConfig tol / max_it: the kernel builds the solver scalars itself
+  long long max_it;
   T* x_old_out;        // Field.VARo on request
   SolverScalars* sc;
   unsigned long long* counter;
@@ -65,7 +67,6 @@ struct ResArgs {
   unsigned spin_max;
   unsigned o_h, o_p1, o_p2, o_bcc, o_sh, o_meta, o_lists;   // LDS byte offsets: haloed array, two plain arrays, BC constants, shell, per-cell words, work lists
   unsigned o_h2, o_h3, o_p3;   // BiCGSTAB: two more haloed arrays, one more plain one
-  const T* rb0;        // BiCGSTAB: the shadow residual r0 (global, read once)
 };
 
 template <typename T>
@@ -263,7 +264,7 @@ __global__ void __launch_bounds__(NT) k_resident(DevGeom G, DevEq<T> E, ResArgs<
   unsigned short* rcvH = pubO + 6 * A.nface;
   unsigned* rcvO = (unsigned*)(smem + A.o_lists + (size_t)10 * 6 * A.nface);
   __shared__ int fm_cnt[6], fm_base[6], fm_sst[6], fm_n[6];   // BC slot w: nodes of this box, list base, signed stride to prev, axis length
-  __shared__ int n_sh, n_pub, n_rcv;
+  __shared__ int n_sh, n_sh_all, n_pub, n_rcv;
   const BoxView<T>& X = SOLVER == 1 ? H : P1;   // the iterate (BC fill, shell term)
   BoxView<T> H2 = H, H3 = H, P3 = P1;
   if (SOLVER == 2) {
@@ -282,9 +283,15 @@ __global__ void __launch_bounds__(NT) k_resident(DevGeom G, DevEq<T> E, ResArgs<
   ResSync S;
   S.counter = A.counter; S.fail = A.fail; S.step = 0; S.G = gridDim.x; S.spin_max = A.spin_max;
 
-  if (tid == 0) sc = *A.sc;
+  if (tid == 0) {   // init_scalars of pa_solver.hip (linalg.py:90, 109, 201-204)
+    sc = SolverScalars{};
+    sc.tolerance = A.tol;
+    sc.max_it = A.max_it;
+    sc.tol = 1.0;
+    sc.rho = 1.0; sc.alpha = 1.0; sc.omega = 1.0;
+    sc.done = (SOLVER != 2 && !(1.0 > A.tol)) ? 1 : 0;   // `while tol > tolerance` with tol = 1.0; BiCGSTAB: `while not finished`
+  }
   __syncthreads();
-  if (sc.done) return;   // `while tol > tolerance` false at entry (linalg.py:109): nothing runs
 
   // neighbour boxes: workgroup index, or -1 at the ends of the mesh
   int nb[6];
@@ -318,37 +325,26 @@ __global__ void __launch_bounds__(NT) k_resident(DevGeom G, DevEq<T> E, ResArgs<
     m |= rowc(1, j, G.n1) << 28;
     m |= rowc(2, k, G.n2) << 30;
     meta[c] = m;
-    if (SOLVER == 0) {
-      P1p[pidx] = A.x[o];
-      const T rv = A.r0[o];
-      P2p[pidx] = rv;
-      Hp[hidx] = rv;   // d = r (linalg.py:107)
-    } else if (SOLVER == 2) {
-      P1p[pidx] = A.x[o];
-      Hp[hidx] = A.r0[o];     // r (linalg.py:196-199)
-      P2p[pidx] = A.rb0[o];   // r0
+    // the start as the caller hands it over (BCs not yet filled) and the right-hand side; everything else is
+    // built below, in the kernel: BC fill, residual, its norm (what pa_cg_begin does with five launches)
+    if (SOLVER == 1) Hp[hidx] = A.x[o]; else P1p[pidx] = A.x[o];
+    P2p[pidx] = A.rhs[o];
+    if (SOLVER == 2) {
       H2p[hidx] = (T)0;       // p = v = 0 (linalg.py:203-204)
       H3p[hidx] = (T)0;
-    } else {
-      Hp[hidx] = A.x[o];
-      P2p[pidx] = A.rhs[o];
     }
   }
-  // halo of H from the global arrays (complete at this point)
+  if (SOLVER == 2) {   // halo of p and v: zero like the fields
 #pragma unroll
-  for (int dir = 0; dir < 6; ++dir) {
-    const int a = dir >> 1, side = dir & 1;
-    if (nb[dir] < 0) continue;
-    int nu, nv;
-    face_dims(a, nu, nv);
-    const int pos = side == 0 ? LO(a) - 1 : LO(a) + BB(a);
-    for (int q = tid; q < nu * nv; q += NT) {
-      int i, j, k;
-      face_node(a, pos, q, nv, i, j, k);
-      // (beyond a periodic end: the node at the other end of the axis)
-      const int64_t ow = pa_wrap(i, G.n0) * G.s0 + pa_wrap(j, G.n1) * G.s1 + pa_wrap(k, G.n2);
-      H(i, j, k) = SOLVER == 1 ? A.x[ow] : A.r0[ow];
-      if (SOLVER == 2) {
+    for (int dir = 0; dir < 6; ++dir) {
+      const int a = dir >> 1, side = dir & 1;
+      if (nb[dir] < 0) continue;
+      int nu, nv;
+      face_dims(a, nu, nv);
+      const int pos = side == 0 ? LO(a) - 1 : LO(a) + BB(a);
+      for (int q = tid; q < nu * nv; q += NT) {
+        int i, j, k;
+        face_node(a, pos, q, nv, i, j, k);
         H2(i, j, k) = (T)0;
         H3(i, j, k) = (T)0;
       }
@@ -419,11 +415,13 @@ __global__ void __launch_bounds__(NT) k_resident(DevGeom G, DevEq<T> E, ResArgs<
         if (a >= 1 && G.act[0] && (i == 0 || i == G.n0 - 1)) owned = false;
         if (a == 2 && G.act[1] && (j == 0 || j == G.n1 - 1)) owned = false;
         shD[base + q] = owned ? (unsigned short)(i * X.s0 + j * X.s1 + k + X.off) : (unsigned short)0xffff;
-        shold[base + q] = X(i, j, k);   // the filled shell as x_old (k_shell, mode 0)
       }
       base += nu * nv;
     }
-    if (tid == 0) n_sh = (A.bc_static || SOLVER == 2) ? 0 : base;   // (BiCGSTAB stops on the residual: no shell term)
+    if (tid == 0) {
+      n_sh_all = base;
+      n_sh = (A.bc_static || SOLVER == 2) ? 0 : base;   // (BiCGSTAB stops on the residual: no shell term)
+    }
   }
   {
     const BoxView<T>& SRC = SOLVER == 0 ? P2 : H;   // what travels: CG the residual, Jacobi the iterate (BiCGSTAB: haloed arrays)
@@ -507,7 +505,7 @@ __global__ void __launch_bounds__(NT) k_resident(DevGeom G, DevEq<T> E, ResArgs<
 
   // the ordered BC fill of the box's part of the shell (literal: face after face, a later face reads what an
   // earlier one wrote), then sum (x_new - x_old)^2 over the shell nodes this box owns
-  auto bc_fill_and_shell = [&](double& acc) {
+  auto bc_fill = [&]() {
 #pragma unroll
     for (int w = 0; w < 6; ++w) {
       const int cnt = fm_cnt[w];
@@ -537,6 +535,9 @@ __global__ void __launch_bounds__(NT) k_resident(DevGeom G, DevEq<T> E, ResArgs<
         __syncthreads();
       }
     }
+  };
+  auto bc_fill_and_shell = [&](double& acc) {
+    bc_fill();
     const int ns = n_sh;
     for (int n = tid; n < ns; n += NT) {
       const int d = shD[n];
@@ -564,6 +565,70 @@ __global__ void __launch_bounds__(NT) k_resident(DevGeom G, DevEq<T> E, ResArgs<
       DSTp[rcvH[n]] = __hip_atomic_load(theirs + (rcvO[n] & 0x7fffffffu), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   };
 
+  // ---- set-up, in the kernel: what pa_cg_begin / the heads of pa_jacobi and pa_bicgstab do with a BC-fill launch,
+  //      the A x and residual kernels and a single-block reduction (linalg.py:97-107, 196-212) ----------------
+  bool timed_out = false, entry_done = false;
+  do {
+    bc_fill();                                   // x <- B(x) (linalg.py:97), literal like every later fill
+    __syncthreads();
+    {
+      const int ns = n_sh_all;                   // the filled shell as x_old (k_shell, mode 0)
+      for (int n = tid; n < ns; n += NT) {
+        const int d = shD[n];
+        if (d != 0xffff) shold[n] = Xp[d];
+      }
+    }
+    if (SOLVER != 1)                             // x with a halo, for the first residual (H becomes d / r below)
+      for (int c = tid; c < nbox; c += NT) {
+        const unsigned m = meta[c];
+        Hp[RES_M_H(m)] = P1p[RES_M_P(m)];
+      }
+    __syncthreads();
+    if (sc.done) { entry_done = true; break; }   // `while tol > tolerance` false at entry: only the fill happened
+    publish(SOLVER == 0 ? P1p : Hp);             // the neighbours' outer layers of the FILLED x
+    double z[1] = {0.0};
+    if (!res_allreduce(S, A.parts, z, red)) { timed_out = true; break; }
+    receive(Hp);
+    __syncthreads();
+    if (SOLVER == 1) break;
+    // r = (b - A x) on S, 0 elsewhere ; sum r.r (k_cg_init) ; d = r (CG) ; r0 = r, p = v = 0 (BiCGSTAB)
+    double v1[1] = {0.0};
+    for (int c = tid; c < nbox; c += NT) {
+      const unsigned m = meta[c];
+      const int px = RES_M_P(m);
+      T rv = (T)0;
+      if (RES_M_S(m)) {
+        const T ax = stencil(H, c, m, Hp[RES_M_H(m)]);
+        rv = P2p[px] - ax;
+        T p = rv * rv;
+        v1[0] += (double)p;
+      }
+      P2p[px] = rv;
+    }
+    __syncthreads();
+    for (int c = tid; c < nbox; c += NT) {
+      const unsigned m = meta[c];
+      Hp[RES_M_H(m)] = P2p[RES_M_P(m)];
+    }
+    __syncthreads();
+    publish(SOLVER == 0 ? P2p : Hp);
+    if (!res_allreduce(S, A.parts, v1, red)) { timed_out = true; break; }
+    receive(Hp);
+    if (tid == 0) {
+      sc.rr = (double)(T)red[0];                 // k_cg_post_init
+      if (SOLVER == 2) {                         // linalg.py:201-212: rho' = r0.r0, tol0, the first beta = rho' / 1 * 1 / 1
+        sc.rho_next = sc.rr;
+        sc.tol = (double)(T)sqrt((T)sc.rr);
+        T b = (T)sc.rho_next / (T)1.0;
+        b = b * (T)1.0;
+        b = b / (T)1.0;
+        sc.beta = (double)b;
+        sc.rho = sc.rho_next;
+      }
+    }
+    __syncthreads();
+  } while (0);
+
 #ifdef PA_RES_TIMING   // measurement build (PA_EXTRA_FLAGS=-DPA_RES_TIMING): where an iteration's time goes, workgroup 0
   unsigned long long tt[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tl = wall_clock64();
   long long tn = 0;
@@ -571,8 +636,7 @@ __global__ void __launch_bounds__(NT) k_resident(DevGeom G, DevEq<T> E, ResArgs<
 #else
 #define RES_T(q) do { } while (0)
 #endif
-  bool timed_out = false;
-  for (;;) {
+  for (; !timed_out && !entry_done;) {
     if (A.x_old_out) {   // Field.VARo: the iterate before this iteration's update
       for (int c = tid; c < nbox; c += NT) {
         int bi, bj, bk;
@@ -995,7 +1059,7 @@ static bool res_applicable(const pa_ctx* c) {
 }
 
 template <typename T>
-int pa_resident_launch(pa_ctx* c, int solver, T* x, const T* r0, const T* rhs, double omega) {
+int pa_resident_launch(pa_ctx* c, int solver, T* x, const T* rhs, double tol, int64_t max_it, double omega) {
   if (!res_applicable(c)) return 0;
   ResPlan R;
   if (!res_plan(c, sizeof(T), solver, R)) return 0;
@@ -1011,20 +1075,29 @@ int pa_resident_launch(pa_ctx* c, int solver, T* x, const T* r0, const T* rhs, d
   else if (nt == 1024) fn = pick((const void*)k_resident<T, 0, true, 1024>, (const void*)k_resident<T, 1, true, 1024>, (const void*)k_resident<T, 2, true, 1024>);
   else if (nt == 512) fn = pick((const void*)k_resident<T, 0, true, 512>, (const void*)k_resident<T, 1, true, 512>, (const void*)k_resident<T, 2, true, 512>);
   else { nt = 256; fn = pick((const void*)k_resident<T, 0, true, 256>, (const void*)k_resident<T, 1, true, 256>, (const void*)k_resident<T, 2, true, 256>); }
-  // co-residency: one workgroup per CU at this LDS size; the cooperative launch itself refuses a grid that
-  // does not fit (then the launch-per-phase loops run)
-  if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)R.lds) != hipSuccess) {
-    (void)hipGetLastError();
-    return 0;
+  // co-residency: one workgroup per CU at this LDS size; the cooperative launch itself refuses a grid that does
+  // not fit (then the launch-per-phase loops run).  The attribute / occupancy queries are made once per kernel and
+  // LDS size (they cost more host time than the launch).
+  struct Fit { const void* fn; unsigned lds; int nt, device, max_grid; };
+  static Fit fits[64];
+  static int nfits = 0;
+  static std::mutex fits_mu;   // ctxs of different threads share the table
+  std::lock_guard<std::mutex> lock(fits_mu);
+  int max_grid = -1;
+  for (int q = 0; q < nfits; ++q)
+    if (fits[q].fn == fn && fits[q].lds == R.lds && fits[q].nt == nt && fits[q].device == c->device) max_grid = fits[q].max_grid;
+  if (max_grid < 0) {
+    max_grid = 0;
+    int per_cu = 0, cus = 0;
+    if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)RES_LDS_LIMIT) == hipSuccess &&
+        hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, nt, R.lds) == hipSuccess && per_cu >= 1 &&
+        hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device) == hipSuccess)
+      max_grid = per_cu * cus;
+    else
+      (void)hipGetLastError();
+    if (nfits < 64) fits[nfits++] = Fit{fn, R.lds, nt, c->device, max_grid};
   }
-  int per_cu = 0;
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, nt, R.lds) != hipSuccess || per_cu < 1) {
-    (void)hipGetLastError();
-    return 0;
-  }
-  int cus = 0;
-  if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device) != hipSuccess || per_cu * cus < R.G)
-    return 0;
+  if (max_grid < R.G) return 0;
   // scratch: counter + fail flag | partial sums | mailboxes
   const size_t head = 256;
   const size_t parts_b = (size_t)2 * R.G * RES_NS * sizeof(double);
@@ -1063,8 +1136,8 @@ int pa_resident_launch(pa_ctx* c, int solver, T* x, const T* r0, const T* rhs, d
   A.nface = R.nface;
   A.bc_static = pa_bc_is_static(c) ? 1 : 0;
   A.omega = (T)omega;
-  A.x = x; A.r0 = r0; A.rhs = rhs;
-  A.rb0 = solver == 2 ? rhs : nullptr;   // BiCGSTAB: the `rhs` argument carries the shadow residual r0
+  A.x = x; A.rhs = rhs;
+  A.tol = tol; A.max_it = (long long)max_it;
   A.x_old_out = (T*)c->x_old_out;
   A.sc = c->sc;
   A.counter = (unsigned long long*)base;
@@ -1101,5 +1174,5 @@ int pa_resident_plan(pa_ctx* c, int solver, int* boxes) {   // what a solve on t
 }
 }  // extern "C"
 
-template int pa_resident_launch<float>(pa_ctx*, int, float*, const float*, const float*, double);
-template int pa_resident_launch<double>(pa_ctx*, int, double*, const double*, const double*, double);
+template int pa_resident_launch<float>(pa_ctx*, int, float*, const float*, double, int64_t, double);
+template int pa_resident_launch<double>(pa_ctx*, int, double*, const double*, double, int64_t, double);

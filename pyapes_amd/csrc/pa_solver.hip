@@ -1110,17 +1110,18 @@ int pa_cg_slab_flush(pa_ctx* c) {
 
 template <typename T>
 static int cg_run_t(pa_ctx* c, T* x, const T* rhs, double tol, int64_t max_it, pa_report* out) {
-  int rc = cg_begin_t<T>(c, x, rhs, tol, max_it);
-  if (rc) return rc;
-  const int poll = poll_interval(c);
+  // small meshes: the whole solve -- set-up included -- in one cooperative launch (pa_resident.hip)
   PA_HIP(c, hipEventRecord(c->ev0, c->stream));
-  // small meshes: the whole loop in one cooperative launch (pa_resident.hip); r = d = the initial residual
-  c->resident_used = pa_resident_launch<T>(c, 0, x, (const T*)c->scr[SCR_R], (const T*)nullptr, 1.0);
-  if (c->resident_used < 0) { c->solver_live = 0; return c->resident_used; }
+  c->resident_used = pa_resident_launch<T>(c, 0, x, rhs, tol, max_it, 1.0);
+  if (c->resident_used < 0) return c->resident_used;
   if (c->resident_used > 0) {
     int rrc = PA_OK;
     if (resident_finish(c, out, &rrc)) return rrc;
   }
+  int rc = cg_begin_t<T>(c, x, rhs, tol, max_it);
+  if (rc) return rc;
+  const int poll = poll_interval(c);
+  PA_HIP(c, hipEventRecord(c->ev0, c->stream));
   int64_t enq = 0;
   c->in_iterate = 1;  // scalar steps folded into the next tiled kernel's prologue (flushed before every poll)
   PollPipe P;
@@ -1164,6 +1165,13 @@ static int jacobi_run_t(pa_ctx* c, T* x, const T* rhs, double tol, int64_t max_i
   for (int q = 0; q < c->nterms; ++q)
     if (c->terms[q].kind != PA_OP_LAPLACIAN) { pa_set_err(c, "pa_jacobi: laplacian terms only"); return PA_E_ARG; }
   if (c->slab) { pa_set_err(c, "pa_jacobi is single-GPU only"); return PA_E_ARG; }
+  PA_HIP(c, hipEventRecord(c->ev0, c->stream));
+  c->resident_used = pa_resident_launch<T>(c, 1, x, rhs, tol, max_it, omega);   // small meshes: pa_resident.hip
+  if (c->resident_used < 0) return c->resident_used;
+  if (c->resident_used > 0) {
+    int rrc = PA_OK;
+    if (resident_finish(c, out, &rrc)) return rrc;
+  }
   const size_t fb = (size_t)G.ncell * sizeof(T);
   const int nblk = pa_grid_blocks(G.ncell);
   int rc;
@@ -1194,12 +1202,6 @@ static int jacobi_run_t(pa_ctx* c, T* x, const T* rhs, double tol, int64_t max_i
   int cur = 0;
   const int poll = poll_interval(c);
   PA_HIP(c, hipEventRecord(c->ev0, c->stream));
-  c->resident_used = pa_resident_launch<T>(c, 1, x, (const T*)nullptr, rhs, omega);
-  if (c->resident_used < 0) return c->resident_used;
-  if (c->resident_used > 0) {
-    int rrc = PA_OK;
-    if (resident_finish(c, out, &rrc)) return rrc;
-  }
   int64_t enq = 0;
   // the stop test of sweep q is left to the prologue of sweep q+1 (pa_cg3d_kernel.h) when both are
   // tiled; this runs it as the single-block kernel it replaces (before a poll, before a generic sweep)
@@ -1285,6 +1287,13 @@ template <typename T>
 static int bicg_run_t(pa_ctx* c, T* x, const T* rhs, double tol, int64_t max_it, pa_report* out) {
   const DevGeom& G = c->G;
   if (c->slab) { pa_set_err(c, "pa_bicgstab is single-GPU only in this build"); return PA_E_ARG; }
+  PA_HIP(c, hipEventRecord(c->ev0, c->stream));
+  c->resident_used = pa_resident_launch<T>(c, 2, x, rhs, tol, max_it, 1.0);   // small meshes: pa_resident.hip
+  if (c->resident_used < 0) return c->resident_used;
+  if (c->resident_used > 0) {
+    int rrc = PA_OK;
+    if (resident_finish(c, out, &rrc)) return rrc;
+  }
   const size_t fb = (size_t)G.ncell * sizeof(T);
   const int nblk = pa_grid_blocks(G.ncell);
   int rc;
@@ -1327,13 +1336,6 @@ static int bicg_run_t(pa_ctx* c, T* x, const T* rhs, double tol, int64_t max_it,
   int cur = 0;
   const int poll = poll_interval(c);
   PA_HIP(c, hipEventRecord(c->ev0, c->stream));
-  // small meshes: the whole loop in one cooperative launch (pa_resident.hip); r and r0 hold the initial residual
-  c->resident_used = pa_resident_launch<T>(c, 2, x, (const T*)r, (const T*)r0, 1.0);
-  if (c->resident_used < 0) return c->resident_used;
-  if (c->resident_used > 0) {
-    int rrc = PA_OK;
-    if (resident_finish(c, out, &rrc)) return rrc;
-  }
   int64_t enq = 0;
   // The three single-block scalar kernels of an iteration are folded into the prologue of the kernel
   // that follows each (pa_cg3d_kernel.h phases 5 / 6, k_bicg_x) when that kernel is a tiled one / the
