@@ -4,8 +4,9 @@
 // On the meshes the reference's tests and demos run (128^2, 33^3, 64^3 ...) an iteration of the launch-per-
 // phase loops costs ~10 us per dependent kernel whatever the kernel does (DESIGN "small meshes").  Here the
 // mesh is cut into <= 128 boxes, one workgroup each, all co-resident (hipLaunchCooperativeKernel); the fields
-// (CG: x, r and the direction d with a one-cell halo) live in the workgroup's LDS for the whole solve and an
-// iteration costs two grid-wide steps:
+// (CG: x, r and the direction d with a one-cell halo) live in the workgroup's LDS for the whole solve -- the
+// set-up included: the solver scalars come from the kernel arguments, the start is BC-filled and the first
+// residual formed in the kernel (two more grid-wide steps) -- and an iteration costs two grid-wide steps:
 //   step 1: partial d.Ad -> mailbox, arrive, wait, every workgroup sums all partials in the same fixed
 //           order (same bits everywhere) -> alpha
 //   step 2: x, r update, ordered BC fill (literal, face after face, in LDS), boundary-shell stop-test
