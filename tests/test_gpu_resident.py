@@ -250,3 +250,22 @@ def test_resident_wait_timeout_falls_back(monkeypatch, method):
     assert plan[0] > 1 and ub == 0
     assert ra["itr"] == rb["itr"] and ra["tol"] == rb["tol"]
     assert torch.equal(xa, xb)
+
+
+@pytest.mark.parametrize("method", ["cg", "jacobi", "bicgstab"])
+def test_resident_nonfinite_stop_test_raises(monkeypatch, method):
+    """an infinite right-hand side makes the stop-test value NaN / inf: RuntimeError("Invalid tolerance detected!")
+    like linalg.py:334-336, from inside the one launch as from the launch-per-phase loops"""
+    monkeypatch.setenv("PYAPES_HIP_RESIDENT", "1")
+    mesh = Mesh(Box([0.0, 0.0], [1.0, 1.0]), None, [40, 36], "cuda", "double")
+    cfg = [{"bc_face": FACES[i], "bc_type": "dirichlet", "bc_val": 0.0, "bc_val_opt": None} for i in range(4)]
+    var = Field("p", 1, mesh, {"domain": cfg, "obstacle": None})
+    rhs = torch.full((1, 40, 36), float("inf"), dtype=torch.float64, device="cuda")
+    s = Solver({"fdm": {"method": method, "tol": 1e-6, "max_it": 5, "report": False}})
+    s.set_eq(FDM().laplacian(1.0, var) == rhs)
+    assert context_for(mesh).resident_plan(method)[0] > 0
+    with pytest.raises(RuntimeError, match="Invalid tolerance"):
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            s.solve()
+    assert context_for(mesh).resident_used() > 0
