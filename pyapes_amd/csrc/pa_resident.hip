@@ -100,6 +100,10 @@ struct ResSync {
 __device__ __forceinline__ bool res_grid_wait(ResSync& S) {
   __shared__ int ok;
   __syncthreads();
+  if (S.G == 1) {   // the mesh is one box: the workgroup barrier is the whole step (what the box writes into its own
+    S.step += 1;    // mailbox along a periodic axis is ordered by that barrier too)
+    return true;
+  }
   if (threadIdx.x == 0) {
     __hip_atomic_fetch_add(S.counter, 1ull, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
     const unsigned long long target = (S.step + 1) * S.G;
@@ -163,9 +167,11 @@ __device__ __forceinline__ bool res_allreduce(ResSync& S, double* parts, double 
     const int s = threadIdx.x;
     double x = sm[s][0];
     for (int w = 1; w < (int)(blockDim.x >> 6); ++w) x += sm[s][w];
-    __hip_atomic_store(row + (size_t)blockIdx.x * RES_NS + s, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (S.G == 1) out[s] = x;   // one box: its partial IS the sum (the general path would add zeros to it)
+    else __hip_atomic_store(row + (size_t)blockIdx.x * RES_NS + s, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   if (!res_grid_wait(S)) return false;
+  if (S.G == 1) return true;   // (res_grid_wait's barrier has published out[])
   if (wave == 0) {
 #pragma unroll
     for (int s = 0; s < NU; ++s) {
