@@ -150,7 +150,12 @@ def main():
     m2 = lambda nn: (lambda: Mesh(Box[0:1, 0:1], None, [nn, nn], "cuda", "double"))
     m3 = lambda nn: (lambda: Mesh(Box[0:1, 0:1, 0:1], None, [nn, nn, nn], "cuda", "double"))
     mixbc = mixed_bcs([0, 0, 0, 0, 1, 0], ["dirichlet", "neumann"] * 3)
-    small = [("jacobi 2-D 128x128 f64 dirichlet (config 1)", m2(128), poisson_bcs(2), "jacobi", 1000, 3, poisson_rhs_nd),
+    m1 = lambda nn: (lambda: Mesh(Box[0:1], None, [nn], "cuda", "double"))
+    small = [("cg 1-D 101 nodes f64 dirichlet (the reference's 1-D Poisson test: one box, no grid-wide step)", m1(101), poisson_bcs(1), "cg", 100,
+              10, poisson_rhs_nd),
+             ("bicgstab 1-D 101 nodes f64 dirichlet", m1(101), poisson_bcs(1), "bicgstab", 60, 22, poisson_rhs_nd),
+             ("cg 2-D 32x32 f64 dirichlet (one box)", m2(32), poisson_bcs(2), "cg", 100, 10, poisson_rhs_nd),
+             ("jacobi 2-D 128x128 f64 dirichlet (config 1)", m2(128), poisson_bcs(2), "jacobi", 1000, 3, poisson_rhs_nd),
              ("cg 2-D 128x128 f64 dirichlet (config 1 inputs)", m2(128), poisson_bcs(2), "cg", 271, 10, poisson_rhs_nd),
              ("bicgstab 2-D 128x128 f64 dirichlet (config 1 inputs)", m2(128), poisson_bcs(2), "bicgstab", 100, 22, poisson_rhs_nd)]
     for nn in (32, 64):
