@@ -101,19 +101,68 @@ def _run_ranks(n: int, argv: list[str], extra_env: dict, timeout_s: float):
     return p.returncode, line
 
 
+EXIT_CONFIG = 3   # a rank refused the configuration (too few GPUs, single-GPU workload ...): running it again cannot help
+
+
+def refuse_config(msg: str):
+    """A rank that cannot run the requested configuration at all: say so on stderr, tell the launching parent
+    (torch.distributed.run flattens every child exit code to 1, so through a file it named) and leave."""
+    log(msg)
+    path = os.environ.get("BENCH_STATUS_FILE")
+    if path:
+        try:
+            with open(path, "a") as f:
+                f.write("config\n")
+        except OSError:
+            pass
+    raise SystemExit(EXIT_CONFIG)
+
+
 def launch_ranks(n: int, argv: list[str]) -> int:
     """Start ``python -m torch.distributed.run --nproc-per-node n bench.py <argv>`` as a CHILD process,
     pass its stderr through, print the one JSON line rank 0 wrote, return the child's exit code.
     Nothing here imports torch.cuda or calls HIP: a process that has initialised the GPU must not be
-    replaced or forked into ranks.  Watchdog: if the ranks give no result within BENCH_RANKS_TIMEOUT seconds
-    (default 900) or fail, ONE more attempt runs with the stepwise torch.distributed slab driver
-    (PYAPES_HIP_COMM=0) instead of the library-side RCCL loop -- its record says so in config.parallelism."""
-    tmo = float(os.environ.get("BENCH_RANKS_TIMEOUT", "900"))
-    rc, line = _run_ranks(n, argv, {}, tmo)
-    if (rc != 0 or line is None) and os.environ.get("PYAPES_HIP_COMM", "1") != "0":
-        log(f"first attempt {'timed out' if rc is None else f'ended with rc {rc}'}; retrying with PYAPES_HIP_COMM=0")
-        rc, line = _run_ranks(n, argv, {"PYAPES_HIP_COMM": "0"}, tmo)
+    replaced or forked into ranks.
+
+    Watchdog, sized for the driver's 600 s limit on the whole command: the first attempt gets
+    BENCH_RANKS_TIMEOUT seconds (default 240); if it gives no result or fails -- and did not refuse the
+    configuration -- ONE more attempt runs on the stepwise torch.distributed slab driver (PYAPES_HIP_COMM=0)
+    with what is left of BENCH_RANKS_BUDGET (default 540 s for both).  A record produced by the second attempt
+    says so: ``first_attempt`` = how the first one ended.  (The ranks bound their own first iterations of the
+    library-side loop too -- BENCH_WARMUP_TIMEOUT in main() -- so this is the second line of defence.)"""
+    import tempfile
+    budget = float(os.environ.get("BENCH_RANKS_BUDGET", "540"))
+    tmo = min(float(os.environ.get("BENCH_RANKS_TIMEOUT", "240")), budget)
+    t0 = time.monotonic()
+    fd, status = tempfile.mkstemp(prefix="bench_status_")
+    os.close(fd)
+    rc, line = _run_ranks(n, argv, {"BENCH_STATUS_FILE": status}, tmo)
+    try:
+        with open(status) as f:
+            refused = "config" in f.read()
+        os.unlink(status)
+    except OSError:
+        refused = False
+    first = None
+    if refused:
+        log("a rank refused the configuration: not retried")
+    elif (rc != 0 or line is None) and os.environ.get("PYAPES_HIP_COMM", "1") != "0":
+        first = f"timeout after {tmo:.0f} s" if rc is None else (f"rc={rc}" if rc != 0 else "rc=0 without a JSON line")
+        left = budget - (time.monotonic() - t0)
+        if left >= 30:
+            log(f"first attempt ended with {first}; ONE more on the stepwise driver (PYAPES_HIP_COMM=0), {left:.0f} s left")
+            rc, line = _run_ranks(n, argv, {"PYAPES_HIP_COMM": "0"}, left)
+        else:
+            log(f"first attempt ended with {first}; {left:.0f} s left are too few for another")
     if line is not None:
+        if first is not None:
+            try:
+                rec = json.loads(line)
+                rec["first_attempt"] = {"path": "library-side RCCL loop (pa_cg_iterate_comm)", "outcome": first,
+                                        "then": "all ranks restarted on the stepwise torch.distributed driver"}
+                line = json.dumps(rec)
+            except ValueError:
+                pass
         print(line, flush=True)
     elif rc == 0:
         log("the ranks exited 0 but printed no JSON line")
@@ -344,14 +393,15 @@ def main():
         gn = tuple(int(v) for v in args.n.split(","))
         assert len(gn) == len(upper), "--size must have the workload's dimension"
     if world > 1 and solver != "cg":
-        raise SystemExit(f"workload {args.workload} is single-GPU (replicas only); the slab path is the CG solve")
+        refuse_config(f"workload {args.workload} is single-GPU (replicas only); the slab path is the CG solve")
 
     # rehearsal switches (one-GPU box): BENCH_SINGLE_DEVICE=1 puts every rank on cuda:0,
     # BENCH_BACKEND=gloo moves the planes through the host instead of RCCL
     single_dev = bool(os.environ.get("BENCH_SINGLE_DEVICE"))
     if world > 1 and not single_dev and torch.cuda.device_count() < world:
-        raise SystemExit(f"bench.py --gpus {world}: only {torch.cuda.device_count()} GPUs visible")
-    assert torch.cuda.is_available(), "bench.py needs the MI355X; there is no CPU path"
+        refuse_config(f"bench.py --gpus {world}: only {torch.cuda.device_count()} GPUs visible")
+    if not torch.cuda.is_available():
+        refuse_config("bench.py needs the MI355X; there is no CPU path")
     if single_dev:
         local_rank = 0
     torch.cuda.set_device(local_rank)
@@ -380,6 +430,11 @@ def main():
         else:
             dist.init_process_group(backend)
     slab = world > 1 or force_slab
+    # agreements that must not depend on the GPU's streams (watchdog of the slab warm-up) go over the host
+    host_group = None
+    if dist is not None:
+        host_group = dist.new_group(backend="gloo") if dist.get_backend() != "gloo" else dist.group.WORLD
+    first_attempt = None
 
     mesh = Mesh(Box([0.0] * nd, list(upper)), None, list(gn), "cuda", dtype, slab=(rank, world) if slab else None)
     var = Field("p", 1, mesh, {"domain": make_bcs(kind), "obstacle": None})
@@ -430,6 +485,35 @@ def main():
         drv = SlabCG(mesh, var, rhs, terms, dist)
         drv.begin(-1.0, W + K + 10)
         drv.iterate(W)
+        if drv.lib_comm:
+            # The warm-up is the first time the library-side loop's collectives run between THESE ranks: its
+            # completion is waited for with a deadline.  A rank that sees none aborts the library's communicators
+            # (its stream is released), the ranks agree over the host (gloo: nothing of this may queue behind a
+            # stuck stream), and all of them restart on the stepwise torch.distributed driver -- recorded in the line.
+            wtmo = float(os.environ.get("BENCH_WARMUP_TIMEOUT", "120"))
+            ok_here = drv.be.stream_wait(wtmo)
+            if not ok_here:
+                log(f"rank {rank}: no completion of the library-side warm-up within {wtmo:.0f} s: aborting its communicators")
+                drv.be.comm_abort()
+            flag = torch.tensor([1 if ok_here else 0], dtype=torch.int32)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=host_group)
+            if int(flag.item()) == 0:
+                bad = [None] * world
+                dist.all_gather_object(bad, bool(ok_here), group=host_group)
+                first_attempt = {"path": "library-side RCCL loop (pa_cg_iterate_comm)",
+                                 "outcome": f"timeout after {wtmo:.0f} s in the warm-up iterations on rank(s) "
+                                            f"{[q for q, v in enumerate(bad) if not v]}",
+                                 "then": "communicators aborted, all ranks restarted on the stepwise torch.distributed driver"}
+                if ok_here:
+                    drv.be.comm_abort()
+                drv.be.cg_abort()
+                drv.be.slab_set(None)
+                os.environ["PYAPES_HIP_COMM"] = "0"
+                var = Field("p", 1, mesh, {"domain": make_bcs(kind), "obstacle": None})
+                drv = SlabCG(mesh, var, rhs, terms, dist)
+                assert not drv.lib_comm
+                drv.begin(-1.0, W + K + 10, adjust_rhs=False)
+                drv.iterate(W)
         torch.cuda.synchronize()
         dist.barrier()
         torch.cuda.synchronize()
@@ -562,6 +646,8 @@ def main():
         }
         if roof is not None:
             out["roofline"] = roof
+        if first_attempt is not None:
+            out["first_attempt"] = first_attempt
         if not args.no_cpu_baseline and world == 1 and not slab:   # reported baseline: rank 0 at N = 1 only
             out["cpu_baseline"] = cpu_baseline(solver, kind, dtype, gn)
         sys.stdout.flush()
@@ -571,6 +657,11 @@ def main():
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+    if os.environ.get("BENCH_DUMP_MAPS"):
+        # diagnostics: the address map of this process, so that raw frames of a crash inside exit() handlers
+        # (profiles/README.md "c1 under rocprofv3") can be attributed to a library + offset afterwards
+        with open("/proc/self/maps") as src, open(os.environ["BENCH_DUMP_MAPS"], "w") as dst:
+            dst.write(src.read())
 
 
 if __name__ == "__main__":

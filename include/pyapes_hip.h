@@ -306,6 +306,17 @@ int pa_comm_selftest(pa_ctx* ctx, double timeout_s);
 int pa_comm_plan(pa_ctx* ctx, const pa_exchange* plan);
 int pa_cg_iterate_comm(pa_ctx* ctx, int64_t n);
 int pa_comm_destroy(pa_ctx* ctx);
+/* Give up on the library's communicators while work that uses them may still be queued (a collective some rank
+ * never joined): ncclCommAbort on both, then the ctx streams are drained.  The stepwise calls remain usable. */
+int pa_comm_abort(pa_ctx* ctx);
+/* Wait until everything enqueued on the ctx stream(s) has run, at most timeout_s seconds: PA_OK, or PA_E_STATE
+ * when work is still queued (watchdog of multi-rank drivers: bench.py bounds its first slab iterations with it) */
+int pa_stream_wait(pa_ctx* ctx, double timeout_s);
+/* Which implementation is behind pa_comm_*: "rccl", or the test stand-in selected by the explicit hook
+ * PYAPES_HIP_COMM_IMPL=hostring (ranks as processes that may share one GPU; csrc/pa_comm_hostring.hip) */
+const char* pa_comm_impl(void);
+/* 1 when the plane exchange of pa_cg_iterate_comm runs on the second communicator + stream, 0 when on the ctx stream */
+int pa_comm_overlap(const pa_ctx* ctx);
 
 /* ---- measurement (bench.py roofline leg) ---------------------------------
  * on: bracket each launch of the two dominant CG kernels (phase A stencil+dot,

@@ -12,26 +12,10 @@
 
 #include "../../include/pyapes_hip.h"
 #include "pa_device.h"
+#include "pa_comm_table.h"
 #include "pa_host.h"
 
 namespace {
-
-struct Rccl {
-  void* h = nullptr;
-  int tried = 0;
-  ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
-  ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
-  ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
-  ncclResult_t (*CommAbort)(ncclComm_t) = nullptr;
-  ncclResult_t (*CommCount)(const ncclComm_t, int*) = nullptr;
-  ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
-  ncclResult_t (*Broadcast)(const void*, void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
-  ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
-  ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
-  ncclResult_t (*GroupStart)() = nullptr;
-  ncclResult_t (*GroupEnd)() = nullptr;
-  const char* (*GetErrorString)(ncclResult_t) = nullptr;
-};
 
 Rccl g_rccl;
 
@@ -45,6 +29,11 @@ Rccl* rccl() {
   Rccl& R = g_rccl;
   if (R.tried) return R.h ? &R : nullptr;
   R.tried = 1;
+  // explicit test hook: the stand-in of pa_comm_hostring.hip (ranks as processes that may share one GPU, host
+  // shared memory as the wire); never selected implicitly
+  if (const char* impl = getenv("PYAPES_HIP_COMM_IMPL")) {
+    if (!strcmp(impl, "hostring")) { pa_hostring_table(&R); return &R; }
+  }
   void* h = dlopen("librccl.so.1", RTLD_NOW | RTLD_NOLOAD);  // the copy the process already uses
   if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_NOLOAD);
   if (!h) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
@@ -145,61 +134,106 @@ int pa_comm_init(pa_ctx* c, int rank, int nranks, const void* id128) {
   // 64 x 512^2 slab): there is no link latency to hide.  PYAPES_HIP_COMM_OVERLAP=1 / 0 forces either.
   const char* ov = getenv("PYAPES_HIP_COMM_OVERLAP");
   int want = ov ? (atoi(ov) != 0) : (nranks > 1);
-  struct Box { ncclUniqueId id; int ok; int pad[3]; };
-  Box h;
-  memset(&h, 0, sizeof(h));
+  // Host side of every bounded wait below is PINNED: a device-to-host copy into pageable memory blocks the host
+  // until the stream reaches it, i.e. inside the very collective whose completion is in doubt -- the deadline
+  // would never be looked at -- and a copy that is still queued when this frame is left would land in a dead
+  // stack frame.  hb lives until the stream has been waited for (or drained after an abort).
+  struct Box { ncclUniqueId id; int ok; int all; int pad[2]; };
+  Box* hb = nullptr;
   Box* dev = nullptr;
-  if (hipMalloc((void**)&dev, sizeof(Box)) != hipSuccess) { (void)hipGetLastError(); return PA_OK; }
-  if (rank == 0) {
-    h.ok = (want && R->GetUniqueId(&h.id) == ncclSuccess) ? 1 : 0;
-    (void)hipMemcpyAsync(dev, &h, sizeof(Box), hipMemcpyHostToDevice, c->stream);
-  }
-  // every wait on a collective is bounded (a rank that never arrives must not hang the others for good): on
-  // expiry the first communicator is aborted too and the caller falls back to the stepwise driver
   const char* to = getenv("PYAPES_HIP_COMM_TIMEOUT");
   const double tmo = to ? atof(to) : 60.0;
-  auto give_up = [&]() {
+  // leave with the first communicator aborted: a rank that cannot go on must not keep a communicator the others
+  // are about to give up on (they do so after `tmo`; the caller's agreement then puts every rank on the stepwise path)
+  auto give_up = [&](const char* why) {
     (void)R->CommAbort(comm);
     c->comm = nullptr;
-    (void)hipFree(dev);
-    pa_set_err(c, "pa_comm_init: no completion of the second communicator's set-up within %.0f s", tmo);
+    (void)hipStreamSynchronize(c->stream);   // nothing queued may still write to hb / dev
+    if (dev) (void)hipFree(dev);
+    if (hb) (void)hipHostFree(hb);
+    (void)hipGetLastError();
+    pa_set_err(c, "pa_comm_init: %s (limit %.0f s); communicator aborted", why, tmo);
     return PA_E_STATE;
   };
-  ncclResult_t e = R->Broadcast(dev, dev, sizeof(Box), ncclChar, 0, comm, c->stream);
-  if (e == ncclSuccess && hipMemcpyAsync(&h, dev, sizeof(Box), hipMemcpyDeviceToHost, c->stream) == hipSuccess) {
-    if (!stream_done_within(c->stream, tmo)) return give_up();
-  } else {
-    h.ok = 0;
+  if (hipHostMalloc((void**)&hb, sizeof(Box), hipHostMallocDefault) != hipSuccess || hipMalloc((void**)&dev, sizeof(Box)) != hipSuccess)
+    return give_up("no memory for the set-up of the second communicator");
+  memset(hb, 0, sizeof(Box));
+  if (rank == 0) {
+    hb->ok = (want && R->GetUniqueId(&hb->id) == ncclSuccess) ? 1 : 0;
+    if (hipMemcpyAsync(dev, hb, sizeof(Box), hipMemcpyHostToDevice, c->stream) != hipSuccess) return give_up("hipMemcpyAsync failed");
   }
-  if (e == ncclSuccess && h.ok) {
+  if (R->Broadcast(dev, dev, sizeof(Box), ncclChar, 0, comm, c->stream) != ncclSuccess ||
+      hipMemcpyAsync(hb, dev, sizeof(Box), hipMemcpyDeviceToHost, c->stream) != hipSuccess)
+    return give_up("broadcast of the second communicator's id could not be enqueued");
+  if (!stream_done_within(c->stream, tmo)) return give_up("no completion of the id broadcast");
+  if (hb->ok) {
     ncclComm_t comm2 = nullptr;
     int prio_lo = 0, prio_hi = 0;   // highest priority: its own hardware queue, and its few workgroups first
     (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
-    int ok = want && R->CommInitRank(&comm2, nranks, h.id, rank) == ncclSuccess &&
+    int ok = want && R->CommInitRank(&comm2, nranks, hb->id, rank) == ncclSuccess &&
              hipStreamCreateWithPriority(&c->xstream, hipStreamNonBlocking, prio_hi) == hipSuccess &&
              hipEventCreateWithFlags(&c->ev_b, hipEventDisableTiming) == hipSuccess &&
              hipEventCreateWithFlags(&c->ev_x, hipEventDisableTiming) == hipSuccess;
-    h.ok = ok;
-    (void)hipMemcpyAsync(&dev->ok, &h.ok, sizeof(int), hipMemcpyHostToDevice, c->stream);
-    e = R->AllReduce(&dev->ok, &dev->ok, 1, ncclInt, ncclMin, comm, c->stream);
-    int all = 0;
-    bool copied = e == ncclSuccess && hipMemcpyAsync(&all, &dev->ok, sizeof(int), hipMemcpyDeviceToHost, c->stream) == hipSuccess;
-    if (copied && !stream_done_within(c->stream, tmo)) {
-      if (comm2) (void)R->CommAbort(comm2);
-      return give_up();
-    }
-    if (copied && all) {
-      c->comm2 = comm2;
-    } else {
-      if (comm2) (void)R->CommDestroy(comm2);
+    auto drop2 = [&]() {
       if (c->xstream) { (void)hipStreamDestroy(c->xstream); c->xstream = nullptr; }
       if (c->ev_b) { (void)hipEventDestroy(c->ev_b); c->ev_b = nullptr; }
       if (c->ev_x) { (void)hipEventDestroy(c->ev_x); c->ev_x = nullptr; }
+    };
+    hb->ok = ok;
+    hb->all = 0;
+    bool queued = hipMemcpyAsync(&dev->ok, &hb->ok, sizeof(int), hipMemcpyHostToDevice, c->stream) == hipSuccess &&
+                  R->AllReduce(&dev->ok, &dev->ok, 1, ncclInt, ncclMin, comm, c->stream) == ncclSuccess &&
+                  hipMemcpyAsync(&hb->all, &dev->ok, sizeof(int), hipMemcpyDeviceToHost, c->stream) == hipSuccess;
+    if (!queued || !stream_done_within(c->stream, tmo)) {
+      if (comm2) (void)R->CommAbort(comm2);
+      drop2();
+      return give_up(queued ? "no completion of the agreement on the second communicator" : "agreement could not be enqueued");
+    }
+    if (hb->all) {
+      c->comm2 = comm2;
+    } else {
+      if (comm2) (void)R->CommDestroy(comm2);
+      drop2();
     }
   }
   (void)hipGetLastError();
   (void)hipFree(dev);
+  (void)hipHostFree(hb);
   return PA_OK;
+}
+
+int pa_comm_abort(pa_ctx* c) {
+  if (!c) return PA_E_ARG;
+  Rccl* R = rccl();
+  if (R) {   // kernels of a collective that will never complete return once their communicator is aborted
+    if (c->comm2) (void)R->CommAbort((ncclComm_t)c->comm2);
+    if (c->comm) (void)R->CommAbort((ncclComm_t)c->comm);
+  }
+  c->comm2 = nullptr;
+  c->comm = nullptr;
+  if (c->xstream) (void)hipStreamSynchronize(c->xstream);
+  (void)hipStreamSynchronize(c->stream);
+  if (c->xstream) { (void)hipStreamDestroy(c->xstream); c->xstream = nullptr; }
+  if (c->ev_b) { (void)hipEventDestroy(c->ev_b); c->ev_b = nullptr; }
+  if (c->ev_x) { (void)hipEventDestroy(c->ev_x); c->ev_x = nullptr; }
+  (void)hipGetLastError();
+  c->plan_set = 0;
+  c->slab_fold_live = 0;
+  return PA_OK;
+}
+
+int pa_stream_wait(pa_ctx* c, double timeout_s) {
+  if (!c) return PA_E_ARG;
+  if (stream_done_within(c->stream, timeout_s) && (!c->xstream || stream_done_within(c->xstream, timeout_s))) return PA_OK;
+  pa_set_err(c, "pa_stream_wait: work still queued after %.1f s", timeout_s);
+  return PA_E_STATE;
+}
+
+int pa_comm_overlap(const pa_ctx* c) { return c && c->comm && c->comm2 && c->xstream ? 1 : 0; }
+
+const char* pa_comm_impl(void) {
+  Rccl* R = rccl();
+  return R ? R->impl : "none";
 }
 
 int pa_comm_destroy(pa_ctx* c) {

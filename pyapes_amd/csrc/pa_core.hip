@@ -206,6 +206,7 @@ int pa_ctx_create(int device, void* hip_stream, pa_ctx** out) {
   if (const char* fp = getenv("PYAPES_HIP_FASTPATH")) c->fastpath = atoi(fp) != 0;
   if (const char* sf = getenv("PYAPES_HIP_SF")) c->sf = atoi(sf) != 0;
   if (const char* rs = getenv("PYAPES_HIP_RESIDENT")) c->resident = atoi(rs) != 0;
+  if (const char* rc = getenv("PYAPES_HIP_RESIDENT_COOP")) c->resident_coop = atoi(rc) != 0;
   if (hipMalloc((void**)&c->sc_base, 2 * sizeof(SolverScalars)) != hipSuccess ||
       hipMalloc((void**)&c->sums, PA_NSUM * sizeof(double)) != hipSuccess ||
       hipHostMalloc((void**)&c->h_sc, sizeof(SolverScalars)) != hipSuccess ||
@@ -233,7 +234,21 @@ int pa_ctx_set_stream(pa_ctx* c, void* hip_stream) {
     pa_set_err(c, "pa_ctx_set_stream during a stepwise solve");
     return PA_E_STATE;
   }
-  c->stream = (hipStream_t)hip_stream;
+  hipStream_t next = (hipStream_t)hip_stream;
+  if (next != c->stream) {
+    // work still queued on the old stream(s) -- asynchronous explicit operators, uploads of BC values, the
+    // create-time memsets of the scalars and partial rows, the exchange stream of a slab -- writes ctx-owned
+    // state the kernels on the new stream read: order the new stream after it
+    PA_HIP(c, hipSetDevice(c->device));
+    if (!c->ev_switch) PA_HIP(c, hipEventCreateWithFlags(&c->ev_switch, hipEventDisableTiming));
+    PA_HIP(c, hipEventRecord(c->ev_switch, c->stream));
+    PA_HIP(c, hipStreamWaitEvent(next, c->ev_switch, 0));
+    if (c->xstream) {
+      PA_HIP(c, hipEventRecord(c->ev_switch, c->xstream));
+      PA_HIP(c, hipStreamWaitEvent(next, c->ev_switch, 0));
+    }
+  }
+  c->stream = next;
   return PA_OK;
 }
 
@@ -244,6 +259,7 @@ int pa_ctx_set_option(pa_ctx* c, const char* name, int value) {
   else if (!strcmp(name, "sf")) c->sf = value != 0;             // k_sf (else k_cg3d's single-field phases)
   else if (!strcmp(name, "fold")) c->fold = value != 0;         // scalar steps in the next kernel's prologue
   else if (!strcmp(name, "resident")) c->resident = value != 0; // small meshes: one cooperative launch per solve
+  else if (!strcmp(name, "resident_coop")) c->resident_coop = value != 0;   // 0: plain launch of the same grid (profiling, below)
   else { pa_set_err(c, "pa_ctx_set_option: unknown option '%s'", name); return PA_E_ARG; }
   return PA_OK;
 }
@@ -266,6 +282,7 @@ int pa_ctx_destroy(pa_ctx* c) {
   }
   if (c->ev0) (void)hipEventDestroy(c->ev0);
   if (c->ev1) (void)hipEventDestroy(c->ev1);
+  if (c->ev_switch) (void)hipEventDestroy(c->ev_switch);
   for (int q = 0; q < 4; ++q)
     if (c->pev[q]) (void)hipEventDestroy(c->pev[q]);
   delete c;

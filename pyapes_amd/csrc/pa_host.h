@@ -81,6 +81,7 @@ struct pa_ctx {
   double* sums = nullptr;         // device, PA_NSUM (internal)
   double* ext_sums = nullptr;     // slab: caller-owned sums buffer (all-reduced by the host driver)
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  hipEvent_t ev_switch = nullptr;   // pa_ctx_set_stream: orders the new stream after what the old one still holds
   // CG state
   int solver_live = 0, cur = 0, bc_static = 0, pending_init_logic = 0, b_blocks = 0;
   int bc_pair = 0;  // per-axis pair kernels (lower + upper face + shell stop-test term in one launch)
@@ -115,6 +116,12 @@ struct pa_ctx {
   int fastpath = 1;
   int sf = 1;                    // k_sf for the Div-carrying single-field operations (else k_cg3d's phases)
   int resident = 1;              // small meshes: the whole CG / Jacobi solve in one cooperative launch (pa_resident.hip)
+  // 1: hipLaunchCooperativeKernel (the runtime guarantees co-residency).  0: a plain launch of the same grid, which
+  // the occupancy query of pa_resident_launch has already shown to fit an idle device; the bounded waits make a
+  // grid that was NOT co-resident (device shared with other work) fall back like any other wait that gives up.
+  // Exists for collections under rocprofv3: ANY process that has made a cooperative launch dies with SIGSEGV in
+  // libhsa-runtime64 inside exit() under rocprofv3 7.2 (profiles/README.md, tools/coop_exit_repro.sh)
+  int resident_coop = 1;
   int resident_used = 0;         // workgroups of the last solve's resident launch (0: launch-per-phase loops ran)
   // RCCL communicator owned by the library (pa_comm_*): slab iterations without host work
   void* comm = nullptr;          // ncclComm_t

@@ -105,15 +105,30 @@ __device__ __forceinline__ bool res_grid_wait(ResSync& S) {
     return true;
   }
   if (threadIdx.x == 0) {
+    // The outcome of a step must be the SAME in every workgroup -- one that passes the last step stores its box of
+    // x, one that gives up tells the host to redo the solve from the x it was handed -- so giving up is an update
+    // of the counter itself: a compare-and-swap that sets RES_POISON, which only succeeds while the counter is
+    // still below the step's target.  Either every arrival is in before anybody gives up (all pass) or the poison
+    // is in before the last arrival (nobody passes, now or in any later step).
+    const unsigned long long RES_POISON = 1ull << 62;
     __hip_atomic_fetch_add(S.counter, 1ull, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
     const unsigned long long target = (S.step + 1) * S.G;
     int good = 0;
+    unsigned long long v = 0;
     // relaxed polls, ONE acquire fence after the last: an acquire load per poll would invalidate the caches of
     // the XCD on every round, under the feet of the workgroups that are still working
     for (unsigned spin = 0; spin < S.spin_max; ++spin) {
-      if (__hip_atomic_load(S.counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= target) { good = 1; break; }
-      if ((spin & 63u) == 63u && __hip_atomic_load(S.fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
+      v = __hip_atomic_load(S.counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (v & RES_POISON) break;
+      if (v >= target) { good = 1; break; }
       __builtin_amdgcn_s_sleep(1);
+    }
+    if (!good && !(v & RES_POISON)) {
+      v = __hip_atomic_load(S.counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      while (!(v & RES_POISON)) {
+        if (v >= target) { good = 1; break; }
+        if (__hip_atomic_compare_exchange_strong(S.counter, &v, v | RES_POISON, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
+      }
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     if (!good) __hip_atomic_store(S.fail, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1159,7 +1174,8 @@ int pa_resident_launch(pa_ctx* c, int solver, T* x, const T* rhs, double tol, in
   DevEq<T> E;
   pa_build_eq<T>(c, c->nterms, c->terms, E);
   void* args[] = {&G, &E, &A};
-  hipError_t e = hipLaunchCooperativeKernel(fn, dim3(R.G), dim3(nt), args, R.lds, c->stream);
+  hipError_t e = c->resident_coop ? hipLaunchCooperativeKernel(fn, dim3(R.G), dim3(nt), args, R.lds, c->stream)
+                                  : hipLaunchKernel(fn, dim3(R.G), dim3(nt), args, R.lds, c->stream);
   if (e != hipSuccess) {   // e.g. the device is shared and the grid cannot be co-resident right now
     (void)hipGetLastError();
     return 0;

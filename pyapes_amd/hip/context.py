@@ -406,6 +406,24 @@ class HipContext:
         self._rc(self.lib.pa_comm_destroy(self.h))
         self._keep.pop("plan", None)
 
+    def comm_abort(self) -> None:
+        """Abort the library's communicators (a collective that some rank never joined) and drain the streams."""
+        self._rc(self.lib.pa_comm_abort(self.h))
+        self._keep.pop("plan", None)
+        self.comm_ready = None
+
+    def comm_overlap(self) -> bool:
+        """True when the plane exchange runs on the library's second communicator + stream."""
+        return bool(self.lib.pa_comm_overlap(self.h))
+
+    def comm_impl(self) -> str:
+        return self.lib.pa_comm_impl().decode()
+
+    def stream_wait(self, timeout_s: float) -> bool:
+        """True once everything enqueued on the ctx stream(s) has run; False if work is still queued after
+        ``timeout_s`` seconds."""
+        return self.lib.pa_stream_wait(self.h, float(timeout_s)) == L.PA_OK
+
     def slab_set(self, bufs: dict[str, Tensor | None] | None) -> None:
         if bufs is None:
             self._rc(self.lib.pa_slab_set(self.h, None))

@@ -114,6 +114,10 @@ SIGNATURES: dict[str, tuple[Any, list[Any]]] = {
     "pa_comm_plan": (C.c_int, [_VP, C.POINTER(PaExchange)]),
     "pa_cg_iterate_comm": (C.c_int, [_VP, C.c_int64]),
     "pa_comm_destroy": (C.c_int, [_VP]),
+    "pa_comm_abort": (C.c_int, [_VP]),
+    "pa_stream_wait": (C.c_int, [_VP, C.c_double]),
+    "pa_comm_impl": (C.c_char_p, []),
+    "pa_comm_overlap": (C.c_int, [_VP]),
     "pa_report_read": (C.c_int, [_VP, C.POINTER(PaReport)]),
     "pa_profile_set": (C.c_int, [_VP, C.c_int]),
     "pa_profile_read": (C.c_int, [_VP, _F64P, _I64P, _F64P, _I64P]),

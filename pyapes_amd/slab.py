@@ -110,12 +110,16 @@ class SlabCG:
         be, d = self.be, self.dist
         if os.environ.get("PYAPES_HIP_COMM", "1") == "0" or not hasattr(be, "comm_init"):
             return False
-        if not self.x.is_cuda or d.get_backend(self.group) != "nccl":
+        # the test stand-in of csrc/pa_comm_hostring.hip (explicit hook PYAPES_HIP_COMM_IMPL=hostring): ranks are
+        # processes that may share one GPU, so the process group is gloo and the small agreement tensors live on the host
+        standin = os.environ.get("PYAPES_HIP_COMM_IMPL") == "hostring"
+        if not self.x.is_cuda or (d.get_backend(self.group) != "nccl" and not standin):
             return False
         if getattr(be, "comm_ready", None) == (self.rank, self.world):   # an earlier solve on this mesh made it
             be.comm_plan(self.nb_lo, self.nb_hi, self.send_lo, self.send_hi, self.recv_lo, self.recv_hi)
             return True
-        dev = self.x.device
+        dev = self.x.device if d.get_backend(self.group) == "nccl" else torch.device("cpu")
+        self._agree_dev = dev
         # every step that can fail on ONE rank is followed by an agreement (all-reduce MIN of an ok flag)
         # before any rank enters a call the others must join: ncclCommInitRank blocks until all ranks
         # arrive, so a rank that could not even load librccl must make everybody skip it
@@ -132,11 +136,13 @@ class SlabCG:
         if int(flag.item()) == 0:
             return False
         d.broadcast(uid, src=src, group=self.group)
+        self.lib_comm_error = None
         try:
             be.comm_init(self.rank, self.world, bytes(uid.cpu().numpy().tobytes()))
             be.comm_selftest(float(os.environ.get("PYAPES_HIP_COMM_TIMEOUT", "30")))
-        except Exception:
+        except Exception as e:   # this rank is out; the agreement below takes every rank to the stepwise driver
             ok = 0
+            self.lib_comm_error = str(e)
         flag.fill_(ok)
         d.all_reduce(flag, op=d.ReduceOp.MIN, group=self.group)
         if int(flag.item()) == 0:
@@ -240,7 +246,7 @@ class SlabCG:
         if not self.lib_comm or not hasattr(be, "cg_fold_plan") or os.environ.get("PYAPES_HIP_SLAB_FOLD", "1") == "0":
             return False
         rows = be.cg_fold_plan()
-        t = torch.tensor([*rows, -min(rows[0], rows[1])], dtype=torch.int64, device=self.x.device)
+        t = torch.tensor([*rows, -min(rows[0], rows[1])], dtype=torch.int64, device=getattr(self, "_agree_dev", self.x.device))
         d.all_reduce(t, op=d.ReduceOp.MAX, group=self.group)
         agreed = [int(v) for v in t[:3].tolist()]
         if -int(t[3].item()) <= 0:          # some rank has no tiled phase kernels here

@@ -71,3 +71,100 @@ def test_every_workload_runs(wl, size):
     rec = json.loads([ln for ln in p.stdout.splitlines() if ln.strip()][0])
     assert rec["steps"] == 6 and rec["value"] > 0 and rec["n_gpus"] == 1
     assert "roofline" in rec and rec["roofline"]["kernel_ms"] > 0
+
+
+def test_launcher_budget_and_first_attempt_record(monkeypatch, capsys):
+    """launch_ranks on the host only (the attempts are stand-ins): a first attempt that times out is followed by
+    ONE attempt on the stepwise driver with what is left of the budget -- both inside the driver's 600 s -- and the
+    relayed record carries how the first attempt ended; a refused configuration is not retried."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_mod", BENCH)
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    calls = []
+    clock = [0.0]
+
+    def fake_run(n, argv, env, tmo):
+        calls.append((dict(env), tmo))
+        if env.get("PYAPES_HIP_COMM") == "0":
+            clock[0] += 50.0
+            return 0, json.dumps({"metric": "m", "value": 1.0, "config": {"parallelism": "slab2 (torch.distributed-stepwise/nccl)"}})
+        clock[0] += tmo       # the library-side attempt hangs until its limit
+        return None, None
+
+    monkeypatch.setattr(bench, "_run_ranks", fake_run)
+    monkeypatch.setattr(bench.time, "monotonic", lambda: clock[0])
+    monkeypatch.delenv("PYAPES_HIP_COMM", raising=False)
+    monkeypatch.delenv("BENCH_RANKS_TIMEOUT", raising=False)
+    monkeypatch.delenv("BENCH_RANKS_BUDGET", raising=False)
+    rc = bench.launch_ranks(8, ["--gpus", "8"])
+    assert rc == 0 and len(calls) == 2
+    assert calls[0][1] + calls[1][1] <= 560 and clock[0] < 600      # both attempts fit the driver's limit
+    assert calls[1][0]["PYAPES_HIP_COMM"] == "0"
+    rec = json.loads(capsys.readouterr().out.strip().splitlines()[-1])
+    assert rec["first_attempt"]["outcome"].startswith("timeout after")
+
+    # a rank that refuses the configuration: one attempt, no retry, non-zero exit
+    calls.clear()
+
+    def fake_refuse(n, argv, env, tmo):
+        calls.append(env)
+        with open(env["BENCH_STATUS_FILE"], "a") as f:
+            f.write("config\n")
+        return 1, None
+
+    monkeypatch.setattr(bench, "_run_ranks", fake_refuse)
+    assert bench.launch_ranks(8, ["--gpus", "8"]) == 1 and len(calls) == 1
+
+
+HOSTRING = {"BENCH_SINGLE_DEVICE": "1", "BENCH_BACKEND": "gloo", "PYAPES_HIP_COMM_IMPL": "hostring"}
+
+
+@pytest.mark.gpu
+def test_two_ranks_library_side_loop_through_the_entry_path():
+    """python bench.py --gpus 2 with the library-side loop REALLY running between two ranks (they share cuda:0, so
+    the wire is the test stand-in of csrc/pa_comm_hostring.hip; everything else is what runs over RCCL)"""
+    p = _run(["--gpus", "2", "--size", "48,40,136", "--steps", "4", "--warmup", "2", "--no-cpu-baseline"], HOSTRING)
+    assert p.returncode == 0, p.stderr[-3000:]
+    rec = json.loads([ln for ln in p.stdout.splitlines() if ln.strip()][0])
+    assert rec["n_gpus"] == 2 and rec["config"]["parallelism"] == "slab2 (rccl-in-library)"
+    assert "first_attempt" not in rec
+
+
+@pytest.mark.gpu
+def test_hung_collective_in_the_warm_up_falls_back_inside_the_run():
+    """Rank 1's first row all-reduce of the folded loop never completes (injected).  Both ranks must notice within
+    BENCH_WARMUP_TIMEOUT, abort the library's communicators, agree over the host and finish on the stepwise
+    driver IN THE SAME PROCESSES -- the case of the driver's own torch.distributed.run launch, which has no parent
+    to retry -- and the record must say so."""
+    import time
+    t0 = time.time()
+    p = _run(["--gpus", "2", "--size", "48,40,136", "--steps", "4", "--warmup", "2", "--no-cpu-baseline"],
+             dict(HOSTRING, PYAPES_HIP_HOSTRING_FAIL="1:hang:1", BENCH_WARMUP_TIMEOUT="6", PYAPES_HIP_HOSTRING_TIMEOUT="40"))
+    assert p.returncode == 0, p.stderr[-3000:]
+    assert time.time() - t0 < 300
+    rec = json.loads([ln for ln in p.stdout.splitlines() if ln.strip()][0])
+    assert rec["config"]["parallelism"].startswith("slab2 (torch.distributed-stepwise")
+    assert "timeout after 6 s in the warm-up" in rec["first_attempt"]["outcome"]
+    assert rec["value"] > 0 and rec["steps"] == 4
+
+
+@pytest.mark.gpu
+def test_failed_first_attempt_is_retried_once_by_the_launcher():
+    """The second line of defence: the ranks' own watchdog is out of the way (BENCH_WARMUP_TIMEOUT far away) and a
+    collective of the first attempt fails for good (the stand-in gives up on it after 10 s and refuses further
+    work, as RCCL does after an asynchronous error): the ranks die with an error, the launching parent runs ONE
+    attempt on the stepwise driver and the record carries how the first attempt ended.  (That a HUNG attempt is
+    stopped after BENCH_RANKS_TIMEOUT and both attempts fit 600 s is pinned on the host by
+    test_launcher_budget_and_first_attempt_record: killing ranks in the middle of a GPU wait is not something to
+    rehearse on a shared box.)"""
+    import time
+    t0 = time.time()
+    p = _run(["--gpus", "2", "--size", "48,40,136", "--steps", "4", "--warmup", "2", "--no-cpu-baseline"],
+             dict(HOSTRING, PYAPES_HIP_HOSTRING_FAIL="1:hang:1", BENCH_WARMUP_TIMEOUT="900", PYAPES_HIP_HOSTRING_TIMEOUT="10",
+                  BENCH_RANKS_TIMEOUT="200", BENCH_RANKS_BUDGET="400"))
+    assert p.returncode == 0, p.stderr[-3000:]
+    assert time.time() - t0 < 400
+    rec = json.loads([ln for ln in p.stdout.splitlines() if ln.strip()][0])
+    assert rec["first_attempt"]["outcome"].startswith("rc="), rec["first_attempt"]
+    assert rec["config"]["parallelism"].startswith("slab2 (torch.distributed-stepwise")

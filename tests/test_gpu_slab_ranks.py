@@ -1,0 +1,216 @@
+"""-m gpu: the library-side slab loop (pa_cg_iterate_comm, csrc/pa_comm.hip) with MORE THAN ONE rank.
+
+RCCL refuses two ranks on one device and the test box has one GPU, so these tests select the stand-in of
+csrc/pa_comm_hostring.hip (explicit hook PYAPES_HIP_COMM_IMPL=hostring): the ranks are PROCESSES that share
+cuda:0, each with its own ctx / streams / events; everything in pa_comm.hip runs as it does over RCCL (grouped
+send / recv between distinct peers and, on a 2-rank periodic ring, twice to the same peer; out-of-place row
+all-reduces with uneven slabs; the cross-stream event pair of the second communicator; k_slab_mid) -- only the wire
+(host shared memory, stream-ordered through pinned staging) differs.  Every case is compared with the stepwise
+torch.distributed driver (gloo; the path tests/test_gpu_slab.py pins) on the same ranks, and with the
+single-domain oracle.
+
+What "equal" can mean.  stepwise-in-library adds the same per-rank sums as the stepwise driver, so with two ranks
+(a + b is commutative) the iterates are bit-identical.  The folded sequence all-reduces the per-workgroup partial
+ROWS and every rank then adds the rows: sum over rows of sums over ranks instead of the reverse -- the same numbers
+added in another order, so those runs are held to 1e-12 against the stepwise driver (and, like everything, to
+1e-10 against the oracle) with identical iteration counts.
+"""
+import os
+import warnings
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import pyapes_oracle as O
+from test_slab_gloo import CASES, _free_port
+
+pytestmark = pytest.mark.gpu
+
+TERMS = [{"kind": 0, "sign": -1.0, "coeff": 0.7}]
+MODES = {
+    "stepwise_driver": {"PYAPES_HIP_COMM": "0"},                       # the reference sequence (torch.distributed, gloo)
+    "folded": {},                                                     # default for N > 1: rows all-reduced, exchange on
+                                                                      # the second communicator + stream
+    "folded_one_stream": {"PYAPES_HIP_COMM_OVERLAP": "0"},            # exchange on the ctx stream
+    "stepwise_in_library": {"PYAPES_HIP_SLAB_FOLD": "0"},             # round 1's sequence inside the C loop
+}
+ENV_KEYS = ("PYAPES_HIP_COMM", "PYAPES_HIP_COMM_OVERLAP", "PYAPES_HIP_SLAB_FOLD", "PYAPES_HIP_HOSTRING_FAIL",
+            "PYAPES_HIP_COMM_TIMEOUT", "PYAPES_HIP_HOSTRING_TIMEOUT")
+
+
+def _worker(rank, world, port, name, n, K, dtype, runs, out):
+    """runs: list of (label, env dict, generic_rank or None) executed one after the other in ONE process group,
+    each on a fresh mesh / ctx / communicator."""
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    sys.path.insert(0, here)
+    sys.path.insert(0, os.path.dirname(here))
+    warnings.filterwarnings("ignore")
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ["PYAPES_HIP_COMM_IMPL"] = "hostring"
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from pyapes_amd.geometry import Box
+        from pyapes_amd.hip.context import context_for
+        from pyapes_amd.mesh import Mesh
+        from pyapes_amd.slab import SlabCG
+        from pyapes_amd.variables import Field
+        torch.cuda.set_device(0)
+        bcs = [{"bc_face": O.FACES[i], "bc_type": t, "bc_val": v, "bc_val_opt": None}
+               for i, (t, v) in enumerate(CASES[name])]
+        g = torch.Generator().manual_seed(7)
+        rhs_g = torch.randn((1, *n), generator=g, dtype=torch.float64)
+        if name == "per":
+            rhs_g -= rhs_g.mean()
+        res = {}
+        for label, env, generic_rank in runs:
+            for k in ENV_KEYS:
+                os.environ.pop(k, None)
+            os.environ.update(env)
+            mesh = Mesh(Box[0:1, 0:1, 0:0.5], None, list(n), "cuda", dtype, slab=(rank, world))
+            ctx = context_for(mesh)
+            if generic_rank == rank:
+                ctx.set_option("fastpath", False)     # this rank runs the generic kernels: it cannot fold
+            var = Field("p", 1, mesh, {"domain": bcs, "obstacle": None})
+            rhs = rhs_g.to(mesh.dtype.float)[:, mesh.i_off:mesh.i_off + mesh.nx[0]].contiguous().cuda()
+            drv = SlabCG(mesh, var, rhs, TERMS, dist)
+            info = {"lib_comm": bool(drv.lib_comm), "impl": ctx.comm_impl(),
+                    "overlap": bool(drv.lib_comm and ctx.comm_overlap()), "err": getattr(drv, "lib_comm_error", None)}
+            rep = drv.solve(1e-30, K, poll=3)
+            info["folded"] = bool(drv.folded)
+            if drv.lib_comm:      # release the communicators while every rank is alive
+                torch.cuda.synchronize()
+                ctx.comm_destroy()
+                ctx.comm_ready = None
+            parts, infos = [None] * world, [None] * world
+            dist.all_gather_object(parts, var().cpu())
+            dist.all_gather_object(infos, info)
+            res[label] = {"x": torch.cat(parts, dim=1), "itr": int(rep.itr), "tol": float(rep.tol), "ranks": infos}
+        if rank == 0:
+            torch.save(res, out)
+    finally:
+        dist.destroy_process_group()
+
+
+def _spawn(world, name, n, K, dtype, runs, tmp_path):
+    out = str(tmp_path / "res.pt")
+    mp.spawn(_worker, args=(world, _free_port(), name, n, K, dtype, runs, out), nprocs=world, join=True)
+    return torch.load(out)
+
+
+def _oracle(name, n, K, dtype):
+    mesh = O.OMesh([0, 0, 0], [1, 1, 0.5], list(n), dtype)
+    cfg = [{"bc_face": O.FACES[i], "bc_type": t, "bc_val": v} for i, (t, v) in enumerate(CASES[name])]
+    g = torch.Generator().manual_seed(7)
+    rhs = torch.randn((1, *n), generator=g, dtype=torch.float64)
+    if name == "per":
+        rhs -= rhs.mean()
+    rhs = rhs.to(mesh.dtype)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        return O.solve_poisson(mesh, cfg, rhs, method="cg", tol=1e-30, max_it=K, coeff=0.7, sign=-1.0)
+
+
+def _rel(a, b):
+    return float(torch.linalg.norm(a.double() - b.double()) / torch.linalg.norm(b.double()))
+
+
+def _check_against_oracle(res, name, n, K, dtype):
+    xo, ro = _oracle(name, n, K, dtype)
+    for label, r in res.items():
+        assert r["itr"] == ro["itr"] == K + 1, (label, r["itr"])
+        err = _rel(r["x"], xo)
+        assert err < (1e-10 if dtype == "double" else 1e-5), (label, err)
+
+
+@pytest.mark.parametrize("name", ["per", "xper", "mix", "dir"])
+def test_two_ranks_every_library_mode(name, tmp_path):
+    """P = 2.  On the periodic ring ("per", "xper") both neighbours of a rank are the SAME peer: two sends and two
+    receives per group to one rank, paired in program order (pa_comm.hip exchange())."""
+    if name not in CASES:
+        pytest.skip(name)
+    n, K = (24, 20, 132), 6
+    res = _spawn(2, name, n, K, "double", [(m, MODES[m], None) for m in MODES], tmp_path)
+    ref = res["stepwise_driver"]
+    assert all(not r["lib_comm"] for r in ref["ranks"])
+    for m in ("folded", "folded_one_stream", "stepwise_in_library"):
+        r = res[m]
+        assert all(k["lib_comm"] and k["impl"].startswith("hostring") for k in r["ranks"]), r["ranks"]
+        assert all(k["folded"] == (m != "stepwise_in_library") for k in r["ranks"]), r["ranks"]
+        assert all(k["overlap"] == (m != "folded_one_stream") for k in r["ranks"]), r["ranks"]
+    # same per-rank sums, two ranks: bit for bit
+    assert torch.equal(res["stepwise_in_library"]["x"], ref["x"]) and res["stepwise_in_library"]["tol"] == ref["tol"]
+    # folded: rows summed after the ranks instead of before; the two stream layouts run the same arithmetic
+    assert torch.equal(res["folded"]["x"], res["folded_one_stream"]["x"]) and res["folded"]["tol"] == res["folded_one_stream"]["tol"]
+    assert _rel(res["folded"]["x"], ref["x"]) < 1e-12
+    assert abs(res["folded"]["tol"] - ref["tol"]) <= 1e-9 * abs(ref["tol"])
+    _check_against_oracle(res, name, n, K, "double")
+
+
+@pytest.mark.parametrize("name", ["per", "xper", "mix"])
+def test_four_ranks_uneven_slabs(name, tmp_path):
+    """P = 4, 26 planes = 7 + 7 + 6 + 6: interior ranks with two DISTINCT neighbours and no global x face, a ring
+    longer than its end ranks, and per-rank grids of different size -- ranks 2 and 3 write fewer partial rows than
+    the agreed counts, so their row all-reduces run out of place (rows they never write stay zero)."""
+    n, K = (26, 20, 132), 6
+    runs = [(m, MODES[m], None) for m in ("stepwise_driver", "folded", "stepwise_in_library")]
+    res = _spawn(4, name, n, K, "double", runs, tmp_path)
+    ref = res["stepwise_driver"]
+    for m in ("folded", "stepwise_in_library"):
+        r = res[m]
+        assert all(k["lib_comm"] and k["overlap"] and k["folded"] == (m == "folded") for k in r["ranks"]), r["ranks"]
+        # four ranks: gloo's all-reduce adds the ranks in its own order, the stand-in in rank order
+        assert _rel(r["x"], ref["x"]) < 1e-12, m
+        assert abs(r["tol"] - ref["tol"]) <= 1e-9 * abs(ref["tol"])
+    _check_against_oracle(res, name, n, K, "double")
+
+
+def test_fp32_two_ranks(tmp_path):
+    n, K = (16, 12, 136), 6
+    res = _spawn(2, "xper", n, K, "single", [(m, MODES[m], None) for m in ("stepwise_driver", "folded", "stepwise_in_library")],
+                 tmp_path)
+    assert torch.equal(res["stepwise_in_library"]["x"], res["stepwise_driver"]["x"])
+    assert all(k["lib_comm"] and k["folded"] for k in res["folded"]["ranks"])
+    assert _rel(res["folded"]["x"], res["stepwise_driver"]["x"]) < 1e-5
+    _check_against_oracle(res, "xper", n, K, "single")
+
+
+@pytest.mark.parametrize("world,n", [(2, (24, 20, 132)), (4, (26, 20, 132))])
+def test_one_rank_cannot_fold_all_stay_stepwise(world, n, tmp_path):
+    """Rank 1 runs the generic kernels (no partial rows to fold): the ranks must agree to stay on the stepwise
+    sequence INSIDE the library -- a rank folding alone would all-reduce rows against its peers' sums."""
+    K = 6
+    runs = [("stepwise_driver", MODES["stepwise_driver"], 1), ("library", {}, 1)]
+    res = _spawn(world, "xper", n, K, "double", runs, tmp_path)
+    assert all(k["lib_comm"] and not k["folded"] for k in res["library"]["ranks"]), res["library"]["ranks"]
+    if world == 2:
+        assert torch.equal(res["library"]["x"], res["stepwise_driver"]["x"])
+    else:
+        assert _rel(res["library"]["x"], res["stepwise_driver"]["x"]) < 1e-12
+    _check_against_oracle(res, "xper", n, K, "double")
+
+
+@pytest.mark.parametrize("fail,expect", [
+    ("1:init:1", "no_second_communicator"),     # rank 1 cannot create the exchange communicator
+    ("1:corrupt:0", "stepwise_driver"),          # rank 1 fails the collective self-test (wrong sum)
+    ("1:init:0", "stepwise_driver"),             # rank 1 cannot create a communicator at all
+])
+def test_a_rank_failing_set_up_takes_every_rank_to_the_same_fallback(fail, expect, tmp_path):
+    """pa_comm_init / pa_comm_selftest failing on ONE rank: the agreements (MIN all-reduce of an ok flag inside
+    pa_comm_init and in SlabCG._setup_lib_comm) must put every rank on the same path -- without the second
+    communicator, or on the stepwise torch.distributed driver -- and the solve must still be right."""
+    n, K = (24, 20, 132), 6
+    env = {"PYAPES_HIP_HOSTRING_FAIL": fail, "PYAPES_HIP_COMM_TIMEOUT": "6", "PYAPES_HIP_HOSTRING_TIMEOUT": "12"}
+    res = _spawn(2, "per", n, K, "double", [("stepwise_driver", MODES["stepwise_driver"], None), ("faulty", env, None)], tmp_path)
+    ranks = res["faulty"]["ranks"]
+    if expect == "no_second_communicator":
+        assert all(k["lib_comm"] and k["folded"] and not k["overlap"] for k in ranks), ranks
+        assert _rel(res["faulty"]["x"], res["stepwise_driver"]["x"]) < 1e-12
+    else:
+        assert all(not k["lib_comm"] and not k["folded"] for k in ranks), ranks
+        assert ranks[1]["err"], "rank 1 should have recorded why it left the library-side path"
+        assert torch.equal(res["faulty"]["x"], res["stepwise_driver"]["x"])
+    _check_against_oracle(res, "per", n, K, "double")
