@@ -258,6 +258,13 @@ int pa_cg_abort(pa_ctx* ctx);                     /* drop the live stepwise solv
 /* While a stepwise solve is live (pa_cg_begin ... pa_cg_end / pa_cg_abort) pa_bc_clear, pa_bc_set and
  * pa_eq_set return PA_E_STATE: every phase re-reads that state. */
 int pa_report_read(pa_ctx* ctx, pa_report* out);  /* synchronises */
+/* The solver's scalar state as the last executed iteration left it (the reference computes these inline and
+ * drops them, linalg.py:118-141 / 205-262; here they live on the device): out[PA_NSCALAR] =
+ * { alpha, beta, r.r, r.r of the iteration before, d.Ad, tol, rho, omega, rho_next, r0.v, t.s, t.t, r0.t, itr, 0, 0 }
+ * (CG uses the first six, BiCGSTAB alpha + the rho ... r0.t group).  Parity tests compare them, iteration by
+ * iteration, with the reference's. */
+#define PA_NSCALAR 16
+int pa_scalars_read(pa_ctx* ctx, double* out);
 
 /* ---- RCCL inside the library (slab mode, SURVEY 8e: "pa_comm_init(ctx, rank, nranks, rccl_unique_id)") --
  * The stepwise calls above let a host driver run the exchange; these entry points put the whole

@@ -943,6 +943,33 @@ def poisson_cfg(dim: int) -> list[dict]:
     return [{"bc_face": FACES[i], "bc_type": "dirichlet", "bc_val": val} for i in range(2 * dim)]
 
 
+# BC values that READ THE FIELD they are given -- the reference evaluates a callable inside every BC fill with the
+# current, partly filled iterate (bcs.py:200-213, 223-253).  One set of functions drives the reference
+# (tests/golden/make_golden.py), this oracle and the product (tests/helpers.py), on CPU and GPU tensors alike.
+def _robin_lo(grid, mask, var, *_):      # Dirichlet value tied to the first interior plane next to a LOWER face of axis 0
+    return 0.4 * var[0][torch.roll(mask, 1, 0)] + 0.2 * grid[-1][mask]
+
+
+def _robin_hi_flux(grid, mask, var, *_):  # Neumann flux proportional to the first interior plane next to an UPPER face of axis 0
+    return 0.3 * var[0][torch.roll(mask, -1, 0)] - 0.1
+
+
+def _robin_edge(grid, mask, var, *_):    # reads the plane next to a lower face of the LAST axis: sees what the axis-0 faces wrote
+    return 0.25 * var[0][torch.roll(mask, 1, mask.dim() - 1)] + grid[0][mask]
+
+
+def robin_cfg(dim: int) -> list[dict]:
+    """faces in factory order: xl Dirichlet(var), xu Neumann(var), then Dirichlet 0 / ... , the lower face of the last
+    axis Dirichlet(var) again (its corner nodes read nodes the earlier faces of the same fill have written)"""
+    cfg = [{"bc_face": "xl", "bc_type": "dirichlet", "bc_val": _robin_lo},
+           {"bc_face": "xu", "bc_type": "neumann", "bc_val": _robin_hi_flux}]
+    for a in range(1, dim):
+        lo, hi = FACES[2 * a], FACES[2 * a + 1]
+        cfg.append({"bc_face": lo, "bc_type": "dirichlet", "bc_val": _robin_edge if a == dim - 1 else 0.0})
+        cfg.append({"bc_face": hi, "bc_type": "dirichlet", "bc_val": 0.5})
+    return cfg
+
+
 # axisymmetric Poisson problem of the reference's tests/test_solver.py:309-358:
 # u = exp(-z) cos(r) on Cylinder[0:1, 0:1]; rl neumann 0, the other faces dirichlet (exact values)
 def _rz_ru(grid, mask, *_):

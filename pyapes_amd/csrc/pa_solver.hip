@@ -1627,6 +1627,19 @@ int pa_report_read(pa_ctx* c, pa_report* out) {
   return PA_OK;
 }
 
+int pa_scalars_read(pa_ctx* c, double* out) {
+  if (!c || !out) return PA_E_ARG;
+  if (c->solver_live) {   // a stepwise solve: fetch the live state; after pa_cg / pa_bicgstab / pa_jacobi the mirror is current
+    int rc = read_scalars(c);
+    if (rc) return rc;
+  }
+  const SolverScalars& h = *c->h_sc;
+  const double v[PA_NSCALAR] = {h.alpha, h.beta, h.rr, h.rr_old, h.dAd, h.tol, h.rho, h.omega, h.rho_next, h.r0v,
+                                h.ts, h.tt, h.r0t, (double)h.itr, 0.0, 0.0};
+  for (int q = 0; q < PA_NSCALAR; ++q) out[q] = v[q];
+  return PA_OK;
+}
+
 int pa_cg_abort(pa_ctx* c) {   // drop a stepwise solve without reading it back (error paths of a host driver)
   if (!c) return PA_E_ARG;
   c->solver_live = 0;

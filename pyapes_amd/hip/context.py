@@ -90,13 +90,15 @@ class HipContext:
         return t
 
     # -- boundary conditions -----------------------------------------------------
-    def bind_bcs(self, var: Tensor, bcs: Sequence[Any], comp: int = 0, for_rhs: bool = False) -> None:
-        """(Re)load the ordered BC list for component ``comp`` of ``var`` ((dim,*nx) tensor)."""
+    def bind_bcs(self, var: Tensor, bcs: Sequence[Any], comp: int = 0, for_rhs: bool = False,
+                 types_only: bool = False) -> None:
+        """(Re)load the ordered BC list for component ``comp`` of ``var`` ((dim,*nx) tensor).  ``types_only``: the
+        faces' types without their values (no callable is evaluated) -- all the stencil rows of ``aop`` depend on."""
         self.use_current_stream()
         self._rc(self.lib.pa_bc_clear(self.h))
         keep = []
         for pos, bc in enumerate(bcs):
-            scalar, arr = bc.resolve(var, comp, for_rhs=for_rhs)
+            scalar, arr = (0.0, None) if types_only else bc.resolve(var, comp, for_rhs=for_rhs)
             if arr is not None:
                 keep.append(arr)
             dxf = self.mesh.face_dxf(bc.bc_face) if bc.bc_type == "neumann" else 0.0
@@ -342,6 +344,13 @@ class HipContext:
         rep = L.PaReport()
         self._rc(self.lib.pa_report_read(self.h, C.byref(rep)))
         return rep
+
+    def scalars(self) -> dict[str, float]:
+        """alpha, beta, rho, omega ... of the last executed solver iteration (pa_scalars_read)"""
+        v = (C.c_double * 16)()
+        self._rc(self.lib.pa_scalars_read(self.h, v))
+        names = ("alpha", "beta", "rr", "rr_old", "dAd", "tol", "rho", "omega", "rho_next", "r0v", "ts", "tt", "r0t", "itr")
+        return {n: float(v[i]) for i, n in enumerate(names)}
 
     def profile(self, on: bool) -> None:
         self._rc(self.lib.pa_profile_set(self.h, int(on)))

@@ -119,6 +119,7 @@ SIGNATURES: dict[str, tuple[Any, list[Any]]] = {
     "pa_comm_impl": (C.c_char_p, []),
     "pa_comm_overlap": (C.c_int, [_VP]),
     "pa_report_read": (C.c_int, [_VP, C.POINTER(PaReport)]),
+    "pa_scalars_read": (C.c_int, [_VP, _F64P]),
     "pa_profile_set": (C.c_int, [_VP, C.c_int]),
     "pa_profile_read": (C.c_int, [_VP, _F64P, _I64P, _F64P, _I64P]),
 }

@@ -97,15 +97,23 @@ def _run(method: str, var: Field, rhs: Tensor, eqs: dict[int, OPStype], config: 
     boundary_slicer(mesh.dim, var.bcs)
     ctx = context_for(mesh)
     terms, _ = terms_of(eqs)
-    # a callable BC value is evaluated ONCE per solve (the loops run on the device); the reference
-    # re-evaluates it with the current iterate inside every BC fill (bcs.py:203, 245).  The two agree
-    # unless the callable reads the iterate -- which is detected here and refused, not silently frozen.
-    for bc in var.bcs:
-        if bc.depends_on_var(var()):
-            raise NotImplementedError(
-                f"pyapes_amd: the callable bc_val of face '{bc.bc_face}' depends on the field it is given; the "
-                "device solvers evaluate BC callables once per solve (the reference calls them in every BC "
-                "fill, bcs.py:200-213). Use a callable of (grid, mask) only, or a tensor.")
+    # a callable BC value is evaluated ONCE per solve by the device loops; the reference re-evaluates it with
+    # the current iterate inside every BC fill (bcs.py:203, 245).  The two agree unless the callable reads the
+    # iterate -- detected here, and such a solve takes the host-stepped loop (solver/host_stepped.py), which
+    # comes back to Python for every face of every fill exactly as the reference does.
+    if any(bc.depends_on_var(var()) for bc in var.bcs):
+        from . import host_stepped
+        res = host_stepped.run(method, var, rhs, terms, ctx, tol, max_it)
+        itr, rtol = int(res["itr"]), float(res["tol"])
+        hit_max = (itr > max_it) if method != "bicgstab" else (itr >= max_it and rtol > tol)
+        if hit_max:
+            warnings.warn(f"Maximum iteration reached! max_it: {max_it}", RuntimeWarning)
+        elif config.get("report", False) and method != "bicgstab":
+            _solution_report(itr, rtol, method.upper())
+        if config.get("report", False) and method == "bicgstab":
+            _solution_report(itr, rtol, "BICGSTAB")
+        var.last_gpu_ms = None
+        return {"itr": itr, "tol": rtol, "converge": bool(itr < max_it)}
     ctx.bind_bcs(var(), var.bcs, 0)          # the BC fill uses the solved field's own list
     ctx.set_terms(terms)
     # Field.VARo: the reference's loops call var.save_old() at the top of every iteration (linalg.py:110, 210).

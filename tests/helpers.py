@@ -2,6 +2,8 @@
 (tests only) and the product path (pyapes_amd on the GPU through the C ABI)."""
 from __future__ import annotations
 
+import contextlib
+
 import numpy as np
 import torch
 
@@ -26,6 +28,8 @@ def oracle_cfg(case):
         return O.poisson_cfg(nd)
     if case["bcs"] == "poisson_rz":
         return O.poisson_rz_cfg()
+    if case["bcs"] == "robin":
+        return O.robin_cfg(nd)
     faces = case_faces(case)
     return [{"bc_face": faces[i], "bc_type": t, "bc_val": v} for i, (t, v) in enumerate(case["bcs"])]
 
@@ -37,6 +41,8 @@ def product_cfg(case):
     if case["bcs"] == "poisson_rz":
         from pyapes_amd.testing.poisson import poisson_rz_bcs
         return poisson_rz_bcs()
+    if case["bcs"] == "robin":   # callables that READ THE FIELD (the same functions drive reference, oracle and product)
+        return [dict(d, bc_val_opt=None) for d in O.robin_cfg(nd)]
     faces = case_faces(case)
     return [{"bc_face": faces[i], "bc_type": t, "bc_val": v, "bc_val_opt": None}
             for i, (t, v) in enumerate(case["bcs"])]
@@ -86,7 +92,61 @@ def bit_equal(a, b):
     return torch.equal(torch.as_tensor(a).cpu(), torch.as_tensor(b).cpu())
 
 
-def oracle_solve(case, rhs0, K, variant=0):
+class SumTap:
+    """Records the value of every ``torch.sum(t, dim=...)`` made while it is active -- the dot products of the
+    reference's (and the oracle's) solver loops (linalg.py:119-137, 204-250), which is all they use it for.
+    It wraps whatever ``torch.sum`` is at that moment, so it goes on LAST (outside a reordering ``fsum``)."""
+
+    def __init__(self):
+        self.vals = []
+
+    def __enter__(self):
+        self.prev = torch.sum
+        prev, vals = self.prev, self.vals
+
+        def tap(t, dim=None, **kw):
+            if dim is None:
+                return prev(t, **kw)
+            r = prev(t, dim=dim, **kw)
+            vals.append(float(r.reshape(-1)[0]))
+            return r
+
+        torch.sum = tap
+        return self
+
+    def __exit__(self, *exc):
+        torch.sum = self.prev
+
+
+def scalar_history(method, sums):
+    """The per-iteration scalars the solver loops compute from their dot products and drop, rebuilt from the
+    recorded sums: CG -> rows (alpha, beta) from (r.r, d.Ad, r.r, r'.r') per iteration (linalg.py:118-137);
+    BiCGSTAB -> rows (alpha, omega, rho_next) from r0.r0, then (r0.v [, t.s, t.t, r0.t]) per iteration
+    (linalg.py:204-250; the iteration that leaves through the first stop test has alpha only)."""
+    def nn(v):
+        return 0.0 if (v != v or v in (float("inf"), float("-inf"))) else v
+    rows = []
+    if method == "cg":
+        for i in range(len(sums) // 4):
+            rr, dad, rr2, rrn = sums[4 * i:4 * i + 4]
+            rows.append((nn(rr / dad) if dad != 0 else 0.0, rrn / rr2 if rr2 != 0 else float("nan")))
+        return np.array(rows, dtype=np.float64).reshape(-1, 2)
+    rho, i = sums[0], 1
+    while i < len(sums):
+        alpha = nn(rho / sums[i]) if sums[i] != 0 else 0.0
+        if i + 3 <= len(sums) - 1:
+            ts, tt, r0t = sums[i + 1:i + 4]
+            omega = nn(ts / tt) if tt != 0 else 0.0
+            rho = -omega * r0t
+            rows.append((alpha, omega, rho))
+            i += 4
+        else:
+            rows.append((alpha, float("nan"), float("nan")))
+            i += 1
+    return np.array(rows, dtype=np.float64).reshape(-1, 3)
+
+
+def oracle_solve(case, rhs0, K, variant=0, tap=None):
     """The oracle on a golden case.  variant > 0 evaluates every torch.sum in a different, equally
     valid order (reversed along all / the first / the last summed axis, or as two half sums):
     same algorithm, same inputs, same arithmetic otherwise."""
@@ -113,9 +173,10 @@ def oracle_solve(case, rhs0, K, variant=0):
     try:
         with warnings.catch_warnings():
             warnings.simplefilter("ignore")
-            return O.solve_poisson(mesh, oracle_cfg(case), torch.as_tensor(rhs0).clone(), method=case["method"],
-                                   tol=case["tol"], max_it=K, coeff=case.get("coeff", 1.0),
-                                   sign=case.get("sign", 1.0))
+            with (tap if tap is not None else contextlib.nullcontext()):
+                return O.solve_poisson(mesh, oracle_cfg(case), torch.as_tensor(rhs0).clone(), method=case["method"],
+                                       tol=case["tol"], max_it=K, coeff=case.get("coeff", 1.0),
+                                       sign=case.get("sign", 1.0))
     finally:
         torch.sum = orig
 
@@ -134,7 +195,7 @@ def summation_band(case, rhs0, K):
     return dev, its
 
 
-def _oracle_solve_random_order(case, rhs0, K, seed):
+def _oracle_solve_random_order(case, rhs0, K, seed, tap=None):
     """the oracle with every torch.sum evaluated over a random permutation of its addends, split into a
     random number of partial sums: one more equally valid summation order of the same algorithm"""
     import warnings
@@ -155,31 +216,56 @@ def _oracle_solve_random_order(case, rhs0, K, seed):
     try:
         with warnings.catch_warnings():
             warnings.simplefilter("ignore")
-            return O.solve_poisson(oracle_mesh(case), oracle_cfg(case), torch.as_tensor(rhs0).clone(),
-                                   method=case["method"], tol=case["tol"], max_it=K,
-                                   coeff=case.get("coeff", 1.0), sign=case.get("sign", 1.0))
+            with (tap if tap is not None else contextlib.nullcontext()):
+                return O.solve_poisson(oracle_mesh(case), oracle_cfg(case), torch.as_tensor(rhs0).clone(),
+                                       method=case["method"], tol=case["tol"], max_it=K,
+                                       coeff=case.get("coeff", 1.0), sign=case.get("sign", 1.0))
     finally:
         torch.sum = orig
 
 
-def summation_hull(case, rhs0, K, x_ref, n_random=24):
+def summation_hull(case, rhs0, K, x_ref, n_random=24, histories=None):
     """The REFERENCE ALGORITHM evaluated with 5 structured + ``n_random`` random summation orders of its
     dot products -> (band, diam, iteration counts): band = largest rel. distance of a sample from ``x_ref``
     (the reference's own result), diam = largest rel. distance between two samples.
-    See test_solve_vs_reference for how they grade."""
+    See test_solve_vs_reference for how they grade.  ``histories`` (a list) receives every sample's
+    per-iteration scalars (``scalar_history``)."""
     xs, its = [], []
     for v in range(5):
-        x, r = oracle_solve(case, rhs0, K, v)
+        tap = SumTap() if histories is not None else None
+        x, r = oracle_solve(case, rhs0, K, v, tap=tap)
         xs.append(x)
         its.append(r["itr"])
+        if tap is not None:
+            histories.append(scalar_history(case["method"], tap.vals))
     for s in range(n_random):
-        x, r = _oracle_solve_random_order(case, rhs0, K, s)
+        tap = SumTap() if histories is not None else None
+        x, r = _oracle_solve_random_order(case, rhs0, K, s, tap=tap)
         xs.append(x)
         its.append(r["itr"])
+        if tap is not None:
+            histories.append(scalar_history(case["method"], tap.vals))
     band = max(rel_err(x, x_ref) for x in xs)
     n = len(xs)
     diam = max(rel_err(xs[i], xs[j]) for i in range(n) for j in range(i + 1, n))
     return band, diam, its
+
+
+def agreement_horizon(ref_hist, histories, rtol):
+    """First iteration (0-based) at which some reordered run of the reference algorithm differs from the
+    reference's recorded scalars by more than ``rtol`` (relative, any column); len(ref_hist) if none does."""
+    n = len(ref_hist)
+    for i in range(n):
+        for h in histories:
+            if i >= len(h):
+                return i
+            a, b = ref_hist[i], h[i]
+            for u, v in zip(a, b):
+                if u != u and v != v:
+                    continue
+                if not abs(u - v) <= rtol * max(abs(u), 1e-300):
+                    return i
+    return n
 
 
 def true_residual(case, rhs0, x):

@@ -279,34 +279,48 @@ def test_varo_is_the_iterate_before_the_last_iteration(method, n):
     assert bit_equal(plain.VARo, plain())
 
 
-def test_bc_callable_that_reads_the_field_is_refused_by_the_solvers():
+def test_bc_callable_that_reads_the_field_takes_the_host_stepped_loop():
     """The reference calls a callable bc_val inside every BC fill with the current iterate (bcs.py:203,
     245); the device solvers evaluate it once per solve.  A callable of (grid, mask) alone -- all the
-    reference's own tests use -- is the same thing either way; one that reads ``var`` is detected and
-    raises instead of being silently frozen.  Outside the solvers (BC fill of a field) it is evaluated
-    with the field at hand, like the reference."""
+    reference's own tests use -- is the same thing either way; one that reads ``var`` is detected and the
+    solve goes through solver/host_stepped.py, which returns to Python for every face of every fill like the
+    reference (results against the REFERENCE: the *_robin_* goldens of test_gpu_parity_golden.py; here the
+    literal oracle on another mesh, CG and BiCGSTAB).  Jacobi has no reference behaviour and stays refused."""
     n = [12, 14]
     mesh = Mesh(Box[0:1, 0:1], None, n, "cuda", "double")
     robin = lambda grid, mask, var, opt: 0.5 * var[0][torch.roll(mask, 1, 0)]   # noqa: E731  reads the field
-    bcs = [{"bc_face": f, "bc_type": "dirichlet", "bc_val": (robin if f == "xl" else 0.0), "bc_val_opt": None}
-           for f in ("xl", "xu", "yl", "yu")]
-    var = Field("p", 1, mesh, {"domain": bcs, "obstacle": None}, init_val="random")
-    assert var.bcs[0].depends_on_var(var()) and not var.bcs[1].depends_on_var(var())
-    s = Solver({"fdm": {"method": "cg", "tol": 1e-8, "max_it": 10, "report": False}})
+    faces = ("xl", "xu", "yl", "yu")
+    bcs = [{"bc_face": f, "bc_type": "dirichlet", "bc_val": (robin if f == "xl" else 0.0), "bc_val_opt": None} for f in faces]
+    orc = [{"bc_face": f, "bc_type": "dirichlet", "bc_val": (robin if f == "xl" else 0.0)} for f in faces]
+    om = O.OMesh([0, 0], [1, 1], n, "double")
+    g = torch.Generator().manual_seed(3)
+    rhs0 = torch.randn((1, *n), generator=g, dtype=torch.float64)
+    for method, K in (("cg", 9), ("bicgstab", 7)):
+        var = Field("p", 1, mesh, {"domain": bcs, "obstacle": None})
+        assert var.bcs[0].depends_on_var(var()) and not var.bcs[1].depends_on_var(var())
+        s = Solver({"fdm": {"method": method, "tol": 1e-30, "max_it": K, "report": False}})
+        s.set_eq(FDM().laplacian(1.0, var) == rhs0.cuda().clone())
+        with pytest.warns(RuntimeWarning):
+            rep = s.solve()
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            xo, ro = O.solve_poisson(om, orc, rhs0.clone(), method=method, tol=1e-30, max_it=K)
+        assert rep["itr"] == ro["itr"]
+        assert rel_err(var(), xo) < 1e-10, (method, rel_err(var(), xo))
+        assert abs(rep["tol"] - ro["tol"]) <= 1e-9 * abs(ro["tol"])
+    var = Field("p", 1, mesh, {"domain": bcs, "obstacle": None})
+    s = Solver({"fdm": {"method": "jacobi", "tol": 1e-8, "max_it": 10, "report": False}})
     s.set_eq(FDM().laplacian(1.0, var) == torch.ones_like(var()))
-    with pytest.raises(NotImplementedError, match="depends on the field"):
+    with pytest.raises(NotImplementedError, match="Jacobi"):
         s.solve()
     # the explicit BC fill evaluates it with the current field (oracle: literal sequential fill)
+    var = Field("p", 1, mesh, {"domain": bcs, "obstacle": None}, init_val="random")
     x0 = var().clone()
     var.apply_bcs()
-    om = O.OMesh([0, 0], [1, 1], n, "double")
-    orc = [{"bc_face": f, "bc_type": "dirichlet",
-            "bc_val": ((lambda grid, mask, v, opt: 0.5 * v[0][torch.roll(mask, 1, 0)]) if f == "xl" else 0.0)}
-           for f in ("xl", "xu", "yl", "yu")]
     xo = x0.cpu().clone()
     O.bc_fill(xo, O.make_bcs(om, orc))
     assert bit_equal(var(), xo)
-    # a callable of (grid, mask) only is accepted by the solvers
+    # a callable of (grid, mask) only runs on the device loops
     ok = Field("q", 1, mesh, {"domain": poisson_bcs(2), "obstacle": None})
     s2 = Solver({"fdm": {"method": "cg", "tol": 1e-8, "max_it": 50, "report": False}})
     s2.set_eq(FDM().laplacian(1.0, ok) == poisson_rhs_nd(mesh, ok))
@@ -322,3 +336,41 @@ def test_dirichlet_and_neumann_need_a_value_like_the_reference():
     var = Field("p", 1, mesh, {"domain": bcs, "obstacle": None})
     with pytest.raises(AssertionError, match="bc_val is not specified"):   # bcs.py:200
         var.apply_bcs()
+
+
+def test_switching_streams_orders_the_new_stream_after_the_old():
+    """One ctx per mesh; its scratch (BC shell buffers, partial rows, solver scalars) is shared by everything that
+    runs on the mesh.  A caller that enqueues a long asynchronous march on one torch stream and then solves on
+    ANOTHER (``with torch.cuda.stream(s)``) moves the ctx to that stream: pa_ctx_set_stream must order the new
+    stream after what the old one still holds, or the two race on the scratch.  Results must equal the serial ones."""
+    from pyapes_amd.solver.march import euler_march
+    n = [96, 64, 72]
+    nsym = mixed_bcs([0.0, 0.0, None, None, None, None], ["neumann", "neumann", "symmetry", "symmetry", "symmetry", "symmetry"])
+    mixd = mixed_bcs([0.0, 0.5, 0.0, 0.0, 1.0, -0.25], ["dirichlet", "neumann", "dirichlet", "neumann", "dirichlet", "neumann"])
+    g = torch.Generator().manual_seed(11)
+    phi0 = torch.rand((1, *n), generator=g, dtype=torch.float64)
+    rhs0 = torch.randn((1, *n), generator=g, dtype=torch.float64)
+
+    def run(two_streams):
+        mesh = Mesh(Box[0:1, 0:1, 0:1], None, n, "cuda", "double")
+        phi = Field("phi", 1, mesh, {"domain": nsym, "obstacle": None})
+        phi.set_var_tensor(phi0.cuda().clone())
+        phi.apply_bcs()
+        var = Field("p", 1, mesh, {"domain": mixd, "obstacle": None})
+        rhs = rhs0.cuda().clone()
+        solver = Solver({"fdm": {"method": "cg", "tol": 1e-30, "max_it": 30, "report": False}})
+        solver.set_eq(FDM().laplacian(1.0, var) == rhs)
+        torch.cuda.synchronize()
+        dt = 0.1 * float(mesh.dx_list[0]) ** 2 / 6e-3
+        euler_march(phi, 0.7, 1e-3, dt, 400)                 # asynchronous: ~400 x (step + BC fill) queued
+        side = torch.cuda.Stream() if two_streams else torch.cuda.current_stream()
+        with torch.cuda.stream(side), warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            rep = solver.solve()
+        torch.cuda.synchronize()
+        return phi().clone(), var().clone(), rep
+
+    phi_a, x_a, rep_a = run(False)
+    phi_b, x_b, rep_b = run(True)
+    assert rep_a == rep_b
+    assert bit_equal(phi_a, phi_b) and bit_equal(x_a, x_b)

@@ -146,6 +146,53 @@ def test_solve_vs_reference(case, path, monkeypatch):
             assert abs(rep["tol"] - ref["tol"]) <= 1e-6 * abs(ref["tol"]) + 1e-13, (rep, ref)
 
 
+_HISTS = {}   # case -> (reference history, histories of the reordered oracle runs)
+
+
+@pytest.mark.parametrize("path", ["resident", "launch_per_phase"])
+@pytest.mark.parametrize("case", [c for c in golden_cases("solve") if c.get("sensitive") and c["dtype"] == "double"],
+                         ids=lambda c: c["name"])
+def test_scalar_history_vs_reference(case, path, monkeypatch):
+    """What separates "rounding drift" from "a different algorithm" in the cases graded on a summation-order hull:
+    the per-iteration scalars.  The fixture holds every dot product and stop-test value of the REFERENCE's own run
+    (make_golden.run_solve taps its torch.sum / _tolerance_check); alpha, beta (CG) / alpha, omega, rho_next
+    (BiCGSTAB) are rebuilt from them (helpers.scalar_history).  The horizon is the first iteration at which one of
+    the 29 reordered runs of the reference algorithm (the oracle under other summation orders) differs from the
+    reference's scalars by more than 1e-10; up to there the HIP solver's scalars -- read back after solves of
+    1, 2, 3 ... iterations (pa_scalars_read) -- must match the reference's to 1e-9, and its stop-test value too.
+    The hull of test_solve_vs_reference grades the tail."""
+    import numpy as np
+    from helpers import agreement_horizon, scalar_history, summation_hull
+    from pyapes_amd.hip.context import context_for
+    monkeypatch.setenv("PYAPES_HIP_RESIDENT", "1" if path == "resident" else "0")
+    g = golden_load(case["name"])
+    K = max(case["max_its"])
+    method = case["method"]
+    ref = scalar_history(method, list(g[f"hist_sums_K{K}"]))
+    tols = np.asarray(g[f"hist_tol_K{K}"])
+    if case["name"] not in _HISTS:
+        hs = []
+        summation_hull(case, g["rhs0"], K, g[f"x_K{K}"], histories=hs)
+        _HISTS[case["name"]] = hs
+    hs = _HISTS[case["name"]]
+    # the oracle in the reference's own summation order reproduces the reference's scalars (a check of the tap)
+    n0 = min(len(ref), len(hs[0]), 5)
+    assert np.allclose(ref[:n0], hs[0][:n0], rtol=1e-11, atol=0, equal_nan=True)
+    horizon = min(agreement_horizon(ref, hs, 1e-10), 48)
+    assert horizon >= 3, (case["name"], horizon)
+    per_it = 1 if method == "cg" else 2          # stop-test values per iteration (BiCGSTAB has two)
+    for k in range(1, horizon + 1):
+        max_it = k - 1 if method == "cg" else k    # linalg.py: CG runs max_it + 1 iterations, BiCGSTAB max_it
+        _, rep, solver = product_solve(case, g["rhs0"], max_it)
+        assert rep["itr"] == k, (case["name"], k, rep)
+        sc = context_for(solver.var.mesh).scalars()
+        got = (sc["alpha"], sc["beta"]) if method == "cg" else (sc["alpha"], sc["omega"], sc["rho_next"])
+        for name, a, b in zip(("alpha", "beta / omega", "rho_next"), got, ref[k - 1]):
+            assert abs(a - b) <= 1e-9 * abs(b), (case["name"], path, k, name, a, b)
+        t_ref = tols[per_it * k - 1]
+        assert abs(rep["tol"] - t_ref) <= 1e-9 * abs(t_ref) + 1e-300, (case["name"], path, k, rep["tol"], t_ref)
+
+
 @pytest.mark.parametrize("case", golden_cases("euler"), ids=lambda c: c["name"])
 def test_euler_steps_vs_reference_pieces(case):
     """BASELINE config 4's family: explicit Euler steps whose Laplacian, Div (central; literal upwind) and

@@ -21,6 +21,8 @@ def _cfg(case):
         return O.poisson_cfg(nd)
     if case["bcs"] == "poisson_rz":
         return O.poisson_rz_cfg()
+    if case["bcs"] == "robin":
+        return O.robin_cfg(nd)
     faces = O.FACES_RZ if case.get("coord", "xyz") == "rz" else O.FACES
     return [{"bc_face": faces[i], "bc_type": t, "bc_val": v} for i, (t, v) in enumerate(case["bcs"])]
 
@@ -227,3 +229,27 @@ def test_edge_div_scalar_target_raises_like_the_reference():
     for adv in (1.5, torch.rand(1, 6, 7, dtype=torch.float64)):
         with pytest.raises(IndexError):
             O.apply_div(O.div_tables(adv, v, mesh, [], "none"), v, 2, (mesh, adv))
+
+
+@pytest.mark.parametrize("case", [c for c in golden_cases("solve") if c.get("sensitive") and c["dtype"] == "double"],
+                         ids=lambda c: c["name"])
+def test_oracle_scalar_history_is_the_references(case):
+    """The fixtures of the summation-order-sensitive cases hold every dot product and stop-test value of the
+    REFERENCE's own run (make_golden.run_solve).  The oracle, summing in torch's order like the reference, must
+    reproduce that history -- alpha / beta (CG), alpha / omega / rho_next (BiCGSTAB) -- for as long as the
+    reference algorithm is reproducible at all (first 12 iterations: 1e-10), which pins the oracle's LOOP, not
+    only its end result; tests/test_gpu_parity_golden.py::test_scalar_history_vs_reference holds the HIP solvers
+    to the same record."""
+    import numpy as np
+    from helpers import SumTap, oracle_solve, scalar_history
+    g = golden_load(case["name"])
+    K = max(case["max_its"])
+    ref = scalar_history(case["method"], list(g[f"hist_sums_K{K}"]))
+    tap = SumTap()
+    _, rep = oracle_solve(case, g["rhs0"], K, 0, tap=tap)
+    mine = scalar_history(case["method"], tap.vals)
+    assert rep["itr"] == g["_reports"][str(K)]["itr"] == len(ref)
+    n = min(12, len(ref))
+    assert np.allclose(mine[:n], ref[:n], rtol=1e-10, atol=0, equal_nan=True), (mine[:n], ref[:n])
+    per_it = 1 if case["method"] == "cg" else 2
+    assert len(g[f"hist_tol_K{K}"]) in (per_it * len(ref), per_it * len(ref) - 1)
