@@ -4,11 +4,12 @@
 
 template <typename T>
 int pa_cg3d_phase_a(pa_ctx* c, const DevEq<T>& E, Vec<T> r, Vec<T> d, T* dnew, double* partials) {
-  const int mode = cg3d_mode<T>(c, E, {r.p, d.p, dnew, r.glo, r.ghi, d.glo, d.ghi});
+  const int mode = c->cg_pitch ? 3 : cg3d_mode<T>(c, E, {r.p, d.p, dnew, r.glo, r.ghi, d.glo, d.ghi});
   if (!mode) return 0;
   Cg3dArgs<T> A;
   memset(&A, 0, sizeof(A));
   fill_common<T>(c, E, A);
+  A.ps1 = c->cg_ps1; A.ps0 = c->cg_ps1 * c->G.n1;
   A.r = r; A.d = d; A.dnew = dnew; A.partials = partials;
   A.reverse = 0;
   if (c->fold_b_n > 0) {  // close the previous iteration in this kernel's prologue (next state -> the other slot)
@@ -31,11 +32,12 @@ int pa_cg3d_phase_a(pa_ctx* c, const DevEq<T>& E, Vec<T> r, Vec<T> d, T* dnew, d
 
 template <typename T>
 int pa_cg3d_phase_b(pa_ctx* c, const DevEq<T>& E, Vec<T> d, T* x, T* r, double* partials) {
-  const int mode = cg3d_mode<T>(c, E, {d.p, x, r, d.glo, d.ghi, c->r_send_lo, c->r_send_hi});
+  const int mode = c->cg_pitch ? 3 : cg3d_mode<T>(c, E, {d.p, x, r, d.glo, d.ghi, c->r_send_lo, c->r_send_hi});
   if (!mode) return 0;
   Cg3dArgs<T> A;
   memset(&A, 0, sizeof(A));
   fill_common<T>(c, E, A);
+  A.ps1 = c->cg_ps1; A.ps0 = c->cg_ps1 * c->G.n1;
   A.d = d; A.x = x; A.rw = r; A.partials = partials;
   if (!c->slab_fold_live) {   // folded slab iterations: the mid kernel has produced the send planes already
     A.send_lo = (T*)c->r_send_lo; A.send_hi = (T*)c->r_send_hi;

@@ -67,6 +67,8 @@ struct Cg3dArgs {
   int lap_off;          // KIND != 0: the equation is the Div term alone (explicit Div, pure advection)
   GradCoef<T> grd;      // phase 7 (explicit gradient): the row coefficients of k_grad
   int gnd;              // phase 7: mesh dimension (components written: gnd, one field of ncell each)
+  // PITCH layout (odd row lengths, below): row / plane strides of the ctx-owned arrays r, d, d'; x keeps G.s0 / G.s1
+  int64_t ps0, ps1;
   int interior_only;    // A x: zero outside the interior set
   int out_all;          // Euler step (k_sf): the caller overwrites every node outside the interior set (its BC
                         // fill covers all 2 * ndim faces), so the step need not preserve phi there
@@ -96,11 +98,19 @@ __device__ __forceinline__ int64_t pa_wrapmod(int64_t v, int64_t n) {
 // KIND: the Div scheme of the explicit Euler step (PHASE 3) as a compile-time constant -- with all three
 // schemes in one body the uniform operands no longer fit the scalar registers and get spilled into
 // vector lanes (v_readlane / v_writelane were a third of the VALU instructions of that kernel)
-// NARROW: one cell per lane instead of a 16-byte vector.  For rows whose length is not a multiple of
+// LAY 1 = NARROW: one cell per lane instead of a 16-byte vector.  For rows whose length is not a multiple of
 // the vector width (node-based meshes love 2^k + 1) or operands that are not 16-byte aligned: no
 // partial vectors, no alignment demand beyond sizeof(T); everything else is the same code.
-template <typename T, int RJ, int PHASE, bool CF = false, int KIND = 0, bool NARROW = false>
+// LAY 2 = PITCH (CG phases on one GPU, non-periodic contiguous axis): the same odd rows, but the arrays the ctx
+// OWNS -- r and the two direction buffers -- live with a row pitch rounded up to the vector (pa_cg_begin lays them
+// out; the pad cells hold 0 and are written as 0), so every access to them is the aligned 16-byte lane access of
+// LAY 0.  Only x, the caller's contiguous field, is touched cell by cell: phase A is fully vector, phase B on
+// three of its five streams.  A pad cell is never a neighbour anybody uses: the last real cell of a row is a
+// boundary node of a non-periodic axis, outside the interior set.
+template <typename T, int RJ, int PHASE, bool CF = false, int KIND = 0, int LAY = 0>
 __global__ void __launch_bounds__(256) k_cg3d(Cg3dArgs<T> A) {
+  constexpr bool NARROW = LAY == 1, PITCH = LAY == 2;
+  static_assert(!PITCH || ((PHASE == 0 || PHASE == 1) && !CF && KIND == 0), "PITCH: the CG phases of a plain Laplacian");
   constexpr int VEC = NARROW ? 1 : VecOf<T>::N;
   typedef T V __attribute__((ext_vector_type(VEC)));
   constexpr int TJ = 4 * RJ, TK = 64 * VEC, TKP = TK + 2 * VEC;
@@ -124,6 +134,10 @@ __global__ void __launch_bounds__(256) k_cg3d(Cg3dArgs<T> A) {
   const int64_t kg = k0 + (int64_t)lane * VEC;            // global k of element 0 (may be >= n2)
   const int64_t kc = pa_wrapmod(kg, G.n2);                // wrapped column used for loads
   const bool kvalid = kg < G.n2;
+  // strides / column of the arrays staged through LDS (r, d, v): pitched rows in the PITCH layout, where a lane
+  // beyond the padded row reads column 0 (aligned; its values are never used)
+  const int64_t fs0 = PITCH ? A.ps0 : G.s0, fs1 = PITCH ? A.ps1 : G.s1;
+  const int64_t kcf = PITCH ? (kg < fs1 ? kg : 0) : kc;
   int64_t jrow[RJ];
   unsigned rowS = 0, rowShell = 0, rowValid = 0, rowLo = 0, rowHi = 0;
 #pragma unroll
@@ -168,12 +182,12 @@ __global__ void __launch_bounds__(256) k_cg3d(Cg3dArgs<T> A) {
   const bool hvec = (wv == 0 || wv == 3);
   const bool hsc = (wv == 1 && lane < 2 * TJ);
   const int hs_row = lane >> 1, hs_side = lane & 1;
-  const int64_t hs_off = pa_wrapmod(j0 + hs_row, G.n1) * G.s1 +
+  const int64_t hs_off = pa_wrapmod(j0 + hs_row, G.n1) * fs1 +
                          (hs_side ? pa_wrapmod(k0 + TK, G.n2) : pa_wrapmod(k0 - 1, G.n2));
 
   auto plane_of = [&](int q) -> int64_t { return rev ? (i1 - 1 - q) : (i0 + q); };
   auto pptr = [&](const Vec<T>& v, int64_t ii) -> const T* {
-    return ii < 0 ? v.glo : (ii >= G.n0 ? v.ghi : v.p + ii * G.s0);
+    return ii < 0 ? v.glo : (ii >= G.n0 ? v.ghi : v.p + ii * fs0);
   };
 
   // Raw loads of one plane (own cells + this wave's share of the halo ring).  They are only
@@ -194,14 +208,14 @@ __global__ void __launch_bounds__(256) k_cg3d(Cg3dArgs<T> A) {
     const T* qp = HAS_Q ? pptr(A.v, ii) : dp;
 #pragma unroll
     for (int jj = 0; jj < RJ; ++jj) {
-      const int64_t o = jrow[jj] * G.s1 + kc;
+      const int64_t o = jrow[jj] * fs1 + kcf;
       w.d[jj] = *reinterpret_cast<const V*>(dp + o);
       if (HAS_R) w.r[jj] = *reinterpret_cast<const V*>(rp + o);
       if (HAS_Q) w.q[jj] = *reinterpret_cast<const V*>(qp + o);
     }
     if (with_halo) {
       if (hvec) {
-        const int64_t o = hrow * G.s1 + kc;
+        const int64_t o = hrow * fs1 + kcf;
         w.hd = *reinterpret_cast<const V*>(dp + o);
         if (HAS_R) w.hr = *reinterpret_cast<const V*>(rp + o);
         if (HAS_Q) w.hq = *reinterpret_cast<const V*>(qp + o);
@@ -518,7 +532,12 @@ __global__ void __launch_bounds__(256) k_cg3d(Cg3dArgs<T> A) {
         // x and r are touched exactly once per iteration: non-temporal, so that they do not evict the
         // halo rows / planes of d' other workgroups are about to re-read from L2 (measured -3 % on
         // the iteration at 512^3; non-temporal loads of d / r themselves cost +6 % in phase A)
-        if (NARROW) {   // 8-byte / 4-byte lanes: the streaming hint costs 8-17 % here (interleaved A/B)
+        if (PITCH) {    // r: pitched, aligned vector; x: the caller's contiguous rows, cell by cell
+          rv[jj] = __builtin_nontemporal_load(reinterpret_cast<const V*>(A.rw + ii * fs0 + jrow[jj] * fs1 + kcf));
+          const T* xp = A.x + ii * G.s0 + jrow[jj] * G.s1;
+#pragma unroll
+          for (int v = 0; v < VEC; ++v) xv[jj][v] = xp[kg + v < G.n2 ? kg + v : G.n2 - 1];
+        } else if (NARROW) {   // 8-byte / 4-byte lanes: the streaming hint costs 8-17 % here (interleaved A/B)
           xv[jj] = *reinterpret_cast<const V*>(A.x + o);
           rv[jj] = *reinterpret_cast<const V*>(A.rw + o);
         } else {
@@ -865,10 +884,17 @@ __global__ void __launch_bounds__(256) k_cg3d(Cg3dArgs<T> A) {
         } else if (PHASE >= 2) {
           *reinterpret_cast<V*>(A.out + o) = outd;
         } else if (PHASE == 0) {
-          if (NARROW) *reinterpret_cast<V*>(A.dnew + o) = outd;
+          if (PITCH) __builtin_nontemporal_store(outd, reinterpret_cast<V*>(A.dnew + ii * fs0 + jrow[jj] * fs1 + kcf));
+          else if (NARROW) *reinterpret_cast<V*>(A.dnew + o) = outd;
           else __builtin_nontemporal_store(outd, reinterpret_cast<V*>(A.dnew + o));  // -1.5 % (measured)
         } else {
-          if (NARROW) {
+          if (PITCH) {
+            __builtin_nontemporal_store(outd, reinterpret_cast<V*>(A.rw + ii * fs0 + jrow[jj] * fs1 + kcf));
+            T* xp = A.x + ii * G.s0 + jrow[jj] * G.s1;
+#pragma unroll
+            for (int v = 0; v < VEC; ++v)
+              if (kg + v < G.n2) xp[kg + v] = outx[v];
+          } else if (NARROW) {
             *reinterpret_cast<V*>(A.x + o) = outx;
             *reinterpret_cast<V*>(A.rw + o) = outd;
           } else {
@@ -964,22 +990,23 @@ static int cus_of(pa_ctx* c) {
   return cus;
 }
 
-template <typename T, int RJ, int PHASE, bool CF, int KIND = 0, bool NARROW = false>
+template <typename T, int RJ, int PHASE, bool CF, int KIND = 0, int LAY = 0>
 static int blocks_per_cu() {
   static int cached = 0;
   if (!cached) {
     const char* e = getenv(PHASE == 0 ? "PYAPES_HIP_BPC_A" : (PHASE == 1 ? "PYAPES_HIP_BPC_B" : "PYAPES_HIP_BPC_X"));
     int n = e ? atoi(e) : 0;
     if (n <= 0) {
-      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_cg3d<T, RJ, PHASE, CF, KIND, NARROW>, 256, 0) != hipSuccess || n <= 0) n = 2;
+      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_cg3d<T, RJ, PHASE, CF, KIND, LAY>, 256, 0) != hipSuccess || n <= 0) n = 2;
     }
     cached = n;
   }
   return cached;
 }
 
-template <typename T, int RJ, int PHASE, bool CF = false, int KIND = 0, bool NARROW = false>
+template <typename T, int RJ, int PHASE, bool CF = false, int KIND = 0, int LAY = 0>
 static int launch_cg3d(pa_ctx* c, Cg3dArgs<T>& A) {
+  constexpr bool NARROW = LAY == 1;
   constexpr int VEC = NARROW ? 1 : VecOf<T>::N;
   constexpr int TJ = 4 * RJ, TK = 64 * VEC;
   const DevGeom& G = c->G;
@@ -995,7 +1022,7 @@ static int launch_cg3d(pa_ctx* c, Cg3dArgs<T>& A) {
   A.tiles_j = (int)((n1e + TJ - 1) / TJ);
   A.tiles_k = (int)((n2e + TK - 1) / TK);
   const int tiles = A.tiles_j * A.tiles_k;
-  const int capacity = cus_of(c) * blocks_per_cu<T, RJ, PHASE, CF, KIND, NARROW>();
+  const int capacity = cus_of(c) * blocks_per_cu<T, RJ, PHASE, CF, KIND, LAY>();
   int chunks = capacity / tiles;
   if (chunks < 1) chunks = 1;
   if (chunks > G.n0) chunks = (int)G.n0;
@@ -1010,11 +1037,11 @@ static int launch_cg3d(pa_ctx* c, Cg3dArgs<T>& A) {
   if (dbg > 0) {
     --dbg;
     fprintf(stderr, "[pyapes_hip] k_cg3d phase %c%s: tiles %dx%d chunks %d (CI ~%lld) blocks %d, %d blocks/CU x %d CUs\n",
-            (char)('A' + PHASE), NARROW ? " (narrow)" : "", A.tiles_j, A.tiles_k, chunks, (long long)(G.n0 / chunks), nblk,
-            blocks_per_cu<T, RJ, PHASE, CF, KIND, NARROW>(), cus_of(c));
+            (char)('A' + PHASE), LAY == 1 ? " (narrow)" : (LAY == 2 ? " (pitched)" : ""), A.tiles_j, A.tiles_k, chunks, (long long)(G.n0 / chunks), nblk,
+            blocks_per_cu<T, RJ, PHASE, CF, KIND, LAY>(), cus_of(c));
   }
   if (c->plan_only) return nblk;   // pa_cg_fold_plan: the grid this launch would use
-  hipLaunchKernelGGL((k_cg3d<T, RJ, PHASE, CF, KIND, NARROW>), dim3(nblk), dim3(256), 0, c->stream, A);
+  hipLaunchKernelGGL((k_cg3d<T, RJ, PHASE, CF, KIND, LAY>), dim3(nblk), dim3(256), 0, c->stream, A);
   return nblk;
 }
 
@@ -1024,7 +1051,7 @@ static int launch_cg3d(pa_ctx* c, Cg3dArgs<T>& A) {
 // by a hair exactly where 16-row tiles leave chunks shorter than 24 planes and 8-row tiles do not (256^3
 // fp64).  The explicit Euler step is instruction-bound and keeps its own rule.
 template <typename T, int PHASE = 0>
-static int pick_rj(pa_ctx* c, bool narrow = false) {
+static int pick_rj(pa_ctx* c, bool narrow = false, bool cg_phase = false) {
   if (const char* e = getenv("PYAPES_HIP_RJ")) {
     int v = atoi(e);
     if (v == 1 || v == 2 || v == 4) return v;
@@ -1032,10 +1059,14 @@ static int pick_rj(pa_ctx* c, bool narrow = false) {
   const int VEC = narrow ? 1 : VecOf<T>::N;
   const DevGeom& G = c->G;
   if (!G.act[0]) return 4;  // 2-D: one plane, nothing to march; the biggest tile has the least halo
-  const int64_t tk = (G.n2 + 64 * VEC - 1) / (64 * VEC);
+  // the CG phases do not tile the last boundary row / column of a non-periodic axis (launch_cg3d): 257 nodes are
+  // 256 cells to cover, and the rule must see the tiles that will really be launched
+  const int64_t n1e = G.n1 - ((cg_phase && G.bct[3] != PA_BC_PERIODIC && G.n1 > 2) ? 1 : 0);
+  const int64_t n2e = G.n2 - ((cg_phase && G.bct[5] != PA_BC_PERIODIC && G.n2 > 2) ? 1 : 0);
+  const int64_t tk = (n2e + 64 * VEC - 1) / (64 * VEC);
   const int cap = cus_of(c) * 2;
   auto chunk_len = [&](int rj) {
-    const int64_t tiles = ((G.n1 + 4 * rj - 1) / (4 * rj)) * tk;
+    const int64_t tiles = ((n1e + 4 * rj - 1) / (4 * rj)) * tk;
     const int64_t chunks = cap / tiles > 0 ? cap / tiles : 1;
     return G.n0 / chunks;
   };
@@ -1050,13 +1081,13 @@ static int pick_rj(pa_ctx* c, bool narrow = false) {
   return (chunk_len(4) < 24 && chunk_len(2) >= 24) ? 2 : 4;
 }
 
-template <typename T, int PHASE, bool NARROW>
+template <typename T, int PHASE, int NARROW>   // NARROW = LAY of k_cg3d: 0 vector, 1 one cell per lane, 2 pitched
 static int launch_any_w(pa_ctx* c, Cg3dArgs<T>& A) {
   constexpr bool CF_OK = (PHASE == 0 || PHASE == 1 || PHASE == 2 || PHASE == 4);
   if (A.coeff_f) {  // tensor coefficient: separate instantiation, so the scalar-coefficient kernels stay lean
     if (!CF_OK) return 0;
     if constexpr (CF_OK) {
-      switch (pick_rj<T>(c, NARROW)) {
+      switch (pick_rj<T>(c, NARROW == 1)) {
         case 1: return launch_cg3d<T, 1, PHASE, true, 0, NARROW>(c, A);
         case 2: return launch_cg3d<T, 2, PHASE, true, 0, NARROW>(c, A);
         default: return launch_cg3d<T, 4, PHASE, true, 0, NARROW>(c, A);
@@ -1064,7 +1095,7 @@ static int launch_any_w(pa_ctx* c, Cg3dArgs<T>& A) {
     }
   }
   if constexpr (PHASE == 3) {  // one instantiation per Div scheme
-    const int rj = pick_rj<T, 3>(c, NARROW);
+    const int rj = pick_rj<T, 3>(c, NARROW == 1);
 #define PA_EULER_CASE(K)                                                   \
     case K:                                                                \
       switch (rj) {                                                        \
@@ -1082,7 +1113,7 @@ static int launch_any_w(pa_ctx* c, Cg3dArgs<T>& A) {
   }
   if constexpr (PHASE == 2 || PHASE == 5 || PHASE == 6) {
     if (A.kind != 0) {  // Laplacian + Div(scalar u): one instantiation per scheme, two or four rows per thread
-      const bool four = pick_rj<T>(c, NARROW) == 4;
+      const bool four = pick_rj<T>(c, NARROW == 1) == 4;
 #define PA_DIV_CASE(K)                                                                   \
       case K:                                                                            \
         return four ? launch_cg3d<T, 4, PHASE, false, K, NARROW>(c, A)                   \
@@ -1096,16 +1127,31 @@ static int launch_any_w(pa_ctx* c, Cg3dArgs<T>& A) {
 #undef PA_DIV_CASE
     }
   }
-  switch (pick_rj<T>(c, NARROW)) {
+  switch (pick_rj<T>(c, NARROW == 1, PHASE == 0 || PHASE == 1)) {
     case 1: return launch_cg3d<T, 1, PHASE, false, 0, NARROW>(c, A);
     case 2: return launch_cg3d<T, 2, PHASE, false, 0, NARROW>(c, A);
     default: return launch_cg3d<T, 4, PHASE, false, 0, NARROW>(c, A);
   }
 }
 
+// the CG phases in the PITCH layout (a plain Laplacian only: the other instantiations do not exist)
+template <typename T, int PHASE>
+static int launch_pitched(pa_ctx* c, Cg3dArgs<T>& A) {
+  static_assert(PHASE == 0 || PHASE == 1, "PITCH: CG phases");
+  if (A.coeff_f || A.kind != 0) return 0;
+  switch (pick_rj<T>(c, false, true)) {
+    case 1: return launch_cg3d<T, 1, PHASE, false, 0, 2>(c, A);
+    case 2: return launch_cg3d<T, 2, PHASE, false, 0, 2>(c, A);
+    default: return launch_cg3d<T, 4, PHASE, false, 0, 2>(c, A);
+  }
+}
+
 template <typename T, int PHASE>
 static int launch_any(pa_ctx* c, Cg3dArgs<T>& A, int mode) {
-  return mode == 2 ? launch_any_w<T, PHASE, true>(c, A) : launch_any_w<T, PHASE, false>(c, A);
+  if constexpr (PHASE == 0 || PHASE == 1) {
+    if (mode == 3) return launch_pitched<T, PHASE>(c, A);
+  }
+  return mode == 2 ? launch_any_w<T, PHASE, 1>(c, A) : launch_any_w<T, PHASE, 0>(c, A);
 }
 
 template <typename T>

@@ -87,6 +87,9 @@ struct pa_ctx {
   int bc_pair = 0;  // per-axis pair kernels (lower + upper face + shell stop-test term in one launch)
   int bc_fused = 0, shell_cur = 0;  // fused BC fill: which half of SCR_SHELL holds x_old on the shell
   void* cg_x = nullptr;
+  int pitch = 1;             // option "pitch" / PYAPES_HIP_PITCH: allow that layout (0: odd rows stay on the NARROW kernels)
+  int cg_pitch = 0;          // live CG solve keeps r and the direction buffers in the PITCH layout of k_cg3d
+  int64_t cg_ps1 = 0;        // ... with this row pitch (cells)
   // Field.VARo (var.save_old() at the top of every solver iteration, linalg.py:110 / 210): when the caller
   // hands a buffer (pa_solver_keep_old) the loops copy the iterate into it before each update -- one extra
   // pass per iteration, paid only on request

@@ -64,6 +64,36 @@ __global__ void __launch_bounds__(PA_BLOCK) k_cg_init_ax(DevGeom G, const T* __r
   pa_block_reduce_store<1>(s, partials);
 }
 
+// the same for the PITCH layout of the tiled CG phases (pa_cg3d_kernel.h, odd row lengths): A x arrives in a
+// contiguous scratch, r and d leave with a row pitch of ps1 cells, pad cells zero.  Same loop, grid and partial sums.
+template <typename T>
+__global__ void __launch_bounds__(PA_BLOCK) k_cg_init_ax_pitch(DevGeom G, const T* __restrict__ rhs, const T* __restrict__ ax,
+                                                                T* __restrict__ r, T* __restrict__ d, int64_t ps1,
+                                                                double* __restrict__ partials) {
+  double s[1] = {0.0};
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x, t0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  for (int64_t idx = t0; idx < G.ncell; idx += stride) {
+    int64_t i, j, k;
+    pa_decode(G, idx, i, j, k);
+    T rv = (T)0;
+    if (pa_in_S(G, i, j, k)) {
+      rv = rhs[idx] - ax[idx];
+      T p = rv * rv;
+      s[0] += (double)p;
+    }
+    const int64_t o = (i * G.n1 + j) * ps1 + k;
+    r[o] = rv;
+    d[o] = rv;
+  }
+  const int64_t rows = G.n0 * G.n1, pw = ps1 - G.n2;
+  for (int64_t q = t0; q < rows * pw; q += stride) {
+    const int64_t o = (q / pw) * ps1 + G.n2 + q % pw;
+    r[o] = (T)0;
+    d[o] = (T)0;
+  }
+  pa_block_reduce_store<1>(s, partials);
+}
+
 // ---- CG phase A: d' = r + beta d ; partial sum d'.(A d')  (linalg.py:115-120, 141) ----
 template <typename T>
 __global__ void __launch_bounds__(PA_BLOCK) k_cg_a(DevGeom G, DevEq<T> E, const SolverScalars* __restrict__ sc,
@@ -804,16 +834,36 @@ static int cg_begin_t(pa_ctx* c, T* x, const T* rhs, double tol, int64_t max_it)
   const size_t fb = (size_t)G.ncell * sizeof(T);
   const int nblk = pa_grid_blocks(G.ncell);
   int rc;
-  if ((rc = pa_scratch(c, &c->scr[SCR_R], &c->cap[SCR_R], fb))) return rc;
-  if ((rc = pa_scratch(c, &c->scr[SCR_D0], &c->cap[SCR_D0], fb))) return rc;
-  if ((rc = pa_scratch(c, &c->scr[SCR_D1], &c->cap[SCR_D1], fb))) return rc;
+  // Row lengths that are not a multiple of the 16-byte vector -- the normal case of a node-based mesh (11, 101,
+  // 2^k + 1 nodes: _mesh.py:67-93) -- on one GPU: r and the two direction buffers, which the ctx owns, get a row
+  // pitch rounded up to the vector (PITCH layout of k_cg3d), so the CG phases keep their 16-byte lane accesses on
+  // everything but the caller's x.  Needs a non-periodic contiguous axis (a pad cell must never be a neighbour
+  // that is used) and a plain Laplacian; everything else stays on the one-cell-per-lane (NARROW) kernels.
+  constexpr int VECW = 16 / (int)sizeof(T);
+  c->cg_pitch = 0;
+  c->cg_ps1 = 0;
+  {
+    const int want = c->pitch;
+    const bool shape = (c->ndim == 3 && G.n0 >= 3 && G.n1 >= 3) || (c->ndim == 2 && G.n1 >= 3);
+    if (want && c->fastpath && !c->slab && c->coord == PA_COORD_XYZ && shape && G.n2 % VECW != 0 && G.n2 >= 2 * VECW &&
+        c->nterms == 1 && c->terms[0].kind == PA_OP_LAPLACIAN && !c->terms[0].coeff_field &&
+        G.bct[4] != PA_BC_PERIODIC && G.bct[5] != PA_BC_PERIODIC && ((uintptr_t)x & (sizeof(T) - 1)) == 0 &&
+        ((G.n1 + 3) / 4) * ((G.n2 + 64 * VECW - 1) / (64 * VECW)) <= PA_MAX_PARTIALS) {
+      c->cg_pitch = 1;
+      c->cg_ps1 = (G.n2 + VECW - 1) / VECW * VECW;
+    }
+  }
+  const size_t fbp = c->cg_pitch ? (size_t)G.n0 * G.n1 * c->cg_ps1 * sizeof(T) : fb;
+  if ((rc = pa_scratch(c, &c->scr[SCR_R], &c->cap[SCR_R], fbp))) return rc;
+  if ((rc = pa_scratch(c, &c->scr[SCR_D0], &c->cap[SCR_D0], fbp))) return rc;
+  if ((rc = pa_scratch(c, &c->scr[SCR_D1], &c->cap[SCR_D1], fbp))) return rc;
   if ((rc = pa_scratch(c, &c->scr[SCR_PART], &c->cap[SCR_PART], (size_t)PA_MAX_PARTIALS * 4 * sizeof(double)))) return rc;
   if ((rc = pa_scratch(c, &c->scr[SCR_PART2], &c->cap[SCR_PART2], (size_t)3 * PA_MAX_GRID * sizeof(double)))) return rc;
   if ((rc = pa_scratch(c, &c->scr[SCR_SHELL], &c->cap[SCR_SHELL], 2 * (size_t)pa_shell_elems(c) * sizeof(T)))) return rc;
   if ((rc = init_scalars(c, tol, max_it))) return rc;
   // the tiled phase kernels do not visit the last boundary row / column of non-periodic axes: the
   // direction there is 0 by definition and has to be 0 in the buffer the first phase A writes into
-  PA_HIP(c, hipMemsetAsync(c->scr[SCR_D1], 0, fb, c->stream));
+  if (!c->cg_pitch) PA_HIP(c, hipMemsetAsync(c->scr[SCR_D1], 0, fb, c->stream));   // (pitched: it first carries A x, below)
   c->cg_x = x;
   c->cur = 0;
   c->fold_a_n = c->fold_b_n = c->fold_b_nsh = 0;  // nothing of an earlier (possibly failed) solve is pending
@@ -848,7 +898,21 @@ static int cg_begin_t(pa_ctx* c, T* x, const T* rhs, double tol, int64_t max_it)
   double* part = (double*)c->scr[SCR_PART];
   Vec<T> xv = pa_vec_self<T>(c, x);
   if (c->slab) { xv.glo = (const T*)c->x_glo; xv.ghi = (const T*)c->x_ghi; }
-  if ((rc = cg_residual_init<T>(c, E, xv, rhs, r, d, (T*)c->r_send_lo, (T*)c->r_send_hi, part))) return rc;
+  if (c->cg_pitch) {
+    // A x (tiled kernel, contiguous) into the buffer that becomes the zeroed second direction buffer afterwards
+    T* ax = (T*)c->scr[SCR_D1];
+    const int fr = pa_tile3d_aop<T>(c, E, xv, ax, 1);
+    if (fr < 0) return fr;
+    if (fr > 0) {
+      hipLaunchKernelGGL(k_cg_init_ax_pitch<T>, dim3(nblk), dim3(PA_BLOCK), 0, c->stream, c->G, rhs, (const T*)ax, r, d,
+                         c->cg_ps1, part);
+    } else {
+      c->cg_pitch = 0;   // the tiled A x declined: contiguous layout, as before (the buffers are merely larger)
+      c->cg_ps1 = 0;
+    }
+    PA_HIP(c, hipMemsetAsync(c->scr[SCR_D1], 0, fbp, c->stream));
+  }
+  if (!c->cg_pitch && (rc = cg_residual_init<T>(c, E, xv, rhs, r, d, (T*)c->r_send_lo, (T*)c->r_send_hi, part))) return rc;
   hipLaunchKernelGGL(k_cg_post_init<T>, dim3(1), dim3(PA_BLOCK), 0, c->stream, c->sc, part, nblk, pa_sums(c),
                      c->slab ? 0 : 2);
   c->pending_init_logic = c->slab ? 1 : 0;
@@ -882,6 +946,7 @@ void pa_profile_stop(pa_ctx* c, int which) {
 template <typename T>
 static Vec<T> cg_vec(pa_ctx* c, const T* p, int which /*0 r, 1 d cur*/) {
   Vec<T> v = pa_vec_self<T>(c, p);
+  if (c->cg_pitch) v.glo = p + (c->G.n0 - 1) * c->G.n1 * c->cg_ps1;   // the wrap-around plane of a pitched array
   if (c->slab) {
     // a NULL recv pointer marks a physical (non-periodic) end: that ghost plane is never used in a
     // result, the field's own plane stands in so that speculative loads stay inside valid memory
@@ -947,6 +1012,7 @@ int pa_cg_phase_a_t(pa_ctx* c, int stage_post) {
   if (rc < 0) return rc;
   int used_blocks = rc;
   if (rc == 0 && live) { pa_set_err(c, "folded slab iteration: the tiled phase A declined after the plan"); return PA_E_STATE; }
+  if (rc == 0 && c->cg_pitch) { pa_set_err(c, "pitched CG: the tiled phase A declined"); return PA_E_STATE; }
   if (rc == 0) {
     cg_flush_fold<T>(c);  // the tiled kernel declined: the previous iteration is closed by its own kernel
     hipLaunchKernelGGL(k_cg_a<T>, dim3(nblk), dim3(PA_BLOCK), 0, c->stream, G, E, c->sc, rv, dv, dnew, part);
@@ -984,6 +1050,7 @@ int pa_cg_phase_b_t(pa_ctx* c, int stage_post) {
   if (rc < 0) return rc;
   int used_blocks = rc;
   if (rc == 0 && live) { pa_set_err(c, "folded slab iteration: the tiled phase B declined after the plan"); return PA_E_STATE; }
+  if (rc == 0 && c->cg_pitch) { pa_set_err(c, "pitched CG: the tiled phase B declined"); return PA_E_STATE; }
   if (rc == 0) {
     cg_flush_fold<T>(c);  // alpha by its own kernel
     hipLaunchKernelGGL(k_cg_b<T>, dim3(nblk), dim3(PA_BLOCK), 0, c->stream, G, E, c->sc, dv, x, r,
