@@ -247,6 +247,77 @@ def host_cores() -> int:
 
 
 # ------------------------------------------------------------------------------------------------
+#  clocks / power while the timed region runs (evidence for box-to-box spread: DESIGN.md "Measurement")
+# ------------------------------------------------------------------------------------------------
+class ClockSampler:
+    """Samples the GPU's engine / memory / fabric clocks and socket power from sysfs every 10 ms on a host thread
+    while the timed region runs (pp_dpm_* mark the active level with '*'; hwmon has the power).  Best effort: a box
+    that hides these files yields an empty record.  Reported in the JSON line as ``clocks`` and on stderr."""
+
+    def __init__(self, index: int = 0):
+        import glob
+        self.files = {}
+        cards = sorted(glob.glob("/sys/class/drm/card[0-9]*/device/pp_dpm_sclk"))
+        if cards:
+            dev = os.path.dirname(cards[min(index, len(cards) - 1)])
+            for key, name in (("sclk_mhz", "pp_dpm_sclk"), ("mclk_mhz", "pp_dpm_mclk"), ("fclk_mhz", "pp_dpm_fclk")):
+                if os.path.exists(os.path.join(dev, name)):
+                    self.files[key] = os.path.join(dev, name)
+            for hw in glob.glob(os.path.join(dev, "hwmon", "hwmon*")):
+                for name in ("power1_average", "power1_input"):
+                    if os.path.exists(os.path.join(hw, name)):
+                        self.files.setdefault("power_w", os.path.join(hw, name))
+        self.samples = {k: [] for k in self.files}
+        self._stop = False
+        self._thread = None
+
+    def _read(self, key, path):
+        try:
+            txt = open(path).read()
+        except OSError:
+            return None
+        if key == "power_w":
+            try:
+                return int(txt.strip()) / 1e6
+            except ValueError:
+                return None
+        for ln in txt.splitlines():
+            if "*" in ln:
+                try:
+                    return float(ln.split(":")[1].lower().replace("mhz", "").replace("*", "").strip())
+                except (IndexError, ValueError):
+                    return None
+        return None
+
+    def _run(self):
+        while not self._stop:
+            for k, pth in self.files.items():
+                v = self._read(k, pth)
+                if v is not None:
+                    self.samples[k].append(v)
+            time.sleep(0.01)
+
+    def __enter__(self):
+        import threading
+        if self.files:
+            self._thread = threading.Thread(target=self._run, daemon=True)
+            self._thread.start()
+        return self
+
+    def __exit__(self, *exc):
+        self._stop = True
+        if self._thread is not None:
+            self._thread.join(timeout=1.0)
+
+    def record(self):
+        out = {}
+        for k, v in self.samples.items():
+            if v:
+                out[k] = {"min": min(v), "avg": sum(v) / len(v), "max": max(v), "n": len(v)}
+        return out
+
+
+# ------------------------------------------------------------------------------------------------
 #  CPU baseline: the oracle (checker code) timed on this box's host cores -- reported, never measured path
 # ------------------------------------------------------------------------------------------------
 def cpu_baseline(solver, kind, dtype, gn):
@@ -435,6 +506,7 @@ def main():
     if dist is not None:
         host_group = dist.new_group(backend="gloo") if dist.get_backend() != "gloo" else dist.group.WORLD
     first_attempt = None
+    clocks = None
 
     mesh = Mesh(Box([0.0] * nd, list(upper)), None, list(gn), "cuda", dtype, slab=(rank, world) if slab else None)
     var = Field("p", 1, mesh, {"domain": make_bcs(kind), "obstacle": None})
@@ -456,12 +528,16 @@ def main():
         torch.cuda.synchronize()
         e0 = torch.cuda.Event(enable_timing=True)
         e1 = torch.cuda.Event(enable_timing=True)
-        t0 = time.perf_counter()
-        e0.record(ctx.stream)
-        ctx.cg_iterate(K)
-        e1.record(ctx.stream)
-        torch.cuda.synchronize()
-        secs = time.perf_counter() - t0
+        log("array bases: x %#x rhs %#x (ctx-owned r / d buffers: hipMalloc, 2 MiB-aligned)" % (var().data_ptr(), rhs.data_ptr()))
+        with ClockSampler(local_rank) as clk:
+            t0 = time.perf_counter()
+            e0.record(ctx.stream)
+            ctx.cg_iterate(K)
+            e1.record(ctx.stream)
+            torch.cuda.synchronize()
+            secs = time.perf_counter() - t0
+        clocks = clk.record()
+        log(f"clocks / power during the timed region: {clocks}")
         ev_ms = e0.elapsed_time(e1)
         rep = ctx.report()
         assert rep.itr == W + K and rep.status == 0, f"work was skipped: itr={rep.itr} status={rep.status}"
@@ -648,6 +724,8 @@ def main():
             out["roofline"] = roof
         if first_attempt is not None:
             out["first_attempt"] = first_attempt
+        if clocks:
+            out["clocks"] = clocks
         if not args.no_cpu_baseline and world == 1 and not slab:   # reported baseline: rank 0 at N = 1 only
             out["cpu_baseline"] = cpu_baseline(solver, kind, dtype, gn)
         sys.stdout.flush()

@@ -32,6 +32,11 @@
 #include <algorithm>
 #include <mutex>
 
+#define RES_MAXG_LIMIT 256   // one workgroup per CU of the MI355X
+// Default 128: measured in round 3 with PYAPES_HIP_RES_MAXG=256 (boxes of <= 4096 cells up to 100^3), the grid-wide
+// step of 150-256 workgroups eats what the saved launches give -- CG 80^3 22.4 us / iteration against 22.9
+// launch-per-phase, 96^3 30.7 against 27.4, 1024^2 26.3 against 23.0; BiCGSTAB 64^3 (150 boxes) 40.8 against 41.8,
+// Jacobi 96^3 23.8 against 24.4 -- so above 128 boxes the launch-per-phase loops stay.
 #define RES_MAXG 128
 #define RES_MAXBOX 4096
 #define RES_NS 4            // partial sums per grid-wide step (row width of the mailbox; CG / Jacobi use 2)
@@ -1017,7 +1022,8 @@ static bool res_plan(const pa_ctx* c, size_t es, int solver, ResPlan& R) {
   const int64_t N[3] = {G.n0, G.n1, G.n2};
   const int maxbox = std::min(RES_MAXBOX, res_tune("PYAPES_HIP_RES_BOX", RES_MAXBOX));
   const int per_wg = res_tune("PYAPES_HIP_RES_CELLS", 1024);   // cells per workgroup aimed at (<= 64 workgroups)
-  if (G.ncell > (int64_t)RES_MAXG * maxbox) return false;
+  const int maxg = std::min(RES_MAXG_LIMIT, res_tune("PYAPES_HIP_RES_MAXG", RES_MAXG));
+  if (G.ncell > (int64_t)maxg * maxbox) return false;
   int P[3] = {1, 1, 1};
   const int want = (int)std::max<int64_t>(1, std::min<int64_t>(res_tune("PYAPES_HIP_RES_MAXWANT", 64), (G.ncell + per_wg - 1) / per_wg));
   for (;;) {
@@ -1060,7 +1066,7 @@ static bool res_plan(const pa_ctx* c, size_t es, int solver, ResPlan& R) {
       if (G.act[a] && c->bc[2 * a].type != PA_BC_PERIODIC && N[a] / (P[a] + 1) >= 3 && (best < 0 || b[a] > b[best])) best = a;
     if (best < 0) return fits ? accept() : false;   // nothing left to cut (periodic / short axes): fewer, larger boxes
     P[best] += 1;
-    if (P[0] * P[1] * P[2] > RES_MAXG) return false;
+    if (P[0] * P[1] * P[2] > maxg) return false;
   }
 }
 
