@@ -1,6 +1,7 @@
 // pa_cg3d.hip -- instantiations of the tiled kernel: CG phases A / B, Jacobi sweep
 // (kernel and launch helpers: pa_cg3d_kernel.h)
 #include "pa_cg3d_kernel.h"
+#include "pa_cg2d_kernel.h"
 
 template <typename T>
 int pa_cg3d_phase_a(pa_ctx* c, const DevEq<T>& E, Vec<T> r, Vec<T> d, T* dnew, double* partials) {
@@ -20,7 +21,8 @@ int pa_cg3d_phase_a(pa_ctx* c, const DevEq<T>& E, Vec<T> r, Vec<T> d, T* dnew, d
     A.sc_w = c->sc_alt;
     A.pre_sums = pa_sums(c);
   }
-  int n = launch_any<T, 0>(c, A, mode);
+  int n = (mode == 1 || mode == 3) ? launch_cg2d<T, 0>(c, A, mode == 3) : 0;   // 2-D meshes: marching along the slow axis
+  if (n == 0) n = launch_any<T, 0>(c, A, mode);
   if (n > 0 && hipGetLastError() != hipSuccess) { pa_set_err(c, "k_cg3d phase A launch failed"); return PA_E_HIP; }
   if (n > 0 && c->fold_b_n > 0) {
     SolverScalars* t = c->sc; c->sc = c->sc_alt; c->sc_alt = t;
@@ -49,7 +51,8 @@ int pa_cg3d_phase_b(pa_ctx* c, const DevEq<T>& E, Vec<T> d, T* x, T* r, double* 
     A.sc_w = c->sc;
     A.pre_sums = pa_sums(c);
   }
-  int n = launch_any<T, 1>(c, A, mode);
+  int n = (mode == 1 || mode == 3) ? launch_cg2d<T, 1>(c, A, mode == 3) : 0;
+  if (n == 0) n = launch_any<T, 1>(c, A, mode);
   if (n > 0 && hipGetLastError() != hipSuccess) { pa_set_err(c, "k_cg3d phase B launch failed"); return PA_E_HIP; }
   if (n > 0) c->fold_a_n = 0;
   return n;
