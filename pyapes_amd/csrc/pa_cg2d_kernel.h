@@ -320,17 +320,13 @@ template <typename T, int PHASE>
 static int launch_cg2d(pa_ctx* c, Cg3dArgs<T>& A, bool pitched) {
   constexpr int VEC = VecOf<T>::N;
   const DevGeom& G = c->G;
-  static int want = -1, minrows_env = 0;
-  static int64_t mincells = 0;
-  if (want < 0) {
-    const char* e = getenv("PYAPES_HIP_CG2D");
-    want = e ? atoi(e) : 1;
+  static int minrows_env = -1;
+  if (minrows_env < 0) {
     const char* r = getenv("PYAPES_HIP_CG2D_ROWS");
     minrows_env = r ? atoi(r) : 0;
-    const char* m = getenv("PYAPES_HIP_CG2D_MINCELLS");
-    mincells = m ? atoll(m) : 1500000;
   }
-  if (!want || c->ndim != 2 || G.act[0] || A.coeff_f || A.kind != 0 || c->slab) return 0;
+  const int64_t mincells = c->cg2d_mincells;   // option "cg2d_mincells" / PYAPES_HIP_CG2D_MINCELLS; < 0: never
+  if (mincells < 0 || c->ndim != 2 || G.act[0] || A.coeff_f || A.kind != 0 || c->slab) return 0;
   if (G.n1 < 8 || G.n2 < 2 * VEC) return 0;
   // Below ~1.5 M cells the one-plane tiling of k_cg3d stays: a wave here walks its rows one after the other (about
   // a microsecond each), and a small mesh has too few strips x chunks to hide that (measured, fp64 Dirichlet, us per

@@ -72,6 +72,11 @@ struct Cg3dArgs {
   int interior_only;    // A x: zero outside the interior set
   int out_all;          // Euler step (k_sf): the caller overwrites every node outside the interior set (its BC
                         // fill covers all 2 * ndim faces), so the step need not preserve phi there
+  // BC on load (explicit Euler MARCH on k_sf, pa_sf_kernel.h "BCL"): type of internal face f -- 0 none, 1 dirichlet
+  // (bcl_val = g), 2 neumann (bcl_val = the additive constant ((2/3) V) dxf ndir of the fill kernels), 3 symmetry
+  int bcl_type[6];
+  T bcl_val[6];
+  T bcl_c43, bcl_c13;
   // folded scalar step (pre_n > 0; single GPU inside pa_cg_iterate): EVERY block first reduces the partial
   // rows the previous kernel left (same fixed order as k_cg_post_a / k_cg_post_b -> the same bits in
   // every block, no fence, no atomics: the kernel boundary made the rows visible) and runs the scalar

@@ -208,6 +208,8 @@ int pa_ctx_create(int device, void* hip_stream, pa_ctx** out) {
   if (const char* rs = getenv("PYAPES_HIP_RESIDENT")) c->resident = atoi(rs) != 0;
   if (const char* rc = getenv("PYAPES_HIP_RESIDENT_COOP")) c->resident_coop = atoi(rc) != 0;
   if (const char* pt = getenv("PYAPES_HIP_PITCH")) c->pitch = atoi(pt) != 0;
+  if (const char* bl = getenv("PYAPES_HIP_BCL")) c->bcl = atoi(bl) != 0;
+  if (const char* m2 = getenv("PYAPES_HIP_CG2D_MINCELLS")) c->cg2d_mincells = atoll(m2);
   if (hipMalloc((void**)&c->sc_base, 2 * sizeof(SolverScalars)) != hipSuccess ||
       hipMalloc((void**)&c->sums, PA_NSUM * sizeof(double)) != hipSuccess ||
       hipHostMalloc((void**)&c->h_sc, sizeof(SolverScalars)) != hipSuccess ||
@@ -260,6 +262,8 @@ int pa_ctx_set_option(pa_ctx* c, const char* name, int value) {
   else if (!strcmp(name, "sf")) c->sf = value != 0;             // k_sf (else k_cg3d's single-field phases)
   else if (!strcmp(name, "fold")) c->fold = value != 0;         // scalar steps in the next kernel's prologue
   else if (!strcmp(name, "resident")) c->resident = value != 0; // small meshes: one cooperative launch per solve
+  else if (!strcmp(name, "cg2d_mincells")) c->cg2d_mincells = value;   // k_cg2d from this many cells on (< 0: never)
+  else if (!strcmp(name, "bcl")) c->bcl = value != 0;         // Euler march: face values formed on load, one fill at the end
   else if (!strcmp(name, "pitch")) c->pitch = value != 0;     // odd row lengths: pitched r / d buffers in the CG phases
   else if (!strcmp(name, "resident_coop")) c->resident_coop = value != 0;   // 0: plain launch of the same grid (profiling, below)
   else { pa_set_err(c, "pa_ctx_set_option: unknown option '%s'", name); return PA_E_ARG; }

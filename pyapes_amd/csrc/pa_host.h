@@ -87,6 +87,8 @@ struct pa_ctx {
   int bc_pair = 0;  // per-axis pair kernels (lower + upper face + shell stop-test term in one launch)
   int bc_fused = 0, shell_cur = 0;  // fused BC fill: which half of SCR_SHELL holds x_old on the shell
   void* cg_x = nullptr;
+  int64_t cg2d_mincells = 1500000;   // 2-D meshes of at least this many cells run the CG phases on k_cg2d (< 0: never)
+  int bcl = 1;               // option "bcl" / PYAPES_HIP_BCL: explicit Euler march without a BC-fill launch per step (pa_sf_kernel.h)
   int pitch = 1;             // option "pitch" / PYAPES_HIP_PITCH: allow that layout (0: odd rows stay on the NARROW kernels)
   int cg_pitch = 0;          // live CG solve keeps r and the direction buffers in the PITCH layout of k_cg3d
   int64_t cg_ps1 = 0;        // ... with this row pitch (cells)
@@ -206,7 +208,8 @@ int pa_tile3d_aop(pa_ctx* c, const DevEq<T>& E, Vec<T> x, T* y, int interior_onl
 template <typename T>
 int pa_tile3d_grad(pa_ctx* c, Vec<T> x, T* y, int nd);
 template <typename T>
-int pa_tile3d_euler(pa_ctx* c, Vec<T> phi, T* out, int kind, double u, const void* u_field, double nu, double dt);
+int pa_tile3d_euler(pa_ctx* c, Vec<T> phi, T* out, int kind, double u, const void* u_field, double nu, double dt,
+                    int bcl = 0);   // bcl: "BC on load" (pa_sf_kernel.h); 0 is returned when that form does not apply
 template <typename T>
 int pa_tile3d_jacobi(pa_ctx* c, const DevEq<T>& E, Vec<T> x, const T* rhs, T* xnew, double omega, double* partials);
 template <typename T>

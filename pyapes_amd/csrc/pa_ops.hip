@@ -423,6 +423,18 @@ static int euler_t(pa_ctx* c, const T* in, T* out, int kind, double u, const voi
   return pa_bc_apply_auto<T>(c, out, false);
 }
 
+// One step of the march in the "BC on load" form (pa_sf_kernel.h): the step kernel alone, no fill behind it -- the
+// boundary nodes of `out` stay whatever they were.  1: launched; 0: the form does not apply here; < 0: error.
+template <typename T>
+static int euler_bcl_t(pa_ctx* c, const T* in, T* out, int kind, double u, const void* u_field, double nu, double dt) {
+  Vec<T> pv = pa_vec_self<T>(c, in);
+  if (c->profile) (void)hipEventRecord(c->pev[0], c->stream);
+  const int fr = pa_tile3d_euler<T>(c, pv, out, kind, u, u_field, nu, dt, 1);
+  if (fr <= 0) return fr;
+  if (c->profile) pa_profile_stop(c, 0);
+  return 1;
+}
+
 extern "C" {
 
 int pa_aop(pa_ctx* c, const void* x, void* y, int interior_only) {
@@ -510,11 +522,32 @@ int pa_euler_march(pa_ctx* c, void* phi, void* tmp, int kind, double u, const vo
   if (phi == tmp || nsteps < 0) { pa_set_err(c, "pa_euler_march: bad buffers / step count"); return PA_E_ARG; }
   PA_HIP(c, hipSetDevice(c->device));
   void* buf[2] = {phi, tmp};
+  // "BC on load" (pa_sf_kernel.h): when every face has a scalar dirichlet / neumann / symmetry BC the steps of a
+  // march need no fill between them -- each forms the face values it reads from its own operands, bit for bit what
+  // the fill would have stored -- and ONE ordered fill after the last step completes the result.
+  bool bcl = c->bcl && c->sf && !c->slab && c->ndim == 3 && kind == PA_OP_DIV_UPWIND && nsteps >= 2 &&
+             c->G.n0 >= 5 && c->G.n1 >= 5 && c->G.n2 >= 5;
+  for (int f = 0; f < 6 && bcl; ++f)
+    bcl = c->bc[f].type >= PA_BC_DIRICHLET && c->bc[f].type <= PA_BC_SYMMETRY && !c->bc[f].vals;
   for (int64_t s = 0; s < nsteps; ++s) {
+    if (bcl) {
+      const int fr = c->dtype == PA_F64
+                         ? euler_bcl_t<double>(c, (const double*)buf[s & 1], (double*)buf[(s + 1) & 1], kind, u, u_field, nu, dt)
+                         : euler_bcl_t<float>(c, (const float*)buf[s & 1], (float*)buf[(s + 1) & 1], kind, u, u_field, nu, dt);
+      if (fr < 0) return fr;
+      if (fr > 0) continue;
+      if (s > 0) { pa_set_err(c, "pa_euler_march: the BC-on-load step declined in the middle of a march"); return PA_E_STATE; }
+      bcl = false;   // not for k_sf (row length, alignment ...): the classic sequence from the first step on
+    }
     rc = c->dtype == PA_F64
              ? euler_t<double>(c, (const double*)buf[s & 1], (double*)buf[(s + 1) & 1], kind, u, u_field, nu, dt)
              : euler_t<float>(c, (const float*)buf[s & 1], (float*)buf[(s + 1) & 1], kind, u, u_field, nu, dt);
     if (rc) return rc;
+  }
+  if (bcl && nsteps > 0) {
+    PA_HIP(c, hipGetLastError());
+    return c->dtype == PA_F64 ? pa_bc_apply_auto<double>(c, (double*)buf[nsteps & 1], false)
+                              : pa_bc_apply_auto<float>(c, (float*)buf[nsteps & 1], false);
   }
   return PA_OK;
 }

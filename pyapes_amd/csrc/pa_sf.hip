@@ -7,7 +7,7 @@
 #include "pa_sf_kernel.h"
 
 template <typename T>
-int pa_tile3d_euler(pa_ctx* c, Vec<T> phi, T* out, int kind, double u, const void* u_field, double nu, double dt) {
+int pa_tile3d_euler(pa_ctx* c, Vec<T> phi, T* out, int kind, double u, const void* u_field, double nu, double dt, int bcl) {
   DevEq<T> E;
   pa_term t;
   memset(&t, 0, sizeof(t));
@@ -25,6 +25,23 @@ int pa_tile3d_euler(pa_ctx* c, Vec<T> phi, T* out, int kind, double u, const voi
     int faces = 0;
     for (int f = 0; f < 6; ++f) faces += (c->G.act[f >> 1] && c->bc[f].type != PA_BC_NONE) ? 1 : 0;
     A.out_all = faces == 2 * c->ndim ? 1 : 0;
+  }
+  if (bcl) {   // BC on load (k_sf only): the fill values of the face interiors are formed from the stencil's own operands
+    if (!A.out_all || !sf_applies<T, 3>(c, A, mode) || kind != PA_OP_DIV_UPWIND) return 0;
+    A.bcl_c43 = (T)(4.0 / 3.0);
+    A.bcl_c13 = (T)(1.0 / 3.0);
+    for (int f = 0; f < 6; ++f) {
+      const HostBC& b = c->bc[f];
+      if (b.vals || b.type < PA_BC_DIRICHLET || b.type > PA_BC_SYMMETRY) return 0;
+      A.bcl_type[f] = b.type;
+      if (b.type == PA_BC_DIRICHLET) A.bcl_val[f] = (T)b.value;
+      if (b.type == PA_BC_NEUMANN) {   // the additive constant as pa_bc.hip forms it
+        T pre = (T)((2.0 / 3.0) * b.value);
+        pre = pre * (T)b.dxf;
+        pre = pre * ((f & 1) == 0 ? (T)-1 : (T)1);
+        A.bcl_val[f] = pre;
+      }
+    }
   }
   int n = 0;
   if (sf_applies<T, 3>(c, A, mode)) {
@@ -88,8 +105,8 @@ int pa_tile3d_grad(pa_ctx* c, Vec<T> x, T* y, int nd) {
   return n;
 }
 
-template int pa_tile3d_euler<float>(pa_ctx*, Vec<float>, float*, int, double, const void*, double, double);
-template int pa_tile3d_euler<double>(pa_ctx*, Vec<double>, double*, int, double, const void*, double, double);
+template int pa_tile3d_euler<float>(pa_ctx*, Vec<float>, float*, int, double, const void*, double, double, int);
+template int pa_tile3d_euler<double>(pa_ctx*, Vec<double>, double*, int, double, const void*, double, double, int);
 template int pa_tile3d_grad<float>(pa_ctx*, Vec<float>, float*, int);
 template int pa_tile3d_grad<double>(pa_ctx*, Vec<double>, double*, int);
 template int pa_tile3d_aop<float>(pa_ctx*, const DevEq<float>&, Vec<float>, float*, int);

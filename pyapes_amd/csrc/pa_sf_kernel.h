@@ -65,8 +65,20 @@ template <> struct SfBits<double> {
 // the loop, planes beside an axis-0 face take a second copy of the body so that the common one has no
 // coefficient selects, and there is no interior-set select: k_sf only takes launches whose output is wanted
 // at every node (sf_applies).
-template <typename T, int RJ, int PHASE, int KIND, bool HASU>
+//
+// BCL ("BC on load", the explicit Euler MARCH without a BC-fill launch per step).  The stencil at a node of the
+// interior set reads boundary nodes only at face INTERIORS -- a node on an edge or corner is never the neighbour of
+// an interior node -- and what the ordered BC fill stores there is a function of the two nodes behind it along the
+// face normal (bcs.py:200-262: dirichlet g; neumann 4/3 x[prev] - 1/3 x[prev2] + (2/3) V dx n; symmetry x[prev]).
+// For a node with index 1 (or N - 2) on an axis those two nodes are the node itself and its inner neighbour --
+// operands the stencil holds anyway.  So a step of the march does not need the boundary values of its input at all:
+// it REPLACES the outer operand by the face formula (same operations, same order, same bits as the fill kernels
+// of pa_bc.hip), the boundary nodes of the intermediate states stay unfilled, and ONE ordered fill after the last
+// step makes the result's boundary what the step-by-step sequence leaves there.  Without periodic faces only
+// (their fill reads the far end of the axis and puts boundary nodes into the interior set).
+template <typename T, int RJ, int PHASE, int KIND, bool HASU, bool BCL = false>
 __global__ void __launch_bounds__(256) k_sf(Cg3dArgs<T> A) {
+  static_assert(!BCL || PHASE == 3, "BC on load: the Euler step");
   constexpr int VEC = VecOf<T>::N;
   typedef T V __attribute__((ext_vector_type(VEC)));
   constexpr int TJ = 4 * RJ, TK = 64 * VEC;
@@ -95,9 +107,22 @@ __global__ void __launch_bounds__(256) k_sf(Cg3dArgs<T> A) {
   T cPj[RJ], cCj[RJ], cMj[RJ];     // Laplacian rows along j (uniform per row)
   T gPj[RJ], gCj[RJ], gMj[RJ];     // gradient rows along j
   bool rPLo[RJ], rPHi[RJ];
+  // BCL comes in two forms, by what the register allocator makes of them (measured, us per step, classic -> BCL):
+  //   PATCH  (fp64)  the loaded boundary values are replaced in registers, the stencil body is untouched: VGPRs as the
+  //                  plain kernel (156 / 236); 256^3 66 -> 54.  In fp32 the same costs 40 VGPRs (single components of
+  //                  packed rows) and is SLOWER than the classic sequence (256^3 35 -> 41, 128^3 16 -> 24).
+  //   SUBST  (fp32)  the stencil's outer operand is replaced where it is read: 171 / 248 VGPRs (158 / 233 plain -- three
+  //                  registers too many for a third wave per SIMD with two rows; forcing it spills);
+  //                  256^3 34.8 -> 33.3, 128^3 16 -> 11.2, 512^3 250 -> 221.
+  constexpr bool PATCH = BCL && sizeof(T) == 8, SUBST = BCL && !PATCH;
+  bool rTop[RJ];                    // PATCH: the row is the upper j face (its value is formed from the two rows below)
+  bool rBLo[RJ], rBHi[RJ];          // SUBST: row 1 / n1 - 2 of an axis whose face has a BC
 #pragma unroll
   for (int jj = 0; jj < RJ; ++jj) {
     const int jg = j0 + jj;
+    rTop[jj] = PATCH && jg == n1 - 1 && A.bcl_type[3] != 0;
+    rBLo[jj] = SUBST && jg == 1 && A.bcl_type[2] != 0;
+    rBHi[jj] = SUBST && jg == n1 - 2 && A.bcl_type[3] != 0;
     const unsigned ro = (unsigned)wrap(jg, n1) * (unsigned)n2;
     off[jj] = (ro + (unsigned)kc) * (unsigned)sizeof(T);
     offe[jj] = (ro + (unsigned)ecol) * (unsigned)sizeof(T);
@@ -139,6 +164,34 @@ __global__ void __launch_bounds__(256) k_sf(Cg3dArgs<T> A) {
       gPkV[v] = gp; gCkV[v] = gc; gMkV[v] = gm;
     }
   }
+  // BCL.  The boundary VALUES of the input are replaced in registers, once per plane, when the plane becomes the
+  // current one (its boundary rows / cells feed the j / k neighbours of its interior nodes) and, for the two axis-0
+  // faces, when the plane next to the face is current (the face plane is its i - 1 / i + 1 operand); the stencil
+  // body is untouched.  Along k: cell 0 is component 0 of the lane that starts the row, cell n2 - 1 the last
+  // component of the lane that ends it (rows are whole vectors: sf_applies).  (Forming the k-face cells on STORE
+  // instead -- from the row's new values -- was tried: 282 / 320 VGPRs for the fp32 kernels against 199 / 268.)
+  const bool cBLo = BCL && kg == 0 && A.bcl_type[4] != 0;
+  const bool cBHi = BCL && kg + VEC == n2 && A.bcl_type[5] != 0;
+  const bool jBot = PATCH && j0 == 0 && A.bcl_type[2] != 0;
+  // the value the ordered fill stores on face f, from the node behind it (a) and the one behind that (b): the
+  // operations of k_bc_face / k_bc_compute in their order.  The face's type is uniform: no arithmetic for the
+  // faces that need none.
+  // (whole rows under a wave-uniform branch -- the planes / rows on a face are few; along k, where every row has
+  // its two cells, the arithmetic of a neumann face sits behind ONE uniform branch and the rest is selects.
+  // First attempt: the substitution inside the stencil body, per operand -- 170-280 VGPRs instead of 157-248, a
+  // wave less per SIMD, the step 29 % slower)
+  auto bcvV = [&](int f, const V& a, const V& b) -> V {
+    const int ty = A.bcl_type[f];
+    if (ty == 2) {
+      V t1 = A.bcl_c43 * a;
+      V t2 = A.bcl_c13 * b;
+      t1 = t1 - t2;
+      return t1 + A.bcl_val[f];
+    }
+    if (ty == 1) return (V)A.bcl_val[f];
+    return a;
+  };
+  const bool kNeu = BCL && (A.bcl_type[4] == 2 || A.bcl_type[5] == 2);
   const size_t pstride = (size_t)G.s0 * sizeof(T);
   // Uniform and BRANCH-FREE: with a branch between the issue of a load and its use the compiler's waitcnt
   // pass loses count of what is outstanding and falls back to s_waitcnt vmcnt(0) right behind the loads --
@@ -227,7 +280,46 @@ __global__ void __launch_bounds__(256) k_sf(Cg3dArgs<T> A) {
     const int rci = pa_row_case(G, 0, gi, G.g0, G.treat);
     const bool iPLo_ = G.bct[0] == 4 && gi == 1;
     const bool iPHi_ = G.bct[1] == 4 && gi == G.g0 - 2;
+    const bool iBLo_ = BCL && gi == 1 && A.bcl_type[0] != 0;
+    const bool iBHi_ = BCL && gi == G.g0 - 2 && A.bcl_type[1] != 0;
     char* const po = (char*)A.out + (size_t)ii * pstride;
+    if constexpr (PATCH) {
+#pragma unroll
+      for (int jj = 0; jj < RJ; ++jj) {   // k faces of the current plane's rows
+        V& r = P[SC][jj];
+        T lo = r[1], hi = r[VEC - 2];     // symmetry: x[face] = x[prev]
+        if (kNeu) {
+          const T in2 = VEC > 2 ? r[VEC > 2 ? 2 : 0] : SfBits<T>::next(r[0], r[0]);               // cell 2
+          const T in3 = VEC > 2 ? r[VEC > 2 ? VEC - 3 : 0] : SfBits<T>::prev(r[VEC - 1], r[0]);   // cell n2 - 3
+          T t1 = A.bcl_c43 * r[1];
+          T t2 = A.bcl_c13 * in2;
+          t1 = t1 - t2;
+          t1 = t1 + A.bcl_val[4];
+          lo = A.bcl_type[4] == 2 ? t1 : lo;
+          t1 = A.bcl_c43 * r[VEC - 2];
+          t2 = A.bcl_c13 * in3;
+          t1 = t1 - t2;
+          t1 = t1 + A.bcl_val[5];
+          hi = A.bcl_type[5] == 2 ? t1 : hi;
+        }
+        lo = A.bcl_type[4] == 1 ? A.bcl_val[4] : lo;
+        hi = A.bcl_type[5] == 1 ? A.bcl_val[5] : hi;
+        r[0] = cBLo ? lo : r[0];
+        r[VEC - 1] = cBHi ? hi : r[VEC - 1];
+      }
+      if (jBot) P[SC][0] = bcvV(2, P[SC][RJ > 1 ? 1 : 0], RJ > 2 ? P[SC][RJ > 2 ? 2 : 0] : Hd[HC]);   // row 0 from rows 1, 2
+#pragma unroll
+      for (int jj = 1; jj < RJ; ++jj)      // row n1 - 1 from the two rows below it (same block: launch_sf_any)
+        if (rTop[jj]) P[SC][jj] = bcvV(3, P[SC][jj - 1], jj >= 2 ? P[SC][jj >= 2 ? jj - 2 : 0] : Hu[HC]);
+      if (iBLo_) {
+#pragma unroll
+        for (int jj = 0; jj < RJ; ++jj) P[SB][jj] = bcvV(0, P[SC][jj], P[SA][jj]);
+      }
+      if (iBHi_) {
+#pragma unroll
+        for (int jj = 0; jj < RJ; ++jj) P[SA][jj] = bcvV(1, P[SC][jj], P[SB][jj]);
+      }
+    }
     auto body = [&](auto PLAINC) {
     constexpr bool PLAIN = decltype(PLAINC)::value;
     const bool iPLo = PLAIN ? false : iPLo_, iPHi = PLAIN ? false : iPHi_;
@@ -246,10 +338,19 @@ __global__ void __launch_bounds__(256) k_sf(Cg3dArgs<T> A) {
 #pragma unroll
     for (int jj = 0; jj < RJ; ++jj) {
       const V xc = P[SC][jj];
-      const V xpi = P[SA][jj], xmi = P[SB][jj];
+      V xpi = P[SA][jj], xmi = P[SB][jj];
       V up, dn;   // rows j-1 / j+1
       if (jj > 0) up = P[SC][jj - 1]; else up = Hu[HC];
       if (jj < RJ - 1) dn = P[SC][jj + 1]; else dn = Hd[HC];
+      if constexpr (SUBST) {   // planes 1 / n0 - 2 and rows 1 / n1 - 2: the outer operand is the face's fill value
+        if (!PLAIN) {
+          if (iBLo_) xmi = bcvV(0, xc, P[SA][jj]);
+          if (iBHi_) xpi = bcvV(1, xc, P[SB][jj]);
+        }
+        const V up0 = up, dn0 = dn;
+        if (rBLo[jj]) up = bcvV(2, xc, dn0);
+        if (rBHi[jj]) dn = bcvV(3, xc, up0);
+      }
       // k-1 / k+1: inside the lane's vector, across lanes by DPP (lane 0 / 63 keep the tile's edge cell)
       V xpk, xmk;
       const T edge = He[HC][jj];
@@ -259,6 +360,25 @@ __global__ void __launch_bounds__(256) k_sf(Cg3dArgs<T> A) {
       for (int v = 0; v < VEC; ++v) {
         xpk[v] = (v < VEC - 1) ? xc[v + 1 < VEC ? v + 1 : v] : fromNext;
         xmk[v] = (v > 0) ? xc[v > 0 ? v - 1 : 0] : fromPrev;
+      }
+      if constexpr (SUBST) {   // cells 1 / n2 - 2 (one lane each): per-lane selects
+        T lo = xc[1], hi = xc[VEC - 2];   // symmetry: x[face] = x[prev]
+        if (kNeu) {
+          T t1 = A.bcl_c43 * xc[1];
+          T t2 = A.bcl_c13 * xpk[1];
+          t1 = t1 - t2;
+          t1 = t1 + A.bcl_val[4];
+          lo = A.bcl_type[4] == 2 ? t1 : lo;
+          t1 = A.bcl_c43 * xc[VEC - 2];
+          t2 = A.bcl_c13 * xmk[VEC - 2];
+          t1 = t1 - t2;
+          t1 = t1 + A.bcl_val[5];
+          hi = A.bcl_type[5] == 2 ? t1 : hi;
+        }
+        lo = A.bcl_type[4] == 1 ? A.bcl_val[4] : lo;
+        hi = A.bcl_type[5] == 1 ? A.bcl_val[5] : hi;
+        xmk[1] = cBLo ? lo : xmk[1];
+        xpk[VEC - 2] = cBHi ? hi : xpk[VEC - 2];
       }
       if constexpr (PHASE == 7) {
         V s = gP0 * xpi;
@@ -394,7 +514,7 @@ __global__ void __launch_bounds__(256) k_sf(Cg3dArgs<T> A) {
       }
     }
     };   // body
-    if (rci != 0 || iPLo_ || iPHi_) body(std::false_type{}); else body(std::true_type{});
+    if (rci != 0 || iPLo_ || iPHi_ || (SUBST && (iBLo_ || iBHi_))) body(std::false_type{}); else body(std::true_type{});
   };
 
   for (int q = 0; q < CI; q += 4) {
@@ -406,21 +526,21 @@ __global__ void __launch_bounds__(256) k_sf(Cg3dArgs<T> A) {
 }
 
 // ---- host side ---------------------------------------------------------------------------------------
-template <typename T, int RJ, int PHASE, int KIND, bool HASU>
+template <typename T, int RJ, int PHASE, int KIND, bool HASU, bool BCL = false>
 static int sf_blocks_per_cu() {
   static int cached = 0;
   if (!cached) {
     const char* e = getenv("PYAPES_HIP_BPC_SF");
     int n = e ? atoi(e) : 0;
-    if (n <= 0 &&
-        (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_sf<T, RJ, PHASE, KIND, HASU>, 256, 0) != hipSuccess || n <= 0))
-      n = 4;
+    if (n <= 0) {
+      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_sf<T, RJ, PHASE, KIND, HASU, BCL>, 256, 0) != hipSuccess || n <= 0) n = 4;
+    }
     cached = n;
   }
   return cached;
 }
 
-template <typename T, int RJ, int PHASE, int KIND, bool HASU>
+template <typename T, int RJ, int PHASE, int KIND, bool HASU, bool BCL = false>
 static int launch_sf(pa_ctx* c, Cg3dArgs<T>& A) {
   constexpr int VEC = VecOf<T>::N;
   constexpr int TJ = 4 * RJ, TK = 64 * VEC;
@@ -428,7 +548,7 @@ static int launch_sf(pa_ctx* c, Cg3dArgs<T>& A) {
   A.tiles_j = (int)((G.n1 + TJ - 1) / TJ);
   A.tiles_k = (int)((G.n2 + TK - 1) / TK);
   const int tiles = A.tiles_j * A.tiles_k;
-  const int capacity = cus_of(c) * sf_blocks_per_cu<T, RJ, PHASE, KIND, HASU>();
+  const int capacity = cus_of(c) * sf_blocks_per_cu<T, RJ, PHASE, KIND, HASU, BCL>();
   int chunks = capacity / tiles;
   if (chunks < 1) chunks = 1;
   if (chunks > G.n0) chunks = (int)G.n0;
@@ -439,11 +559,11 @@ static int launch_sf(pa_ctx* c, Cg3dArgs<T>& A) {
   if (dbg < 0) dbg = getenv("PYAPES_HIP_DEBUG") ? 8 : 0;
   if (dbg > 0) {
     --dbg;
-    fprintf(stderr, "[pyapes_hip] k_sf phase %d kind %d RJ %d: tiles %dx%d chunks %d (CI ~%lld) blocks %d, %d blocks/CU\n",
-            PHASE, KIND, RJ, A.tiles_j, A.tiles_k, chunks, (long long)(G.n0 / chunks), nblk,
-            sf_blocks_per_cu<T, RJ, PHASE, KIND, HASU>());
+    fprintf(stderr, "[pyapes_hip] k_sf phase %d kind %d RJ %d%s: tiles %dx%d chunks %d (CI ~%lld) blocks %d, %d blocks/CU\n",
+            PHASE, KIND, RJ, BCL ? " (BC on load)" : "", A.tiles_j, A.tiles_k, chunks, (long long)(G.n0 / chunks), nblk,
+            sf_blocks_per_cu<T, RJ, PHASE, KIND, HASU, BCL>());
   }
-  hipLaunchKernelGGL((k_sf<T, RJ, PHASE, KIND, HASU>), dim3(nblk), dim3(256), 0, c->stream, A);
+  hipLaunchKernelGGL((k_sf<T, RJ, PHASE, KIND, HASU, BCL>), dim3(nblk), dim3(256), 0, c->stream, A);
   return nblk;
 }
 
@@ -467,6 +587,13 @@ static int launch_sf_any(pa_ctx* c, Cg3dArgs<T>& A) {
     const int64_t tiles4 = ((G.n1 + 15) / 16) * ((G.n2 + 64 * VEC - 1) / (64 * VEC));
     const int64_t chunks4 = std::max<int64_t>(1, (int64_t)cus_of(c) * 2 / tiles4);
     rj = G.n0 / chunks4 >= 32 ? 4 : 2;
+  }
+  if constexpr (PHASE == 3 && KIND == PA_OP_DIV_UPWIND) {   // BC on load: the upwind march (BASELINE config 4)
+    if (A.bcl_type[0] | A.bcl_type[1] | A.bcl_type[2] | A.bcl_type[3] | A.bcl_type[4] | A.bcl_type[5]) {
+      if (rj < 2 || (sizeof(T) == 8 && (c->G.n1 - 1) % rj == 0)) return 0;   // PATCH: rows n1 - 2, n1 - 1 in one wave's block
+      if (A.aux) return rj == 2 ? launch_sf<T, 2, 3, KIND, true, true>(c, A) : launch_sf<T, 4, 3, KIND, true, true>(c, A);
+      return rj == 2 ? launch_sf<T, 2, 3, KIND, false, true>(c, A) : launch_sf<T, 4, 3, KIND, false, true>(c, A);
+    }
   }
   constexpr bool CAN_U = (PHASE == 3 || (PHASE == 2 && KIND != 0));
   if constexpr (CAN_U) {
