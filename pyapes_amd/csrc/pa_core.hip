@@ -5,6 +5,7 @@
 // drivers), pa_cg3d*.hip (the tiled marching kernel), pa_rfp.hip, pa_comm.hip.
 #include "pa_host.h"
 
+#include <dlfcn.h>
 #include <math.h>
 #include <stdlib.h>
 #include <stdio.h>
@@ -63,6 +64,35 @@ void pa_set_err(pa_ctx* c, const char* fmt, ...) {
   else vsnprintf(g_create_err, sizeof(g_create_err), fmt, ap);
   va_end(ap);
 }
+
+namespace {
+struct Roctx {
+  int state = 0;   // 0 untried, 1 on, -1 off
+  int (*push)(const char*) = nullptr;
+  int (*pop)() = nullptr;
+};
+Roctx g_roctx;
+bool roctx_on() {
+  Roctx& R = g_roctx;
+  if (R.state == 0) {
+    R.state = -1;
+    const char* e = getenv("PYAPES_HIP_ROCTX");
+    if (e && atoi(e) != 0) {
+      void* h = dlopen("libroctx64.so.4", RTLD_NOW | RTLD_GLOBAL);
+      if (!h) h = dlopen("libroctx64.so", RTLD_NOW | RTLD_GLOBAL);
+      if (h) {
+        R.push = reinterpret_cast<int (*)(const char*)>(dlsym(h, "roctxRangePushA"));
+        R.pop = reinterpret_cast<int (*)()>(dlsym(h, "roctxRangePop"));
+        if (R.push && R.pop) R.state = 1;
+      }
+    }
+  }
+  return R.state == 1;
+}
+}  // namespace
+
+void pa_range_push(const char* name) { if (roctx_on()) (void)g_roctx.push(name); }
+void pa_range_pop() { if (roctx_on()) (void)g_roctx.pop(); }
 
 int pa_hip_fail(pa_ctx* c, hipError_t e, const char* what) {
   pa_set_err(c, "HIP error in %s: %s", what, hipGetErrorString(e));

@@ -147,6 +147,14 @@ static inline double* pa_sums(const pa_ctx* c) { return (c->slab && c->ext_sums)
 static inline const int* pa_done_flag(const pa_ctx* c) { return &c->sc->done; }
 
 void pa_set_err(pa_ctx* c, const char* fmt, ...);
+// roctx ranges around the solver phases (host-side enqueue ranges; rocprofv3 --marker-trace shows them beside the
+// kernel trace).  Off unless PYAPES_HIP_ROCTX=1; libroctx64 is resolved at run time, like librccl.
+void pa_range_push(const char* name);
+void pa_range_pop();
+struct PaRange {
+  explicit PaRange(const char* name) { pa_range_push(name); }
+  ~PaRange() { pa_range_pop(); }
+};
 int pa_hip_fail(pa_ctx* c, hipError_t e, const char* what);
 int pa_grid_blocks(int64_t work);
 int pa_scratch(pa_ctx* c, void** slot, size_t* cap, size_t bytes);

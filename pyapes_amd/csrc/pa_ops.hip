@@ -520,6 +520,7 @@ int pa_euler_march(pa_ctx* c, void* phi, void* tmp, int kind, double u, const vo
   int rc = check_div_kind(c, kind);
   if (rc) return rc;
   if (phi == tmp || nsteps < 0) { pa_set_err(c, "pa_euler_march: bad buffers / step count"); return PA_E_ARG; }
+  PaRange range_("pyapes explicit Euler march");
   PA_HIP(c, hipSetDevice(c->device));
   void* buf[2] = {phi, tmp};
   // "BC on load" (pa_sf_kernel.h): when every face has a scalar dirichlet / neumann / symmetry BC the steps of a

@@ -1088,6 +1088,7 @@ static bool res_applicable(const pa_ctx* c) {
 
 template <typename T>
 int pa_resident_launch(pa_ctx* c, int solver, T* x, const T* rhs, double tol, int64_t max_it, double omega) {
+  PaRange range_("pyapes resident solve (one cooperative launch)");
   if (!res_applicable(c)) return 0;
   ResPlan R;
   if (!res_plan(c, sizeof(T), solver, R)) return 0;

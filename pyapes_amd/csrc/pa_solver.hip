@@ -986,6 +986,7 @@ static void cg_flush_fold(pa_ctx* c) {
 
 template <typename T>
 int pa_cg_phase_a_t(pa_ctx* c, int stage_post) {
+  PaRange range_("pyapes CG phase A: d' = r + beta d, sum d'.(A d')");
   const DevGeom& G = c->G;
   const int nblk = pa_grid_blocks(G.ncell);
   DevEq<T> E;
@@ -1038,6 +1039,7 @@ int pa_cg_phase_a_t(pa_ctx* c, int stage_post) {
 
 template <typename T>
 int pa_cg_phase_b_t(pa_ctx* c, int stage_post) {
+  PaRange range_("pyapes CG phase B: x += alpha d', r -= alpha A d', BC fill, sums");
   const DevGeom& G = c->G;
   const int nblk = pa_grid_blocks(G.ncell);
   DevEq<T> E;

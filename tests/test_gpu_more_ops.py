@@ -374,3 +374,27 @@ def test_switching_streams_orders_the_new_stream_after_the_old():
     phi_b, x_b, rep_b = run(True)
     assert rep_a == rep_b
     assert bit_equal(phi_a, phi_b) and bit_equal(x_a, x_b)
+
+
+def test_roctx_ranges_do_not_change_anything(tmp_path):
+    """PYAPES_HIP_ROCTX=1 wraps the solver phases in roctx ranges (libroctx64 resolved at run time; visible with
+    rocprofv3 --marker-trace).  Here: the switch loads the library, the solve runs and gives the same bits."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+            "import torch, warnings; warnings.simplefilter('ignore')\n"
+            "from helpers import product_solve\n"
+            "case = {'lower': [0, 0, 0], 'upper': [1, 1, 1], 'spacing': [40, 36, 72], 'dtype': 'double', 'method': 'cg', 'tol': 1e-30,\n"
+            "        'bcs': [['dirichlet', 0.0], ['neumann', 0.5], ['dirichlet', 0.0], ['neumann', 0.0], ['dirichlet', 1.0], ['neumann', -0.25]]}\n"
+            "g = torch.Generator().manual_seed(1); rhs = torch.randn((1, 40, 36, 72), generator=g, dtype=torch.float64)\n"
+            "x, rep, _ = product_solve(case, rhs, 12)\n"
+            "torch.save({'x': x, 'tol': rep['tol']}, sys.argv[1])\n" % (root, os.path.join(root, "tests")))
+    outs = []
+    for flag in ("0", "1"):
+        out = str(tmp_path / f"r{flag}.pt")
+        env = dict(os.environ, PYAPES_HIP_ROCTX=flag, PYAPES_HIP_RESIDENT="0",
+                   PYTHONPATH=os.pathsep.join([os.path.join(root, "oracle"), os.environ.get("PYTHONPATH", "")]))
+        r = subprocess.run([sys.executable, "-c", code, out], capture_output=True, text=True, env=env)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append(torch.load(out))
+    assert torch.equal(outs[0]["x"], outs[1]["x"]) and outs[0]["tol"] == outs[1]["tol"]

@@ -88,7 +88,18 @@ def test_ops_bit_exact(case):
         assert bit_equal(FDC(cfg).div(ut, var), g["div_upwind_t"]), "div_upwind compat (tensor u)"
 
 
-_HULLS = {}   # (case, K) -> summation hull of the reference algorithm (CPU, seconds each): shared by the two paths
+_HULLS = {}   # (case, K) -> summation hull of the reference algorithm (CPU, seconds to minutes each) + the scalar
+              # histories of its 29 samples: computed once, shared by both solver paths and both tests below
+
+
+def _hull(case, g, K):
+    from helpers import summation_hull
+    key = (case["name"], K)
+    if key not in _HULLS:
+        hs = []
+        band, diam, its = summation_hull(case, g["rhs0"], K, g[f"x_K{K}"], histories=hs)
+        _HULLS[key] = (band, diam, its, hs)
+    return _HULLS[key]
 
 
 @pytest.mark.parametrize("path", ["resident", "launch_per_phase"])
@@ -125,9 +136,7 @@ def test_solve_vs_reference(case, path, monkeypatch):
         x, rep, _ = product_solve(case, g["rhs0"], K)
         err = rel_err(x, g[f"x_K{K}"])
         if case.get("sensitive") and K > 10:
-            if (case["name"], K) not in _HULLS:
-                _HULLS[(case["name"], K)] = summation_hull(case, g["rhs0"], K, g[f"x_K{K}"])
-            band, diam, its = _HULLS[(case["name"], K)]
+            band, diam, its, _ = _hull(case, g, K)
             its = its + [ref["itr"]]
             W = max(4, max(its) - min(its))
             assert min(its) - W / 4 <= rep["itr"] <= max(its) + W / 4, (case["name"], K, rep, sorted(its))
@@ -144,9 +153,6 @@ def test_solve_vs_reference(case, path, monkeypatch):
         assert err <= rtol, (case["name"], K, err)
         if case["dtype"] == "double":
             assert abs(rep["tol"] - ref["tol"]) <= 1e-6 * abs(ref["tol"]) + 1e-13, (rep, ref)
-
-
-_HISTS = {}   # case -> (reference history, histories of the reordered oracle runs)
 
 
 @pytest.mark.parametrize("path", ["resident", "launch_per_phase"])
@@ -170,11 +176,7 @@ def test_scalar_history_vs_reference(case, path, monkeypatch):
     method = case["method"]
     ref = scalar_history(method, list(g[f"hist_sums_K{K}"]))
     tols = np.asarray(g[f"hist_tol_K{K}"])
-    if case["name"] not in _HISTS:
-        hs = []
-        summation_hull(case, g["rhs0"], K, g[f"x_K{K}"], histories=hs)
-        _HISTS[case["name"]] = hs
-    hs = _HISTS[case["name"]]
+    hs = _hull(case, g, K)[3]
     # the oracle in the reference's own summation order reproduces the reference's scalars (a check of the tap)
     n0 = min(len(ref), len(hs[0]), 5)
     assert np.allclose(ref[:n0], hs[0][:n0], rtol=1e-11, atol=0, equal_nan=True)

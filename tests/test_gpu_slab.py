@@ -12,7 +12,7 @@ import torch.distributed as dist
 import torch.multiprocessing as mp
 
 import pyapes_oracle as O
-from test_slab_gloo import CASES, _free_port
+from test_slab_gloo import CASES, _free_port, spawn_ranks
 
 pytestmark = pytest.mark.gpu
 
@@ -57,7 +57,7 @@ def _worker(rank, world, port, name, n, K, dtype, out):
 def test_two_slabs_on_one_gpu(name, shape, tmp_path, world=2):
     (n, dtype), K = shape, 6
     out = str(tmp_path / "x.pt")
-    mp.spawn(_worker, args=(world, _free_port(), name, n, K, dtype, out), nprocs=world, join=True)
+    spawn_ranks(_worker, lambda port: (world, port, name, n, K, dtype, out), world)
     res = torch.load(out)
     mesh = O.OMesh([0, 0, 0], [1, 1, 0.5], list(n), dtype)
     cfg = [{"bc_face": O.FACES[i], "bc_type": t, "bc_val": v} for i, (t, v) in enumerate(CASES[name])]
@@ -151,8 +151,7 @@ def test_library_side_rccl_one_rank(name, mode, tmp_path):
     res = {}
     for lib_comm in (True, False):
         out = str(tmp_path / f"x{int(lib_comm)}.pt")
-        mp.spawn(_worker_rccl, args=(1, _free_port(), name, n, K, out, lib_comm, LIB_MODES[mode] if lib_comm else None),
-                 nprocs=1, join=True)
+        spawn_ranks(_worker_rccl, lambda port: (1, port, name, n, K, out, lib_comm, LIB_MODES[mode] if lib_comm else None), 1)
         res[lib_comm] = torch.load(out)
     assert torch.equal(res[True]["x"], res[False]["x"]) and res[True]["itr"] == res[False]["itr"] == K + 1
     assert res[True]["tol"] == res[False]["tol"]

@@ -24,7 +24,7 @@ import torch.distributed as dist
 import torch.multiprocessing as mp
 
 import pyapes_oracle as O
-from test_slab_gloo import CASES, _free_port
+from test_slab_gloo import CASES, _free_port, spawn_ranks
 
 pytestmark = pytest.mark.gpu
 
@@ -97,7 +97,7 @@ def _worker(rank, world, port, name, n, K, dtype, runs, out):
 
 def _spawn(world, name, n, K, dtype, runs, tmp_path):
     out = str(tmp_path / "res.pt")
-    mp.spawn(_worker, args=(world, _free_port(), name, n, K, dtype, runs, out), nprocs=world, join=True)
+    spawn_ranks(_worker, lambda port: (world, port, name, n, K, dtype, runs, out), world)
     return torch.load(out)
 
 

@@ -48,6 +48,19 @@ def _free_port():
     return p
 
 
+def spawn_ranks(fn, args_of_port, nprocs):
+    """mp.spawn with a fresh rendezvous port; a port that was free when looked up can be taken by the time the
+    TCPStore listens on it (many spawns in a row): try again with another one instead of failing the test."""
+    for attempt in range(4):
+        try:
+            mp.spawn(fn, args=args_of_port(_free_port()), nprocs=nprocs, join=True)
+            return
+        except Exception as e:   # ProcessRaisedException carries the child's traceback as text
+            if "EADDRINUSE" in str(e) and attempt < 3:
+                continue
+            raise
+
+
 def _worker(rank, world, port, name, n, K, dtype, out):
     import sys
     here = os.path.dirname(os.path.abspath(__file__))
@@ -86,7 +99,7 @@ def _worker(rank, world, port, name, n, K, dtype, out):
 def test_slab_driver_two_ranks_matches_oracle(name, tmp_path):
     n, K, dtype = (12, 9, 10), 7, "double"
     out = str(tmp_path / "x.pt")
-    mp.spawn(_worker, args=(2, _free_port(), name, n, K, dtype, out), nprocs=2, join=True)
+    spawn_ranks(_worker, lambda port: (2, port, name, n, K, dtype, out), 2)
     res = torch.load(out)
     mesh = O.OMesh([0, 0, 0], [1, 1, 0.5], list(n), dtype)
     cfg = [{"bc_face": O.FACES[i], "bc_type": t, "bc_val": v} for i, (t, v) in enumerate(CASES[name])]
