@@ -107,22 +107,21 @@ __global__ void __launch_bounds__(256) k_sf(Cg3dArgs<T> A) {
   T cPj[RJ], cCj[RJ], cMj[RJ];     // Laplacian rows along j (uniform per row)
   T gPj[RJ], gCj[RJ], gMj[RJ];     // gradient rows along j
   bool rPLo[RJ], rPHi[RJ];
-  // BCL comes in two forms, by what the register allocator makes of them (measured, us per step, classic -> BCL):
-  //   PATCH  (fp64)  the loaded boundary values are replaced in registers, the stencil body is untouched: VGPRs as the
-  //                  plain kernel (156 / 236); 256^3 66 -> 54.  In fp32 the same costs 40 VGPRs (single components of
-  //                  packed rows) and is SLOWER than the classic sequence (256^3 35 -> 41, 128^3 16 -> 24).
-  //   SUBST  (fp32)  the stencil's outer operand is replaced where it is read: 171 / 248 VGPRs (158 / 233 plain -- three
-  //                  registers too many for a third wave per SIMD with two rows; forcing it spills);
-  //                  256^3 34.8 -> 33.3, 128^3 16 -> 11.2, 512^3 250 -> 221.
-  constexpr bool PATCH = BCL && sizeof(T) == 8, SUBST = BCL && !PATCH;
+  // BCL, by what the register allocator makes of it (measured, us per step, classic -> BCL).  Faces normal to the
+  // march axis and to j are whole ROWS of a wave: their fill values replace the loaded rows in registers, under a
+  // wave-uniform branch, and the stencil body is untouched (PATCH_IJ, both precisions).  The two k-face cells of a row:
+  //   PATCH_K (fp64)  replaced in the row's registers as well: VGPRs as the plain kernel (156 / 236); 256^3 66 -> 54.
+  //   SUBST_K (fp32)  single components of packed rows do not patch cheaply (+40 VGPRs, slower than the classic
+  //                   sequence: 256^3 35 -> 41) -- the stencil's k - 1 / k + 1 operand of cells 1 / n2 - 2 is replaced
+  //                   where it is read instead (one select per row when no k face is a Neumann face).
+  //   (round 3, first form: every face substituted at the operand, fp32 -- 171 / 248 VGPRs, 706 v_readlane of spilled
+  //   SGPRs, 6,100 instructions against 2,800 for the plain kernel; 256^3 34.8 -> 33.3)
+  constexpr bool PATCH = BCL, PATCH_K = BCL && sizeof(T) == 8, SUBST = BCL && !PATCH_K;
   bool rTop[RJ];                    // PATCH: the row is the upper j face (its value is formed from the two rows below)
-  bool rBLo[RJ], rBHi[RJ];          // SUBST: row 1 / n1 - 2 of an axis whose face has a BC
 #pragma unroll
   for (int jj = 0; jj < RJ; ++jj) {
     const int jg = j0 + jj;
     rTop[jj] = PATCH && jg == n1 - 1 && A.bcl_type[3] != 0;
-    rBLo[jj] = SUBST && jg == 1 && A.bcl_type[2] != 0;
-    rBHi[jj] = SUBST && jg == n1 - 2 && A.bcl_type[3] != 0;
     const unsigned ro = (unsigned)wrap(jg, n1) * (unsigned)n2;
     off[jj] = (ro + (unsigned)kc) * (unsigned)sizeof(T);
     offe[jj] = (ro + (unsigned)ecol) * (unsigned)sizeof(T);
@@ -284,6 +283,7 @@ __global__ void __launch_bounds__(256) k_sf(Cg3dArgs<T> A) {
     const bool iBHi_ = BCL && gi == G.g0 - 2 && A.bcl_type[1] != 0;
     char* const po = (char*)A.out + (size_t)ii * pstride;
     if constexpr (PATCH) {
+      if constexpr (PATCH_K) {
 #pragma unroll
       for (int jj = 0; jj < RJ; ++jj) {   // k faces of the current plane's rows
         V& r = P[SC][jj];
@@ -306,6 +306,7 @@ __global__ void __launch_bounds__(256) k_sf(Cg3dArgs<T> A) {
         hi = A.bcl_type[5] == 1 ? A.bcl_val[5] : hi;
         r[0] = cBLo ? lo : r[0];
         r[VEC - 1] = cBHi ? hi : r[VEC - 1];
+      }
       }
       if (jBot) P[SC][0] = bcvV(2, P[SC][RJ > 1 ? 1 : 0], RJ > 2 ? P[SC][RJ > 2 ? 2 : 0] : Hd[HC]);   // row 0 from rows 1, 2
 #pragma unroll
@@ -342,15 +343,6 @@ __global__ void __launch_bounds__(256) k_sf(Cg3dArgs<T> A) {
       V up, dn;   // rows j-1 / j+1
       if (jj > 0) up = P[SC][jj - 1]; else up = Hu[HC];
       if (jj < RJ - 1) dn = P[SC][jj + 1]; else dn = Hd[HC];
-      if constexpr (SUBST) {   // planes 1 / n0 - 2 and rows 1 / n1 - 2: the outer operand is the face's fill value
-        if (!PLAIN) {
-          if (iBLo_) xmi = bcvV(0, xc, P[SA][jj]);
-          if (iBHi_) xpi = bcvV(1, xc, P[SB][jj]);
-        }
-        const V up0 = up, dn0 = dn;
-        if (rBLo[jj]) up = bcvV(2, xc, dn0);
-        if (rBHi[jj]) dn = bcvV(3, xc, up0);
-      }
       // k-1 / k+1: inside the lane's vector, across lanes by DPP (lane 0 / 63 keep the tile's edge cell)
       V xpk, xmk;
       const T edge = He[HC][jj];
@@ -514,7 +506,7 @@ __global__ void __launch_bounds__(256) k_sf(Cg3dArgs<T> A) {
       }
     }
     };   // body
-    if (rci != 0 || iPLo_ || iPHi_ || (SUBST && (iBLo_ || iBHi_))) body(std::false_type{}); else body(std::true_type{});
+    if (rci != 0 || iPLo_ || iPHi_) body(std::false_type{}); else body(std::true_type{});
   };
 
   for (int q = 0; q < CI; q += 4) {
@@ -590,7 +582,7 @@ static int launch_sf_any(pa_ctx* c, Cg3dArgs<T>& A) {
   }
   if constexpr (PHASE == 3 && KIND == PA_OP_DIV_UPWIND) {   // BC on load: the upwind march (BASELINE config 4)
     if (A.bcl_type[0] | A.bcl_type[1] | A.bcl_type[2] | A.bcl_type[3] | A.bcl_type[4] | A.bcl_type[5]) {
-      if (rj < 2 || (sizeof(T) == 8 && (c->G.n1 - 1) % rj == 0)) return 0;   // PATCH: rows n1 - 2, n1 - 1 in one wave's block
+      if (rj < 2 || (c->G.n1 - 1) % rj == 0) return 0;   // PATCH: rows n1 - 2, n1 - 1 in one wave's block
       if (A.aux) return rj == 2 ? launch_sf<T, 2, 3, KIND, true, true>(c, A) : launch_sf<T, 4, 3, KIND, true, true>(c, A);
       return rj == 2 ? launch_sf<T, 2, 3, KIND, false, true>(c, A) : launch_sf<T, 4, 3, KIND, false, true>(c, A);
     }
