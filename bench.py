@@ -230,6 +230,25 @@ def euler_params(dx, u=1.0, nu=1e-3):
     return nu, 0.2 * min(dx * dx / (6 * nu), dx / abs(u))
 
 
+def host_mem_available() -> int:
+    """Bytes of host memory this process may still take: MemAvailable, capped by the cgroup limit."""
+    avail = 0
+    try:
+        for ln in open("/proc/meminfo"):
+            if ln.startswith("MemAvailable:"):
+                avail = int(ln.split()[1]) * 1024
+    except Exception:
+        pass
+    try:
+        lim = open("/sys/fs/cgroup/memory.max").read().strip()
+        if lim != "max":
+            cur = int(open("/sys/fs/cgroup/memory.current").read().strip())
+            avail = min(avail, max(0, int(lim) - cur)) if avail else max(0, int(lim) - cur)
+    except Exception:
+        pass
+    return avail
+
+
 def host_cores() -> int:
     """CPUs this process may actually use: min(os.cpu_count(), affinity, cgroup cpu.max quota)."""
     n = os.cpu_count() or 1
@@ -335,6 +354,20 @@ def cpu_baseline(solver, kind, dtype, gn):
         if solver == "cg":
             n = [min(256, gn[0]), min(256, gn[1]), min(256, gn[2] if kind != "mixed" else 128)]
             its = 24
+            why = ""
+            cells_full = gn[0] * gn[1] * gn[2]
+            if list(n) != list(gn):
+                # The literal algorithm holds ~34 arrays (15 coefficient tables, rolled copies, r / d / Ad / x / x_old):
+                # 34 GiB at 512^3 fp64.  Run the FULL size when the host has the memory for it and an iteration is
+                # short enough for a bounded sample (3 iterations, ~10 s each on 16 threads); else say why not.
+                need = 34 * cells_full * (8 if dtype == "double" else 4)
+                avail = host_mem_available()
+                per_it = cells_full / (1.4e7 * max(1, cores) / 16.0)
+                if os.environ.get("BENCH_CPU_FULL", "1") != "0" and avail >= 1.5 * need and 3 * per_it <= 45.0:
+                    n, its = list(gn), 3
+                else:
+                    why = (f" (full size {'x'.join(map(str, gn))} not run: needs ~{need / 2**30:.0f} GiB of host memory "
+                           f"[{avail / 2**30:.0f} GiB available] and ~{per_it:.0f} s per iteration)")
             up = [1.0, 1.0, 0.5 if kind == "mixed" else 1.0]
             mesh = O.OMesh([0, 0, 0], up, n, dtype)
             bcs = O.make_bcs(mesh, oracle_cfg(O, kind))
@@ -347,7 +380,7 @@ def cpu_baseline(solver, kind, dtype, gn):
             t0 = time.perf_counter()
             _, rep = O.cg(x, rhs, terms, mesh, bcs, -1.0, its - 1)
             dt = time.perf_counter() - t0
-            steps, what = rep["itr"], "CG iterations"
+            steps, what = rep["itr"], "CG iterations" + why
         elif solver in ("euler", "euler_t"):
             n = [min(256, v) for v in gn]
             mesh = O.OMesh([0, 0, 0], [1, 1, 1], n, dtype)
@@ -375,6 +408,11 @@ def cpu_baseline(solver, kind, dtype, gn):
     cells = 1
     for v in n:
         cells *= v
+    try:
+        import resource
+        log(f"cpu_baseline: done in {dt:.1f} s; peak host RSS of this process {resource.getrusage(resource.RUSAGE_SELF).ru_maxrss / 2**20:.1f} GiB")
+    except Exception:
+        pass
     return {"value": cells * steps / dt, "unit": "cell-updates*iters/s", "cores": cores, "kind": "port",
             "sample": f"oracle (torch-CPU literal restatement of the reference algorithm), {'x'.join(map(str, n))} {dtype} "
                       f"{kind} BCs, same synthetic input family as the GPU leg, {steps} {what}, {dt:.1f} s"}

@@ -158,6 +158,23 @@ def main():
              ("jacobi 2-D 128x128 f64 dirichlet (config 1)", m2(128), poisson_bcs(2), "jacobi", 1000, 3, poisson_rhs_nd),
              ("cg 2-D 128x128 f64 dirichlet (config 1 inputs)", m2(128), poisson_bcs(2), "cg", 271, 10, poisson_rhs_nd),
              ("bicgstab 2-D 128x128 f64 dirichlet (config 1 inputs)", m2(128), poisson_bcs(2), "bicgstab", 100, 22, poisson_rhs_nd)]
+    # the reference's own solver tests at their sizes: x-periodic 101^2 (tests/test_solver.py:164-207) and the
+    # axisymmetric 101^2 Poisson problem (tests/test_solver.py:309-358; round 3: the resident solver's lean stencil
+    # takes the r rows from an LDS copy of pa_coord_set's table)
+    from pyapes_amd.geometry import Cylinder
+    from pyapes_amd.testing.poisson import poisson_rz_bcs, poisson_rz_rhs
+    from pyapes_amd.variables.bcs import CylinderBoundary
+    rzc = poisson_rz_bcs()
+    rz_bcs = CylinderBoundary(rl={"bc_type": "neumann", "bc_val": 0.0}, ru={"bc_type": "dirichlet", "bc_val": rzc[1]["bc_val"]},
+                              zl={"bc_type": "dirichlet", "bc_val": rzc[2]["bc_val"]},
+                              zu={"bc_type": "dirichlet", "bc_val": rzc[3]["bc_val"]})()
+    mrz = lambda: Mesh(Cylinder[0:1, 0:1], None, [101, 101], "cuda", "double")
+    xper = mixed_bcs([None, None, 0, 0], ["periodic", "periodic", "dirichlet", "dirichlet"])
+    small += [("bicgstab 2-D 101x101 f64 x-periodic / y-dirichlet (the reference's test_poisson_2d_mixed_periodic)", m2(101), xper,
+               "bicgstab", 100, 22, None),
+              ("bicgstab axisymmetric (rz) 101x101 f64 (the reference's test_poisson_rz)", mrz, rz_bcs, "bicgstab", 100, 22,
+               poisson_rz_rhs),
+              ("cg axisymmetric (rz) 101x101 f64", mrz, rz_bcs, "cg", 100, 10, poisson_rz_rhs)]
     for nn in (32, 64):
         for meth, its, passes in (("jacobi", 200, 3), ("cg", 60, 10), ("bicgstab", 40, 22)):
             small.append((f"{meth} 3-D {nn}^3 f64 dirichlet/neumann faces (BC fill every iteration)", m3(nn), mixbc, meth, its,

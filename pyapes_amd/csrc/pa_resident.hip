@@ -73,6 +73,8 @@ struct ResArgs {
   unsigned spin_max;
   unsigned o_h, o_p1, o_p2, o_bcc, o_sh, o_meta, o_lists;   // LDS byte offsets: haloed array, two plain arrays, BC constants, shell, per-cell words, work lists
   unsigned o_h2, o_h3, o_p3;   // BiCGSTAB: two more haloed arrays, one more plain one
+  unsigned o_rz;               // LEAN on an rz mesh: the box's rows of the r-dependent coefficient table, [3][bmax[1]]
+  int rz_on;
 };
 
 template <typename T>
@@ -279,6 +281,11 @@ __global__ void __launch_bounds__(NT) k_resident(DevGeom G, DevEq<T> E, ResArgs<
   T* bcc = (T*)(smem + A.o_bcc);    // [6 list slots][nface]
   T* shold = (T*)(smem + A.o_sh);   // [6 faces][nface]
   unsigned* meta = (unsigned*)(smem + A.o_meta);
+  // LEAN on an axisymmetric mesh: the r-dependent rows (cP, cM, cB of pa_apply_terms; tools.py:86-107) of this box's
+  // r range, read once from the table of pa_coord_set
+  T* const rzl = (T*)(smem + A.o_rz);
+  const int rzs = A.bmax[1];
+  const bool rz_on = LEAN && A.rz_on != 0;
   // work lists of the per-iteration face loops, dense by (face, q) with uniform bases (built once below):
   //   BC fill: index of the face node in X, in list order per BC slot (bcc in the same order)
   //   shell:   index in X of the shell nodes this box owns (0xffff: owned by another face), shold in the same order
@@ -333,6 +340,13 @@ __global__ void __launch_bounds__(NT) k_resident(DevGeom G, DevEq<T> E, ResArgs<
   }
 
   // ---- load ---------------------------------------------------------------------------------------
+  if (rz_on) {
+    for (int j = tid; j < b1; j += NT) {
+      rzl[j] = E.rz[lo1 + j];
+      rzl[rzs + j] = E.rz[E.rz_n + lo1 + j];
+      rzl[2 * rzs + j] = E.rz[2 * E.rz_n + lo1 + j];
+    }
+  }
   for (int c = tid; c < nbox; c += NT) {
     int bi, bj, bk;
     decode(c, bi, bj, bk);
@@ -485,16 +499,24 @@ __global__ void __launch_bounds__(NT) k_resident(DevGeom G, DevEq<T> E, ResArgs<
     if (LEAN) {
       const int hx = RES_M_H(m);
       T ax = (T)0;
+      T rP = E.lap.inv[1], rM = E.lap.inv[1], rB = E.lap.c23[1];   // axis 1: r on an rz mesh
+      if (rz_on) {
+        int bi, bj, bk;
+        decode(c, bi, bj, bk);
+        rP = rzl[bj];
+        rM = rzl[rzs + bj];
+        rB = rzl[2 * rzs + bj];
+      }
       if ((m >> 26) == 0u) {   // no boundary row on any axis (almost every cell): the plain (1, -2, 1) / h^2 rows
 #pragma unroll
         for (int a = 0; a < 3; ++a) {
           if (!G.act[a]) continue;
           const int st = a == 0 ? hs0 : (a == 1 ? hs1 : 1);
           const T xp = Hp[hx + st], xm = Hp[hx - st];
-          T s = E.lap.inv[a] * xp;
+          T s = (a == 1 ? rP : E.lap.inv[a]) * xp;
           T mm = E.lap.m2inv[a] * xc;
           s = s + mm;
-          mm = E.lap.inv[a] * xm;
+          mm = (a == 1 ? rM : E.lap.inv[a]) * xm;
           s = s + mm;
           ax = ax + s;
         }
@@ -507,8 +529,8 @@ __global__ void __launch_bounds__(NT) k_resident(DevGeom G, DevEq<T> E, ResArgs<
         if (!G.act[a]) continue;
         const int st = a == 0 ? hs0 : (a == 1 ? hs1 : 1);
         const int rc = RES_M_RC(m, a);
-        const T cB = E.lap.c23[a];
-        T cP = E.lap.inv[a], cC = E.lap.m2inv[a], cM = E.lap.inv[a];
+        const T cB = a == 1 ? rB : E.lap.c23[a];
+        T cP = a == 1 ? rP : E.lap.inv[a], cC = E.lap.m2inv[a], cM = a == 1 ? rM : E.lap.inv[a];
         if (rc == 1) { cP = cB; cC = -cB; cM = (T)0; }
         if (rc == 2) { cP = (T)0; cC = -cB; cM = cB; }
         const T xp = Hp[hx + st], xm = Hp[hx - st];
@@ -936,6 +958,11 @@ __global__ void __launch_bounds__(NT) k_resident(DevGeom G, DevEq<T> E, ResArgs<
                 decode(c, bi, bj, bk);
                 cB = E.rz[2 * E.rz_n + LO(1) + bj];
               }
+              if (rz_on && a == PA_RZ_AXIS) {
+                int bi, bj, bk;
+                decode(c, bi, bj, bk);
+                cB = rzl[2 * rzs + bj];
+              }
               T cC = (rc == 1 || rc == 2) ? -cB : E.lap.m2inv[a];
               dg = dg + cC;
             }
@@ -1007,7 +1034,7 @@ __global__ void __launch_bounds__(NT) k_resident(DevGeom G, DevEq<T> E, ResArgs<
 // ---- host side ------------------------------------------------------------------------------------------
 struct ResPlan {
   int P[3], bmax[3], nface, G;
-  unsigned o_h, o_p1, o_p2, o_bcc, o_sh, o_meta, o_lists, o_h2, o_h3, o_p3, lds;
+  unsigned o_h, o_p1, o_p2, o_bcc, o_sh, o_meta, o_lists, o_h2, o_h3, o_p3, o_rz, lds;
   int cells;
 };
 
@@ -1051,6 +1078,8 @@ static bool res_plan(const pa_ctx* c, size_t es, int solver, ResPlan& R) {
     R.o_sh = (unsigned)o;  o += up((size_t)6 * nface * es);
     R.o_meta = (unsigned)o; o += up((size_t)cells * sizeof(unsigned));
     R.o_lists = (unsigned)o; o += up((size_t)6 * nface * (5 * sizeof(unsigned short) + sizeof(unsigned)));
+    R.o_rz = (unsigned)o;
+    if (c->coord != PA_COORD_XYZ) o += up((size_t)3 * b[1] * es);   // LEAN on an rz mesh: coefficient rows of the box
     // (the per-cell word has 13 bits for the haloed index, 12 for the plain one)
     const bool fits = cells <= maxbox && halo <= 8192 && o <= RES_LDS_LIMIT;
     auto accept = [&]() {
@@ -1092,7 +1121,11 @@ int pa_resident_launch(pa_ctx* c, int solver, T* x, const T* rhs, double tol, in
   if (!res_applicable(c)) return 0;
   ResPlan R;
   if (!res_plan(c, sizeof(T), solver, R)) return 0;
-  const bool lean = c->nterms == 1 && c->terms[0].kind == PA_OP_LAPLACIAN && c->coord == PA_COORD_XYZ;
+  // LEAN: one Laplacian term with a scalar coefficient -- on an xyz mesh, or on an axisymmetric one (the r axis takes
+  // its rows from the table of pa_coord_set, staged in LDS)
+  const char* rzl_env = getenv("PYAPES_HIP_RES_RZLEAN");   // 0: pa_apply_terms on the box, as before round 3 (tests)
+  const bool rz_lean = c->coord != PA_COORD_XYZ && c->rz_tab && !(rzl_env && atoi(rzl_env) == 0);
+  const bool lean = c->nterms == 1 && c->terms[0].kind == PA_OP_LAPLACIAN && (c->coord == PA_COORD_XYZ || rz_lean);
   // threads per workgroup: more waves hide the LDS latency of the cell passes once a thread has several cells;
   // the general-equation build needs more registers than 512 / 1024 threads leave
   int nt = 256;
@@ -1177,6 +1210,8 @@ int pa_resident_launch(pa_ctx* c, int solver, T* x, const T* rhs, double tol, in
   if (const char* e = getenv("PYAPES_HIP_RES_SPIN")) A.spin_max = (unsigned)atoi(e);   // tests: 0 = every wait gives up
   A.o_h = R.o_h; A.o_p1 = R.o_p1; A.o_p2 = R.o_p2; A.o_bcc = R.o_bcc; A.o_sh = R.o_sh; A.o_meta = R.o_meta; A.o_lists = R.o_lists;
   A.o_h2 = R.o_h2; A.o_h3 = R.o_h3; A.o_p3 = R.o_p3;
+  A.o_rz = R.o_rz;
+  A.rz_on = (lean && c->coord != PA_COORD_XYZ) ? 1 : 0;
   DevGeom G = c->G;
   DevEq<T> E;
   pa_build_eq<T>(c, c->nterms, c->terms, E);

@@ -106,3 +106,37 @@ def test_rz_mesh_rules():
     with pytest.raises(IndexError):   # edge=True Div of a scalar field: 1-D only, like the reference
         v = Field("q", 1, mesh, {"domain": None, "obstacle": None})
         FDC({"div": {"limiter": "none", "edge": True}}).div(1.0, v)
+
+
+@pytest.mark.parametrize("method", ["jacobi", "cg", "bicgstab"])
+@pytest.mark.parametrize("dtype", ["double", "single"])
+def test_rz_resident_lean_path_matches_the_generic_term_evaluation(method, dtype, monkeypatch):
+    """Round 3: the resident solver's LEAN stencil on axisymmetric meshes (the r rows of pa_coord_set's table staged in
+    LDS) against pa_apply_terms on the box (PYAPES_HIP_RES_RZLEAN=0) and the launch-per-phase kernels: the same
+    arithmetic per node, so Jacobi is bit-identical and CG / BiCGSTAB agree to rounding with identical counts."""
+    from pyapes_amd.hip.context import context_for
+    n = (37, 45)
+    cfg = O.mixed_cfg([0.0, 1.0, 0.3, 0.5], ["neumann", "dirichlet", "dirichlet", "neumann"], O.FACES_RZ)
+    pcfg = [dict(c, bc_val_opt=None) for c in cfg]
+    g = torch.Generator().manual_seed(5)
+    rhs = torch.randn((1, *n), generator=g, dtype=torch.float64)
+    out = {}
+    for name, env in (("lean", {"PYAPES_HIP_RESIDENT": "1", "PYAPES_HIP_RES_RZLEAN": "1"}),
+                      ("terms", {"PYAPES_HIP_RESIDENT": "1", "PYAPES_HIP_RES_RZLEAN": "0"}),
+                      ("launch", {"PYAPES_HIP_RESIDENT": "0"})):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        mesh = Mesh(Cylinder([0.0, 0.0], [1.0, 1.5]), None, list(n), "cuda", dtype)
+        var = Field("p", 1, mesh, {"domain": pcfg, "obstacle": None})
+        s = Solver({"fdm": {"method": method, "tol": -1.0, "max_it": 24, "report": False}})
+        s.set_eq(FDM().laplacian(0.9, var) == rhs.to(mesh.dtype.float).cuda().clone())
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            rep = s.solve()
+        out[name] = (var().cpu().double(), rep["itr"], context_for(mesh).resident_used())
+    assert out["lean"][2] > 0 and out["terms"][2] > 0 and out["launch"][2] == 0
+    assert out["lean"][1] == out["terms"][1] == out["launch"][1] == 25
+    tol = 0.0 if method == "jacobi" else (1e-12 if dtype == "double" else 2e-5)
+    for other in ("terms", "launch"):
+        err = rel_err(out["lean"][0], out[other][0])
+        assert err <= tol, (other, err)
