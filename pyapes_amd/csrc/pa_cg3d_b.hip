@@ -25,6 +25,29 @@ int pa_tile3d_bicg_pv(pa_ctx* c, const DevEq<T>& E, Vec<T> r, Vec<T> p, Vec<T> v
   return n;
 }
 
+// the same phase when p' already exists (k_bicg_x formed it, pa_solver.hip): v' = A p' on the interior set, r0 . v'
+template <typename T>
+int pa_tile3d_bicg_v(pa_ctx* c, const DevEq<T>& E, Vec<T> p, const T* r0, T* vnew, double* partials) {
+  const int mode = cg3d_mode<T>(c, E, {p.p, r0, vnew, p.glo, p.ghi}, true);
+  if (!mode) return 0;
+  Cg3dArgs<T> A;
+  memset(&A, 0, sizeof(A));
+  fill_common<T>(c, E, A);
+  A.d = p; A.aux = r0; A.out2 = vnew; A.partials = partials;
+  if (c->fold_b_n > 0) {  // close the previous iteration in this kernel's prologue (next state -> the other slot)
+    A.pre_part = c->fold_b_part;
+    A.pre_n = c->fold_b_n;
+    A.sc_w = c->sc_alt;
+  }
+  int n = launch_any<T, 8>(c, A, mode);
+  if (n > 0 && hipGetLastError() != hipSuccess) { pa_set_err(c, "k_cg3d BiCGSTAB v launch failed"); return PA_E_HIP; }
+  if (n > 0 && c->fold_b_n > 0) {
+    SolverScalars* t = c->sc; c->sc = c->sc_alt; c->sc_alt = t;
+    c->fold_b_n = 0;
+  }
+  return n;
+}
+
 template <typename T>
 int pa_tile3d_bicg_st(pa_ctx* c, const DevEq<T>& E, Vec<T> r, Vec<T> v, const T* r0, T* s_out, T* t_out,
                       double* partials) {
@@ -46,5 +69,7 @@ int pa_tile3d_bicg_st(pa_ctx* c, const DevEq<T>& E, Vec<T> r, Vec<T> v, const T*
 
 template int pa_tile3d_bicg_pv<float>(pa_ctx*, const DevEq<float>&, Vec<float>, Vec<float>, Vec<float>, const float*, float*, float*, double*);
 template int pa_tile3d_bicg_pv<double>(pa_ctx*, const DevEq<double>&, Vec<double>, Vec<double>, Vec<double>, const double*, double*, double*, double*);
+template int pa_tile3d_bicg_v<float>(pa_ctx*, const DevEq<float>&, Vec<float>, const float*, float*, double*);
+template int pa_tile3d_bicg_v<double>(pa_ctx*, const DevEq<double>&, Vec<double>, const double*, double*, double*);
 template int pa_tile3d_bicg_st<float>(pa_ctx*, const DevEq<float>&, Vec<float>, Vec<float>, const float*, float*, float*, double*);
 template int pa_tile3d_bicg_st<double>(pa_ctx*, const DevEq<double>&, Vec<double>, Vec<double>, const double*, double*, double*, double*);

@@ -121,7 +121,7 @@ __global__ void __launch_bounds__(256) k_cg3d(Cg3dArgs<T> A) {
   constexpr int TJ = 4 * RJ, TK = 64 * VEC, TKP = TK + 2 * VEC;
   __shared__ __attribute__((aligned(16))) T tile[2][TJ + 2][TKP];
 
-  (void)sizeof(int[PHASE >= 0 && PHASE <= 7 ? 1 : -1]);
+  (void)sizeof(int[PHASE >= 0 && PHASE <= 8 ? 1 : -1]);
   T beta = (T)0, alpha = (T)0;
   T omega = (T)0;
   const DevGeom& G = A.G;
@@ -384,7 +384,7 @@ __global__ void __launch_bounds__(256) k_cg3d(Cg3dArgs<T> A) {
     }
     __syncthreads();
     alpha = (T)pre_sm[4];
-  } else if (PHASE == 5 && A.pre_n > 0) {
+  } else if ((PHASE == 5 || PHASE == 8) && A.pre_n > 0) {
     // BiCGSTAB: the step that closes the PREVIOUS iteration (k_bicg_post stage 3; linalg.py:212-214,
     // 236-262): early exit, stop test 2, next beta, rho <- rho_next.  Next state -> the other slot.
     __shared__ double pre_sm[8];
@@ -557,7 +557,7 @@ __global__ void __launch_bounds__(256) k_cg3d(Cg3dArgs<T> A) {
       for (int jj = 0; jj < RJ; ++jj)
         cv[jj] = *reinterpret_cast<const V*>(A.coeff_f + ii * G.s0 + jrow[jj] * G.s1 + kc);
     }
-    if (PHASE == 4 || PHASE == 5 || PHASE == 6 || ((PHASE == 3 || (PHASE == 2 && KIND != 0)) && A.aux)) {  // rhs / u / r0 of this plane
+    if (PHASE == 4 || PHASE == 5 || PHASE == 6 || PHASE == 8 || ((PHASE == 3 || (PHASE == 2 && KIND != 0)) && A.aux)) {  // rhs / u / r0 of this plane
 #pragma unroll
       for (int jj = 0; jj < RJ; ++jj)
         xv[jj] = *reinterpret_cast<const V*>(A.aux + ii * G.s0 + jrow[jj] * G.s1 + kc);
@@ -829,14 +829,14 @@ __global__ void __launch_bounds__(256) k_cg3d(Cg3dArgs<T> A) {
       for (int v = 0; v < VEC; ++v) {
         const bool inS = iS && (rowS >> jj & 1) && (colS >> v & 1);
         const T xc = ec[jj][v];
-        if (PHASE == 5 || PHASE == 6) {
+        if (PHASE == 5 || PHASE == 6 || PHASE == 8) {
           // own cells: p' (or s) everywhere, v' = A p' (or t = A s) on the interior set
           const bool mine = kvalid && (rowValid >> jj & 1);
           const T an = inS ? res[jj][v] : (T)0;
           outd[v] = xc;
           outx[v] = an;
           const T r0c = xv[jj][v];
-          if (PHASE == 5) {
+          if (PHASE == 5 || PHASE == 8) {
             T p = r0c * an;
             s0 += inS ? (double)p : 0.0;
           } else {
@@ -883,7 +883,9 @@ __global__ void __launch_bounds__(256) k_cg3d(Cg3dArgs<T> A) {
       }
       if (kvalid && (rowValid >> jj & 1)) {
         const int64_t o = ii * G.s0 + jrow[jj] * G.s1 + kc;
-        if (PHASE == 5 || PHASE == 6) {
+        if (PHASE == 8) {   // p' is the input field itself (k_bicg_x formed it): only v' = A p' leaves
+          *reinterpret_cast<V*>(A.out2 + o) = outx;
+        } else if (PHASE == 5 || PHASE == 6) {   // (non-temporal r0 loads / p, v, s, t stores: within the noise, A/B)
           *reinterpret_cast<V*>(A.out + o) = outd;
           *reinterpret_cast<V*>(A.out2 + o) = outx;
         } else if (PHASE >= 2) {
@@ -931,7 +933,7 @@ __global__ void __launch_bounds__(256) k_cg3d(Cg3dArgs<T> A) {
   } else if (PHASE == 1 || PHASE == 4) {
     double s[2] = {s0, s1};
     pa_block_reduce_store<2>(s, A.partials);
-  } else if (PHASE == 5) {
+  } else if (PHASE == 5 || PHASE == 8) {
     double s[1] = {s0};
     pa_block_reduce_store<1>(s, A.partials);
   } else if (PHASE == 6) {
@@ -1116,7 +1118,7 @@ static int launch_any_w(pa_ctx* c, Cg3dArgs<T>& A) {
     }
 #undef PA_EULER_CASE
   }
-  if constexpr (PHASE == 2 || PHASE == 5 || PHASE == 6) {
+  if constexpr (PHASE == 2 || PHASE == 5 || PHASE == 6 || PHASE == 8) {
     if (A.kind != 0) {  // Laplacian + Div(scalar u): one instantiation per scheme, two or four rows per thread
       const bool four = pick_rj<T>(c, NARROW == 1) == 4;
 #define PA_DIV_CASE(K)                                                                   \

@@ -224,5 +224,7 @@ template <typename T>
 int pa_tile3d_bicg_pv(pa_ctx* c, const DevEq<T>& E, Vec<T> r, Vec<T> p, Vec<T> v, const T* r0, T* pnew, T* vnew,
                       double* partials);
 template <typename T>
+int pa_tile3d_bicg_v(pa_ctx* c, const DevEq<T>& E, Vec<T> p, const T* r0, T* vnew, double* partials);
+template <typename T>
 int pa_tile3d_bicg_st(pa_ctx* c, const DevEq<T>& E, Vec<T> r, Vec<T> v, const T* r0, T* s_out, T* t_out,
                       double* partials);

@@ -118,6 +118,11 @@ __device__ __forceinline__ bool res_grid_wait(ResSync& S) {
     // still below the step's target.  Either every arrival is in before anybody gives up (all pass) or the poison
     // is in before the last arrival (nobody passes, now or in any later step).
     const unsigned long long RES_POISON = 1ull << 62;
+    // test hook (PYAPES_HIP_RES_SPIN=0, "every wait gives up"): workgroup 0 poisons the counter BEFORE it arrives, so
+    // no workgroup can ever find the step complete -- without this the outcome would hang on whether all arrivals
+    // happen to be in before the first look at the counter (seen: 8 workgroups passing every step of a solve)
+    if (S.spin_max == 0 && blockIdx.x == 0)
+      __hip_atomic_fetch_or(S.counter, RES_POISON, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __hip_atomic_fetch_add(S.counter, 1ull, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
     const unsigned long long target = (S.step + 1) * S.G;
     int good = 0;

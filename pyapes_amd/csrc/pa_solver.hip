@@ -553,15 +553,24 @@ __global__ void __launch_bounds__(PA_BLOCK) k_bicg_t(DevGeom G, DevEq<T> E, cons
 }
 
 // early exit: x += alpha p ; otherwise x = x + alpha p + s omega ; r = s - omega t ; |r|^2
-template <typename T>
+// VEC cells per lane and step (16-byte lane accesses where the four arrays allow them: 166 -> 1xx us at 256^3 fp64,
+// DESIGN.md section 4; 1: any alignment / cell count)
+template <typename T, int VEC>
 __global__ void __launch_bounds__(PA_BLOCK) k_bicg_x(DevGeom G, const SolverScalars* __restrict__ sc,
-                                                      T* __restrict__ x, const T* __restrict__ p,
+                                                      T* __restrict__ x, const T* p,   // (p_next may be p: in place)
                                                       const T* __restrict__ s_in, const T* __restrict__ t_in,
                                                       T* __restrict__ r, double* __restrict__ partials,
-                                                      const double* pre_part, int pre_n, SolverScalars* sc_w) {
+                                                      const double* pre_part, int pre_n, SolverScalars* sc_w,
+                                                      const T* v_in, T* p_next) {
+  // p_next != null: also the NEXT direction p'' = r_new + beta (p' - omega v') (linalg.py:217) -- beta = rho_next / rho
+  // alpha / omega is complete as soon as omega and rho_next = -omega (r0 . t) are (linalg.py:212, 246-247): the p / v
+  // phase of the next iteration then reads ONE field with a halo instead of three and stores one instead of two
+  // (v' = A p'' from the stored p'', phase 8 of k_cg3d); p'' goes unused when the stop test that follows ends the solve
   const T alpha = (T)sc->alpha;
   T omega;
   int early;
+  T beta_n = (T)0;
+  const double rho_cur = sc->rho;
   if (pre_n > 0) {
     // folded k_bicg_post stage 12 (rows {|s|^2, t.s, t.t, r0.t} of the fused s / t kernel): stop test 1,
     // then omega and rho_next -- every block on its own, same summation order; block 0 stores
@@ -596,6 +605,14 @@ __global__ void __launch_bounds__(PA_BLOCK) k_bicg_x(DevGeom G, const SolverScal
       pre_sm[16] = (double)om;
       pre_sm[17] = fe ? 1.0 : 0.0;
       pre_sm[18] = bad ? 1.0 : 0.0;
+      {   // the next beta, as the stage that closes the iteration forms it (k_bicg_post stage 3 / phase 5 prologue)
+        T rn = -om;
+        rn = rn * (T)t4[3];
+        T bq = (T)(double)rn / (T)rho_cur;
+        bq = bq * alpha;
+        bq = bq / om;
+        pre_sm[19] = (double)bq;
+      }
       if (blockIdx.x == 0) {
         sc_w->tol = (double)tol;
         if (bad) {
@@ -616,26 +633,53 @@ __global__ void __launch_bounds__(PA_BLOCK) k_bicg_x(DevGeom G, const SolverScal
     if (pre_sm[18] != 0.0) return;
     omega = (T)pre_sm[16];
     early = pre_sm[17] != 0.0;
+    beta_n = (T)pre_sm[19];
   } else {
     if (sc->done) return;
     omega = (T)sc->omega;
     early = sc->finished_early;
+    T bq = (T)sc->rho_next / (T)rho_cur;
+    bq = bq * alpha;
+    bq = bq / omega;
+    beta_n = bq;
   }
+  const bool pn = p_next != nullptr && !early;
   double s[1] = {0.0};
-  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < G.ncell;
-       idx += (int64_t)gridDim.x * blockDim.x) {
-    T ap = alpha * p[idx];
-    T xn = x[idx] + ap;
+  typedef T V __attribute__((ext_vector_type(VEC)));
+  const int64_t nvec = G.ncell / VEC;   // (the host launches VEC > 1 only for ncell % VEC == 0)
+  for (int64_t iv = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; iv < nvec; iv += (int64_t)gridDim.x * blockDim.x) {
+    const V pv = reinterpret_cast<const V*>(p)[iv];
+    const V xv = reinterpret_cast<const V*>(x)[iv];
+    V xn, rn, sv, tv, vv, pq;
     if (!early) {
-      T so = s_in[idx] * omega;
-      xn = xn + so;
-      T ot = omega * t_in[idx];
-      T rn = s_in[idx] - ot;
-      r[idx] = rn;
-      T q = rn * rn;
-      s[0] += (double)q;
+      sv = reinterpret_cast<const V*>(s_in)[iv];
+      tv = reinterpret_cast<const V*>(t_in)[iv];
     }
-    x[idx] = xn;
+    if (pn) vv = reinterpret_cast<const V*>(v_in)[iv];
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) {
+      T ap = alpha * pv[v];
+      T xq = xv[v] + ap;
+      if (!early) {
+        T so = sv[v] * omega;
+        xq = xq + so;
+        T ot = omega * tv[v];
+        T rq = sv[v] - ot;
+        rn[v] = rq;
+        T q = rq * rq;
+        s[0] += (double)q;
+        if (pn) {   // combine of k_cg3d phase 5
+          T tq = omega * vv[v];
+          tq = pv[v] - tq;
+          tq = beta_n * tq;
+          pq[v] = rq + tq;
+        }
+      }
+      xn[v] = xq;
+    }
+    if (pn) reinterpret_cast<V*>(p_next)[iv] = pq;
+    if (!early) reinterpret_cast<V*>(r)[iv] = rn;
+    reinterpret_cast<V*>(x)[iv] = xn;
   }
   pa_block_reduce_store<1>(s, partials);
 }
@@ -1420,6 +1464,11 @@ static int bicg_run_t(pa_ctx* c, T* x, const T* rhs, double tol, int64_t max_it,
   double* const reg2 = part + 5 * (size_t)PA_MAX_PARTIALS;     // |r|^2            (1 column)
   const bool fold = c->fold && !c->slab;
   int pend3 = 0;
+  // the next direction formed by k_bicg_x (one array pass less per iteration, one haloed input instead of three in the
+  // p / v phase); PYAPES_HIP_BICG_PFOLD=0: every iteration through the p / v phase, as before round 3
+  const char* pf_env = getenv("PYAPES_HIP_BICG_PFOLD");
+  const bool pfold = !(pf_env && atoi(pf_env) == 0);
+  bool pgiven = false;
   c->fold_a_n = c->fold_b_n = c->fold_b_nsh = 0;
   auto flush3 = [&]() {
     if (pend3 > 0) hipLaunchKernelGGL(k_bicg_post<T>, dim3(1), dim3(PA_BLOCK), 0, c->stream, c->sc, reg2, pend3, 3);
@@ -1441,8 +1490,14 @@ static int bicg_run_t(pa_ctx* c, T* x, const T* rhs, double tol, int64_t max_it,
     Vec<T> rv = pa_vec_self<T>(c, r), pv = pa_vec_self<T>(c, p[cur]), vv = pa_vec_self<T>(c, v[cur]);
     c->fold_b_n = pend3;          // phase 5 closes the previous iteration (and swaps the scalar slots)
     c->fold_b_part = reg2;
-    int used = pa_tile3d_bicg_pv<T>(c, E, rv, pv, vv, (const T*)r0, p[cur ^ 1], v[cur ^ 1], reg0);
+    // p' of this iteration: formed by the p / v phase into p[cur ^ 1] -- or already there, in p[cur], left by the
+    // previous iteration's k_bicg_x (`pgiven`; tiled kernels only), and the phase is v' = A p' alone
+    T* const p_it = pgiven ? p[cur] : p[cur ^ 1];
+    int used = pgiven ? pa_tile3d_bicg_v<T>(c, E, pv, (const T*)r0, v[cur ^ 1], reg0)
+                      : pa_tile3d_bicg_pv<T>(c, E, rv, pv, vv, (const T*)r0, p[cur ^ 1], v[cur ^ 1], reg0);
     if (used < 0) return used;
+    if (pgiven && used == 0) { pa_set_err(c, "pa_bicgstab: the tiled v phase declined in the middle of a solve"); return PA_E_STATE; }
+    const bool pnext = pfold && used > 0;   // the tiled kernels took this iteration: they take the next one
     if (used > 0) {
       pend3 = 0;
     } else {
@@ -1474,8 +1529,19 @@ static int bicg_run_t(pa_ctx* c, T* x, const T* rhs, double tol, int64_t max_it,
       hipLaunchKernelGGL(k_bicg_t<T>, dim3(nblk), dim3(PA_BLOCK), 0, c->stream, G, E, c->sc, sv, (const T*)r0, t, reg1);
       hipLaunchKernelGGL(k_bicg_post<T>, dim3(1), dim3(PA_BLOCK), 0, c->stream, c->sc, reg1, nblk, 2);
     }
-    hipLaunchKernelGGL(k_bicg_x<T>, dim3(nblk), dim3(PA_BLOCK), 0, c->stream, G, c->sc, x, (const T*)p[cur ^ 1],
-                       (const T*)s, (const T*)t, r, reg2, (const double*)reg1, pend12, c->sc);
+    {
+      constexpr int XV = 16 / (int)sizeof(T);
+      const bool vec = G.ncell % XV == 0 && ((((uintptr_t)x | (uintptr_t)p[cur ^ 1] | (uintptr_t)s | (uintptr_t)t | (uintptr_t)r) & 15) == 0);
+      if (vec)
+        hipLaunchKernelGGL((k_bicg_x<T, XV>), dim3(nblk), dim3(PA_BLOCK), 0, c->stream, G, c->sc, x, (const T*)p_it,
+                           (const T*)s, (const T*)t, r, reg2, (const double*)reg1, pend12, c->sc, (const T*)v[cur ^ 1],
+                           pnext ? p[cur ^ 1] : (T*)nullptr);
+      else
+        hipLaunchKernelGGL((k_bicg_x<T, 1>), dim3(nblk), dim3(PA_BLOCK), 0, c->stream, G, c->sc, x, (const T*)p_it,
+                           (const T*)s, (const T*)t, r, reg2, (const double*)reg1, pend12, c->sc, (const T*)v[cur ^ 1],
+                           pnext ? p[cur ^ 1] : (T*)nullptr);
+      pgiven = pnext;   // (p[cur ^ 1] is p[cur] of the next iteration; in place when p' came from the p / v phase)
+    }
     if ((rc = pa_bc_apply_auto<T>(c, x, true))) return rc;
     if (fold && nblk <= PA_MAX_GRID)
       pend3 = nblk;

@@ -61,8 +61,10 @@ solver.set_eq(FDM().laplacian(1.0, var) == rhs)
 rep = solver.solve()
 assert rep["converge"] and bool(torch.isfinite(var()).all()), rep
 print("axisymmetric: itr", rep["itr"], "tol", rep["tol"], "acc", float(torch.linalg.norm(torch.exp(-2.0 * mesh.Z) * (1 - mesh.R ** 2) - var()[0])))
-# the notebook's recorded output: 195 iterations, tol 8.149016007661279e-08 (BiCGSTAB: summation-order band)
-assert abs(rep["itr"] - 195) <= 20 and rep["tol"] <= 1e-7, rep
+# the notebook's recorded output: 195 iterations, tol 8.149016007661279e-08.  BiCGSTAB on this problem is summation-order
+# sensitive: the REFERENCE ALGORITHM itself (the oracle, tests/tools/axisymmetric_demo_band.py) needs 201 iterations
+# with torch.sum as it is and 200 ... 244 under 40 random orders of its dot products -- the band, with a margin
+assert 175 <= rep["itr"] <= 260 and rep["tol"] <= 1e-7, rep
 
 # ---- ss_advection_diffusion.ipynb ----------------------------------------------------------------------
 from math import exp

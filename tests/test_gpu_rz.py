@@ -135,7 +135,8 @@ def test_rz_resident_lean_path_matches_the_generic_term_evaluation(method, dtype
             rep = s.solve()
         out[name] = (var().cpu().double(), rep["itr"], context_for(mesh).resident_used())
     assert out["lean"][2] > 0 and out["terms"][2] > 0 and out["launch"][2] == 0
-    assert out["lean"][1] == out["terms"][1] == out["launch"][1] == 25
+    # max_it = 24: 25 iterations for CG / Jacobi (`itr > max_it`, Q6), 24 for BiCGSTAB (`itr >= max_it`, linalg.py:264)
+    assert out["lean"][1] == out["terms"][1] == out["launch"][1] == (24 if method == "bicgstab" else 25)
     tol = 0.0 if method == "jacobi" else (1e-12 if dtype == "double" else 2e-5)
     for other in ("terms", "launch"):
         err = rel_err(out["lean"][0], out[other][0])

@@ -77,3 +77,22 @@ def test_tiled_bicgstab(case, monkeypatch):
         assert rf["converge"] and rg["converge"], (rf, rg)
         assert abs(rf["itr"] - rg["itr"]) <= max(3, rg["itr"] // 5), (rf, rg)
         assert rel_err(xf, xg) <= 1e-7
+
+
+@pytest.mark.parametrize("case", CASES, ids=lambda c: "x".join(map(str, c[0])) + c[1][0])
+def test_next_direction_formed_by_the_x_update_changes_no_bit(case, monkeypatch):
+    """Round 3: from the second iteration on the p / v phase is v' = A p' alone (k_cg3d phase 8) -- p' was formed by the
+    previous iteration's x / r update (k_bicg_x: beta is complete as soon as omega and rho_next are, linalg.py:212,
+    246-247).  The same operations on the same operands, the same partial sums: every bit of the iterate, the
+    iteration count and the stop-test value must equal the sequence with the full p / v phase in every iteration."""
+    n, dtype, bcs = case
+    tdt = torch.float64 if dtype == "double" else torch.float32
+    g = torch.Generator().manual_seed(17)
+    rhs0 = torch.randn((1, *n), generator=g, dtype=torch.float64).to(tdt)
+    for K, tol in ((1, 1e-30), (2, 1e-30), (3, 1e-30), (12, 1e-30), (400, 1e-7 if dtype == "double" else 1e-3)):
+        monkeypatch.setenv("PYAPES_HIP_BICG_PFOLD", "1")
+        xa, ra = _run(n, dtype, bcs, rhs0, K, tol, True, monkeypatch)
+        monkeypatch.setenv("PYAPES_HIP_BICG_PFOLD", "0")
+        xb, rb = _run(n, dtype, bcs, rhs0, K, tol, True, monkeypatch)
+        assert ra["itr"] == rb["itr"] and ra["tol"] == rb["tol"], (K, ra, rb)
+        assert torch.equal(xa, xb), (K, float((xa - xb).abs().max()))
