@@ -5,11 +5,13 @@
 template <typename T>
 int pa_tile3d_bicg_pv(pa_ctx* c, const DevEq<T>& E, Vec<T> r, Vec<T> p, Vec<T> v, const T* r0, T* pnew, T* vnew,
                       double* partials) {
-  const int mode = cg3d_mode<T>(c, E, {r.p, p.p, v.p, r0, pnew, vnew, r.glo, r.ghi, p.glo, p.ghi, v.glo, v.ghi}, true);
+  // (a pitched solve, bicg_run_t: every array of these phases is the ctx's, rows padded to 128 bytes)
+  const int mode = c->cg_pitch ? 3 : cg3d_mode<T>(c, E, {r.p, p.p, v.p, r0, pnew, vnew, r.glo, r.ghi, p.glo, p.ghi, v.glo, v.ghi}, true);
   if (!mode) return 0;
   Cg3dArgs<T> A;
   memset(&A, 0, sizeof(A));
   fill_common<T>(c, E, A);
+  A.ps1 = c->cg_ps1; A.ps0 = c->cg_ps1 * c->G.n1;
   A.r = r; A.d = p; A.v = v; A.aux = r0; A.out = pnew; A.out2 = vnew; A.partials = partials;
   if (c->fold_b_n > 0) {  // close the previous iteration in this kernel's prologue (next state -> the other slot)
     A.pre_part = c->fold_b_part;
@@ -28,11 +30,12 @@ int pa_tile3d_bicg_pv(pa_ctx* c, const DevEq<T>& E, Vec<T> r, Vec<T> p, Vec<T> v
 // the same phase when p' already exists (k_bicg_x formed it, pa_solver.hip): v' = A p' on the interior set, r0 . v'
 template <typename T>
 int pa_tile3d_bicg_v(pa_ctx* c, const DevEq<T>& E, Vec<T> p, const T* r0, T* vnew, double* partials) {
-  const int mode = cg3d_mode<T>(c, E, {p.p, r0, vnew, p.glo, p.ghi}, true);
+  const int mode = c->cg_pitch ? 3 : cg3d_mode<T>(c, E, {p.p, r0, vnew, p.glo, p.ghi}, true);
   if (!mode) return 0;
   Cg3dArgs<T> A;
   memset(&A, 0, sizeof(A));
   fill_common<T>(c, E, A);
+  A.ps1 = c->cg_ps1; A.ps0 = c->cg_ps1 * c->G.n1;
   A.d = p; A.aux = r0; A.out2 = vnew; A.partials = partials;
   if (c->fold_b_n > 0) {  // close the previous iteration in this kernel's prologue (next state -> the other slot)
     A.pre_part = c->fold_b_part;
@@ -51,11 +54,12 @@ int pa_tile3d_bicg_v(pa_ctx* c, const DevEq<T>& E, Vec<T> p, const T* r0, T* vne
 template <typename T>
 int pa_tile3d_bicg_st(pa_ctx* c, const DevEq<T>& E, Vec<T> r, Vec<T> v, const T* r0, T* s_out, T* t_out,
                       double* partials) {
-  const int mode = cg3d_mode<T>(c, E, {r.p, v.p, r0, s_out, t_out, r.glo, r.ghi, v.glo, v.ghi}, true);
+  const int mode = c->cg_pitch ? 3 : cg3d_mode<T>(c, E, {r.p, v.p, r0, s_out, t_out, r.glo, r.ghi, v.glo, v.ghi}, true);
   if (!mode) return 0;
   Cg3dArgs<T> A;
   memset(&A, 0, sizeof(A));
   fill_common<T>(c, E, A);
+  A.ps1 = c->cg_ps1; A.ps0 = c->cg_ps1 * c->G.n1;
   A.r = r; A.d = v; A.aux = r0; A.out = s_out; A.out2 = t_out; A.partials = partials;
   if (c->fold_a_n > 0) {  // alpha (and the iteration count) in this kernel's prologue
     A.pre_part = (const double*)c->scr[SCR_PART];

@@ -111,11 +111,13 @@ __device__ __forceinline__ int64_t pa_wrapmod(int64_t v, int64_t n) {
 // out; the pad cells hold 0 and are written as 0), so every access to them is the aligned 16-byte lane access of
 // LAY 0.  Only x, the caller's contiguous field, is touched cell by cell: phase A is fully vector, phase B on
 // three of its five streams.  A pad cell is never a neighbour anybody uses: the last real cell of a row is a
-// boundary node of a non-periodic axis, outside the interior set.
+// boundary node of a non-periodic axis, outside the interior set.  BiCGSTAB (phases 5, 6, 8): EVERY array of these
+// phases is the ctx's (r, p, v, r0, s, t) and pitched; only the x / r update (k_bicg_x, pa_solver.hip) touches x.
 template <typename T, int RJ, int PHASE, bool CF = false, int KIND = 0, int LAY = 0>
 __global__ void __launch_bounds__(256) k_cg3d(Cg3dArgs<T> A) {
   constexpr bool NARROW = LAY == 1, PITCH = LAY == 2;
-  static_assert(!PITCH || ((PHASE == 0 || PHASE == 1) && !CF && KIND == 0), "PITCH: the CG phases of a plain Laplacian");
+  static_assert(!PITCH || ((PHASE == 0 || PHASE == 1 || PHASE == 5 || PHASE == 6 || PHASE == 8) && !CF && KIND == 0),
+                "PITCH: the CG / BiCGSTAB phases of a plain Laplacian");
   constexpr int VEC = NARROW ? 1 : VecOf<T>::N;
   typedef T V __attribute__((ext_vector_type(VEC)));
   constexpr int TJ = 4 * RJ, TK = 64 * VEC, TKP = TK + 2 * VEC;
@@ -560,7 +562,8 @@ __global__ void __launch_bounds__(256) k_cg3d(Cg3dArgs<T> A) {
     if (PHASE == 4 || PHASE == 5 || PHASE == 6 || PHASE == 8 || ((PHASE == 3 || (PHASE == 2 && KIND != 0)) && A.aux)) {  // rhs / u / r0 of this plane
 #pragma unroll
       for (int jj = 0; jj < RJ; ++jj)
-        xv[jj] = *reinterpret_cast<const V*>(A.aux + ii * G.s0 + jrow[jj] * G.s1 + kc);
+        xv[jj] = PITCH ? *reinterpret_cast<const V*>(A.aux + ii * fs0 + jrow[jj] * fs1 + kcf)   // (BiCGSTAB: r0, pitched)
+                       : *reinterpret_cast<const V*>(A.aux + ii * G.s0 + jrow[jj] * G.s1 + kc);
     }
     // loads of plane m+2 (own cells + halo): in flight during the stencil below
     if (more) issue(plane_of(m + 2), w, m + 2 < CI);
@@ -883,11 +886,12 @@ __global__ void __launch_bounds__(256) k_cg3d(Cg3dArgs<T> A) {
       }
       if (kvalid && (rowValid >> jj & 1)) {
         const int64_t o = ii * G.s0 + jrow[jj] * G.s1 + kc;
+        const int64_t ob = PITCH ? ii * fs0 + jrow[jj] * fs1 + kcf : o;   // BiCGSTAB: pitched outputs
         if (PHASE == 8) {   // p' is the input field itself (k_bicg_x formed it): only v' = A p' leaves
-          *reinterpret_cast<V*>(A.out2 + o) = outx;
+          *reinterpret_cast<V*>(A.out2 + ob) = outx;
         } else if (PHASE == 5 || PHASE == 6) {   // (non-temporal r0 loads / p, v, s, t stores: within the noise, A/B)
-          *reinterpret_cast<V*>(A.out + o) = outd;
-          *reinterpret_cast<V*>(A.out2 + o) = outx;
+          *reinterpret_cast<V*>(A.out + ob) = outd;
+          *reinterpret_cast<V*>(A.out2 + ob) = outx;
         } else if (PHASE >= 2) {
           *reinterpret_cast<V*>(A.out + o) = outd;
         } else if (PHASE == 0) {
@@ -1021,8 +1025,10 @@ static int launch_cg3d(pa_ctx* c, Cg3dArgs<T>& A) {
   // axis is a boundary node whose d', r stay 0 and whose x is left alone, so no tile needs to cover
   // it.  For the 2^k + 1 extents node-based meshes like, that removes a whole extra tile row and tile
   // column (257^2 planes: 64 instead of 85 tiles of 16 x 64).  cg_begin zeroes both direction buffers.
+  // The same holds for the BiCGSTAB phases (5, 6, 8): p, v, s, t, r are 0 outside the interior set for the whole
+  // solve (bicg_run_t zeroes every buffer these phases write before the first iteration).
   int64_t n1e = G.n1, n2e = G.n2;
-  if (PHASE == 0 || PHASE == 1) {
+  if (PHASE == 0 || PHASE == 1 || PHASE == 5 || PHASE == 6 || PHASE == 8) {
     if (G.bct[3] != PA_BC_PERIODIC && n1e > 2) n1e -= 1;
     if (G.bct[5] != PA_BC_PERIODIC && n2e > 2) n2e -= 1;
   }
@@ -1134,7 +1140,7 @@ static int launch_any_w(pa_ctx* c, Cg3dArgs<T>& A) {
 #undef PA_DIV_CASE
     }
   }
-  switch (pick_rj<T>(c, NARROW == 1, PHASE == 0 || PHASE == 1)) {
+  switch (pick_rj<T>(c, NARROW == 1, PHASE == 0 || PHASE == 1 || PHASE == 5 || PHASE == 6 || PHASE == 8)) {
     case 1: return launch_cg3d<T, 1, PHASE, false, 0, NARROW>(c, A);
     case 2: return launch_cg3d<T, 2, PHASE, false, 0, NARROW>(c, A);
     default: return launch_cg3d<T, 4, PHASE, false, 0, NARROW>(c, A);
@@ -1144,7 +1150,7 @@ static int launch_any_w(pa_ctx* c, Cg3dArgs<T>& A) {
 // the CG phases in the PITCH layout (a plain Laplacian only: the other instantiations do not exist)
 template <typename T, int PHASE>
 static int launch_pitched(pa_ctx* c, Cg3dArgs<T>& A) {
-  static_assert(PHASE == 0 || PHASE == 1, "PITCH: CG phases");
+  static_assert(PHASE == 0 || PHASE == 1 || PHASE == 5 || PHASE == 6 || PHASE == 8, "PITCH: CG / BiCGSTAB phases");
   if (A.coeff_f || A.kind != 0) return 0;
   switch (pick_rj<T>(c, false, true)) {
     case 1: return launch_cg3d<T, 1, PHASE, false, 0, 2>(c, A);
@@ -1155,7 +1161,7 @@ static int launch_pitched(pa_ctx* c, Cg3dArgs<T>& A) {
 
 template <typename T, int PHASE>
 static int launch_any(pa_ctx* c, Cg3dArgs<T>& A, int mode) {
-  if constexpr (PHASE == 0 || PHASE == 1) {
+  if constexpr (PHASE == 0 || PHASE == 1 || PHASE == 5 || PHASE == 6 || PHASE == 8) {
     if (mode == 3) return launch_pitched<T, PHASE>(c, A);
   }
   return mode == 2 ? launch_any_w<T, PHASE, 1>(c, A) : launch_any_w<T, PHASE, 0>(c, A);

@@ -555,13 +555,15 @@ __global__ void __launch_bounds__(PA_BLOCK) k_bicg_t(DevGeom G, DevEq<T> E, cons
 // early exit: x += alpha p ; otherwise x = x + alpha p + s omega ; r = s - omega t ; |r|^2
 // VEC cells per lane and step (16-byte lane accesses where the four arrays allow them: 166 -> 1xx us at 256^3 fp64,
 // DESIGN.md section 4; 1: any alignment / cell count)
-template <typename T, int VEC>
+// PITCHED (odd row lengths, bicg_run_t): p, s, t, r, v, p_next with a row pitch of ps1 cells (a multiple of the
+// vector), x contiguous and touched cell by cell; pad cells are written as 0.
+template <typename T, int VEC, bool PITCHED = false>
 __global__ void __launch_bounds__(PA_BLOCK) k_bicg_x(DevGeom G, const SolverScalars* __restrict__ sc,
                                                       T* __restrict__ x, const T* p,   // (p_next may be p: in place)
                                                       const T* __restrict__ s_in, const T* __restrict__ t_in,
                                                       T* __restrict__ r, double* __restrict__ partials,
                                                       const double* pre_part, int pre_n, SolverScalars* sc_w,
-                                                      const T* v_in, T* p_next) {
+                                                      const T* v_in, T* p_next, int64_t ps1 = 0) {
   // p_next != null: also the NEXT direction p'' = r_new + beta (p' - omega v') (linalg.py:217) -- beta = rho_next / rho
   // alpha / omega is complete as soon as omega and rho_next = -omega (r0 . t) are (linalg.py:212, 246-247): the p / v
   // phase of the next iteration then reads ONE field with a halo instead of three and stores one instead of two
@@ -646,10 +648,24 @@ __global__ void __launch_bounds__(PA_BLOCK) k_bicg_x(DevGeom G, const SolverScal
   const bool pn = p_next != nullptr && !early;
   double s[1] = {0.0};
   typedef T V __attribute__((ext_vector_type(VEC)));
-  const int64_t nvec = G.ncell / VEC;   // (the host launches VEC > 1 only for ncell % VEC == 0)
+  const unsigned nvr = PITCHED ? (unsigned)(ps1 / VEC) : 1u;   // vectors per pitched row
+  const int64_t nvec = PITCHED ? G.n0 * G.n1 * (int64_t)nvr : G.ncell / VEC;   // (VEC > 1 only for ncell % VEC == 0)
   for (int64_t iv = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; iv < nvec; iv += (int64_t)gridDim.x * blockDim.x) {
     const V pv = reinterpret_cast<const V*>(p)[iv];
-    const V xv = reinterpret_cast<const V*>(x)[iv];
+    V xv;
+    T* xrow = nullptr;      // PITCHED: the cells of this vector in the caller's contiguous x
+    int nval = VEC;         // ... and how many of them are real cells
+    if (PITCHED) {
+      const unsigned row = (unsigned)iv / nvr;
+      const int64_t col = (int64_t)((unsigned)iv - row * nvr) * VEC;
+      if (col >= G.n2) continue;   // a vector of pad cells: zero since the start of the solve, stays zero
+      xrow = x + (int64_t)row * G.n2 + col;
+      nval = (int)(G.n2 - col < VEC ? G.n2 - col : VEC);
+#pragma unroll
+      for (int v = 0; v < VEC; ++v) xv[v] = v < nval ? xrow[v] : (T)0;
+    } else {
+      xv = reinterpret_cast<const V*>(x)[iv];
+    }
     V xn, rn, sv, tv, vv, pq;
     if (!early) {
       sv = reinterpret_cast<const V*>(s_in)[iv];
@@ -673,13 +689,20 @@ __global__ void __launch_bounds__(PA_BLOCK) k_bicg_x(DevGeom G, const SolverScal
           tq = pv[v] - tq;
           tq = beta_n * tq;
           pq[v] = rq + tq;
+          if (PITCHED && v >= nval) pq[v] = (T)0;
         }
       }
       xn[v] = xq;
     }
     if (pn) reinterpret_cast<V*>(p_next)[iv] = pq;
     if (!early) reinterpret_cast<V*>(r)[iv] = rn;
-    reinterpret_cast<V*>(x)[iv] = xn;
+    if (PITCHED) {
+#pragma unroll
+      for (int v = 0; v < VEC; ++v)
+        if (v < nval) xrow[v] = xn[v];
+    } else {
+      reinterpret_cast<V*>(x)[iv] = xn;
+    }
   }
   pa_block_reduce_store<1>(s, partials);
 }
@@ -872,36 +895,39 @@ static int cg_residual_init(pa_ctx* c, const DevEq<T>& E, Vec<T> xv, const T* rh
   return PA_OK;
 }
 
+// Row pitch (cells) of the ctx-owned solver arrays when the PITCH layout applies to a solve on x, else 0.
+// Row lengths that are not a multiple of the 16-byte vector -- the normal case of a node-based mesh (11, 101,
+// 2^k + 1 nodes: _mesh.py:67-93) -- on one GPU: the arrays the ctx owns get a row pitch rounded up (PITCH layout of
+// k_cg3d), so the solver phases keep their 16-byte lane accesses on everything but the caller's x.  Needs a
+// non-periodic contiguous axis (a pad cell must never be a neighbour that is used) and a plain Laplacian; everything
+// else stays on the one-cell-per-lane (NARROW) kernels.
+template <typename T>
+static int64_t solver_pitch(const pa_ctx* c, const T* x) {
+  const DevGeom& G = c->G;
+  constexpr int VECW = 16 / (int)sizeof(T);
+  const bool shape = (c->ndim == 3 && G.n0 >= 3 && G.n1 >= 3) || (c->ndim == 2 && G.n1 >= 3);
+  if (!(c->pitch && c->fastpath && !c->slab && c->coord == PA_COORD_XYZ && shape && G.n2 % VECW != 0 && G.n2 >= 2 * VECW &&
+        c->nterms == 1 && c->terms[0].kind == PA_OP_LAPLACIAN && !c->terms[0].coeff_field &&
+        G.bct[4] != PA_BC_PERIODIC && G.bct[5] != PA_BC_PERIODIC && ((uintptr_t)x & (sizeof(T) - 1)) == 0 &&
+        ((G.n1 + 3) / 4) * ((G.n2 + 64 * VECW - 1) / (64 * VECW)) <= PA_MAX_PARTIALS))
+    return 0;
+  // pitch: a multiple of 128 bytes, not merely of the vector -- measured at 257^3 fp64 with 16-byte granularity
+  // (258 cells): phase A 108 us against 79 at 256^3 on the same tiling, although every access was a vector:
+  // rows that start inside a cache line make every tile edge a line shared by two workgroups, and their
+  // streaming stores partial-line writes
+  const int64_t padw = 128 / (int64_t)sizeof(T);
+  return (G.n2 + padw - 1) / padw * padw;
+}
+
 template <typename T>
 static int cg_begin_t(pa_ctx* c, T* x, const T* rhs, double tol, int64_t max_it) {
   const DevGeom& G = c->G;
   const size_t fb = (size_t)G.ncell * sizeof(T);
   const int nblk = pa_grid_blocks(G.ncell);
   int rc;
-  // Row lengths that are not a multiple of the 16-byte vector -- the normal case of a node-based mesh (11, 101,
-  // 2^k + 1 nodes: _mesh.py:67-93) -- on one GPU: r and the two direction buffers, which the ctx owns, get a row
-  // pitch rounded up to the vector (PITCH layout of k_cg3d), so the CG phases keep their 16-byte lane accesses on
-  // everything but the caller's x.  Needs a non-periodic contiguous axis (a pad cell must never be a neighbour
-  // that is used) and a plain Laplacian; everything else stays on the one-cell-per-lane (NARROW) kernels.
-  constexpr int VECW = 16 / (int)sizeof(T);
-  c->cg_pitch = 0;
-  c->cg_ps1 = 0;
-  {
-    const int want = c->pitch;
-    const bool shape = (c->ndim == 3 && G.n0 >= 3 && G.n1 >= 3) || (c->ndim == 2 && G.n1 >= 3);
-    if (want && c->fastpath && !c->slab && c->coord == PA_COORD_XYZ && shape && G.n2 % VECW != 0 && G.n2 >= 2 * VECW &&
-        c->nterms == 1 && c->terms[0].kind == PA_OP_LAPLACIAN && !c->terms[0].coeff_field &&
-        G.bct[4] != PA_BC_PERIODIC && G.bct[5] != PA_BC_PERIODIC && ((uintptr_t)x & (sizeof(T) - 1)) == 0 &&
-        ((G.n1 + 3) / 4) * ((G.n2 + 64 * VECW - 1) / (64 * VECW)) <= PA_MAX_PARTIALS) {
-      c->cg_pitch = 1;
-      // pitch: a multiple of 128 bytes, not merely of the vector -- measured at 257^3 fp64 with 16-byte granularity
-      // (258 cells): phase A 108 us against 79 at 256^3 on the same tiling, although every access was a vector:
-      // rows that start inside a cache line make every tile edge a line shared by two workgroups, and their
-      // streaming stores partial-line writes
-      const int64_t padw = 128 / (int64_t)sizeof(T);
-      c->cg_ps1 = (G.n2 + padw - 1) / padw * padw;
-    }
-  }
+  // odd row lengths: r and the two direction buffers in the PITCH layout (solver_pitch)
+  c->cg_ps1 = solver_pitch<T>(c, x);
+  c->cg_pitch = c->cg_ps1 > 0 ? 1 : 0;
   const size_t fbp = c->cg_pitch ? (size_t)G.n0 * G.n1 * c->cg_ps1 * sizeof(T) : fb;
   if ((rc = pa_scratch(c, &c->scr[SCR_R], &c->cap[SCR_R], fbp))) return rc;
   if ((rc = pa_scratch(c, &c->scr[SCR_D0], &c->cap[SCR_D0], fbp))) return rc;
@@ -1412,9 +1438,18 @@ static int bicg_run_t(pa_ctx* c, T* x, const T* rhs, double tol, int64_t max_it,
     int rrc = PA_OK;
     if (resident_finish(c, out, &rrc)) return rrc;
   }
-  const size_t fb = (size_t)G.ncell * sizeof(T);
   const int nblk = pa_grid_blocks(G.ncell);
   int rc;
+  // odd row lengths (round 3): ALL eight solver arrays are the ctx's, so all of them take the PITCH layout
+  // (solver_pitch) and the tiled phases keep their 16-byte lanes; only the x / r update touches the caller's x.
+  // (an index of vectors must fit 31 bits in k_bicg_x)
+  // Measured (us / iteration, one-cell-per-lane -> pitched, same box): 257^3 fp64 498-503 -> 470 (256^3: 430), 2-D 4097^2
+  // 574 -> 503, 1025^2 59 -> 50, 129^3 76 -> 78; 257^3 fp32 274 -> 287 -- so: fp64, or a 2-D mesh.
+  c->cg_ps1 = (sizeof(T) == 8 || c->ndim == 2) ? solver_pitch<T>(c, x) : 0;
+  if (c->cg_ps1 > 0 && G.n0 * G.n1 * (c->cg_ps1 / (16 / (int64_t)sizeof(T))) >= ((int64_t)1 << 31)) c->cg_ps1 = 0;
+  c->cg_pitch = c->cg_ps1 > 0 ? 1 : 0;
+  struct PitchOff { pa_ctx* c; ~PitchOff() { c->cg_pitch = 0; c->cg_ps1 = 0; } } pitch_off{c};   // (a CG solve sets its own)
+  const size_t fb = c->cg_pitch ? (size_t)G.n0 * G.n1 * c->cg_ps1 * sizeof(T) : (size_t)G.ncell * sizeof(T);
   const int ids[] = {SCR_R, SCR_D0, SCR_D1, SCR_R0, SCR_V0, SCR_V1, SCR_S, SCR_TT};
   for (int id : ids)
     if ((rc = pa_scratch(c, &c->scr[id], &c->cap[id], fb))) return rc;
@@ -1431,7 +1466,29 @@ static int bicg_run_t(pa_ctx* c, T* x, const T* rhs, double tol, int64_t max_it,
   T* t = (T*)c->scr[SCR_TT];
   double* part = (double*)c->scr[SCR_PART];
   Vec<T> xv = pa_vec_self<T>(c, x);
-  if ((rc = cg_residual_init<T>(c, E, xv, rhs, r0, r, (T*)nullptr, (T*)nullptr, part))) return rc;
+  // a field of the solver as the tiled phases see it (wrap-around planes of a pitched array: its own)
+  auto vec_of = [&](const T* q) -> Vec<T> {
+    Vec<T> w = pa_vec_self<T>(c, q);
+    if (c->cg_pitch) { w.glo = q + (G.n0 - 1) * G.n1 * c->cg_ps1; w.ghi = q; }
+    return w;
+  };
+  if (c->cg_pitch) {
+    // A x (tiled kernel, contiguous) into t, then r0 = r = b - A x scattered into the pitched rows with the loop and
+    // partial sums of the contiguous form (k_cg_init_ax_pitch); pad cells of every array zero for the whole solve
+    const int fr = pa_tile3d_aop<T>(c, E, xv, t, 1);
+    if (fr < 0) return fr;
+    if (fr > 0) {
+      hipLaunchKernelGGL(k_cg_init_ax_pitch<T>, dim3(nblk), dim3(PA_BLOCK), 0, c->stream, c->G, rhs, (const T*)t, r0, r,
+                         c->cg_ps1, part);
+    } else {   // the tiled A x declined: contiguous layout (the buffers are merely larger)
+      c->cg_pitch = 0;
+      c->cg_ps1 = 0;
+    }
+  }
+  // the tiled phases do not visit the last boundary row / column of non-periodic axes (launch_cg3d): p, v, s, t are 0
+  // there by definition and have to be 0 in every buffer the phases write into (and in the pad cells of pitched rows)
+  for (T* q : {p[1], v[1], s, t}) PA_HIP(c, hipMemsetAsync(q, 0, fb, c->stream));
+  if (!c->cg_pitch && (rc = cg_residual_init<T>(c, E, xv, rhs, r0, r, (T*)nullptr, (T*)nullptr, part))) return rc;
   PA_HIP(c, hipMemsetAsync(p[0], 0, fb, c->stream));
   PA_HIP(c, hipMemsetAsync(v[0], 0, fb, c->stream));
   // rho_next = sum r0.r0 ; tol0 = sqrt(rho_next) ; first beta = rho_next / 1 * 1 / 1 (linalg.py:201-212)
@@ -1487,7 +1544,7 @@ static int bicg_run_t(pa_ctx* c, T* x, const T* rhs, double tol, int64_t max_it,
       nb = 1;
     }
    for (int64_t qi = 0; qi < nb; ++qi) {
-    Vec<T> rv = pa_vec_self<T>(c, r), pv = pa_vec_self<T>(c, p[cur]), vv = pa_vec_self<T>(c, v[cur]);
+    Vec<T> rv = vec_of(r), pv = vec_of(p[cur]), vv = vec_of(v[cur]);
     c->fold_b_n = pend3;          // phase 5 closes the previous iteration (and swaps the scalar slots)
     c->fold_b_part = reg2;
     // p' of this iteration: formed by the p / v phase into p[cur ^ 1] -- or already there, in p[cur], left by the
@@ -1497,6 +1554,7 @@ static int bicg_run_t(pa_ctx* c, T* x, const T* rhs, double tol, int64_t max_it,
                       : pa_tile3d_bicg_pv<T>(c, E, rv, pv, vv, (const T*)r0, p[cur ^ 1], v[cur ^ 1], reg0);
     if (used < 0) return used;
     if (pgiven && used == 0) { pa_set_err(c, "pa_bicgstab: the tiled v phase declined in the middle of a solve"); return PA_E_STATE; }
+    if (c->cg_pitch && used == 0) { pa_set_err(c, "pitched BiCGSTAB: the tiled p / v phase declined"); return PA_E_STATE; }
     const bool pnext = pfold && used > 0;   // the tiled kernels took this iteration: they take the next one
     if (used > 0) {
       pend3 = 0;
@@ -1511,11 +1569,12 @@ static int bicg_run_t(pa_ctx* c, T* x, const T* rhs, double tol, int64_t max_it,
                          (T*)c->x_old_out, G.ncell);
     int pend0 = (fold && used <= PA_MAX_GRID) ? used : 0;
     if (!pend0) hipLaunchKernelGGL(k_bicg_post<T>, dim3(1), dim3(PA_BLOCK), 0, c->stream, c->sc, reg0, used, 0);
-    Vec<T> vnv = pa_vec_self<T>(c, v[cur ^ 1]);
+    Vec<T> vnv = vec_of(v[cur ^ 1]);
     c->fold_a_n = pend0;          // phase 6 computes alpha itself
     int used2 = pa_tile3d_bicg_st<T>(c, E, rv, vnv, (const T*)r0, s, t, reg1);
     c->fold_a_n = 0;
     if (used2 < 0) return used2;
+    if (c->cg_pitch && used2 == 0) { pa_set_err(c, "pitched BiCGSTAB: the tiled s / t phase declined"); return PA_E_STATE; }
     int pend12 = 0;
     if (used2 > 0) {
       pend12 = (fold && used2 <= PA_MAX_GRID) ? used2 : 0;
@@ -1532,7 +1591,11 @@ static int bicg_run_t(pa_ctx* c, T* x, const T* rhs, double tol, int64_t max_it,
     {
       constexpr int XV = 16 / (int)sizeof(T);
       const bool vec = G.ncell % XV == 0 && ((((uintptr_t)x | (uintptr_t)p[cur ^ 1] | (uintptr_t)s | (uintptr_t)t | (uintptr_t)r) & 15) == 0);
-      if (vec)
+      if (c->cg_pitch)
+        hipLaunchKernelGGL((k_bicg_x<T, XV, true>), dim3(nblk), dim3(PA_BLOCK), 0, c->stream, G, c->sc, x, (const T*)p_it,
+                           (const T*)s, (const T*)t, r, reg2, (const double*)reg1, pend12, c->sc, (const T*)v[cur ^ 1],
+                           pnext ? p[cur ^ 1] : (T*)nullptr, c->cg_ps1);
+      else if (vec)
         hipLaunchKernelGGL((k_bicg_x<T, XV>), dim3(nblk), dim3(PA_BLOCK), 0, c->stream, G, c->sc, x, (const T*)p_it,
                            (const T*)s, (const T*)t, r, reg2, (const double*)reg1, pend12, c->sc, (const T*)v[cur ^ 1],
                            pnext ? p[cur ^ 1] : (T*)nullptr);

@@ -90,3 +90,73 @@ def test_pitched_layout_is_really_taken(monkeypatch, capfd):
         [os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"), os.environ.get("PYTHONPATH", "")])))
     assert p.returncode == 0, p.stderr[-2000:]
     assert "phase A (pitched)" in p.stderr and "phase B (pitched)" in p.stderr, p.stderr[-2000:]
+
+
+# ---- BiCGSTAB (round 3, second session): all eight solver arrays pitched, phases 5 / 6 / 8 on 16-byte lanes ----------
+BICG_CASES = [
+    ("3d_dirichlet_f64", [20, 18, 131], "double", [D(0.0), D(0.5), D(0.0), D(0.0), D(1.0), D(0.0)]),
+    ("3d_mixed_f64", [17, 21, 65], "double", [N(0.3), D(0.0), D(0.3), N(0.0), SY, N(-0.25)]),
+    ("3d_xyper_f64", [16, 12, 33], "double", [PE, PE, PE, PE, D(0.0), N(0.1)]),
+    ("3d_mixed_f32", [12, 16, 257], "single", [D(0.0), N(0.0), D(0.0), N(0.0), D(1.0), N(0.0)]),
+    ("3d_odd_not_mult4_f32", [10, 9, 130], "single", [D(0.0)] * 6),
+    ("2d_dirichlet_f64", [65, 1025], "double", [D(0.0), D(1.0), D(0.0), D(0.5)]),
+    ("3d_short_rows_f64", [9, 8, 5], "double", [D(0.0)] * 6),
+]
+
+
+def _solve_bicg(n, dtype, faces, K, pitch, rhs0, tol=1e-30, pfold=True, monkeypatch=None):
+    if monkeypatch is not None:
+        monkeypatch.setenv("PYAPES_HIP_BICG_PFOLD", "1" if pfold else "0")
+    nd = len(n)
+    mesh = Mesh(Box([0.0] * nd, [1.0] * nd), None, n, "cuda", dtype)
+    ctx = context_for(mesh)
+    ctx.set_option("pitch", pitch)
+    ctx.set_option("resident", False)
+    bcs = [{"bc_face": O.FACES[i], "bc_type": t, "bc_val": v, "bc_val_opt": None} for i, (t, v) in enumerate(faces)]
+    var = Field("p", 1, mesh, {"domain": bcs, "obstacle": None})
+    s = Solver({"fdm": {"method": "bicgstab", "tol": tol, "max_it": K, "report": False}})
+    s.set_eq(-FDM().laplacian(0.7, var) == rhs0.to(mesh.dtype.float).cuda())
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        rep = s.solve()
+    return var().cpu(), rep, ctx.scalars()
+
+
+@pytest.mark.parametrize("name,n,dtype,faces", BICG_CASES, ids=[c[0] for c in BICG_CASES])
+def test_pitched_bicgstab_vs_narrow_and_oracle(name, n, dtype, faces, monkeypatch):
+    g = torch.Generator().manual_seed(4)
+    rhs0 = torch.randn((1, *n), generator=g, dtype=torch.float64)
+    nd = len(n)
+    om = O.OMesh([0.0] * nd, [1.0] * nd, n, dtype)
+    cfg = [{"bc_face": O.FACES[i], "bc_type": t, "bc_val": v} for i, (t, v) in enumerate(faces)]
+    for K in (1, 2, 5):
+        x_p, rep_p, sc_p = _solve_bicg(n, dtype, faces, K, True, rhs0, monkeypatch=monkeypatch)
+        x_n, rep_n, sc_n = _solve_bicg(n, dtype, faces, K, False, rhs0, monkeypatch=monkeypatch)
+        x_q, rep_q, _ = _solve_bicg(n, dtype, faces, K, True, rhs0, pfold=False, monkeypatch=monkeypatch)
+        assert rep_p["itr"] == rep_n["itr"] == rep_q["itr"] == K
+        assert torch.equal(x_p, x_q) and rep_p["tol"] == rep_q["tol"]      # the folded direction update changes no bit
+        tight = 1e-11 if dtype == "double" else 5e-6
+        assert rel_err(x_p, x_n) < tight, (K, rel_err(x_p, x_n))
+        for key in ("alpha", "omega", "tol"):
+            assert abs(sc_p[key] - sc_n[key]) <= (1e-9 if dtype == "double" else 1e-3) * abs(sc_n[key]), (K, key)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            xo, ro = O.solve_poisson(om, cfg, rhs0.to(om.dtype).clone(), method="bicgstab", tol=1e-30, max_it=K, coeff=0.7,
+                                     sign=-1.0)
+        assert ro["itr"] == rep_p["itr"]
+        assert rel_err(x_p, xo) < (1e-10 if dtype == "double" else 1e-5), (K, rel_err(x_p, xo))
+
+
+def test_pitched_bicgstab_is_really_taken():
+    import subprocess, sys, os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys, os; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+            "import torch, warnings; warnings.simplefilter('ignore')\n"
+            "from test_gpu_pitched import _solve_bicg\n"
+            "_solve_bicg([20, 18, 131], 'double', [('dirichlet', 0.0)] * 6, 3, True, torch.ones(1, 20, 18, 131, dtype=torch.float64))\n"
+            % (root, os.path.join(root, "tests")))
+    p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True,
+                       env=dict(os.environ, PYAPES_HIP_DEBUG="1", PYTHONPATH=os.pathsep.join([os.path.join(root, "oracle"), os.environ.get("PYTHONPATH", "")])))
+    assert p.returncode == 0, p.stderr[-2000:]
+    # phases 5 (first iteration), 6 and 8 print as 'F', 'G', 'I' ('A' + PHASE)
+    assert "phase F (pitched)" in p.stderr and "phase G (pitched)" in p.stderr and "phase I (pitched)" in p.stderr, p.stderr[-2000:]

@@ -120,6 +120,9 @@ def test_rz_resident_lean_path_matches_the_generic_term_evaluation(method, dtype
     pcfg = [dict(c, bc_val_opt=None) for c in cfg]
     g = torch.Generator().manual_seed(5)
     rhs = torch.randn((1, *n), generator=g, dtype=torch.float64)
+    # BiCGSTAB amplifies the other grouping of the partial sums (512 against 256 threads per box) by an order of
+    # magnitude every few iterations: a short run for it
+    K = 6 if method == "bicgstab" else 24
     out = {}
     for name, env in (("lean", {"PYAPES_HIP_RESIDENT": "1", "PYAPES_HIP_RES_RZLEAN": "1"}),
                       ("terms", {"PYAPES_HIP_RESIDENT": "1", "PYAPES_HIP_RES_RZLEAN": "0"}),
@@ -128,16 +131,16 @@ def test_rz_resident_lean_path_matches_the_generic_term_evaluation(method, dtype
             monkeypatch.setenv(k, v)
         mesh = Mesh(Cylinder([0.0, 0.0], [1.0, 1.5]), None, list(n), "cuda", dtype)
         var = Field("p", 1, mesh, {"domain": pcfg, "obstacle": None})
-        s = Solver({"fdm": {"method": method, "tol": -1.0, "max_it": 24, "report": False}})
+        s = Solver({"fdm": {"method": method, "tol": -1.0, "max_it": K, "report": False}})
         s.set_eq(FDM().laplacian(0.9, var) == rhs.to(mesh.dtype.float).cuda().clone())
         with warnings.catch_warnings():
             warnings.simplefilter("ignore")
             rep = s.solve()
         out[name] = (var().cpu().double(), rep["itr"], context_for(mesh).resident_used())
     assert out["lean"][2] > 0 and out["terms"][2] > 0 and out["launch"][2] == 0
-    # max_it = 24: 25 iterations for CG / Jacobi (`itr > max_it`, Q6), 24 for BiCGSTAB (`itr >= max_it`, linalg.py:264)
-    assert out["lean"][1] == out["terms"][1] == out["launch"][1] == (24 if method == "bicgstab" else 25)
-    tol = 0.0 if method == "jacobi" else (1e-12 if dtype == "double" else 2e-5)
+    # max_it = K: K + 1 iterations for CG / Jacobi (`itr > max_it`, Q6), K for BiCGSTAB (`itr >= max_it`, linalg.py:264)
+    assert out["lean"][1] == out["terms"][1] == out["launch"][1] == (K if method == "bicgstab" else K + 1)
+    tol = 0.0 if method == "jacobi" else ((1e-12 if method == "cg" else 1e-10) if dtype == "double" else 2e-5)
     for other in ("terms", "launch"):
         err = rel_err(out["lean"][0], out[other][0])
         assert err <= tol, (other, err)
