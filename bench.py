@@ -277,8 +277,26 @@ class ClockSampler:
         import glob
         self.files = {}
         cards = sorted(glob.glob("/sys/class/drm/card[0-9]*/device/pp_dpm_sclk"))
+        self.card = None
         if cards:
-            dev = os.path.dirname(cards[min(index, len(cards) - 1)])
+            # sysfs shows every GPU of the host, the process sees its own: pick the card by PCI address (a box of the
+            # pool lists eight cards; the first one is somebody else's GPU)
+            dev = None
+            try:
+                import torch
+                pr = torch.cuda.get_device_properties(index)
+                bdf = f"{pr.pci_domain_id:04x}:{pr.pci_bus_id:02x}:{pr.pci_device_id:02x}."
+                for cpath in cards:
+                    real = os.path.realpath(os.path.dirname(cpath))
+                    if bdf in real.lower():
+                        dev = os.path.dirname(cpath)
+                        self.card = os.path.basename(os.path.dirname(dev)) + " " + os.path.basename(real)
+                        break
+            except Exception:
+                dev = None
+            if dev is None:
+                dev = os.path.dirname(cards[min(index, len(cards) - 1)])
+                self.card = "unmatched:" + os.path.basename(os.path.dirname(dev))
             for key, name in (("sclk_mhz", "pp_dpm_sclk"), ("mclk_mhz", "pp_dpm_mclk"), ("fclk_mhz", "pp_dpm_fclk")):
                 if os.path.exists(os.path.join(dev, name)):
                     self.files[key] = os.path.join(dev, name)
@@ -330,6 +348,8 @@ class ClockSampler:
 
     def record(self):
         out = {}
+        if getattr(self, "card", None):
+            out["card"] = self.card
         for k, v in self.samples.items():
             if v:
                 out[k] = {"min": min(v), "avg": sum(v) / len(v), "max": max(v), "n": len(v)}

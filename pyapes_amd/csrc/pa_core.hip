@@ -111,11 +111,21 @@ int pa_scratch(pa_ctx* c, void** slot, size_t* cap, size_t bytes) {
   const int q = (int)(slot - c->scr);  // every caller passes &c->scr[id]
   if (*slot) { (void)hipFree(c->scr_base[q]); c->scr_base[q] = nullptr; *slot = nullptr; *cap = 0; }
   if (bytes == 0) return PA_OK;
-  // hipMalloc returns 2 MB-aligned blocks; fields that are streamed in lockstep (r, d, d') would then
-  // sit at the same offset of their pages at every moment.  Slot q starts q * stagger bytes in.
-  static long stagger = -1;
-  if (stagger < 0) { const char* e = getenv("PYAPES_HIP_STAGGER"); stagger = e ? atol(e) & ~255L : 0; }
-  const size_t off = (size_t)q * (size_t)stagger;
+  // hipMalloc returns 2 MB-aligned blocks; fields that are streamed in lockstep (x, r, d, d') would then sit at the
+  // same offset of their pages at every moment, and whether the memory channels they fall on coincide is left to
+  // where the driver happened to put the pages: on one box of the pool CG phase B at 512^3 fp64 took 929 us with
+  // every array at offset 0 and 853 us with the direction buffers 68.25 / 136.5 KiB in (phase A 571 -> 583, the
+  // iteration 1.557 -> 1.492 ms); on two other boxes the offsets change nothing (1.512-1.520 ms in every setting) --
+  // the box-to-box spread of the headline kernel is page placement, not clocks.  Slot q starts
+  // q * stagger bytes in; default 68 KiB + 256 B (PYAPES_HIP_STAGGER=0: none).
+  static long stagger = -1, sbase = 0;
+  if (stagger < 0) {
+    const char* e = getenv("PYAPES_HIP_STAGGER");
+    stagger = e ? atol(e) & ~255L : 69888;
+    const char* b = getenv("PYAPES_HIP_STAGGER_BASE");
+    sbase = b ? atol(b) : 0;
+  }
+  const size_t off = (size_t)(q + sbase) * (size_t)stagger;
   void* base = nullptr;
   PA_HIP(c, hipMalloc(&base, bytes + off));
   c->scr_base[q] = base;
