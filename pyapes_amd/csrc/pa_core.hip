@@ -117,13 +117,13 @@ int pa_scratch(pa_ctx* c, void** slot, size_t* cap, size_t bytes) {
   // every array at offset 0 and 853 us with the direction buffers 68.25 / 136.5 KiB in (phase A 571 -> 583, the
   // iteration 1.557 -> 1.492 ms); on two other boxes the offsets change nothing (1.512-1.520 ms in every setting) --
   // the box-to-box spread of the headline kernel is page placement, not clocks.  Slot q starts
-  // q * stagger bytes in; default 68 KiB + 256 B (PYAPES_HIP_STAGGER=0: none).
+  // (q + 1) * stagger bytes in; default 68 KiB + 256 B (PYAPES_HIP_STAGGER=0: none).
   static long stagger = -1, sbase = 0;
   if (stagger < 0) {
     const char* e = getenv("PYAPES_HIP_STAGGER");
     stagger = e ? atol(e) & ~255L : 69888;
     const char* b = getenv("PYAPES_HIP_STAGGER_BASE");
-    sbase = b ? atol(b) : 0;
+    sbase = b ? atol(b) : 1;   // slot 0 (r) one step in as well: x, the caller's array, is the one at offset 0
   }
   const size_t off = (size_t)(q + sbase) * (size_t)stagger;
   void* base = nullptr;
