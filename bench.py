@@ -711,7 +711,19 @@ def main():
             ctx.euler_march(fin, cur if fin is oth else oth, kindc, u, nu, dts, min(K, 10))
             pr = ctx.profile_read()
             ctx.profile(False)
-            roof = roofline("euler_step", pr["phase_a_ms"], passes * esize * mesh.N, args.workload, bool(args.n))
+            # The probe brackets ONE launch at a time with HIP events and the host waits in between: a launch from an
+            # idle stream, which for a 30 us kernel reads ~8 us long.  In the march the steps run back to back -- with BC
+            # on load a step IS one launch -- so the stream time per step bounds the kernel's duration from above.
+            k_ms = min(pr["phase_a_ms"], ev_ms / K)
+            extra = {"kernel_ms_probe": pr["phase_a_ms"], "step_stream_ms": ev_ms / K,
+                     "kernel_ms_source": "min(per-launch HIP-event probe, stream time of the timed march / steps)"}
+            arr_mib = esize * mesh.N / 2 ** 20
+            if (passes + 0) * arr_mib <= 256:
+                extra["remark"] = (f"{arr_mib:.0f} MiB per array: the step's arrays sit in the 256 MiB Infinity Cache, and the step "
+                                   "carries ~32 VALU instructions per cell that may not be fused (13.8 us of pure issue at 256^3): "
+                                   "bound by instruction issue plus one dependent launch per step, not by HBM -- the fraction "
+                                   "of the HBM roofline is reported for comparison only (DESIGN.md section 4)")
+            roof = roofline("euler_step", k_ms, passes * esize * mesh.N, args.workload, bool(args.n), extra)
         wl_text = (f"3-D advection-diffusion {'x'.join(map(str, gn))} {dtype}, Div(upwind)+Laplacian explicit Euler march, "
                    f"{'scalar u' if solver == 'euler' else 'speed tensor u(x)'}, Neumann/Symmetry BCs (BASELINE config 4)")
     else:  # jacobi (config 1)

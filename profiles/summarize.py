@@ -49,7 +49,7 @@ def counters(root):
     return out
 
 
-PHASES = {0: "phaseA", 1: "phaseB", 2: "Ax", 3: "euler", 4: "jacobi", 5: "bicg_pv", 6: "bicg_st", 7: "grad"}
+PHASES = {0: "phaseA", 1: "phaseB", 2: "Ax", 3: "euler", 4: "jacobi", 5: "bicg_pv", 6: "bicg_st", 7: "grad", 8: "bicg_v"}
 
 
 def short(name):
@@ -64,10 +64,11 @@ def short(name):
         if m.group(6) == "true":
             s += "_narrow"
         return s
-    m = re.search(r"k_sf<(\w+), (\d+), (\d+), (\d+), (\w+)>", name)
+    m = re.search(r"k_sf<(\w+), (\d+), (\d+), (\d+), (\w+)(?:, (\w+))?>", name)   # (..., HASU[, BCL])
     if m:
         t = "f64" if m.group(1) == "double" else "f32"
-        return f"k_sf_{PHASES.get(int(m.group(3)), m.group(3))}_{t}_RJ{m.group(2)}_kind{m.group(4)}" + ("_ufield" if m.group(5) == "true" else "")
+        return (f"k_sf_{PHASES.get(int(m.group(3)), m.group(3))}_{t}_RJ{m.group(2)}_kind{m.group(4)}" +
+                ("_ufield" if m.group(5) == "true" else "") + ("_bcl" if m.group(6) == "true" else ""))
     m = re.search(r"k_resident<(\w+), (\d+), (\w+), (\d+)>", name)
     if m:
         t = "f64" if m.group(1) == "double" else "f32"
