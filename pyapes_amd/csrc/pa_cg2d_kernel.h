@@ -1,4 +1,6 @@
-// pa_cg2d_kernel.h -- k_cg2d: the CG phases on 2-D meshes, marching along the mesh's slow axis.
+// pa_cg2d_kernel.h -- k_cg2d: the solver phases on 2-D meshes, marching along the mesh's slow axis (CG phases A / B;
+// since the second session of round 3 also the Jacobi sweep, phase 4, and the BiCGSTAB phases 6 (s / t) and 8 (v' = A p'
+// from a stored p'): the same strip walk, the outputs / partial sums / prologues of k_cg3d's phases).
 //
 // k_cg3d treats a 2-D mesh as ONE plane of its tiling: every workgroup handles a 16-row tile once, pays the full
 // halo ring (two extra rows, two columns of single-cell loads) for it and never reuses a row -- 4096^2 fp64 CG ran
@@ -22,7 +24,8 @@
 
 template <typename T, int PHASE, bool PITCH>
 __global__ void __launch_bounds__(256) k_cg2d(Cg3dArgs<T> A) {
-  static_assert(PHASE == 0 || PHASE == 1, "CG phases");
+  static_assert(PHASE == 0 || PHASE == 1 || PHASE == 4 || PHASE == 6 || PHASE == 8, "CG phases, Jacobi sweep, BiCGSTAB s / t and v phases");
+  static_assert(!PITCH || PHASE != 4, "the Jacobi sweep works on the caller's arrays");
   constexpr int VEC = VecOf<T>::N;
   typedef T V __attribute__((ext_vector_type(VEC)));
   constexpr int TK = 64 * VEC;
@@ -47,7 +50,7 @@ __global__ void __launch_bounds__(256) k_cg2d(Cg3dArgs<T> A) {
   // ---- the scalar step folded into this kernel's prologue (k_cg3d, same code: every block reduces the partial
   //      rows the previous kernel left, in the same fixed order -> the same bits in every block) -----------------
   T beta = (T)0, alpha = (T)0;
-  if (PHASE == 0 && A.pre_n > 0) {
+  if ((PHASE == 0 || PHASE == 4) && A.pre_n > 0) {
     __shared__ double pre_sm[16];
     const SolverScalars* si = A.sc;
     const int done_in = si->done;
@@ -55,7 +58,7 @@ __global__ void __launch_bounds__(256) k_cg2d(Cg3dArgs<T> A) {
     const long long itr_in = si->itr, max_it = si->max_it;
     double v0 = 0.0, v1 = 0.0, v2 = 0.0;
     for (int b = threadIdx.x; b < A.pre_n; b += 256) {
-      v0 += A.pre_part[2 * (int64_t)b];
+      if (PHASE == 0) v0 += A.pre_part[2 * (int64_t)b];
       v1 += A.pre_part[2 * (int64_t)b + 1];
     }
     for (int b = threadIdx.x; b < A.pre_nsh; b += 256) v2 += A.pre_shell[b];
@@ -95,12 +98,14 @@ __global__ void __launch_bounds__(256) k_cg2d(Cg3dArgs<T> A) {
         if (bad) {
           so->err = 1;
         } else {
-          so->rr_old = (double)rr_old;
-          so->beta = bq;
-          so->rr = (double)rr_new;
+          if (PHASE == 0) {
+            so->rr_old = (double)rr_old;
+            so->beta = bq;
+            so->rr = (double)rr_new;
+          }
           so->itr = itr;
         }
-        A.pre_sums[1] = rr;
+        if (PHASE == 0) A.pre_sums[1] = rr;
         A.pre_sums[2] = dx2 + sh;
       }
     }
@@ -132,10 +137,83 @@ __global__ void __launch_bounds__(256) k_cg2d(Cg3dArgs<T> A) {
     }
     __syncthreads();
     alpha = (T)pre_sm[4];
+  } else if (PHASE == 8 && A.pre_n > 0) {
+    // BiCGSTAB: the step that closes the PREVIOUS iteration (k_cg3d phase 5 / 8 prologue, k_bicg_post stage 3)
+    __shared__ double pre_sm[8];
+    const SolverScalars* si = A.sc;
+    const int done_in = si->done, fe = si->finished_early;
+    const double tol_lim = si->tolerance, rho_next = si->rho_next, rho_in = si->rho, alpha_in = si->alpha,
+                 omega_in = si->omega;
+    const long long itr_in = si->itr, max_it = si->max_it;
+    double v0 = 0.0;
+    for (int b = threadIdx.x; b < A.pre_n; b += 256) v0 += A.pre_part[b];
+    if (done_in) {
+      if (blockIdx.x == 0 && threadIdx.x == 0) *A.sc_w = *si;
+      return;
+    }
+    for (int off = 32; off > 0; off >>= 1) v0 += __shfl_down(v0, off, 64);
+    if ((threadIdx.x & 63) == 0) pre_sm[threadIdx.x >> 6] = v0;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      double v = 0.0;
+      for (int w = 0; w < 4; ++w) v += pre_sm[w];
+      const T tolv = (T)sqrt(v);
+      const bool bad = !fe && (isnan(tolv) || isinf(tolv));
+      int done = (fe || bad) ? 1 : 0;
+      T bq = (T)0;
+      if (!fe && !bad) {
+        if ((double)tolv <= tol_lim) done = 1;
+        if (itr_in >= max_it) done = 1;
+        bq = (T)rho_next / (T)rho_in;
+        bq = bq * (T)alpha_in;
+        bq = bq / (T)omega_in;
+      }
+      pre_sm[5] = done ? 1.0 : 0.0;
+      if (blockIdx.x == 0) {
+        SolverScalars* so = A.sc_w;
+        *so = *si;
+        so->done = done;
+        if (!fe) {
+          so->tol = (double)tolv;
+          if (bad) {
+            so->err = 1;
+          } else {
+            so->beta = (double)bq;
+            so->rho = rho_next;
+          }
+        }
+      }
+    }
+    __syncthreads();
+    if (pre_sm[5] != 0.0) return;
+  } else if (PHASE == 6 && A.pre_n > 0) {
+    // BiCGSTAB: alpha = rho / (r0 . v) of THIS iteration, iteration count (k_bicg_post stage 0)
+    __shared__ double pre_sm[8];
+    const int done_in = A.sc->done;
+    const double rho_in = A.sc->rho;
+    double v0 = 0.0;
+    for (int b = threadIdx.x; b < A.pre_n; b += 256) v0 += A.pre_part[b];
+    if (done_in) return;
+    for (int off = 32; off > 0; off >>= 1) v0 += __shfl_down(v0, off, 64);
+    if ((threadIdx.x & 63) == 0) pre_sm[threadIdx.x >> 6] = v0;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      double v = 0.0;
+      for (int w = 0; w < 4; ++w) v += pre_sm[w];
+      const T q = (T)rho_in / (T)v;
+      const double al = (isnan(q) || isinf(q)) ? 0.0 : (double)q;  // linalg.py:302-305
+      pre_sm[4] = al;
+      if (blockIdx.x == 0) {
+        A.sc_w->itr += 1;   // no other block of this launch reads itr
+        A.sc_w->alpha = al;
+      }
+    }
+    __syncthreads();
+    alpha = (T)pre_sm[4];
   } else {
     if (A.sc->done) return;
     if (PHASE == 0) beta = (T)A.sc->beta;
-    if (PHASE == 1) alpha = (T)A.sc->alpha;
+    if (PHASE == 1 || PHASE == 6) alpha = (T)A.sc->alpha;
   }
 
   // ---- per-lane constants of the contiguous axis -------------------------------------------------------------
@@ -162,7 +240,7 @@ __global__ void __launch_bounds__(256) k_cg2d(Cg3dArgs<T> A) {
     const T* dp = A.d.p + jw * fs1;
     w.d = *reinterpret_cast<const V*>(dp + kcf);
     w.ed = dp[ecol];
-    if (PHASE == 0) {
+    if (PHASE == 0 || PHASE == 6) {
       const T* rp = A.r.p + jw * fs1;
       w.r = *reinterpret_cast<const V*>(rp + kcf);
       w.er = rp[ecol];
@@ -177,6 +255,14 @@ __global__ void __launch_bounds__(256) k_cg2d(Cg3dArgs<T> A) {
       }
       T bd = beta * w.ed;
       ee = w.er + bd;
+    } else if (PHASE == 6) {   // s = r - alpha v (linalg.py:230), on the strip and on its edge cell
+#pragma unroll
+      for (int v = 0; v < VEC; ++v) {
+        T av = alpha * w.d[v];
+        e[v] = w.r[v] - av;
+      }
+      T av = alpha * w.ed;
+      ee = w.er - av;
     } else {
       e = w.d;
       ee = w.ed;
@@ -193,7 +279,7 @@ __global__ void __launch_bounds__(256) k_cg2d(Cg3dArgs<T> A) {
   finish(w2, eb, xb);
   (void)xa;
 
-  double s0 = 0.0, s1 = 0.0;
+  double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
   for (int m = 0; m < CJ; ++m) {
     const int jj = row_of(m);
     V xv, rv;
@@ -208,6 +294,8 @@ __global__ void __launch_bounds__(256) k_cg2d(Cg3dArgs<T> A) {
         rv = __builtin_nontemporal_load(reinterpret_cast<const V*>(A.rw + (int64_t)jj * fs1 + kcf));
       }
     }
+    if (PHASE == 4 || PHASE == 6 || PHASE == 8)   // Jacobi: the right-hand side ; BiCGSTAB: r0 (pitched with the rest)
+      xv = *reinterpret_cast<const V*>(A.aux + (int64_t)jj * fs1 + kcf);
     // row m + 2 (wrapped: the rows past the chunk's end are valid memory and their values unused) -- unconditional,
     // a branch between the issue of a load and its use makes the compiler wait for everything outstanding
     Raw w;
@@ -253,6 +341,39 @@ __global__ void __launch_bounds__(256) k_cg2d(Cg3dArgs<T> A) {
         outd[v] = e;
         T p = e * ax;
         s0 += inS ? (double)p : 0.0;
+      } else if (PHASE == 4) {
+        // Jacobi:  x + omega (b - A x) / diag(A)   (k_cg3d phase 4 / k_jacobi, operation for operation)
+        T dg = (T)0;
+        dg = dg + cCj;
+        dg = dg + cCk[v];
+        if (hasc) dg = dg * cf;
+        dg = dg * sgn;
+        T q = xv[v] - ax;
+        q = q / dg;
+        q = A.p0 * q;
+        const T xn = inS ? xc + q : xc;
+        const bool offshell = inS && !(jShell || (colShell >> v & 1));
+        T df = xn - xc;
+        T p2 = df * df;
+        s1 += offshell ? (double)p2 : 0.0;
+        outd[v] = xn;
+      } else if (PHASE == 6 || PHASE == 8) {
+        // own cells: s (phase 6) everywhere, t = A s / v' = A p' on the interior set (k_cg3d phases 6 / 8)
+        const T an = inS ? ax : (T)0;
+        outd[v] = xc;
+        outx[v] = an;
+        const T r0c = xv[v];
+        if (PHASE == 8) {
+          T p = r0c * an;
+          s0 += inS ? (double)p : 0.0;
+        } else {
+          T p = xc * xc;
+          s0 += (kg + v < n2) ? (double)p : 0.0;   // |s|^2 over every node (tol of linalg.py:233)
+          T a = an * xc, b = an * an, cc = r0c * an;
+          s1 += inS ? (double)a : 0.0;
+          s2 += inS ? (double)b : 0.0;
+          s3 += inS ? (double)cc : 0.0;
+        }
       } else {
         const T xo = xv[v];
         T ad = alpha * xc;
@@ -274,6 +395,13 @@ __global__ void __launch_bounds__(256) k_cg2d(Cg3dArgs<T> A) {
     if (kvalid) {
       if (PHASE == 0) {
         __builtin_nontemporal_store(outd, reinterpret_cast<V*>(A.dnew + (int64_t)jj * fs1 + kcf));
+      } else if (PHASE == 4) {
+        *reinterpret_cast<V*>(A.out + (int64_t)jj * G.s1 + kcf) = outd;
+      } else if (PHASE == 6) {
+        *reinterpret_cast<V*>(A.out + (int64_t)jj * fs1 + kcf) = outd;
+        *reinterpret_cast<V*>(A.out2 + (int64_t)jj * fs1 + kcf) = outx;
+      } else if (PHASE == 8) {
+        *reinterpret_cast<V*>(A.out2 + (int64_t)jj * fs1 + kcf) = outx;
       } else {
         __builtin_nontemporal_store(outd, reinterpret_cast<V*>(A.rw + (int64_t)jj * fs1 + kcf));
         if (PITCH) {
@@ -292,9 +420,12 @@ __global__ void __launch_bounds__(256) k_cg2d(Cg3dArgs<T> A) {
     finish(w, eb, xb);
   }
 
-  if (PHASE == 0) {
+  if (PHASE == 0 || PHASE == 8) {
     double s[1] = {s0};
     pa_block_reduce_store<1>(s, A.partials);
+  } else if (PHASE == 6) {
+    double s[4] = {s0, s1, s2, s3};
+    pa_block_reduce_store<4>(s, A.partials);
   } else {
     double s[2] = {s0, s1};
     pa_block_reduce_store<2>(s, A.partials);
@@ -333,7 +464,13 @@ static int launch_cg2d(pa_ctx* c, Cg3dArgs<T>& A, bool pitched) {
   // iteration old -> new: 1024^2 23 -> 31, 1536^2 56 -> 49, 2048^2 83 -> 57, 4096^2 265 -> 191, 8192^2 1021 -> 800)
   if (G.n1 * G.n2 < mincells) return 0;
   const int groups = (int)((G.n2 + 4 * 64 * VEC - 1) / (4 * 64 * VEC));
-  const int bpc = pitched ? cg2d_blocks_per_cu<T, PHASE, true>() : cg2d_blocks_per_cu<T, PHASE, false>();
+  int bpc;
+  if constexpr (PHASE == 4) {   // (the Jacobi sweep is never pitched: the caller's arrays)
+    if (pitched) return 0;
+    bpc = cg2d_blocks_per_cu<T, PHASE, false>();
+  } else {
+    bpc = pitched ? cg2d_blocks_per_cu<T, PHASE, true>() : cg2d_blocks_per_cu<T, PHASE, false>();
+  }
   const int capacity = cus_of(c) * bpc;
   // rows per chunk: a chunk re-reads two rows, so long chunks where the mesh still fills the chip with them
   // (32 rows: 6 % extra reads), 16 rows otherwise
@@ -355,7 +492,12 @@ static int launch_cg2d(pa_ctx* c, Cg3dArgs<T>& A, bool pitched) {
             (char)('A' + PHASE), pitched ? " (pitched)" : "", groups, chunks, (long long)(G.n1 / chunks), nblk, bpc);
   }
   if (c->plan_only) return nblk;
-  if (pitched) hipLaunchKernelGGL((k_cg2d<T, PHASE, true>), dim3(nblk), dim3(256), 0, c->stream, A);
-  else hipLaunchKernelGGL((k_cg2d<T, PHASE, false>), dim3(nblk), dim3(256), 0, c->stream, A);
+  if constexpr (PHASE != 4) {
+    if (pitched) {
+      hipLaunchKernelGGL((k_cg2d<T, PHASE, true>), dim3(nblk), dim3(256), 0, c->stream, A);
+      return nblk;
+    }
+  }
+  hipLaunchKernelGGL((k_cg2d<T, PHASE, false>), dim3(nblk), dim3(256), 0, c->stream, A);
   return nblk;
 }

@@ -75,7 +75,8 @@ int pa_tile3d_jacobi(pa_ctx* c, const DevEq<T>& E, Vec<T> x, const T* rhs, T* xn
     A.sc_w = c->sc_alt;
     A.pre_sums = pa_sums(c);
   }
-  int n = launch_any<T, 4>(c, A, mode);
+  int n = mode == 1 ? launch_cg2d<T, 4>(c, A, false) : 0;   // large 2-D meshes: marching along the slow axis
+  if (n == 0) n = launch_any<T, 4>(c, A, mode);
   if (n > 0 && hipGetLastError() != hipSuccess) { pa_set_err(c, "k_cg3d Jacobi launch failed"); return PA_E_HIP; }
   if (n > 0 && c->fold_b_n > 0) {
     SolverScalars* t = c->sc; c->sc = c->sc_alt; c->sc_alt = t;

@@ -1,6 +1,7 @@
 // pa_cg3d_b.hip -- instantiations of the tiled kernel: the two BiCGSTAB phases (kernel and launch helpers:
 // pa_cg3d_kernel.h)
 #include "pa_cg3d_kernel.h"
+#include "pa_cg2d_kernel.h"
 
 template <typename T>
 int pa_tile3d_bicg_pv(pa_ctx* c, const DevEq<T>& E, Vec<T> r, Vec<T> p, Vec<T> v, const T* r0, T* pnew, T* vnew,
@@ -42,7 +43,8 @@ int pa_tile3d_bicg_v(pa_ctx* c, const DevEq<T>& E, Vec<T> p, const T* r0, T* vne
     A.pre_n = c->fold_b_n;
     A.sc_w = c->sc_alt;
   }
-  int n = launch_any<T, 8>(c, A, mode);
+  int n = (mode == 1 || mode == 3) ? launch_cg2d<T, 8>(c, A, mode == 3) : 0;   // large 2-D meshes: marching kernel
+  if (n == 0) n = launch_any<T, 8>(c, A, mode);
   if (n > 0 && hipGetLastError() != hipSuccess) { pa_set_err(c, "k_cg3d BiCGSTAB v launch failed"); return PA_E_HIP; }
   if (n > 0 && c->fold_b_n > 0) {
     SolverScalars* t = c->sc; c->sc = c->sc_alt; c->sc_alt = t;
@@ -66,7 +68,8 @@ int pa_tile3d_bicg_st(pa_ctx* c, const DevEq<T>& E, Vec<T> r, Vec<T> v, const T*
     A.pre_n = c->fold_a_n;
     A.sc_w = c->sc;
   }
-  int n = launch_any<T, 6>(c, A, mode);
+  int n = (mode == 1 || mode == 3) ? launch_cg2d<T, 6>(c, A, mode == 3) : 0;
+  if (n == 0) n = launch_any<T, 6>(c, A, mode);
   if (n > 0 && hipGetLastError() != hipSuccess) { pa_set_err(c, "k_cg3d BiCGSTAB s/t launch failed"); return PA_E_HIP; }
   return n;
 }

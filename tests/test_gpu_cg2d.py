@@ -88,3 +88,66 @@ def test_cg2d_is_the_default_on_large_meshes_and_deterministic():
         out.append((var().clone(), rep["tol"]))
     assert torch.equal(out[0][0], out[1][0]) and out[0][1] == out[1][1]
     assert bool(torch.isfinite(out[0][0]).all())
+
+
+# ---- second session of round 3: the Jacobi sweep (phase 4) and the BiCGSTAB phases 6 / 8 on the marching kernel -------
+def _solve_m(n, dtype, faces, K, mincells, rhs0, method, omega=0.9):
+    mesh = Mesh(Box([0.0, 0.0], [1.0, 1.0]), None, n, "cuda", dtype)
+    ctx = context_for(mesh)
+    ctx.set_option("cg2d_mincells", mincells)
+    ctx.set_option("resident", False)
+    bcs = [{"bc_face": O.FACES[i], "bc_type": t, "bc_val": v, "bc_val_opt": None} for i, (t, v) in enumerate(faces)]
+    var = Field("p", 1, mesh, {"domain": bcs, "obstacle": None})
+    cfg = {"method": method, "tol": 1e-30, "max_it": K, "report": False}
+    if method == "jacobi":
+        cfg["omega"] = omega
+    s = Solver({"fdm": cfg})
+    s.set_eq(-FDM().laplacian(0.7, var) == rhs0.to(mesh.dtype.float).cuda())
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        rep = s.solve()
+    return var().cpu(), rep, ctx.scalars()
+
+
+@pytest.mark.parametrize("name,n,dtype,faces,K", CASES, ids=[c[0] for c in CASES])
+def test_cg2d_jacobi_is_bit_identical_to_the_one_plane_tiling(name, n, dtype, faces, K):
+    """no global sum feeds back into a Jacobi iterate: the same arithmetic per node must give the same bits"""
+    g = torch.Generator().manual_seed(7)
+    rhs0 = torch.randn((1, *n), generator=g, dtype=torch.float64)
+    x_m, rep_m, _ = _solve_m(n, dtype, faces, 2 * K, 0, rhs0, "jacobi")
+    x_t, rep_t, _ = _solve_m(n, dtype, faces, 2 * K, -1, rhs0, "jacobi")
+    assert rep_m["itr"] == rep_t["itr"] == 2 * K + 1
+    assert torch.equal(x_m, x_t), float((x_m - x_t).abs().max())
+    assert abs(rep_m["tol"] - rep_t["tol"]) <= 1e-10 * abs(rep_t["tol"])      # (the stop-test sum is grouped differently)
+    om = O.OMesh([0.0, 0.0], [1.0, 1.0], n, dtype)
+    cfg = [{"bc_face": O.FACES[i], "bc_type": t, "bc_val": v} for i, (t, v) in enumerate(faces)]
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        xo, ro = O.solve_poisson(om, cfg, rhs0.to(om.dtype).clone(), method="jacobi", tol=1e-30, max_it=2 * K, coeff=0.7,
+                                 sign=-1.0, omega=0.9)
+    assert ro["itr"] == rep_m["itr"]
+    assert rel_err(x_m, xo) < (1e-10 if dtype == "double" else 1e-5), rel_err(x_m, xo)
+
+
+@pytest.mark.parametrize("name,n,dtype,faces,K", CASES, ids=[c[0] for c in CASES])
+def test_cg2d_bicgstab_vs_one_plane_tiling_and_oracle(name, n, dtype, faces, K):
+    g = torch.Generator().manual_seed(8)
+    rhs0 = torch.randn((1, *n), generator=g, dtype=torch.float64)
+    if all(t == "periodic" for t, _ in faces):
+        rhs0 -= rhs0.mean()
+    f64 = dtype == "double"
+    om = O.OMesh([0.0, 0.0], [1.0, 1.0], n, dtype)
+    cfg = [{"bc_face": O.FACES[i], "bc_type": t, "bc_val": v} for i, (t, v) in enumerate(faces)]
+    for k in (1, 2, 5):
+        x_m, rep_m, sc_m = _solve_m(n, dtype, faces, k, 0, rhs0, "bicgstab")
+        x_t, rep_t, sc_t = _solve_m(n, dtype, faces, k, -1, rhs0, "bicgstab")
+        assert rep_m["itr"] == rep_t["itr"] == k
+        assert rel_err(x_m, x_t) < (1e-11 if f64 else 5e-6), (k, rel_err(x_m, x_t))
+        for key in ("alpha", "omega", "tol"):
+            assert abs(sc_m[key] - sc_t[key]) <= (1e-9 if f64 else 1e-3) * abs(sc_t[key]), (k, key)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            xo, ro = O.solve_poisson(om, cfg, rhs0.to(om.dtype).clone(), method="bicgstab", tol=1e-30, max_it=k, coeff=0.7,
+                                     sign=-1.0)
+        assert ro["itr"] == rep_m["itr"]
+        assert rel_err(x_m, xo) < (1e-10 if f64 else 1e-5), (k, rel_err(x_m, xo))
