@@ -207,7 +207,20 @@ def main():
     m2 = 1024 if q else 4096
     ms, wall, itr, N = solver_ms(lambda: Mesh(Box[0:1, 0:1], None, [m2, m2], "cuda", "double"),
                                  homogeneous_bcs(2, 0.0, "dirichlet"), "cg", 100)
-    emit(f"cg 2-D {m2}x{m2} f64 dirichlet (one plane of the tiled kernels)", N, ms, 10, 8, {"wall_ms_per_iter": wall, "iters": itr})
+    emit(f"cg 2-D {m2}x{m2} f64 dirichlet (marching kernel k_cg2d from 1.5 M cells on)", N, ms, 10, 8, {"wall_ms_per_iter": wall, "iters": itr})
+    # round 3, second session: the Jacobi sweep and the BiCGSTAB phases of large 2-D meshes on the marching kernel too;
+    # odd extents (node-based meshes: 2^k + 1) through the PITCH layout
+    ms, wall, itr, N = solver_ms(lambda: Mesh(Box[0:1, 0:1], None, [m2, m2], "cuda", "double"),
+                                 homogeneous_bcs(2, 0.0, "dirichlet"), "jacobi", 100)
+    emit(f"jacobi 2-D {m2}x{m2} f64 dirichlet (k_cg2d)", N, ms, 3, 8, {"wall_ms_per_iter": wall, "iters": itr})
+    ms, wall, itr, N = solver_ms(lambda: Mesh(Box[0:1, 0:1], None, [m2, m2], "cuda", "double"),
+                                 homogeneous_bcs(2, 0.0, "dirichlet"), "bicgstab", 60)
+    emit(f"bicgstab 2-D {m2}x{m2} f64 dirichlet (k_cg2d phases 6 / 8)", N, ms, 22, 8, {"wall_ms_per_iter": wall, "iters": itr})
+    n3 = 129 if q else 257
+    mixbc3 = mixed_bcs([0, 0, 0, 0, 1, 0], ["dirichlet", "neumann"] * 3)
+    for meth, its, passes in (("cg", 100, 10), ("bicgstab", 60, 22)):
+        ms, wall, itr, N = solver_ms(lambda: Mesh(Box[0:1, 0:1, 0:1], None, [n3, n3, n3], "cuda", "double"), mixbc3, meth, its)
+        emit(f"{meth} 3-D {n3}^3 f64 mixed (odd rows: PITCH layout)", N, ms, passes, 8, {"wall_ms_per_iter": wall, "iters": itr})
 
 
 if __name__ == "__main__":
