@@ -127,7 +127,8 @@ int pa_scratch(pa_ctx* c, void** slot, size_t* cap, size_t bytes) {
   }
   const size_t off = (size_t)(q + sbase) * (size_t)stagger;
   void* base = nullptr;
-  PA_HIP(c, hipMalloc(&base, bytes + off));
+  // (PA_PLACE_ROOM more: the CG set-up may move r and the direction buffers inside their allocations, cg_place_t)
+  PA_HIP(c, hipMalloc(&base, bytes + off + PA_PLACE_ROOM));
   c->scr_base[q] = base;
   *slot = (char*)base + off;
   *cap = bytes;
@@ -248,6 +249,7 @@ int pa_ctx_create(int device, void* hip_stream, pa_ctx** out) {
   if (const char* rs = getenv("PYAPES_HIP_RESIDENT")) c->resident = atoi(rs) != 0;
   if (const char* rc = getenv("PYAPES_HIP_RESIDENT_COOP")) c->resident_coop = atoi(rc) != 0;
   if (const char* pt = getenv("PYAPES_HIP_PITCH")) c->pitch = atoi(pt) != 0;
+  if (const char* pl = getenv("PYAPES_HIP_PLACE")) c->place = atoi(pl) != 0;
   if (const char* bl = getenv("PYAPES_HIP_BCL")) c->bcl = atoi(bl) != 0;
   if (const char* m2 = getenv("PYAPES_HIP_CG2D_MINCELLS")) c->cg2d_mincells = atoll(m2);
   if (hipMalloc((void**)&c->sc_base, 2 * sizeof(SolverScalars)) != hipSuccess ||
@@ -305,6 +307,7 @@ int pa_ctx_set_option(pa_ctx* c, const char* name, int value) {
   else if (!strcmp(name, "cg2d_mincells")) c->cg2d_mincells = value;   // k_cg2d from this many cells on (< 0: never)
   else if (!strcmp(name, "bcl")) c->bcl = value != 0;         // Euler march: face values formed on load, one fill at the end
   else if (!strcmp(name, "pitch")) c->pitch = value != 0;     // odd row lengths: pitched r / d buffers in the CG phases
+  else if (!strcmp(name, "place")) c->place = value != 0;     // large CG solves: probe the placement of r / d (cg_place_t)
   else if (!strcmp(name, "resident_coop")) c->resident_coop = value != 0;   // 0: plain launch of the same grid (profiling, below)
   else { pa_set_err(c, "pa_ctx_set_option: unknown option '%s'", name); return PA_E_ARG; }
   return PA_OK;

@@ -31,6 +31,9 @@ enum {
   SCR_GHOST, SCR_SHELL2, SCR_RZ, SCR_RES, PA_NSCRATCH
 };
 
+// room behind every scratch allocation for the placement probe of the CG set-up (pa_solver.hip, cg_place_t)
+#define PA_PLACE_ROOM ((size_t)2 << 20)
+
 struct pa_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
@@ -89,6 +92,9 @@ struct pa_ctx {
   void* cg_x = nullptr;
   int64_t cg2d_mincells = 1500000;   // 2-D meshes of at least this many cells run the CG phases on k_cg2d (< 0: never)
   int bcl = 1;               // option "bcl" / PYAPES_HIP_BCL: explicit Euler march without a BC-fill launch per step (pa_sf_kernel.h)
+  int place = 1;             // option "place" / PYAPES_HIP_PLACE: large CG solves probe where r / d sit in their allocations
+  const void* place_key[4] = {nullptr, nullptr, nullptr, nullptr};   // (x, r, d0, d1 bases the last probe decided for)
+  size_t place_off[3] = {0, 0, 0};                                    // ... and what it chose (bytes into r, d0, d1)
   int pitch = 1;             // option "pitch" / PYAPES_HIP_PITCH: allow that layout (0: odd rows stay on the NARROW kernels)
   int cg_pitch = 0;          // live CG solve keeps r and the direction buffers in the PITCH layout of k_cg3d
   int64_t cg_ps1 = 0;        // ... with this row pitch (cells)

@@ -919,6 +919,99 @@ static int64_t solver_pitch(const pa_ctx* c, const T* x) {
   return (G.n2 + padw - 1) / padw * padw;
 }
 
+// Where r and the two direction buffers sit inside their allocations (large CG solves, one GPU).
+// The arrays of an iteration are streamed at identical offsets, so whether their memory channels coincide at every
+// moment depends on the low address bits AND on where the driver put the pages: phase B of 512^3 fp64 measures 853 us
+// or 931 us with the SAME kernel and the same virtual offsets, from one process / box to the next, and on a box where
+// it is slow another set of offsets makes it fast.  So the set-up asks the hardware: for a
+// handful of offset triples it runs the two phase kernels of the solve itself -- both ping-pong parities -- on the
+// arrays as they were allocated, with an EMPTY interior set (phase A then writes zeros into the direction buffer it
+// would write anyway, phase B stores x back exactly as loaded and zeros into r, which the set-up initialises right
+// afterwards: no value of the solve is touched, the traffic is that of a real iteration), and keeps the fastest.
+// ~40 launches once per allocation (the choice is remembered for as long as x and the scratch blocks stay where
+// they are); arrays the Infinity Cache holds are left alone.  PYAPES_HIP_PLACE=0 / option "place": off.
+template <typename T>
+static Vec<T> cg_vec(pa_ctx* c, const T* p, int which);
+template <typename T>
+static int cg_place_t(pa_ctx* c, T* x) {
+  const DevGeom G0 = c->G;
+  if (!c->place || c->slab || !c->fastpath || c->profile || c->plan_only) return PA_OK;
+  size_t minbytes = (size_t)128 << 20;   // arrays the Infinity Cache holds are not a matter of HBM channels
+  if (const char* e = getenv("PYAPES_HIP_PLACE_MINBYTES")) minbytes = (size_t)atoll(e);   // (tests: probe small meshes too)
+  if ((size_t)G0.ncell * sizeof(T) < minbytes) return PA_OK;
+  char* const base[3] = {(char*)c->scr_base[SCR_R], (char*)c->scr_base[SCR_D0], (char*)c->scr_base[SCR_D1]};
+  const int slot[3] = {SCR_R, SCR_D0, SCR_D1};
+  const size_t dflt[3] = {(size_t)((char*)c->scr[SCR_R] - base[0]), (size_t)((char*)c->scr[SCR_D0] - base[1]),
+                          (size_t)((char*)c->scr[SCR_D1] - base[2])};
+  if (c->place_key[0] == (const void*)x && c->place_key[1] == base[0] && c->place_key[2] == base[1] && c->place_key[3] == base[2]) {
+    for (int q = 0; q < 3; ++q) c->scr[slot[q]] = base[q] + c->place_off[q];
+    return PA_OK;
+  }
+  const size_t u = 69888, w = 4352, y = 0x2100, z = 0x80100;
+  const size_t cand[6][3] = {{dflt[0], dflt[1], dflt[2]}, {0, 0, 0}, {w, 2 * w, 3 * w}, {y, 2 * y, 3 * y}, {z, 2 * z, 3 * z},
+                             {3 * u, u, 2 * u}};
+  DevEq<T> E;
+  pa_build_eq<T>(c, c->nterms, c->terms, E);
+  double* part = (double*)c->scr[SCR_PART];
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) {
+    if (e0) (void)hipEventDestroy(e0);
+    (void)hipGetLastError();
+    return PA_OK;
+  }
+  c->fold_a_n = c->fold_b_n = c->fold_b_nsh = 0;
+  c->G.slo[0] = c->G.g0 + 1;   // nobody is in the interior set: the phases move the bytes and change nothing
+  auto round = [&]() -> int {   // one iteration pair: both parities of the direction ping-pong
+    T* r = (T*)c->scr[SCR_R];
+    T* d0 = (T*)c->scr[SCR_D0];
+    T* d1 = (T*)c->scr[SCR_D1];
+    int n = pa_cg3d_phase_a<T>(c, E, cg_vec<T>(c, r, 0), cg_vec<T>(c, d0, 1), d1, part);
+    if (n > 0) n = pa_cg3d_phase_b<T>(c, E, cg_vec<T>(c, d1, 1), x, r, part);
+    if (n > 0) n = pa_cg3d_phase_a<T>(c, E, cg_vec<T>(c, r, 0), cg_vec<T>(c, d1, 1), d0, part);
+    if (n > 0) n = pa_cg3d_phase_b<T>(c, E, cg_vec<T>(c, d0, 1), x, r, part);
+    return n;
+  };
+  float best = 0.f, first = 0.f;
+  int kbest = 0, ok = 1;
+  for (int k = 0; k < 6 && ok > 0; ++k) {
+    bool fits = true;
+    for (int q = 0; q < 3; ++q) fits = fits && (k == 0 || cand[k][q] <= PA_PLACE_ROOM - 4096);   // (pa_scratch's room)
+    if (!fits) continue;
+    for (int q = 0; q < 3; ++q) c->scr[slot[q]] = base[q] + cand[k][q];
+    if (k == 0) ok = round();   // code objects, caches
+    float t = 0.f;
+    for (int rep = 0; rep < 2 && ok > 0; ++rep) {
+      (void)hipEventRecord(e0, c->stream);
+      ok = round();
+      (void)hipEventRecord(e1, c->stream);
+      (void)hipEventSynchronize(e1);
+      float ms = 0.f;
+      (void)hipEventElapsedTime(&ms, e0, e1);
+      t = rep == 0 ? ms : (ms < t ? ms : t);
+    }
+    if (ok <= 0) break;
+    if (getenv("PYAPES_HIP_DEBUG"))
+      fprintf(stderr, "[pyapes_hip] placement probe: r +%zu d0 +%zu d1 +%zu: %.1f us per iteration pair\n", cand[k][0], cand[k][1],
+              cand[k][2], t * 1e3f);
+    if (k == 0) { first = best = t; kbest = 0; }
+    else if (t < best) { best = t; kbest = k; }
+  }
+  c->G = G0;
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  if (ok < 0) return ok;
+  if (ok == 0 || !(best < 0.99f * first)) kbest = 0;   // the tiled phases do not take this solve / nothing to gain: the default
+  for (int q = 0; q < 3; ++q) {
+    c->scr[slot[q]] = base[q] + cand[kbest][q];
+    c->place_off[q] = cand[kbest][q];
+  }
+  c->place_key[0] = x; c->place_key[1] = base[0]; c->place_key[2] = base[1]; c->place_key[3] = base[2];
+  if (getenv("PYAPES_HIP_DEBUG"))
+    fprintf(stderr, "[pyapes_hip] placement probe: kept r +%zu d0 +%zu d1 +%zu (%.1f us, default %.1f us)\n", cand[kbest][0],
+            cand[kbest][1], cand[kbest][2], best * 1e3f, first * 1e3f);
+  return PA_OK;
+}
+
 template <typename T>
 static int cg_begin_t(pa_ctx* c, T* x, const T* rhs, double tol, int64_t max_it) {
   const DevGeom& G = c->G;
@@ -936,6 +1029,7 @@ static int cg_begin_t(pa_ctx* c, T* x, const T* rhs, double tol, int64_t max_it)
   if ((rc = pa_scratch(c, &c->scr[SCR_PART2], &c->cap[SCR_PART2], (size_t)3 * PA_MAX_GRID * sizeof(double)))) return rc;
   if ((rc = pa_scratch(c, &c->scr[SCR_SHELL], &c->cap[SCR_SHELL], 2 * (size_t)pa_shell_elems(c) * sizeof(T)))) return rc;
   if ((rc = init_scalars(c, tol, max_it))) return rc;
+  if ((rc = cg_place_t<T>(c, x))) return rc;   // (before anything is written into r / d)
   // the tiled phase kernels do not visit the last boundary row / column of non-periodic axes: the
   // direction there is 0 by definition and has to be 0 in the buffer the first phase A writes into
   if (!c->cg_pitch) PA_HIP(c, hipMemsetAsync(c->scr[SCR_D1], 0, fb, c->stream));   // (pitched: it first carries A x, below)
