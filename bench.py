@@ -587,6 +587,11 @@ def main():
         e0 = torch.cuda.Event(enable_timing=True)
         e1 = torch.cuda.Event(enable_timing=True)
         log("array bases: x %#x rhs %#x (ctx-owned r / d buffers: hipMalloc, 2 MiB-aligned)" % (var().data_ptr(), rhs.data_ptr()))
+        try:   # how much of the card is free: a box whose GiB-sized allocations run slow is worth a look at this
+            free_b, total_b = torch.cuda.mem_get_info()
+            log(f"device memory: {free_b / 2**30:.1f} GiB free of {total_b / 2**30:.1f} GiB")
+        except Exception:
+            pass
         with ClockSampler(local_rank) as clk:
             t0 = time.perf_counter()
             e0.record(ctx.stream)
