@@ -960,7 +960,11 @@ static int cg_place_t(pa_ctx* c, T* x) {
     return PA_OK;
   }
   c->fold_a_n = c->fold_b_n = c->fold_b_nsh = 0;
-  c->G.slo[0] = c->G.g0 + 1;   // nobody is in the interior set: the phases move the bytes and change nothing
+  // nobody is in the interior set: the phases move the bytes and change nothing.  (Every axis: a 2-D mesh has no
+  // axis 0 to speak of, and k_cg2d tests axes 1 and 2 only.)
+  c->G.slo[0] = c->G.g0 + 1;
+  c->G.slo[1] = c->G.n1 + 1;
+  c->G.slo[2] = c->G.n2 + 1;
   auto round = [&]() -> int {   // one iteration pair: both parities of the direction ping-pong
     T* r = (T*)c->scr[SCR_R];
     T* d0 = (T*)c->scr[SCR_D0];

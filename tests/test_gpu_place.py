@@ -30,6 +30,7 @@ CASES = [
     ("odd_rows_pitched_f64", [20, 18, 131], "double", [D(0.0), D(0.5), D(0.0), D(0.0), D(1.0), D(0.0)]),
     ("mixed_f32", [18, 22, 132], "single", [D(0.0), N(0.0), D(0.0), N(0.0), D(1.0), N(0.0)]),
     ("2d_f64", [96, 640], "double", [D(0.0), D(1.0), N(0.0), D(0.5)]),
+    ("2d_odd_rows_f64", [65, 1025], "double", [D(0.0), D(1.0), D(0.0), D(0.5)]),
 ]
 
 
@@ -38,6 +39,8 @@ def _solve(n, dtype, faces, place, rhs0, x0, K=9):
     mesh = Mesh(Box([0.0] * nd, [1.0] * nd), None, n, "cuda", dtype)
     ctx = context_for(mesh)
     ctx.set_option("place", place)
+    if nd == 2:
+        ctx.set_option("cg2d_mincells", 0)     # the marching kernel (what a 2-D mesh large enough for the probe runs)
     ctx.set_option("resident", False)
     bcs = [{"bc_face": O.FACES[i], "bc_type": t, "bc_val": v, "bc_val_opt": None} for i, (t, v) in enumerate(faces)]
     var = Field("p", 1, mesh, {"domain": bcs, "obstacle": None})
