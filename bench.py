@@ -565,6 +565,7 @@ def main():
         host_group = dist.new_group(backend="gloo") if dist.get_backend() != "gloo" else dist.group.WORLD
     first_attempt = None
     clocks = None
+    box = {}            # per-box yardstick (single-GPU CG branch): free device memory, plain copy rate
 
     mesh = Mesh(Box([0.0] * nd, list(upper)), None, list(gn), "cuda", dtype, slab=(rank, world) if slab else None)
     var = Field("p", 1, mesh, {"domain": make_bcs(kind), "obstacle": None})
@@ -587,9 +588,34 @@ def main():
         e0 = torch.cuda.Event(enable_timing=True)
         e1 = torch.cuda.Event(enable_timing=True)
         log("array bases: x %#x rhs %#x (ctx-owned r / d buffers: hipMalloc, 2 MiB-aligned)" % (var().data_ptr(), rhs.data_ptr()))
+        box = {}
         try:   # how much of the card is free: a box whose GiB-sized allocations run slow is worth a look at this
             free_b, total_b = torch.cuda.mem_get_info()
             log(f"device memory: {free_b / 2**30:.1f} GiB free of {total_b / 2**30:.1f} GiB")
+            box["free_gib"] = round(free_b / 2 ** 30, 1)
+        except Exception:
+            pass
+        try:
+            # The yardstick of THIS box: a plain device copy of an array of the workload's size (1 read + 1 write).  The CG
+            # phases of 512^3 measure 853 us on some boxes and 990 us on others with the same bytes moved (DESIGN.md
+            # section 8); the copy says what the box gives a kernel that does nothing else.
+            src = var()[0]
+            dst = torch.empty_like(src)
+            for _ in range(2):
+                dst.copy_(src)
+            torch.cuda.synchronize()
+            c0 = torch.cuda.Event(enable_timing=True)
+            c1 = torch.cuda.Event(enable_timing=True)
+            c0.record()
+            for _ in range(5):
+                dst.copy_(src)
+            c1.record()
+            torch.cuda.synchronize()
+            cms = c0.elapsed_time(c1) / 5
+            box["copy_ms"] = cms
+            box["copy_GBs"] = 2 * src.numel() * src.element_size() / (cms * 1e-3) / 1e9
+            log(f"this box: torch copy_ of one {src.numel() * src.element_size() / 2**20:.0f} MiB array {cms * 1e3:.1f} us = {box['copy_GBs']:.0f} GB/s")
+            del dst
         except Exception:
             pass
         with ClockSampler(local_rank) as clk:
@@ -801,6 +827,8 @@ def main():
             out["first_attempt"] = first_attempt
         if clocks:
             out["clocks"] = clocks
+        if solver == "cg" and box:
+            out["box"] = box
         if not args.no_cpu_baseline and world == 1 and not slab:   # reported baseline: rank 0 at N = 1 only
             out["cpu_baseline"] = cpu_baseline(solver, kind, dtype, gn)
         sys.stdout.flush()
