@@ -135,6 +135,69 @@ def test_seeded_fuzz(monkeypatch):
     assert not bad, bad[:6]
 
 
+def test_seeded_fuzz_bicgstab(monkeypatch):
+    """round 3: BiCGSTAB on the same random meshes (the direction update folded into the x / r update, phases that skip
+    the last boundary row / column, the PITCH layout on odd rows): three iterations through the tiled kernels == the
+    oracle and == the generic kernels, with and without the folded update (equal bits)."""
+    rng = random.Random(20261005)
+    bad = []
+    ran = 0
+    for case in range(260):
+        n, bcs, dtype = _random_case(rng)
+        if len(n) == 1 or (any(t == "periodic" for t, _ in bcs) and min(n) < 5):
+            continue
+        if not any(t == "dirichlet" for t, _ in bcs):
+            continue
+        tdt = torch.float64 if dtype == "double" else torch.float32
+        g = torch.Generator().manual_seed(1000 + case)
+        rhs = torch.randn((1, *n), generator=g, dtype=torch.float64).to(tdt)
+        x0 = torch.randn((1, *n), generator=g, dtype=torch.float64).to(tdt)
+        K = 3
+        om = O.OMesh([0.0] * len(n), [1.0 + 0.1 * a for a in range(len(n))], list(n), dtype)
+        ocfg = [{"bc_face": O.FACES[i], "bc_type": t, "bc_val": v} for i, (t, v) in enumerate(bcs)]
+        try:
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                xo, ro = O.solve_poisson(om, ocfg, rhs.clone(), x0=x0.clone(), method="bicgstab", tol=-1.0, max_it=K,
+                                         coeff=0.8, sign=-1.0)
+        except RuntimeError:
+            continue
+        if not bool(torch.isfinite(xo).all()):
+            continue
+
+        def run(fast, pfold):
+            monkeypatch.setenv("PYAPES_HIP_FASTPATH", "1" if fast else "0")
+            monkeypatch.setenv("PYAPES_HIP_BICG_PFOLD", "1" if pfold else "0")
+            nd = len(n)
+            mesh = Mesh(Box([0.0] * nd, [1.0 + 0.1 * a for a in range(nd)]), None, list(n), "cuda", dtype)
+            cfg = [{"bc_face": O.FACES[i], "bc_type": t, "bc_val": v, "bc_val_opt": None} for i, (t, v) in enumerate(bcs)]
+            var = Field("p", 1, mesh, {"domain": cfg, "obstacle": None})
+            var.set_var_tensor(x0.cuda().clone())
+            s = Solver({"fdm": {"method": "bicgstab", "tol": -1.0, "max_it": K, "report": False}})
+            s.set_eq(-FDM().laplacian(0.8, var) == rhs.cuda().clone())
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                rep = s.solve()
+            return var().cpu(), rep
+
+        try:
+            xf, rf = run(True, True)
+            xq, rq = run(True, False)
+            xg, rg = run(False, True)
+        except RuntimeError as e:
+            bad.append((case, n, [t for t, _ in bcs], dtype, "raised", str(e)[:80]))
+            continue
+        ran += 1
+        tol = 1e-9 if dtype == "double" else 5e-5
+        ok = (rf["itr"] == rq["itr"] == rg["itr"] == ro["itr"] and torch.equal(xf, xq) and rel_err(xf, xo) <= tol
+              and rel_err(xg, xo) <= tol and rel_err(xf, xg) <= (1e-10 if dtype == "double" else 5e-5))
+        if not ok:
+            bad.append((case, n, [t for t, _ in bcs], dtype, rel_err(xf, xo), rel_err(xg, xo), rel_err(xf, xg),
+                        bool(torch.equal(xf, xq)), rf["itr"], rg["itr"], ro["itr"]))
+    assert ran >= 100, ran
+    assert not bad, bad[:6]
+
+
 def test_seeded_fuzz_explicit_operators():
     """general Div (float / tensor / Jac advection, scalar and vector targets, edge or not, all three
     schemes), Grad, DiffFlux, jacobian / hessian and -- on rz meshes -- friction / diffusion, against the
