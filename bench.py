@@ -576,6 +576,14 @@ def main():
 
     if solver == "cg" and not slab:
         rhs = synth_rhs(gn, 0, gn[0], kind, mesh.dtype.float, mesh.device)
+        if os.environ.get("BENCH_FRESH_X"):
+            # diagnostic (slow boxes): x and the right-hand side in blocks the driver hands out NOW,
+            # not in blocks the caching allocator recycled from the mesh / input construction
+            torch.cuda.synchronize()
+            torch.cuda.empty_cache()
+            var.set_var_tensor(var().clone())
+            rhs = rhs.clone()
+            torch.cuda.empty_cache()
         terms = [{"kind": L.OP_LAPLACIAN, "sign": 1.0, "coeff": 1.0}]
         ctx = context_for(mesh)
         ctx.bind_bcs(var(), var.bcs, 0)
