@@ -1,5 +1,5 @@
 """-m gpu: the placement probe of the CG set-up (csrc/pa_solver.hip, cg_place_t).  On large solves the set-up times the
-two phase kernels of the solve itself on a handful of offsets of r / d inside their allocations -- with an EMPTY
+two phase kernels of the solve itself with r / d in a few alternative allocations and at a handful of offsets inside them -- with an EMPTY
 interior set, so that phase A writes zeros into a buffer it would write anyway and phase B stores x back exactly as
 loaded -- and keeps the fastest.  It must not change a single bit of any solve: here it is forced onto small meshes
 (PYAPES_HIP_PLACE_MINBYTES=0) and compared with the probe switched off."""
@@ -82,6 +82,6 @@ def test_placement_probe_runs_and_reports():
                PYTHONPATH=os.pathsep.join([os.path.join(root, "oracle"), os.environ.get("PYTHONPATH", "")]))
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env)
     assert r.returncode == 0, r.stderr[-2000:]
-    kept = [ln for ln in r.stderr.splitlines() if "placement probe: kept" in ln]
+    kept = [ln for ln in r.stderr.splitlines() if "placement probe: kept blocks" in ln]
     assert len(kept) == 1, r.stderr[-2000:]        # once: the second solve re-uses the choice
-    assert sum("us per iteration pair" in ln for ln in r.stderr.splitlines()) >= 5
+    assert sum("placement probe:" in ln for ln in r.stderr.splitlines()) >= 8      # blocks and offsets were tried
