@@ -919,17 +919,17 @@ static int64_t solver_pitch(const pa_ctx* c, const T* x) {
   return (G.n2 + padw - 1) / padw * padw;
 }
 
-// Where r and the two direction buffers sit inside their allocations (large CG solves, one GPU).
-// The arrays of an iteration are streamed at identical offsets, so whether their memory channels coincide at every
-// moment depends on the low address bits AND on where the driver put the pages: phase B of 512^3 fp64 measures 853 us
-// or 931 us with the SAME kernel and the same virtual offsets, from one process / box to the next, and on a box where
-// it is slow another set of offsets makes it fast.  So the set-up asks the hardware: for a
-// handful of offset triples it runs the two phase kernels of the solve itself -- both ping-pong parities -- on the
-// arrays as they were allocated, with an EMPTY interior set (phase A then writes zeros into the direction buffer it
-// would write anyway, phase B stores x back exactly as loaded and zeros into r, which the set-up initialises right
-// afterwards: no value of the solve is touched, the traffic is that of a real iteration), and keeps the fastest.
-// ~40 launches once per allocation (the choice is remembered for as long as x and the scratch blocks stay where
-// they are); arrays the Infinity Cache holds are left alone.  PYAPES_HIP_PLACE=0 / option "place": off.
+// WHICH allocations r and the two direction buffers live in, and where inside them (large CG solves, one GPU).
+// The arrays of an iteration are streamed in lockstep, and whether they collide in the memory system is decided by
+// where the driver put their pages: phase B of 512^3 fp64 measures 853 us or 931 us with the SAME kernel, from one
+// process / box to the next; a plain copy between 1 GiB blocks of one process runs at 4.65 ... 5.51 TB/s by PAIR of
+// blocks while each block alone gives 5.5-5.6.  So the set-up asks the hardware, with the two
+// phase kernels of the solve itself -- both ping-pong parities -- and an EMPTY interior set (phase A then writes zeros
+// into the direction buffer it would write anyway, phase B stores x back exactly as loaded and zeros into r, which the
+// set-up initialises right afterwards: no value of the solve is touched, the traffic is that of a real iteration):
+// first which of a few blocks each role should take beside the caller's x, then a handful of offsets.  ~45 iteration
+// pairs once per allocation (the choice is remembered for as long as x and the blocks stay where they are); arrays
+// the Infinity Cache holds are left alone.  PYAPES_HIP_PLACE=0 / option "place": off.
 template <typename T>
 static Vec<T> cg_vec(pa_ctx* c, const T* p, int which);
 template <typename T>
