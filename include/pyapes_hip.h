@@ -84,7 +84,11 @@ int pa_ctx_destroy(pa_ctx* ctx);
  * for the Div-carrying single-field operations, "fold" 0 = scalar steps as single-block kernels, "resident"
  * 0 = launch-per-phase solver loops on small meshes too.  The first three do not change results
  * (bit-identical paths; tests/test_gpu_properties.py, test_gpu_fold.py); "resident" changes the grouping of
- * the global sums only (tests/test_gpu_resident.py). */
+ * the global sums only (tests/test_gpu_resident.py).  Round 3: "pitch" 0 = odd row lengths on the one-cell-per-lane
+ * kernels (else pitched ctx-owned buffers), "cg2d_mincells" = 2-D marching kernel from this many cells on (< 0:
+ * never), "bcl" 0 = Euler march with a BC fill per step, "place" 0 = no placement probe in the set-up of large CG
+ * solves (which allocations r / d live in beside the caller's x; results do not depend on it, tests/test_gpu_place.py),
+ * "resident_coop" 0 = plain launch of the resident kernel (profiling). */
 int pa_ctx_set_option(pa_ctx* ctx, const char* name, int value);
 /* Small meshes: pa_cg / pa_jacobi / pa_bicgstab run the whole solve in ONE cooperative launch with the fields
  * resident in LDS (pa_resident.hip) when the bound mesh / BCs / equation allow it.  Returns the number of
