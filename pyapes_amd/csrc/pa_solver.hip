@@ -935,7 +935,9 @@ static Vec<T> cg_vec(pa_ctx* c, const T* p, int which);
 template <typename T>
 static int cg_place_t(pa_ctx* c, T* x) {
   const DevGeom G0 = c->G;
-  if (!c->place || c->slab || !c->fastpath || c->profile || c->plan_only) return PA_OK;
+  // (a slab of a multi-GPU solve probes like a single domain, its own wrap-around planes standing in for the ghost
+  // planes: every rank chooses for itself, and the slowest rank sets the pace of all)
+  if (!c->place || !c->fastpath || c->profile || c->plan_only) return PA_OK;
   size_t minbytes = (size_t)128 << 20;   // arrays the Infinity Cache holds are not a matter of HBM channels
   if (const char* e = getenv("PYAPES_HIP_PLACE_MINBYTES")) minbytes = (size_t)atoll(e);   // (tests: probe small meshes too)
   if ((size_t)G0.ncell * sizeof(T) < minbytes) return PA_OK;
@@ -961,19 +963,25 @@ static int cg_place_t(pa_ctx* c, T* x) {
   }
   const bool dbg = getenv("PYAPES_HIP_DEBUG") != nullptr;
   c->fold_a_n = c->fold_b_n = c->fold_b_nsh = 0;
+  c->slab_fold_live = 0;
   // nobody is in the interior set: the phases move the bytes and change nothing.  (Every axis: a 2-D mesh has no
   // axis 0 to speak of, and k_cg2d tests axes 1 and 2 only.)
   c->G.slo[0] = c->G.g0 + 1;
   c->G.slo[1] = c->G.n1 + 1;
   c->G.slo[2] = c->G.n2 + 1;
+  auto vec = [&](const T* p) -> Vec<T> {   // the field with its own wrap-around planes as ghost planes (also on a slab)
+    Vec<T> v = pa_vec_self<T>(c, p);
+    if (c->cg_pitch) v.glo = p + (c->G.n0 - 1) * c->G.n1 * c->cg_ps1;
+    return v;
+  };
   auto round = [&]() -> int {   // one iteration pair: both parities of the direction ping-pong
     T* r = (T*)c->scr[SCR_R];
     T* d0 = (T*)c->scr[SCR_D0];
     T* d1 = (T*)c->scr[SCR_D1];
-    int n = pa_cg3d_phase_a<T>(c, E, cg_vec<T>(c, r, 0), cg_vec<T>(c, d0, 1), d1, part);
-    if (n > 0) n = pa_cg3d_phase_b<T>(c, E, cg_vec<T>(c, d1, 1), x, r, part);
-    if (n > 0) n = pa_cg3d_phase_a<T>(c, E, cg_vec<T>(c, r, 0), cg_vec<T>(c, d1, 1), d0, part);
-    if (n > 0) n = pa_cg3d_phase_b<T>(c, E, cg_vec<T>(c, d0, 1), x, r, part);
+    int n = pa_cg3d_phase_a<T>(c, E, vec(r), vec(d0), d1, part);
+    if (n > 0) n = pa_cg3d_phase_b<T>(c, E, vec(d1), x, r, part);
+    if (n > 0) n = pa_cg3d_phase_a<T>(c, E, vec(r), vec(d1), d0, part);
+    if (n > 0) n = pa_cg3d_phase_b<T>(c, E, vec(d0), x, r, part);
     return n;
   };
   auto timed = [&](float& t) -> int {   // the faster of two rounds
