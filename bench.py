@@ -589,8 +589,22 @@ def main():
         ctx.bind_bcs(var(), var.bcs, 0)
         ctx.set_terms(terms)
         ctx.rhs_adjust(rhs[0])
-        # tolerance -1: the stop test is evaluated but can never end the solve; max_it beyond W + K
-        ctx.cg_begin(var()[0], rhs[0], -1.0, W + K + 10)
+        # tolerance -1: the stop test is evaluated but can never end the solve; max_it beyond everything run below
+        STEADY_MAX = int(os.environ.get("BENCH_STEADY_MAX", "160"))
+        if os.environ.get("BENCH_PLACE") is not None:     # A/B switch: 0 = no online placement search in this run
+            ctx.set_option("place", int(os.environ["BENCH_PLACE"]))
+        # set-up of the solve (pa_cg_begin: scratch allocation, BC fill, first residual): outside the timed region, so
+        # its cost goes into the record -- wall clock and stream time
+        torch.cuda.synchronize()
+        s0 = torch.cuda.Event(enable_timing=True)
+        s1 = torch.cuda.Event(enable_timing=True)
+        ts0 = time.perf_counter()
+        s0.record(ctx.stream)
+        ctx.cg_begin(var()[0], rhs[0], -1.0, W + 2 * K + STEADY_MAX + 20)
+        s1.record(ctx.stream)
+        torch.cuda.synchronize()
+        setup = {"wall_ms": (time.perf_counter() - ts0) * 1e3, "stream_ms": s0.elapsed_time(s1),
+                 "what": "pa_cg_begin: scratch allocation, BC fill, r = b - A x; nothing else runs before the first iteration"}
         ctx.cg_iterate(W)
         torch.cuda.synchronize()
         e0 = torch.cuda.Event(enable_timing=True)
@@ -639,6 +653,33 @@ def main():
         rep = ctx.report()
         assert rep.itr == W + K and rep.status == 0, f"work was skipped: itr={rep.itr} status={rep.status}"
         assert bool(torch.isfinite(var()).all()), "iterate became non-finite inside the timed region"
+        # The online placement search (csrc/pa_place.hip) rides on the iterations above -- warm-up and timed region
+        # alike, its copies and memsets included in `value`.  What it has done so far, and what the SAME solve reaches
+        # once its pass is over (at most BENCH_STEADY_MAX more iterations, then K timed ones): `probe`.
+        st = ctx.place_stats()
+        probe = {"mode": "online (pa_place.hip): trials ride on the solve's own iterations, no set-up cost",
+                 "state_after_timed_region": st["state"], "trials": int(st["trials"]), "kept": int(st["kept"])}
+        if st["state"] != "off" and STEADY_MAX > 0:
+            extra = 0
+            while extra < STEADY_MAX and ctx.place_stats()["state"] == "searching":
+                ctx.cg_iterate(8)
+                torch.cuda.synchronize()
+                extra += 8
+            q0 = torch.cuda.Event(enable_timing=True)
+            q1 = torch.cuda.Event(enable_timing=True)
+            q0.record(ctx.stream)
+            ctx.cg_iterate(K)
+            q1.record(ctx.stream)
+            torch.cuda.synchronize()
+            st = ctx.place_stats()
+            probe.update({"state": st["state"], "trials": int(st["trials"]), "kept": int(st["kept"]),
+                          "allocations": int(st["allocations"]), "iterations_until_steady": W + K + extra,
+                          "steady_ms_per_step": q0.elapsed_time(q1) / K,
+                          "as_allocated_ms_per_step": st["first_pair_us"] / 2e3, "best_ms_per_step": st["best_pair_us"] / 2e3,
+                          "spent_ms": st["spent_us"] / 1e3, "timed_ms": st["timed_us"] / 1e3})
+            gain = (st["first_pair_us"] - st["best_pair_us"]) / 2.0
+            probe["break_even_iterations"] = (st["spent_us"] / gain) if gain > 1.0 else None
+            log(f"placement search: {probe}")
         if not args.no_roofline_probe:
             # per-kernel durations of the two dominant kernels, HIP events on the launch stream
             ctx.profile(True)
@@ -837,6 +878,10 @@ def main():
             out["clocks"] = clocks
         if solver == "cg" and box:
             out["box"] = box
+        if solver == "cg" and not slab:
+            out["setup_ms"] = setup["wall_ms"]
+            out["setup"] = setup
+            out["probe"] = probe
         if not args.no_cpu_baseline and world == 1 and not slab:   # reported baseline: rank 0 at N = 1 only
             out["cpu_baseline"] = cpu_baseline(solver, kind, dtype, gn)
         sys.stdout.flush()

@@ -48,7 +48,11 @@ def emit(name, cells, ms, passes, esize, extra=None):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--quick", action="store_true")
+    ap.add_argument("--sections", default="ops,euler,small,big",
+                    help="comma-separated subset of: ops (explicit operators 512^3), euler (config 4 march), small (the reference's "
+                         "own mesh sizes, resident vs launch per phase), big (Jacobi / BiCGSTAB 256^3, 2-D 4096^2, odd extents)")
     args = ap.parse_args()
+    sections = set(args.sections.split(","))
     from pyapes_amd.geometry import Box
     from pyapes_amd.mesh import Mesh
     from pyapes_amd.solver.fdc import FDC
@@ -66,7 +70,7 @@ def main():
     from pyapes_amd.hip import lib as L
     from pyapes_amd.hip.context import context_for
     n = 256 if q else 512
-    for dt, es in (("double", 8), ("single", 4)):
+    for dt, es in ((("double", 8), ("single", 4)) if "ops" in sections else ()):
         mesh = Mesh(Box[0:1, 0:1, 0:1], None, [n, n, n], "cuda", dt)
         var = Field("p", 1, mesh, {"domain": homogeneous_bcs(3, 0.0, "neumann"), "obstacle": None}, init_val="random")
         ctx = context_for(mesh)
@@ -87,6 +91,17 @@ def main():
         del var, mesh, ctx, x, y, g3
 
     # --- config 4: explicit adv-diff march 256^3 fp32, upwind, Neumann / Symmetry ------------------
+    if "euler" in sections:
+        euler_rows(q, emit)
+    solver_rows(q, emit, sections)
+
+
+def euler_rows(q, emit):
+    from pyapes_amd.geometry import Box
+    from pyapes_amd.mesh import Mesh
+    from pyapes_amd.solver.march import euler_march, euler_step
+    from pyapes_amd.variables import Field
+    from pyapes_amd.variables.bcs import mixed_bcs
     n = 128 if q else 256
     mesh = Mesh(Box[0:1, 0:1, 0:1], None, [n, n, n], "cuda", "single")
     bcs = mixed_bcs([0.0, 0.0, None, None, None, None],
@@ -121,6 +136,17 @@ def main():
         ms = timed(lambda: euler_march(phi, 1.0, nu, dt, 20, cfg), 3) / 20
         emit("euler_march (20 steps per call) 512^3 f32 upwind scalar u", 512 ** 3, ms, 2, 4)
         del phi, mesh
+
+
+
+def solver_rows(q, emit, sections):
+    from pyapes_amd.geometry import Box
+    from pyapes_amd.mesh import Mesh
+    from pyapes_amd.solver.fdm import FDM
+    from pyapes_amd.solver.ops import Solver
+    from pyapes_amd.testing.poisson import poisson_bcs, poisson_rhs_nd
+    from pyapes_amd.variables import Field
+    from pyapes_amd.variables.bcs import homogeneous_bcs, mixed_bcs
 
     # --- solvers: ms per iteration from fixed-iteration solves ------------------------------------
     def solver_ms(meshf, bcsf, method, K, rhs_fn=None, extra_cfg=None, resident=True):
@@ -179,13 +205,15 @@ def main():
         for meth, its, passes in (("jacobi", 200, 3), ("cg", 60, 10), ("bicgstab", 40, 22)):
             small.append((f"{meth} 3-D {nn}^3 f64 dirichlet/neumann faces (BC fill every iteration)", m3(nn), mixbc, meth, its,
                           passes, None))
-    for name, meshf, bcs_, meth, its, passes, rfn in small:
+    for name, meshf, bcs_, meth, its, passes, rfn in (small if "small" in sections else []):
         for res in (True, False):
             torch.manual_seed(0)
             ms, wall, itr, N = solver_ms(meshf, bcs_, meth, its, rfn, resident=res)
             how = f"resident, {solver_ms.boxes} workgroups" if solver_ms.boxes else "launch per phase"
             emit(f"{name} [{how}]", N, ms, passes, 8, {"wall_ms_per_iter": wall, "iters": itr})
     os.environ["PYAPES_HIP_RESIDENT"] = "1"
+    if "big" not in sections:
+        return
     n = 128 if q else 256
     ms, wall, itr, N = solver_ms(lambda: Mesh(Box[0:1, 0:1, 0:1], None, [n, n, n], "cuda", "double"),
                                  homogeneous_bcs(3, 0.0, "dirichlet"), "jacobi", K)

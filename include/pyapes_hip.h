@@ -86,10 +86,17 @@ int pa_ctx_destroy(pa_ctx* ctx);
  * (bit-identical paths; tests/test_gpu_properties.py, test_gpu_fold.py); "resident" changes the grouping of
  * the global sums only (tests/test_gpu_resident.py).  Round 3: "pitch" 0 = odd row lengths on the one-cell-per-lane
  * kernels (else pitched ctx-owned buffers), "cg2d_mincells" = 2-D marching kernel from this many cells on (< 0:
- * never), "bcl" 0 = Euler march with a BC fill per step, "place" 0 = no placement probe in the set-up of large CG
- * solves (which allocations r / d live in beside the caller's x; results do not depend on it, tests/test_gpu_place.py),
- * "resident_coop" 0 = plain launch of the resident kernel (profiling). */
+ * never), "bcl" 0 = Euler march with a BC fill per step, "place" 0 = no online placement search in large CG solves
+ * (which allocations r / d live in beside the caller's x: csrc/pa_place.hip; results do not depend on it,
+ * tests/test_gpu_place.py) with "place_minbytes" (arrays of at least this size; default 128 MiB), "place_blocks"
+ * (candidate allocations per role, default 3) and "place_budget" (what the trials may cost, per cent of the time
+ * solved so far, default 3), "resident_coop" 0 = plain launch of the resident kernel (profiling). */
 int pa_ctx_set_option(pa_ctx* ctx, const char* name, int value);
+/* Accounts of the online placement search of this ctx, out[10]: state (-1 off, 0 not begun / arrays too small,
+ * 1 searching, 2 pass over), trials, trials kept, allocations made, microseconds the trials have cost (copies,
+ * memsets, trial iterations that ran slower), microseconds of iterations timed, best iteration pair (us), blocks
+ * held at the moment, the first clean iteration pair of the context (as allocated, us), x pointers with a finished pass. */
+int pa_place_stats(pa_ctx* ctx, double* out);
 /* Small meshes: pa_cg / pa_jacobi / pa_bicgstab run the whole solve in ONE cooperative launch with the fields
  * resident in LDS (pa_resident.hip) when the bound mesh / BCs / equation allow it.  Returns the number of
  * workgroups (= boxes the mesh is cut into; boxes[3] = boxes per internal axis) such a solve would use

@@ -11,10 +11,10 @@ mkdir -p "$OUT" "$OBJ"
 HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
 FLAGS=(--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Wall -Wno-unused-function -Wno-unused-variable ${PA_EXTRA_FLAGS:-})
 pids=()
-for tu in pa_core pa_bc pa_ops pa_solver pa_cg3d pa_cg3d_b pa_sf pa_comm pa_comm_hostring pa_rfp pa_resident; do
+for tu in pa_core pa_bc pa_ops pa_solver pa_cg3d pa_cg3d_b pa_sf pa_comm pa_comm_hostring pa_rfp pa_resident pa_place; do
   "$HIPCC" "${FLAGS[@]}" -c "$HERE/$tu.hip" -o "$OBJ/$tu.o" &
   pids+=($!)
 done
 for p in "${pids[@]}"; do wait "$p"; done
-"$HIPCC" --offload-arch=gfx950 -shared -fPIC -o "$OUT/libpyapes_hip.so" "$OBJ/pa_core.o" "$OBJ/pa_bc.o" "$OBJ/pa_ops.o" "$OBJ/pa_solver.o" "$OBJ/pa_cg3d.o" "$OBJ/pa_cg3d_b.o" "$OBJ/pa_sf.o" "$OBJ/pa_comm.o" "$OBJ/pa_comm_hostring.o" "$OBJ/pa_rfp.o" "$OBJ/pa_resident.o" -ldl -lrt -lpthread
+"$HIPCC" --offload-arch=gfx950 -shared -fPIC -o "$OUT/libpyapes_hip.so" "$OBJ/pa_core.o" "$OBJ/pa_bc.o" "$OBJ/pa_ops.o" "$OBJ/pa_solver.o" "$OBJ/pa_cg3d.o" "$OBJ/pa_cg3d_b.o" "$OBJ/pa_sf.o" "$OBJ/pa_comm.o" "$OBJ/pa_comm_hostring.o" "$OBJ/pa_rfp.o" "$OBJ/pa_resident.o" "$OBJ/pa_place.o" -ldl -lrt -lpthread
 echo "built $OUT/libpyapes_hip.so"

@@ -403,7 +403,7 @@ __global__ void __launch_bounds__(256) k_cg2d(Cg3dArgs<T> A) {
       } else if (PHASE == 8) {
         *reinterpret_cast<V*>(A.out2 + (int64_t)jj * fs1 + kcf) = outx;
       } else {
-        __builtin_nontemporal_store(outd, reinterpret_cast<V*>(A.rw + (int64_t)jj * fs1 + kcf));
+        __builtin_nontemporal_store(outd, reinterpret_cast<V*>(A.rw_out + (int64_t)jj * fs1 + kcf));
         if (PITCH) {
           T* xp = A.x + (int64_t)jj * G.s1;
 #pragma unroll

@@ -34,13 +34,16 @@ int pa_cg3d_phase_a(pa_ctx* c, const DevEq<T>& E, Vec<T> r, Vec<T> d, T* dnew, d
 
 template <typename T>
 int pa_cg3d_phase_b(pa_ctx* c, const DevEq<T>& E, Vec<T> d, T* x, T* r, double* partials) {
-  const int mode = c->cg_pitch ? 3 : cg3d_mode<T>(c, E, {d.p, x, r, d.glo, d.ghi, c->r_send_lo, c->r_send_hi});
+  // the new residual goes where the old one came from -- or, when the placement search moves r (pa_place.hip), straight
+  // into its new block: the caller re-points SCR_R after this launch
+  T* const r_out = c->cg_r_out ? (T*)c->cg_r_out : r;
+  const int mode = c->cg_pitch ? 3 : cg3d_mode<T>(c, E, {d.p, x, r, r_out, d.glo, d.ghi, c->r_send_lo, c->r_send_hi});
   if (!mode) return 0;
   Cg3dArgs<T> A;
   memset(&A, 0, sizeof(A));
   fill_common<T>(c, E, A);
   A.ps1 = c->cg_ps1; A.ps0 = c->cg_ps1 * c->G.n1;
-  A.d = d; A.x = x; A.rw = r; A.partials = partials;
+  A.d = d; A.x = x; A.rw = r; A.rw_out = r_out; A.partials = partials;
   if (!c->slab_fold_live) {   // folded slab iterations: the mid kernel has produced the send planes already
     A.send_lo = (T*)c->r_send_lo; A.send_hi = (T*)c->r_send_hi;
   }

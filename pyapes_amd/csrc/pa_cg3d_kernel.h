@@ -50,7 +50,9 @@ struct Cg3dArgs {
   Vec<T> r, d;          // phase A: r and the old direction; phase B: d = new direction
   T* dnew;              // phase A output
   T* x;                 // phase B in/out
-  T* rw;                // phase B in/out (residual)
+  T* rw;                // phase B in (residual)
+  T* rw_out;            // phase B out: the new residual -- rw itself, or another block when the placement search moves r
+                        // (pa_place.hip: a move of r costs no copy this way)
   T* send_lo;           // phase B: copies of r's first / last owned plane (slab) or null
   T* send_hi;
   double* partials;
@@ -900,17 +902,17 @@ __global__ void __launch_bounds__(256) k_cg3d(Cg3dArgs<T> A) {
           else __builtin_nontemporal_store(outd, reinterpret_cast<V*>(A.dnew + o));  // -1.5 % (measured)
         } else {
           if (PITCH) {
-            __builtin_nontemporal_store(outd, reinterpret_cast<V*>(A.rw + ii * fs0 + jrow[jj] * fs1 + kcf));
+            __builtin_nontemporal_store(outd, reinterpret_cast<V*>(A.rw_out + ii * fs0 + jrow[jj] * fs1 + kcf));
             T* xp = A.x + ii * G.s0 + jrow[jj] * G.s1;
 #pragma unroll
             for (int v = 0; v < VEC; ++v)
               if (kg + v < G.n2) xp[kg + v] = outx[v];
           } else if (NARROW) {
             *reinterpret_cast<V*>(A.x + o) = outx;
-            *reinterpret_cast<V*>(A.rw + o) = outd;
+            *reinterpret_cast<V*>(A.rw_out + o) = outd;
           } else {
             __builtin_nontemporal_store(outx, reinterpret_cast<V*>(A.x + o));
-            __builtin_nontemporal_store(outd, reinterpret_cast<V*>(A.rw + o));
+            __builtin_nontemporal_store(outd, reinterpret_cast<V*>(A.rw_out + o));
           }
           if (A.send_lo && ii == 0) *reinterpret_cast<V*>(A.send_lo + jrow[jj] * G.s1 + kc) = outd;
           if (A.send_hi && ii == G.n0 - 1) *reinterpret_cast<V*>(A.send_hi + jrow[jj] * G.s1 + kc) = outd;

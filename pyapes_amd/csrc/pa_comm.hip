@@ -332,6 +332,7 @@ int pa_cg_iterate_comm(pa_ctx* c, int64_t n) {
     // stepwise sequence (also the per-kernel timing loop of pa_profile_set): sums are all-reduced, every
     // scalar step is its own single-block kernel
     for (int64_t q = 0; q < n; ++q) {
+      if ((rc = pa_place_tick(c))) return rc;   // every rank searches for itself (the slowest sets the pace of all)
       if ((rc = pa_cg_phase_a(c))) return rc;
       PA_NCCL(c, R, R->AllReduce(sums + PA_SUM_DAD, sums + PA_SUM_DAD, 1, ncclDouble, ncclSum, comm, c->stream));
       if ((rc = pa_cg_phase_b(c))) return rc;
@@ -340,7 +341,7 @@ int pa_cg_iterate_comm(pa_ctx* c, int64_t n) {
       PA_NCCL(c, R, R->AllReduce(sums + PA_SUM_RR, sums + PA_SUM_RR, 2, ncclDouble, ncclSum, comm, c->stream));
       if ((rc = pa_cg_finish_iter(c))) return rc;
     }
-    return PA_OK;
+    return pa_place_batch_end(c);
   }
   // folded sequence (include/pyapes_hip.h "Folded iterations"): 2 tiled kernels + the mid kernel + the BC
   // fill + 2 row all-reduces on the ctx stream, the packed exchange beside them on its own communicator +
@@ -355,6 +356,7 @@ int pa_cg_iterate_comm(pa_ctx* c, int64_t n) {
   c->slab_fold_live = 1;
   rc = PA_OK;
   for (int64_t q = 0; q < n && !rc; ++q) {
+    if ((rc = pa_place_tick(c))) break;
     if ((rc = pa_cg_phase_a(c))) break;
     PA_NC(R->AllReduce(c->rows_send, c->rows_recv, mA, ncclDouble, ncclSum, comm, c->stream));
     if ((rc = pa_cg_slab_mid(c))) break;
@@ -383,6 +385,7 @@ int pa_cg_iterate_comm(pa_ctx* c, int64_t n) {
 #undef PA_NC
   // the batch's last scalar step (beta, stop test, iteration count) by the single-block kernel the prologue
   // of a next phase A would have replaced: pa_report_read / pa_cg_end see the state of n whole iterations
+  if (!rc) rc = pa_place_batch_end(c);
   if (!rc) rc = pa_cg_slab_flush(c);
   c->slab_fold_live = 0;
   if (rc == PA_E_HIP && !c->err[0]) pa_set_err(c, "pa_cg_iterate_comm: HIP / RCCL call failed in the folded sequence");

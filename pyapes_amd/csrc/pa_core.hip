@@ -12,6 +12,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <chrono>
 #include <new>
 
 // ---- axisymmetric meshes: the r-dependent coefficient rows, once per mesh -------------------------
@@ -109,6 +110,8 @@ int pa_grid_blocks(int64_t work) {
 int pa_scratch(pa_ctx* c, void** slot, size_t* cap, size_t bytes) {
   if (*cap >= bytes && *slot) return PA_OK;
   const int q = (int)(slot - c->scr);  // every caller passes &c->scr[id]
+  // (r / d / d' change size: the pool of the placement search was made for the old one)
+  if (*slot && (q == SCR_R || q == SCR_D0 || q == SCR_D1)) pa_place_reset(c);
   if (*slot) { (void)hipFree(c->scr_base[q]); c->scr_base[q] = nullptr; *slot = nullptr; *cap = 0; }
   if (bytes == 0) return PA_OK;
   // hipMalloc returns 2 MB-aligned blocks; fields that are streamed in lockstep (x, r, d, d') would then sit at the
@@ -127,8 +130,15 @@ int pa_scratch(pa_ctx* c, void** slot, size_t* cap, size_t bytes) {
   }
   const size_t off = (size_t)(q + sbase) * (size_t)stagger;
   void* base = nullptr;
-  // (PA_PLACE_ROOM more: the CG set-up may move r and the direction buffers inside their allocations, cg_place_t)
-  PA_HIP(c, hipMalloc(&base, bytes + off + PA_PLACE_ROOM));
+  // (PA_PLACE_ROOM more: every role of a CG solve fits every block of the placement search's pool, pa_place.hip)
+  {
+    static const bool dbg = getenv("PYAPES_HIP_DEBUG") != nullptr;
+    const auto t0 = std::chrono::steady_clock::now();
+    PA_HIP(c, hipMalloc(&base, bytes + off + PA_PLACE_ROOM));
+    if (dbg && bytes >= ((size_t)32 << 20))
+      fprintf(stderr, "[pyapes_hip] scratch slot %d: hipMalloc of %.0f MiB: %.0f us\n", q, bytes / 1048576.0,
+              std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count());
+  }
   c->scr_base[q] = base;
   *slot = (char*)base + off;
   *cap = bytes;
@@ -249,7 +259,10 @@ int pa_ctx_create(int device, void* hip_stream, pa_ctx** out) {
   if (const char* rs = getenv("PYAPES_HIP_RESIDENT")) c->resident = atoi(rs) != 0;
   if (const char* rc = getenv("PYAPES_HIP_RESIDENT_COOP")) c->resident_coop = atoi(rc) != 0;
   if (const char* pt = getenv("PYAPES_HIP_PITCH")) c->pitch = atoi(pt) != 0;
-  if (const char* pl = getenv("PYAPES_HIP_PLACE")) c->place = atoi(pl) != 0;
+  if (const char* pl = getenv("PYAPES_HIP_PLACE")) {   // 0 off, 1 on (default), 2 stress: every CG solve of any size, no budget
+    c->place = atoi(pl) != 0;
+    if (atoi(pl) == 2) { c->ps.minbytes = 0; c->ps.budget = 1e9; }
+  }
   if (const char* bl = getenv("PYAPES_HIP_BCL")) c->bcl = atoi(bl) != 0;
   if (const char* m2 = getenv("PYAPES_HIP_CG2D_MINCELLS")) c->cg2d_mincells = atoll(m2);
   if (hipMalloc((void**)&c->sc_base, 2 * sizeof(SolverScalars)) != hipSuccess ||
@@ -307,7 +320,10 @@ int pa_ctx_set_option(pa_ctx* c, const char* name, int value) {
   else if (!strcmp(name, "cg2d_mincells")) c->cg2d_mincells = value;   // k_cg2d from this many cells on (< 0: never)
   else if (!strcmp(name, "bcl")) c->bcl = value != 0;         // Euler march: face values formed on load, one fill at the end
   else if (!strcmp(name, "pitch")) c->pitch = value != 0;     // odd row lengths: pitched r / d buffers in the CG phases
-  else if (!strcmp(name, "place")) c->place = value != 0;     // large CG solves: probe the placement of r / d (cg_place_t)
+  else if (!strcmp(name, "place")) c->place = value != 0;     // large CG solves: online search for the allocations of r / d (pa_place.hip)
+  else if (!strcmp(name, "place_minbytes")) c->ps.minbytes = value < 0 ? 0 : (size_t)value;   // ... for arrays of at least this size (tests: 0)
+  else if (!strcmp(name, "place_blocks")) c->ps.blocks = value < 0 ? 0 : (value > PA_PLACE_MAXSPARE ? PA_PLACE_MAXSPARE : value);
+  else if (!strcmp(name, "place_budget")) c->ps.budget = 0.01 * (value < 0 ? 0 : value);      // per cent of the time solved so far
   else if (!strcmp(name, "resident_coop")) c->resident_coop = value != 0;   // 0: plain launch of the same grid (profiling, below)
   else { pa_set_err(c, "pa_ctx_set_option: unknown option '%s'", name); return PA_E_ARG; }
   return PA_OK;
@@ -318,6 +334,7 @@ int pa_ctx_destroy(pa_ctx* c) {
   (void)hipSetDevice(c->device);
   (void)hipStreamSynchronize(c->stream);
   if (c->comm) (void)pa_comm_destroy(c);
+  pa_place_destroy(c);
   for (int q = 0; q < PA_NSCRATCH; ++q)
     if (c->scr_base[q]) (void)hipFree(c->scr_base[q]);
   if (c->sc_base) (void)hipFree(c->sc_base);
@@ -376,6 +393,7 @@ int pa_grid_set(pa_ctx* c, int ndim, const int64_t* n, const double* dx, int dty
   c->coord = PA_COORD_XYZ;
   c->rz_tab = nullptr;
   pa_refresh_geom(c);
+  pa_place_reset(c);   // (another grid: what a placement search learnt about the old arrays is void)
   return PA_OK;
 }
 

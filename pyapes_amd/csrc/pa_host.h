@@ -31,8 +31,48 @@ enum {
   SCR_GHOST, SCR_SHELL2, SCR_RZ, SCR_RES, PA_NSCRATCH
 };
 
-// room behind every scratch allocation for the placement probe of the CG set-up (pa_solver.hip, cg_place_t)
+// room behind every scratch allocation: any of the roles r / d / d' of a CG solve fits any block of the placement
+// search's pool at its own offset (pa_place.hip)
 #define PA_PLACE_ROOM ((size_t)2 << 20)
+
+// ---- online placement search of large CG solves (pa_place.hip) --------------------------------------------------
+#define PA_PLACE_MAXSPARE 8
+#define PA_PLACE_NEV 8
+#define PA_PLACE_NDUR 32
+#define PA_PLACE_NX 4
+struct PlaceSearch {
+  // options "place_minbytes", "place_blocks", "place_budget" (per cent)
+  size_t minbytes = (size_t)128 << 20;   // arrays the Infinity Cache holds are left alone
+  int blocks = 3;                        // candidates per role = spare allocations held while a pass is on
+  double budget = 0.03;                  // what the trials may cost, as a share of the time solved so far
+  // pool: blocks no role lives in at the moment
+  char* spare[PA_PLACE_MAXSPARE] = {nullptr};
+  int spare_epoch[PA_PLACE_MAXSPARE] = {0};   // solve in which the block last carried r / d (zero where the phases skip)
+  int nspare = 0;
+  size_t bytes = 0, blk = 0;             // array bytes the pool was made for; allocation size of a block
+  // the pass: role 0 r, 1 d0, 2 d1 tries candidates 0 .. blocks - 1
+  int phase = 0;                         // 0 not begun, 1 searching, 2 over
+  int role = 0, cand = 0;
+  const void* decided[PA_PLACE_NX] = {nullptr};   // x pointers a pass has been completed for
+  int n_decided = 0;
+  // the live solve
+  int active = 0, st = 0, pause = 0;     // st: 0 measuring the best assignment, 1 trial running, 2 trial to be undone,
+                                         //     3 a move of r waits for its phase B (r_move: 1 into the trial block, 2 back)
+  int r_move = 0;
+  int epoch = 0;
+  const void* x = nullptr;
+  int64_t it = 0, known = -1, s = 0, clean_from = 1;
+  double base = 0.0;                     // best iteration pair under the kept assignment, us
+  double dur[PA_PLACE_NDUR] = {0.0};
+  double base_par[2] = {0.0, 0.0};       // best single iteration per parity of the direction ping-pong, us
+  unsigned char par[PA_PLACE_NDUR] = {0};
+  hipEvent_t ev0[PA_PLACE_NEV] = {nullptr}, ev1[PA_PLACE_NEV] = {nullptr};   // start / end of iteration j (ring)
+  hipEvent_t evs[2] = {nullptr, nullptr};   // around the copy / memset of the running trial's switch
+  int closed = 1, sw_timed = 0;
+  // accounts (pa_place_stats)
+  int trials = 0, accepted = 0, mallocs = 0;
+  double spent_us = 0.0, elapsed_us = 0.0, first_pair = 0.0;
+};
 
 struct pa_ctx {
   int device = 0;
@@ -90,11 +130,11 @@ struct pa_ctx {
   int bc_pair = 0;  // per-axis pair kernels (lower + upper face + shell stop-test term in one launch)
   int bc_fused = 0, shell_cur = 0;  // fused BC fill: which half of SCR_SHELL holds x_old on the shell
   void* cg_x = nullptr;
+  void* cg_r_out = nullptr;  // placement search: the NEXT phase B writes the new residual here instead of in place
   int64_t cg2d_mincells = 1500000;   // 2-D meshes of at least this many cells run the CG phases on k_cg2d (< 0: never)
   int bcl = 1;               // option "bcl" / PYAPES_HIP_BCL: explicit Euler march without a BC-fill launch per step (pa_sf_kernel.h)
-  int place = 1;             // option "place" / PYAPES_HIP_PLACE: large CG solves probe where r / d sit in their allocations
-  const void* place_key[4] = {nullptr, nullptr, nullptr, nullptr};   // (x, r, d0, d1 bases the last probe decided for)
-  size_t place_off[3] = {0, 0, 0};                                    // ... and what it chose (bytes into r, d0, d1)
+  int place = 1;             // option "place": large CG solves search, while they run, which allocations r / d live in
+  PlaceSearch ps;            // ... pa_place.hip
   int pitch = 1;             // option "pitch" / PYAPES_HIP_PITCH: allow that layout (0: odd rows stay on the NARROW kernels)
   int cg_pitch = 0;          // live CG solve keeps r and the direction buffers in the PITCH layout of k_cg3d
   int64_t cg_ps1 = 0;        // ... with this row pitch (cells)
@@ -171,6 +211,14 @@ int pa_cg_slab_mid(pa_ctx* c);                // pa_solver.hip: the step between
 int pa_cg_slab_flush(pa_ctx* c);              // close the last iteration of a folded batch (single-block kernel)
 int pa_bc_shell_rows(const pa_ctx* c);        // pa_bc.hip: partial rows the BC fill + shell pass of an iteration writes
 void pa_profile_stop(pa_ctx* c, int which);   // pa_solver.hip: close the HIP-event bracket of dominant kernel `which`
+// pa_place.hip: the online placement search of large CG solves
+int pa_place_begin(pa_ctx* c, const void* x, size_t array_bytes);   // pa_cg_begin, before r / d are written
+int pa_place_tick(pa_ctx* c);                                        // top of every iteration, before phase A
+int pa_place_batch_end(pa_ctx* c);                                   // after the last iteration a call enqueues
+void pa_place_r_written(pa_ctx* c);                                  // phase B has written r into c->cg_r_out
+void pa_place_end(pa_ctx* c, int may_free);                          // the solve is over (or dropped); may_free: the stream has been waited for
+void pa_place_reset(pa_ctx* c);                                      // the arrays changed: free the pool, forget the pass
+void pa_place_destroy(pa_ctx* c);
 
 // ---- BC fill (pa_bc.hip) ---------------------------------------------------------------------------
 int pa_shell_blocks(const pa_ctx* c);

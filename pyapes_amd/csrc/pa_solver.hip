@@ -122,7 +122,7 @@ __global__ void __launch_bounds__(PA_BLOCK) k_cg_a(DevGeom G, DevEq<T> E, const 
 //      (linalg.py:122-134)
 template <typename T>
 __global__ void __launch_bounds__(PA_BLOCK) k_cg_b(DevGeom G, DevEq<T> E, const SolverScalars* __restrict__ sc,
-                                                    Vec<T> dv, T* __restrict__ x, T* __restrict__ r,
+                                                    Vec<T> dv, T* __restrict__ x, const T* r, T* r_out,
                                                     T* __restrict__ send_lo, T* __restrict__ send_hi,
                                                     double* __restrict__ partials) {
   if (sc->done) return;
@@ -143,7 +143,7 @@ __global__ void __launch_bounds__(PA_BLOCK) k_cg_b(DevGeom G, DevEq<T> E, const 
       x[idx] = xn;
       T aAd = alpha * Ad;
       rn = r[idx] - aAd;
-      r[idx] = rn;
+      r_out[idx] = rn;   // (r itself, or r's new block when the placement search moves it; zero outside S there already)
       T p = rn * rn;
       s[0] += (double)p;
       if (!pa_on_shell(G, i, j, k)) {
@@ -919,167 +919,6 @@ static int64_t solver_pitch(const pa_ctx* c, const T* x) {
   return (G.n2 + padw - 1) / padw * padw;
 }
 
-// WHICH allocations r and the two direction buffers live in, and where inside them (large CG solves, one GPU).
-// The arrays of an iteration are streamed in lockstep, and whether they collide in the memory system is decided by
-// where the driver put their pages: phase B of 512^3 fp64 measures 853 us or 931 us with the SAME kernel, from one
-// process / box to the next; a plain copy between 1 GiB blocks of one process runs at 4.65 ... 5.51 TB/s by PAIR of
-// blocks while each block alone gives 5.5-5.6.  So the set-up asks the hardware, with the two
-// phase kernels of the solve itself -- both ping-pong parities -- and an EMPTY interior set (phase A then writes zeros
-// into the direction buffer it would write anyway, phase B stores x back exactly as loaded and zeros into r, which the
-// set-up initialises right afterwards: no value of the solve is touched, the traffic is that of a real iteration):
-// first which of a few blocks each role should take beside the caller's x, then a handful of offsets.  ~45 iteration
-// pairs once per allocation (the choice is remembered for as long as x and the blocks stay where they are); arrays
-// the Infinity Cache holds are left alone.  PYAPES_HIP_PLACE=0 / option "place": off.
-template <typename T>
-static Vec<T> cg_vec(pa_ctx* c, const T* p, int which);
-template <typename T>
-static int cg_place_t(pa_ctx* c, T* x) {
-  const DevGeom G0 = c->G;
-  // (a slab of a multi-GPU solve probes like a single domain, its own wrap-around planes standing in for the ghost
-  // planes: every rank chooses for itself, and the slowest rank sets the pace of all)
-  if (!c->place || !c->fastpath || c->profile || c->plan_only) return PA_OK;
-  size_t minbytes = (size_t)128 << 20;   // arrays the Infinity Cache holds are not a matter of HBM channels
-  if (const char* e = getenv("PYAPES_HIP_PLACE_MINBYTES")) minbytes = (size_t)atoll(e);   // (tests: probe small meshes too)
-  if ((size_t)G0.ncell * sizeof(T) < minbytes) return PA_OK;
-  const int slot[3] = {SCR_R, SCR_D0, SCR_D1};
-  if (c->place_key[0] == (const void*)x && c->place_key[1] == c->scr_base[SCR_R] && c->place_key[2] == c->scr_base[SCR_D0] &&
-      c->place_key[3] == c->scr_base[SCR_D1]) {
-    for (int q = 0; q < 3; ++q) c->scr[slot[q]] = (char*)c->scr_base[slot[q]] + c->place_off[q];
-    return PA_OK;
-  }
-  const size_t u = 69888, w = 4352, y = 0x2100, z = 0x80100;
-  const size_t dflt[3] = {u, 2 * u, 3 * u};   // (pa_scratch's default stagger, or wherever an earlier probe left the arrays)
-  const size_t cur[3] = {(size_t)((char*)c->scr[SCR_R] - (char*)c->scr_base[SCR_R]),
-                         (size_t)((char*)c->scr[SCR_D0] - (char*)c->scr_base[SCR_D0]),
-                         (size_t)((char*)c->scr[SCR_D1] - (char*)c->scr_base[SCR_D1])};
-  DevEq<T> E;
-  pa_build_eq<T>(c, c->nterms, c->terms, E);
-  double* part = (double*)c->scr[SCR_PART];
-  hipEvent_t e0 = nullptr, e1 = nullptr;
-  if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) {
-    if (e0) (void)hipEventDestroy(e0);
-    (void)hipGetLastError();
-    return PA_OK;
-  }
-  const bool dbg = getenv("PYAPES_HIP_DEBUG") != nullptr;
-  c->fold_a_n = c->fold_b_n = c->fold_b_nsh = 0;
-  c->slab_fold_live = 0;
-  // nobody is in the interior set: the phases move the bytes and change nothing.  (Every axis: a 2-D mesh has no
-  // axis 0 to speak of, and k_cg2d tests axes 1 and 2 only.)
-  c->G.slo[0] = c->G.g0 + 1;
-  c->G.slo[1] = c->G.n1 + 1;
-  c->G.slo[2] = c->G.n2 + 1;
-  auto vec = [&](const T* p) -> Vec<T> {   // the field with its own wrap-around planes as ghost planes (also on a slab)
-    Vec<T> v = pa_vec_self<T>(c, p);
-    if (c->cg_pitch) v.glo = p + (c->G.n0 - 1) * c->G.n1 * c->cg_ps1;
-    return v;
-  };
-  auto round = [&]() -> int {   // one iteration pair: both parities of the direction ping-pong
-    T* r = (T*)c->scr[SCR_R];
-    T* d0 = (T*)c->scr[SCR_D0];
-    T* d1 = (T*)c->scr[SCR_D1];
-    int n = pa_cg3d_phase_a<T>(c, E, vec(r), vec(d0), d1, part);
-    if (n > 0) n = pa_cg3d_phase_b<T>(c, E, vec(d1), x, r, part);
-    if (n > 0) n = pa_cg3d_phase_a<T>(c, E, vec(r), vec(d1), d0, part);
-    if (n > 0) n = pa_cg3d_phase_b<T>(c, E, vec(d0), x, r, part);
-    return n;
-  };
-  auto timed = [&](float& t) -> int {   // the faster of two rounds
-    int ok = 1;
-    for (int rep = 0; rep < 2 && ok > 0; ++rep) {
-      (void)hipEventRecord(e0, c->stream);
-      ok = round();
-      (void)hipEventRecord(e1, c->stream);
-      (void)hipEventSynchronize(e1);
-      float ms = 0.f;
-      (void)hipEventElapsedTime(&ms, e0, e1);
-      t = rep == 0 ? ms : (ms < t ? ms : t);
-    }
-    return ok;
-  };
-
-  // ---- 1. WHICH blocks.  Two arrays streamed in lockstep run 9 % apart depending on which two allocations they are
-  //      (a plain copy between 1 GiB blocks of one process: 4.65 ... 5.51 TB/s by pair, each block alone 5.5-5.6): what
-  //      collides is decided by where the driver put the pages, and no offset inside a block changes that.  So a few
-  //      more blocks are allocated, each role (r, d, d') tries each of them beside the caller's x -- a local search,
-  //      one role at a time -- and the blocks that lose are freed.
-  const size_t bytes = c->cap[SCR_R];   // (the three slots hold arrays of one size)
-  const size_t blk = bytes + 3 * u + PA_PLACE_ROOM;
-  int nextra = 5;
-  if (const char* e = getenv("PYAPES_HIP_PLACE_BLOCKS")) nextra = atoi(e);
-  {
-    size_t free_b = 0, total_b = 0;
-    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); nextra = 0; }
-    while (nextra > 0 && (size_t)nextra * blk > free_b / 4) --nextra;   // never more than a quarter of what is free
-  }
-  if (c->cap[SCR_D0] != bytes || c->cap[SCR_D1] != bytes || cur[0] > 3 * u || cur[1] > 3 * u || cur[2] > 3 * u) nextra = 0;
-  char* pool[16];
-  int npool = 3;
-  for (int q = 0; q < 3; ++q) pool[q] = (char*)c->scr_base[slot[q]];
-  for (int q = 0; q < nextra && npool < 16; ++q) {
-    void* b = nullptr;
-    if (hipMalloc(&b, blk) != hipSuccess) { (void)hipGetLastError(); break; }
-    pool[npool++] = (char*)b;
-  }
-  int assign[3] = {0, 1, 2};
-  auto point = [&](const int* a, const size_t* off) { for (int q = 0; q < 3; ++q) c->scr[slot[q]] = pool[a[q]] + off[q]; };
-  float best = 0.f, first = 0.f;
-  point(assign, cur);
-  int ok = round();   // code objects, caches
-  if (ok > 0) ok = timed(first);
-  best = first;
-  if (dbg && ok > 0) fprintf(stderr, "[pyapes_hip] placement probe: as allocated: %.1f us per iteration pair\n", first * 1e3f);
-  for (int role = 0; role < 3 && ok > 0 && npool > 3; ++role) {
-    for (int b = 0; b < npool && ok > 0; ++b) {
-      if (b == assign[0] || b == assign[1] || b == assign[2]) continue;
-      int trial[3] = {assign[0], assign[1], assign[2]};
-      trial[role] = b;
-      point(trial, cur);
-      float t = 0.f;
-      ok = timed(t);
-      if (ok <= 0) break;
-      if (dbg) fprintf(stderr, "[pyapes_hip] placement probe: %s in block %d: %.1f us\n", role == 0 ? "r" : (role == 1 ? "d0" : "d1"), b, t * 1e3f);
-      if (t < 0.995f * best) { best = t; assign[role] = b; }
-    }
-  }
-  if (ok <= 0 || !(best < 0.99f * first)) { assign[0] = 0; assign[1] = 1; assign[2] = 2; best = first; }   // nothing to gain
-
-  // ---- 2. WHERE in them: a handful of offset triples (low address bits) on the chosen blocks
-  const size_t cand[6][3] = {{cur[0], cur[1], cur[2]}, {0, 0, 0}, {w, 2 * w, 3 * w}, {y, 2 * y, 3 * y}, {z, 2 * z, 3 * z},
-                             {dflt[2], dflt[0], dflt[1]}};
-  int kbest = 0;
-  const float before = best;
-  for (int k = 1; k < 6 && ok > 0; ++k) {
-    point(assign, cand[k]);
-    float t = 0.f;
-    ok = timed(t);
-    if (ok <= 0) break;
-    if (dbg) fprintf(stderr, "[pyapes_hip] placement probe: r +%zu d0 +%zu d1 +%zu: %.1f us\n", cand[k][0], cand[k][1], cand[k][2], t * 1e3f);
-    if (t < best) { best = t; kbest = k; }
-  }
-  if (ok <= 0 || !(best < 0.99f * before)) { kbest = 0; best = before; }
-  c->G = G0;
-  (void)hipEventDestroy(e0);
-  (void)hipEventDestroy(e1);
-  // the chosen blocks become the slots' allocations, the others go back to the driver
-  (void)hipStreamSynchronize(c->stream);
-  char* chosen[3] = {pool[assign[0]], pool[assign[1]], pool[assign[2]]};
-  for (int b = 0; b < npool; ++b)
-    if (pool[b] != chosen[0] && pool[b] != chosen[1] && pool[b] != chosen[2]) (void)hipFree(pool[b]);
-  for (int q = 0; q < 3; ++q) {
-    c->scr_base[slot[q]] = chosen[q];
-    c->scr[slot[q]] = chosen[q] + cand[kbest][q];
-    c->cap[slot[q]] = bytes;
-    c->place_off[q] = cand[kbest][q];
-  }
-  if (ok < 0) return ok;
-  c->place_key[0] = x; c->place_key[1] = chosen[0]; c->place_key[2] = chosen[1]; c->place_key[3] = chosen[2];
-  if (dbg)
-    fprintf(stderr, "[pyapes_hip] placement probe: kept blocks %d %d %d of %d, r +%zu d0 +%zu d1 +%zu (%.1f us, as allocated %.1f us)\n",
-            assign[0], assign[1], assign[2], npool, cand[kbest][0], cand[kbest][1], cand[kbest][2], best * 1e3f, first * 1e3f);
-  return PA_OK;
-}
-
 template <typename T>
 static int cg_begin_t(pa_ctx* c, T* x, const T* rhs, double tol, int64_t max_it) {
   const DevGeom& G = c->G;
@@ -1097,7 +936,8 @@ static int cg_begin_t(pa_ctx* c, T* x, const T* rhs, double tol, int64_t max_it)
   if ((rc = pa_scratch(c, &c->scr[SCR_PART2], &c->cap[SCR_PART2], (size_t)3 * PA_MAX_GRID * sizeof(double)))) return rc;
   if ((rc = pa_scratch(c, &c->scr[SCR_SHELL], &c->cap[SCR_SHELL], 2 * (size_t)pa_shell_elems(c) * sizeof(T)))) return rc;
   if ((rc = init_scalars(c, tol, max_it))) return rc;
-  if ((rc = cg_place_t<T>(c, x))) return rc;   // (before anything is written into r / d)
+  // large solves: the online search for the allocations r / d / d' should live in (pa_place.hip) rides on the iterations
+  if ((rc = pa_place_begin(c, x, fb))) return rc;   // (before anything is written into r / d)
   // the tiled phase kernels do not visit the last boundary row / column of non-periodic axes: the
   // direction there is 0 by definition and has to be 0 in the buffer the first phase A writes into
   if (!c->cg_pitch) PA_HIP(c, hipMemsetAsync(c->scr[SCR_D1], 0, fb, c->stream));   // (pitched: it first carries A x, below)
@@ -1292,10 +1132,11 @@ int pa_cg_phase_b_t(pa_ctx* c, int stage_post) {
   if (rc == 0 && c->cg_pitch) { pa_set_err(c, "pitched CG: the tiled phase B declined"); return PA_E_STATE; }
   if (rc == 0) {
     cg_flush_fold<T>(c);  // alpha by its own kernel
-    hipLaunchKernelGGL(k_cg_b<T>, dim3(nblk), dim3(PA_BLOCK), 0, c->stream, G, E, c->sc, dv, x, r,
-                       (T*)c->r_send_lo, (T*)c->r_send_hi, part);
+    hipLaunchKernelGGL(k_cg_b<T>, dim3(nblk), dim3(PA_BLOCK), 0, c->stream, G, E, c->sc, dv, x, (const T*)r,
+                       c->cg_r_out ? (T*)c->cg_r_out : r, (T*)c->r_send_lo, (T*)c->r_send_hi, part);
     used_blocks = nblk;
   }
+  if (c->cg_r_out) pa_place_r_written(c);   // the placement search moved r with this launch: SCR_R is the new block now
   if (c->profile) pa_profile_stop(c, 1);
   c->b_blocks = used_blocks;
   if (c->slab) {  // BC fill + shell + reduction happen in pa_cg_bc, after the driver's plane exchange
@@ -1441,6 +1282,7 @@ static int cg_run_t(pa_ctx* c, T* x, const T* rhs, double tol, int64_t max_it, p
       nb = 1;  // not reached by construction; keeps the loop live if it ever is
     }
     for (int64_t q = 0; q < nb && !rc; ++q) {
+      if ((rc = pa_place_tick(c))) break;
       if ((rc = pa_cg_phase_a_t<T>(c, 2))) break;
       if (c->x_old_out)   // after phase A: its prologue has decided whether this iteration still runs
         hipLaunchKernelGGL(k_copy_guarded<T>, dim3(pa_grid_blocks(c->G.ncell)), dim3(PA_BLOCK), 0, c->stream, c->sc,
@@ -1449,19 +1291,21 @@ static int cg_run_t(pa_ctx* c, T* x, const T* rhs, double tol, int64_t max_it, p
       ++enq;
     }
     if (rc) break;
+    if ((rc = pa_place_batch_end(c))) break;
     cg_flush_fold<T>(c);
     rc = poll_submit(c, P, &done);
     batch = std::min<int64_t>(poll, std::max<int64_t>(1, enq));
   }
   if (!rc) rc = read_scalars(c);
   c->in_iterate = 0;
-  if (rc) { c->fold_a_n = c->fold_b_n = c->fold_b_nsh = 0; return rc; }
+  if (rc) { c->fold_a_n = c->fold_b_n = c->fold_b_nsh = 0; pa_place_end(c, 0); return rc; }
   PA_HIP(c, hipEventRecord(c->ev1, c->stream));
   PA_HIP(c, hipEventSynchronize(c->ev1));
   float ms = 0.f;
   (void)hipEventElapsedTime(&ms, c->ev0, c->ev1);
   fill_report(c, out, ms);
   c->solver_live = 0;
+  pa_place_end(c, 1);
   return c->h_sc->err ? PA_E_NONFINITE : PA_OK;
 }
 
@@ -1806,6 +1650,7 @@ int pa_cg(pa_ctx* c, void* x, const void* rhs, double tol, int64_t max_it, pa_re
   const int rc = c->dtype == PA_F64 ? cg_run_t<double>(c, (double*)x, (const double*)rhs, tol, max_it, out)
                                     : cg_run_t<float>(c, (float*)x, (const float*)rhs, tol, max_it, out);
   c->solver_live = 0;   // also on the error paths: a failed one-shot solve must not lock the BC / equation state
+  pa_place_end(c, 0);
   return rc;
 }
 
@@ -1957,10 +1802,12 @@ int pa_cg_iterate(pa_ctx* c, int64_t n) {
   c->in_iterate = 1;
   int rc = PA_OK;
   for (int64_t q = 0; q < n && !rc; ++q) {
+    if ((rc = pa_place_tick(c))) break;
     rc = c->dtype == PA_F64 ? pa_cg_phase_a_t<double>(c, 2) : pa_cg_phase_a_t<float>(c, 2);
     if (!rc) rc = c->dtype == PA_F64 ? pa_cg_phase_b_t<double>(c, 2) : pa_cg_phase_b_t<float>(c, 2);
   }
   c->in_iterate = 0;
+  if (!rc) rc = pa_place_batch_end(c);
   if (c->dtype == PA_F64) cg_flush_fold<double>(c); else cg_flush_fold<float>(c);  // the last iteration's stop test
   return rc;
 }
@@ -2011,6 +1858,7 @@ int pa_cg_abort(pa_ctx* c) {   // drop a stepwise solve without reading it back 
   c->in_iterate = c->slab_fold_live = 0;
   c->fold_a_n = c->fold_b_n = c->fold_b_nsh = 0;
   c->fold_b_shell = nullptr;
+  pa_place_end(c, 0);   // (no hipFree here: it would wait for a stream that may never drain)
   return PA_OK;
 }
 
@@ -2019,6 +1867,7 @@ int pa_cg_end(pa_ctx* c, pa_report* out) {
   PA_HIP(c, hipSetDevice(c->device));
   int rc = out ? pa_report_read(c, out) : PA_OK;
   c->solver_live = 0;
+  pa_place_end(c, out ? 1 : 0);   // (pa_report_read has waited for the stream)
   if (rc) return rc;
   return (out && out->status) ? PA_E_NONFINITE : PA_OK;
 }

@@ -352,6 +352,16 @@ class HipContext:
         names = ("alpha", "beta", "rr", "rr_old", "dAd", "tol", "rho", "omega", "rho_next", "r0v", "ts", "tt", "r0t", "itr")
         return {n: float(v[i]) for i, n in enumerate(names)}
 
+    def place_stats(self) -> dict[str, float]:
+        """Accounts of the online placement search of large CG solves (pa_place_stats)."""
+        v = (C.c_double * 10)()
+        self._rc(self.lib.pa_place_stats(self.h, v))
+        names = ("state", "trials", "kept", "allocations", "spent_us", "timed_us", "best_pair_us", "blocks_held",
+                 "first_pair_us", "passes_done")
+        out = {n: float(v[i]) for i, n in enumerate(names)}
+        out["state"] = {-1: "off", 0: "idle", 1: "searching", 2: "done"}[int(v[0])]
+        return out
+
     def profile(self, on: bool) -> None:
         self._rc(self.lib.pa_profile_set(self.h, int(on)))
 

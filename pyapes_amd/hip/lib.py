@@ -122,6 +122,7 @@ SIGNATURES: dict[str, tuple[Any, list[Any]]] = {
     "pa_scalars_read": (C.c_int, [_VP, _F64P]),
     "pa_profile_set": (C.c_int, [_VP, C.c_int]),
     "pa_profile_read": (C.c_int, [_VP, _F64P, _I64P, _F64P, _I64P]),
+    "pa_place_stats": (C.c_int, [_VP, _F64P]),
 }
 
 _lib: C.CDLL | None = None

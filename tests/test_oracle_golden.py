@@ -194,6 +194,37 @@ def test_reference_algorithm_is_summation_order_sensitive():
     assert b_cg < 1e-13 and len(set(its_cg)) == 1
 
 
+def test_committed_hull_is_what_the_oracle_gives():
+    """tests/golden/hulls.npz holds the summation-order hulls the GPU suite grades long BiCGSTAB / periodic-CG runs
+    against (tests/golden/make_hulls.py: 29 oracle solves per case, minutes of CPU time in all).  The cheapest one is
+    recomputed here on every CPU run: a fixture that no longer is what the oracle gives -- the oracle, the inputs or
+    helpers.summation_hull changed -- fails here, not silently on the GPU box."""
+    import os
+    import sys
+    import numpy as np
+    from conftest import GOLDEN, golden_cases, golden_load
+    from helpers import summation_hull
+    sys.path.insert(0, GOLDEN)
+    from make_hulls import unpack
+    z = np.load(os.path.join(GOLDEN, "hulls.npz"))
+    cases = {c["name"]: c for c in golden_cases("solve") if c.get("sensitive")}
+    # every long run of a sensitive case is in the fixture
+    for name, c in cases.items():
+        for K in c["max_its"]:
+            if K > 10:
+                assert f"{name}|K{K}|band" in z.files, (name, K)
+    name, K = "bicg2d_heat_f64", 1000        # 11 x 11 nodes: sums this short do not depend on the host's thread count
+    c, g = cases[name], golden_load(name)
+    hs = []
+    band, diam, its = summation_hull(c, g["rhs0"], K, g[f"x_K{K}"], histories=hs)
+    fband, fdiam, fits, fhs = unpack(z, f"{name}|K{K}")
+    assert its == fits
+    assert abs(band - fband) <= 1e-12 * max(band, 1e-300) and abs(diam - fdiam) <= 1e-12 * max(diam, 1e-300)
+    assert len(hs) == len(fhs) == 29
+    for a, b in zip(hs, fhs):
+        assert a.shape == b.shape and np.allclose(a, b, rtol=1e-13, atol=0, equal_nan=True)
+
+
 def _rfp_inputs(case, g):
     mesh = _mesh(case)
     t = lambda k: torch.from_numpy(g[k])   # noqa: E731
