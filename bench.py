@@ -525,7 +525,9 @@ def main():
         refuse_config(f"workload {args.workload} is single-GPU (replicas only); the slab path is the CG solve")
 
     # rehearsal switches (one-GPU box): BENCH_SINGLE_DEVICE=1 puts every rank on cuda:0,
-    # BENCH_BACKEND=gloo moves the planes through the host instead of RCCL
+    # BENCH_BACKEND=gloo moves the planes through the host instead of RCCL, BENCH_COMM_LIB=<path> hands the library a
+    # stand-in for librccl (tests/lib/libpa_hostring.so: pa_comm_use_impl, an explicit call -- the record's
+    # config.parallelism names the implementation)
     single_dev = bool(os.environ.get("BENCH_SINGLE_DEVICE"))
     if world > 1 and not single_dev and torch.cuda.device_count() < world:
         refuse_config(f"bench.py --gpus {world}: only {torch.cuda.device_count()} GPUs visible")
@@ -540,6 +542,9 @@ def main():
     from pyapes_amd.hip import lib as L
     from pyapes_amd.hip.context import context_for
     from pyapes_amd.variables import Field
+    if os.environ.get("BENCH_COMM_LIB"):
+        rc_impl = L.load_library().pa_comm_use_impl(os.environ["BENCH_COMM_LIB"].encode())
+        assert rc_impl == 0, f"pa_comm_use_impl({os.environ['BENCH_COMM_LIB']}) -> {rc_impl}"
 
     esize = 8 if dtype == "double" else 4
     nd = len(gn)
@@ -723,6 +728,7 @@ def main():
                 drv.be.cg_abort()
                 drv.be.slab_set(None)
                 os.environ["PYAPES_HIP_COMM"] = "0"
+                drv.be.set_option("comm", 0)          # (the option of THIS context: the variable is only read when one is created)
                 var = Field("p", 1, mesh, {"domain": make_bcs(kind), "obstacle": None})
                 drv = SlabCG(mesh, var, rhs, terms, dist)
                 assert not drv.lib_comm
@@ -752,7 +758,9 @@ def main():
                             {"phase_a_ms": pr["phase_a_ms"], "phase_b_ms": pr["phase_b_ms"], "scope": "rank 0, per GPU"})
         drv.end()
         n_seen = dist.get_world_size()
-        comm_kind = "rccl-in-library" if drv.lib_comm else f"torch.distributed-stepwise/{dist.get_backend()}"
+        impl = drv.be.comm_impl() if drv.lib_comm else ""
+        comm_kind = (("rccl-in-library" if impl == "rccl" else f"library loop over [{impl}]") if drv.lib_comm
+                     else f"torch.distributed-stepwise/{dist.get_backend()}")
         if drv.lib_comm:
             n_seen = drv.be.comm_size()
             torch.cuda.synchronize()      # release the library's communicators while every rank is still alive

@@ -92,6 +92,14 @@ int pa_ctx_destroy(pa_ctx* ctx);
  * (candidate allocations per role, default 3) and "place_budget" (what the trials may cost, per cent of the time
  * solved so far, default 3), "resident_coop" 0 = plain launch of the resident kernel (profiling). */
 int pa_ctx_set_option(pa_ctx* ctx, const char* name, int value);
+/* Further names (tests and A/B runs; none has an environment variable of its own, PYAPES_HIP_OPTIONS="name=value,..." sets
+ * any option of this list for every ctx of the process): "bc_path" (bit 0: never the closed-form BC fill, bit 1: never
+ * the per-axis pair kernels, bit 2: closed form at any size; all paths bit-identical), "bicg_pfold" 0 = BiCGSTAB with the
+ * full p / v phase in every iteration, "rhs_full" 1 = pa_rhs_adjust over the whole mesh, "res_cells" / "res_nt" /
+ * "res_nt_cells" / "res_spin" / "res_rzlean" (box plan, threads per workgroup, spin bound, rz stencil of the resident
+ * solver), "comm" / "slab_fold" (read back by the slab driver: library-side RCCL loop, folded sequence), "comm_overlap"
+ * (-1 auto), "comm_timeout" (s), "roctx" (process-wide).  pa_ctx_get_option reads a value back. */
+int pa_ctx_get_option(const pa_ctx* ctx, const char* name, int* value);
 /* Accounts of the online placement search of this ctx, out[10]: state (-1 off, 0 not begun / arrays too small,
  * 1 searching, 2 pass over), trials, trials kept, allocations made, microseconds the trials have cost (copies,
  * memsets, trial iterations that ran slower), microseconds of iterations timed, best iteration pair (us), blocks
@@ -266,6 +274,32 @@ int pa_cg_finish_iter(pa_ctx* ctx);
 int pa_cg_iterate(pa_ctx* ctx, int64_t n);
 int pa_cg_end(pa_ctx* ctx, pa_report* out);       /* synchronises */
 int pa_cg_abort(pa_ctx* ctx);                     /* drop the live stepwise solve (no read-back) */
+/* ---- stepwise BiCGSTAB on a slab (linalg.py:162-279 split at its reductions and exchanges; SURVEY 8e + 8f-1) ----
+ * BASELINE config 3 is periodic: CG never meets the reference's stop test there, BiCGSTAB does -- so it has
+ * to exist on slabs.  A host driver (pyapes_amd/slab.py SlabBiCGSTAB) puts the communication between the calls:
+ *   [pa_apply_bc, exchange ghost planes of x]
+ *   begin     r0 = r = b - A x on S, local r0.r0 -> sums[1]; r planes out  -> [exchange r planes] [all-reduce sums[1]]
+ *   start     rho' = r0.r0, first beta (device side)
+ *   per iteration:
+ *     pv      p' = r + beta (p - omega v) (ghost planes by the owner's recurrence: p is never sent), v' = A p' on S,
+ *             local r0.v' -> sums[0]; v' planes out                        -> [all-reduce sums[0]] [exchange v' planes]
+ *     st      alpha; s = r - alpha v', t = A s on S; local |s|^2, t.s, t.t, r0.t -> sums[1..4] -> [all-reduce sums[1..4]]
+ *     x       stop test 1, omega, rho'; x += alpha p' + omega s, r = s - omega t; r planes (+ periodic x planes) out
+ *                                                                           -> [exchange r planes (+ x planes)]
+ *     bc      BC fill of x; local |r|^2 -> sums[5]                          -> [all-reduce sums[5]]
+ *     finish  stop test 2, beta, rho <- rho' (device side)
+ *   end       report (synchronises)
+ * pa_slab_set_v: the planes of v' (n1 * n2 elements each; NULL receive pointer = physical end); the other planes are
+ * those of pa_slab_set.  Nothing here synchronises the stream; iterations enqueued after the stop are no-ops. */
+int pa_slab_set_v(pa_ctx* ctx, void* v_send_lo, void* v_send_hi, const void* v_recv_lo, const void* v_recv_hi);
+int pa_bicg_begin(pa_ctx* ctx, void* x, const void* rhs, double tol, int64_t max_it);
+int pa_bicg_start(pa_ctx* ctx);
+int pa_bicg_pv(pa_ctx* ctx);
+int pa_bicg_st(pa_ctx* ctx);
+int pa_bicg_x(pa_ctx* ctx);
+int pa_bicg_bc(pa_ctx* ctx);
+int pa_bicg_finish(pa_ctx* ctx);
+int pa_bicg_end(pa_ctx* ctx, pa_report* out);
 /* While a stepwise solve is live (pa_cg_begin ... pa_cg_end / pa_cg_abort) pa_bc_clear, pa_bc_set and
  * pa_eq_set return PA_E_STATE: every phase re-reads that state. */
 int pa_report_read(pa_ctx* ctx, pa_report* out);  /* synchronises */
@@ -330,9 +364,14 @@ int pa_comm_abort(pa_ctx* ctx);
 /* Wait until everything enqueued on the ctx stream(s) has run, at most timeout_s seconds: PA_OK, or PA_E_STATE
  * when work is still queued (watchdog of multi-rank drivers: bench.py bounds its first slab iterations with it) */
 int pa_stream_wait(pa_ctx* ctx, double timeout_s);
-/* Which implementation is behind pa_comm_*: "rccl", or the test stand-in selected by the explicit hook
- * PYAPES_HIP_COMM_IMPL=hostring (ranks as processes that may share one GPU; csrc/pa_comm_hostring.hip) */
+/* Which implementation is behind pa_comm_*: "rccl" (librccl, resolved at run time), "none", or "custom: ..." after
+ * pa_comm_use_impl. */
 const char* pa_comm_impl(void);
+/* Take the twelve nccl* entry points from the shared library at so_path instead of librccl.  An explicit call, to be made
+ * before the first communicator of the process; nothing in the environment selects an implementation.  Exists for
+ * tests: tests/lib/libpa_hostring.so runs the ranks as processes that share one GPU (RCCL refuses that), with host
+ * shared memory as the wire. */
+int pa_comm_use_impl(const char* so_path);
 /* 1 when the plane exchange of pa_cg_iterate_comm runs on the second communicator + stream, 0 when on the ctx stream */
 int pa_comm_overlap(const pa_ctx* ctx);
 

@@ -17,8 +17,8 @@ B=(python3 "$REPO/bench.py" --workload "$WL" "${ARGS[@]}" --no-cpu-baseline)
 # crashed must not read as clean.  Known: under rocprofv3 7.2 ANY process that has made a cooperative launch dies
 # with SIGSEGV in libhsa-runtime64 inside exit() (profiles/README.md; tools/coop_exit_repro.sh shows it with an
 # 80-line program) -- after the tool has written its output.  The one workload with such a launch, c1 (resident
-# solver), is therefore collected with a plain launch of the same kernel and grid (PYAPES_HIP_RESIDENT_COOP=0).
-if [ "$WL" = "c1" ]; then export PYAPES_HIP_RESIDENT_COOP="${PYAPES_HIP_RESIDENT_COOP:-0}"; fi
+# solver), is therefore collected with a plain launch of the same kernel and grid (option resident_coop 0, through PYAPES_HIP_OPTIONS).
+if [ "$WL" = "c1" ]; then export PYAPES_HIP_OPTIONS="${PYAPES_HIP_OPTIONS:-resident_coop=0}"; fi
 : > "$OUT/exit_codes.txt"
 FAILED=0
 pass() {   # pass <name> <stdout file> <stderr file> <rocprofv3 args...>

@@ -11,10 +11,17 @@ mkdir -p "$OUT" "$OBJ"
 HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
 FLAGS=(--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Wall -Wno-unused-function -Wno-unused-variable ${PA_EXTRA_FLAGS:-})
 pids=()
-for tu in pa_core pa_bc pa_ops pa_solver pa_cg3d pa_cg3d_b pa_sf pa_comm pa_comm_hostring pa_rfp pa_resident pa_place; do
+for tu in pa_core pa_bc pa_ops pa_solver pa_cg3d pa_cg3d_b pa_sf pa_comm pa_rfp pa_resident pa_place; do
   "$HIPCC" "${FLAGS[@]}" -c "$HERE/$tu.hip" -o "$OBJ/$tu.o" &
   pids+=($!)
 done
 for p in "${pids[@]}"; do wait "$p"; done
-"$HIPCC" --offload-arch=gfx950 -shared -fPIC -o "$OUT/libpyapes_hip.so" "$OBJ/pa_core.o" "$OBJ/pa_bc.o" "$OBJ/pa_ops.o" "$OBJ/pa_solver.o" "$OBJ/pa_cg3d.o" "$OBJ/pa_cg3d_b.o" "$OBJ/pa_sf.o" "$OBJ/pa_comm.o" "$OBJ/pa_comm_hostring.o" "$OBJ/pa_rfp.o" "$OBJ/pa_resident.o" "$OBJ/pa_place.o" -ldl -lrt -lpthread
+"$HIPCC" --offload-arch=gfx950 -shared -fPIC -o "$OUT/libpyapes_hip.so" "$OBJ/pa_core.o" "$OBJ/pa_bc.o" "$OBJ/pa_ops.o" "$OBJ/pa_solver.o" "$OBJ/pa_cg3d.o" "$OBJ/pa_cg3d_b.o" "$OBJ/pa_sf.o" "$OBJ/pa_comm.o" "$OBJ/pa_rfp.o" "$OBJ/pa_resident.o" "$OBJ/pa_place.o" -ldl
 echo "built $OUT/libpyapes_hip.so"
+# TEST-ONLY: the stand-in for librccl that lets the multi-rank tests run their ranks as processes sharing one GPU
+# (tests/lib/pa_hostring.hip; handed to the library through pa_comm_use_impl(path), never linked into it)
+TLIB="$HERE/../../tests/lib"
+if [ -f "$TLIB/pa_hostring.hip" ]; then
+  "$HIPCC" "${FLAGS[@]}" -shared -Wl,-Bsymbolic -o "$TLIB/libpa_hostring.so" "$TLIB/pa_hostring.hip" -lrt -lpthread
+  echo "built $TLIB/libpa_hostring.so"
+fi

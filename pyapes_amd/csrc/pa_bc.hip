@@ -599,12 +599,12 @@ bool pa_bc_is_static(const pa_ctx* c) {
 // ---- fused BC fill (+ shell stop-test term) ------------------------------------------------------
 // usable when the faces are listed in the factory order and every mesh axis has >= 5 nodes
 bool pa_bc_fusable(const pa_ctx* c) {
-  if (getenv("PYAPES_HIP_BC_UNFUSED")) return false;
+  if (c->bc_path & 1) return false;   // option "bc_path" (tests: the paths are bit-identical)
   // Measured on MI355X (512^3 fp64 periodic): the closed form costs 86 + 40 us against 62 + 19 us for
   // six face launches + the shell pass, so it only wins where launches, not bytes, set the time.
   // Against the per-axis pair kernels (explicit Euler step, fp32, us / step fused : pair : faces):
   // 64^3 17 : 20 : 25, 128^3 27.9 : 28.5 : 33, 192^3 44 : 40 : 45, 256^3 65 : 55 : 59 -- the crossover
-  // sits between 98 k and 221 k shell nodes.  PYAPES_HIP_BC_FUSED=1 forces the closed form (tests do).
+  // sits between 98 k and 221 k shell nodes.  Option "bc_path" bit 2 forces the closed form (tests do).
   // Round 2: without a periodic face (and off a slab) the closed form is ONE launch writing straight into the
   // field (pa_bc_shell_fused), and the explicit Euler step in front of it got faster, so the crossover moved:
   // Euler step fp32, us / step fused : pair -- 128^3 17.2 : 23.6, 256^3 35.6 : 40.4, 384^3 134 : 140,
@@ -613,7 +613,7 @@ bool pa_bc_fusable(const pa_ctx* c) {
   for (int f = 0; f < 6; ++f)
     if (c->bc[f].type == PA_BC_PERIODIC) one_pass = false;
   const int64_t limit = pa_bc_pairable(c) ? (one_pass ? 2000000 : 150000) : 400000;
-  if (!getenv("PYAPES_HIP_BC_FUSED") &&
+  if (!(c->bc_path & 4) &&
       2 * (c->G.n1 * c->G.n2 + c->G.n0 * c->G.n2 + c->G.n0 * c->G.n1) > limit)
     return false;
   int last = -1;
@@ -720,7 +720,7 @@ int pa_bc_shell_fused(pa_ctx* c, T* x, double* part2, int with_delta, bool guard
 // BC list in factory order with both faces of every mesh axis present (what the BC factories emit),
 // >= 5 nodes per axis: the per-axis pair kernels apply
 bool pa_bc_pairable(const pa_ctx* c) {
-  if (getenv("PYAPES_HIP_BC_UNPAIRED")) return false;
+  if (c->bc_path & 2) return false;
   int last = -1, cnt = 0;
   for (int w = 0; w < c->nbc; ++w) {
     if (c->bc[c->bc_order[w]].type == PA_BC_NONE) continue;

@@ -439,8 +439,6 @@ static int cg2d_blocks_per_cu() {
   if (!cached) {
     int n = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_cg2d<T, PHASE, PITCH>, 256, 0) != hipSuccess || n <= 0) n = 4;
-    const char* e = getenv("PYAPES_HIP_BPC_2D");
-    if (e && atoi(e) > 0) n = atoi(e);
     cached = n;
   }
   return cached;
@@ -451,12 +449,8 @@ template <typename T, int PHASE>
 static int launch_cg2d(pa_ctx* c, Cg3dArgs<T>& A, bool pitched) {
   constexpr int VEC = VecOf<T>::N;
   const DevGeom& G = c->G;
-  static int minrows_env = -1;
-  if (minrows_env < 0) {
-    const char* r = getenv("PYAPES_HIP_CG2D_ROWS");
-    minrows_env = r ? atoi(r) : 0;
-  }
-  const int64_t mincells = c->cg2d_mincells;   // option "cg2d_mincells" / PYAPES_HIP_CG2D_MINCELLS; < 0: never
+  const int minrows_env = 0;   // (round 3's measurement knob: chunks of >= this many rows; the rule below is what it found)
+  const int64_t mincells = c->cg2d_mincells;   // option "cg2d_mincells"; < 0: never
   if (mincells < 0 || c->ndim != 2 || G.act[0] || A.coeff_f || A.kind != 0 || c->slab) return 0;
   if (G.n1 < 8 || G.n2 < 2 * VEC) return 0;
   // Below ~1.5 M cells the one-plane tiling of k_cg3d stays: a wave here walks its rows one after the other (about

@@ -988,8 +988,7 @@ static int cg3d_mode(const pa_ctx* c, const DevEq<T>& E, std::initializer_list<c
   for (const void* q : ptrs) bits |= (uintptr_t)q;
   if (bits & (sizeof(T) - 1)) return 0;
   constexpr int VEC = VecOf<T>::N;
-  const char* force = getenv("PYAPES_HIP_NARROW");
-  if ((bits & 15) || c->G.n2 % VEC != 0 || c->G.n2 < 2 * VEC || (force && atoi(force) != 0)) return 2;
+  if ((bits & 15) || c->G.n2 % VEC != 0 || c->G.n2 < 2 * VEC) return 2;
   return 1;
 }
 
@@ -1007,11 +1006,8 @@ template <typename T, int RJ, int PHASE, bool CF, int KIND = 0, int LAY = 0>
 static int blocks_per_cu() {
   static int cached = 0;
   if (!cached) {
-    const char* e = getenv(PHASE == 0 ? "PYAPES_HIP_BPC_A" : (PHASE == 1 ? "PYAPES_HIP_BPC_B" : "PYAPES_HIP_BPC_X"));
-    int n = e ? atoi(e) : 0;
-    if (n <= 0) {
-      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_cg3d<T, RJ, PHASE, CF, KIND, LAY>, 256, 0) != hipSuccess || n <= 0) n = 2;
-    }
+    int n = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_cg3d<T, RJ, PHASE, CF, KIND, LAY>, 256, 0) != hipSuccess || n <= 0) n = 2;
     cached = n;
   }
   return cached;
@@ -1041,9 +1037,6 @@ static int launch_cg3d(pa_ctx* c, Cg3dArgs<T>& A) {
   int chunks = capacity / tiles;
   if (chunks < 1) chunks = 1;
   if (chunks > G.n0) chunks = (int)G.n0;
-  static int minci = -1;
-  if (minci < 0) { const char* e = getenv("PYAPES_HIP_MINCI"); minci = e ? atoi(e) : 1; if (minci < 1) minci = 1; }
-  if (chunks > 1 && G.n0 / chunks < minci) chunks = (int)(G.n0 / minci > 0 ? G.n0 / minci : 1);
   A.chunks = chunks;
   const int nblk = tiles * chunks;
   if (nblk > PA_MAX_PARTIALS) return 0;
@@ -1067,10 +1060,6 @@ static int launch_cg3d(pa_ctx* c, Cg3dArgs<T>& A) {
 // fp64).  The explicit Euler step is instruction-bound and keeps its own rule.
 template <typename T, int PHASE = 0>
 static int pick_rj(pa_ctx* c, bool narrow = false, bool cg_phase = false) {
-  if (const char* e = getenv("PYAPES_HIP_RJ")) {
-    int v = atoi(e);
-    if (v == 1 || v == 2 || v == 4) return v;
-  }
   const int VEC = narrow ? 1 : VecOf<T>::N;
   const DevGeom& G = c->G;
   if (!G.act[0]) return 4;  // 2-D: one plane, nothing to march; the biggest tile has the least halo

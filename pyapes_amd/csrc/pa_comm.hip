@@ -7,6 +7,7 @@
 #include <rccl/rccl.h>
 
 #include <chrono>
+#include <cstdio>
 #include <cstring>
 #include <thread>
 
@@ -25,26 +26,24 @@ bool sym(void* h, const char* name, F& f) {
   return f != nullptr;
 }
 
+bool resolve(void* h, Rccl& R) {
+  return sym(h, "ncclGetUniqueId", R.GetUniqueId) && sym(h, "ncclCommInitRank", R.CommInitRank) &&
+         sym(h, "ncclCommDestroy", R.CommDestroy) && sym(h, "ncclCommAbort", R.CommAbort) && sym(h, "ncclCommCount", R.CommCount) &&
+         sym(h, "ncclAllReduce", R.AllReduce) && sym(h, "ncclBroadcast", R.Broadcast) && sym(h, "ncclSend", R.Send) && sym(h, "ncclRecv", R.Recv) &&
+         sym(h, "ncclGroupStart", R.GroupStart) && sym(h, "ncclGroupEnd", R.GroupEnd) &&
+         sym(h, "ncclGetErrorString", R.GetErrorString);
+}
+
 Rccl* rccl() {
   Rccl& R = g_rccl;
   if (R.tried) return R.h ? &R : nullptr;
   R.tried = 1;
-  // explicit test hook: the stand-in of pa_comm_hostring.hip (ranks as processes that may share one GPU, host
-  // shared memory as the wire); never selected implicitly
-  if (const char* impl = getenv("PYAPES_HIP_COMM_IMPL")) {
-    if (!strcmp(impl, "hostring")) { pa_hostring_table(&R); return &R; }
-  }
   void* h = dlopen("librccl.so.1", RTLD_NOW | RTLD_NOLOAD);  // the copy the process already uses
   if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_NOLOAD);
   if (!h) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
   if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_LOCAL);
   if (!h) return nullptr;
-  bool ok = sym(h, "ncclGetUniqueId", R.GetUniqueId) && sym(h, "ncclCommInitRank", R.CommInitRank) &&
-            sym(h, "ncclCommDestroy", R.CommDestroy) && sym(h, "ncclCommAbort", R.CommAbort) && sym(h, "ncclCommCount", R.CommCount) &&
-            sym(h, "ncclAllReduce", R.AllReduce) && sym(h, "ncclBroadcast", R.Broadcast) && sym(h, "ncclSend", R.Send) && sym(h, "ncclRecv", R.Recv) &&
-            sym(h, "ncclGroupStart", R.GroupStart) && sym(h, "ncclGroupEnd", R.GroupEnd) &&
-            sym(h, "ncclGetErrorString", R.GetErrorString);
-  if (!ok) return nullptr;
+  if (!resolve(h, R)) return nullptr;
   R.h = h;
   return &R;
 }
@@ -132,8 +131,7 @@ int pa_comm_init(pa_ctx* c, int rank, int nranks, const void* id128) {
   // Default: only when there is a peer.  A 1-rank communicator "exchanges" with itself through HBM, and a
   // copy kernel beside phase B is starved by it (measured: 14.5 us alone, 114 us beside phase B on a
   // 64 x 512^2 slab): there is no link latency to hide.  PYAPES_HIP_COMM_OVERLAP=1 / 0 forces either.
-  const char* ov = getenv("PYAPES_HIP_COMM_OVERLAP");
-  int want = ov ? (atoi(ov) != 0) : (nranks > 1);
+  int want = c->comm_overlap >= 0 ? c->comm_overlap : (nranks > 1);   // option "comm_overlap" / PYAPES_HIP_COMM_OVERLAP
   // Host side of every bounded wait below is PINNED: a device-to-host copy into pageable memory blocks the host
   // until the stream reaches it, i.e. inside the very collective whose completion is in doubt -- the deadline
   // would never be looked at -- and a copy that is still queued when this frame is left would land in a dead
@@ -141,8 +139,7 @@ int pa_comm_init(pa_ctx* c, int rank, int nranks, const void* id128) {
   struct Box { ncclUniqueId id; int ok; int all; int pad[2]; };
   Box* hb = nullptr;
   Box* dev = nullptr;
-  const char* to = getenv("PYAPES_HIP_COMM_TIMEOUT");
-  const double tmo = to ? atof(to) : 60.0;
+  const double tmo = (double)c->comm_timeout;   // option "comm_timeout" / PYAPES_HIP_COMM_TIMEOUT
   // leave with the first communicator aborted: a rank that cannot go on must not keep a communicator the others
   // are about to give up on (they do so after `tmo`; the caller's agreement then puts every rank on the stepwise path)
   auto give_up = [&](const char* why) {
@@ -234,6 +231,27 @@ int pa_comm_overlap(const pa_ctx* c) { return c && c->comm && c->comm2 && c->xst
 const char* pa_comm_impl(void) {
   Rccl* R = rccl();
   return R ? R->impl : "none";
+}
+
+// Another provider of the twelve nccl* entry points than librccl: an explicit call, made before the first communicator
+// of the process exists, with the path of a shared library that exports them (tests: tests/lib/libpa_hostring.so, ranks as
+// processes sharing one GPU).  No environment variable selects anything here.
+int pa_comm_use_impl(const char* so_path) {
+  Rccl& R = g_rccl;
+  if (!so_path || !so_path[0]) return PA_E_ARG;
+  if (R.tried && R.h) return PA_E_STATE;   // librccl (or another library) is in use already
+  void* h = dlopen(so_path, RTLD_NOW | RTLD_LOCAL);
+  if (!h) { fprintf(stderr, "[pyapes_hip] pa_comm_use_impl: %s\n", dlerror()); return PA_E_ARG; }
+  Rccl T;
+  if (!resolve(h, T)) { dlclose(h); return PA_E_ARG; }
+  R = T;
+  R.tried = 1;
+  R.h = h;
+  const char* (*name)() = nullptr;
+  snprintf(R.impl_buf, sizeof(R.impl_buf), "custom: %s", sym(h, "pa_comm_impl_name", name) ? name() : so_path);
+  R.impl = R.impl_buf;
+  fprintf(stderr, "[pyapes_hip] collectives of this process come from %s, not from librccl\n", so_path);
+  return PA_OK;
 }
 
 int pa_comm_destroy(pa_ctx* c) {

@@ -1,7 +1,8 @@
 // pa_comm_table.h -- the handful of RCCL entry points pa_comm.hip uses, as a table of function pointers.
-// Filled from librccl (dlopen, pa_comm.hip) in the product; tests that must run MORE THAN ONE rank on ONE GPU
-// (RCCL refuses duplicate devices) select the stand-in of pa_comm_hostring.hip with the explicit hook
-// PYAPES_HIP_COMM_IMPL=hostring -- same signatures, same stream-ordered semantics, host shared memory as the link.
+// Filled from librccl (dlopen, pa_comm.hip) -- or from the library a caller names through pa_comm_use_impl(path) before
+// the first communicator exists: tests that must run MORE THAN ONE rank on ONE GPU (RCCL refuses duplicate devices)
+// hand in tests/lib/libpa_hostring.so, which exports the same twelve symbols with the same stream-ordered semantics over
+// host shared memory.  Nothing of that stand-in is linked into this library.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
@@ -10,6 +11,7 @@ struct Rccl {
   void* h = nullptr;
   int tried = 0;
   const char* impl = "rccl";
+  char impl_buf[256] = "";
   ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
   ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
   ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
@@ -23,6 +25,3 @@ struct Rccl {
   ncclResult_t (*GroupEnd)() = nullptr;
   const char* (*GetErrorString)(ncclResult_t) = nullptr;
 };
-
-// pa_comm_hostring.hip: fill the table with the test stand-in (never selected implicitly)
-void pa_hostring_table(Rccl* R);

@@ -68,6 +68,7 @@ void pa_set_err(pa_ctx* c, const char* fmt, ...) {
 
 namespace {
 struct Roctx {
+  int want = -1;   // -1: ask PYAPES_HIP_ROCTX; 0 / 1: option "roctx"
   int state = 0;   // 0 untried, 1 on, -1 off
   int (*push)(const char*) = nullptr;
   int (*pop)() = nullptr;
@@ -78,7 +79,7 @@ bool roctx_on() {
   if (R.state == 0) {
     R.state = -1;
     const char* e = getenv("PYAPES_HIP_ROCTX");
-    if (e && atoi(e) != 0) {
+    if (R.want >= 0 ? R.want != 0 : (e && atoi(e) != 0)) {
       void* h = dlopen("libroctx64.so.4", RTLD_NOW | RTLD_GLOBAL);
       if (!h) h = dlopen("libroctx64.so", RTLD_NOW | RTLD_GLOBAL);
       if (h) {
@@ -120,14 +121,8 @@ int pa_scratch(pa_ctx* c, void** slot, size_t* cap, size_t bytes) {
   // every array at offset 0 and 853 us with the direction buffers 68.25 / 136.5 KiB in (phase A 571 -> 583, the
   // iteration 1.557 -> 1.492 ms); on two other boxes the offsets change nothing (1.512-1.520 ms in every setting) --
   // the box-to-box spread of the headline kernel is page placement, not clocks.  Slot q starts
-  // (q + 1) * stagger bytes in; default 68 KiB + 256 B (PYAPES_HIP_STAGGER=0: none).
-  static long stagger = -1, sbase = 0;
-  if (stagger < 0) {
-    const char* e = getenv("PYAPES_HIP_STAGGER");
-    stagger = e ? atol(e) & ~255L : 69888;
-    const char* b = getenv("PYAPES_HIP_STAGGER_BASE");
-    sbase = b ? atol(b) : 1;   // slot 0 (r) one step in as well: x, the caller's array, is the one at offset 0
-  }
+  // (q + 1) * stagger bytes in: 68 KiB + 256 B.
+  const long stagger = 69888, sbase = 1;   // (slot 0, r, one step in as well: x, the caller's array, is the one at offset 0)
   const size_t off = (size_t)(q + sbase) * (size_t)stagger;
   void* base = nullptr;
   // (PA_PLACE_ROOM more: every role of a CG solve fits every block of the placement search's pool, pa_place.hip)
@@ -254,17 +249,35 @@ int pa_ctx_create(int device, void* hip_stream, pa_ctx** out) {
   c->device = device;
   c->stream = (hipStream_t)hip_stream;
   c->err[0] = 0;
-  if (const char* fp = getenv("PYAPES_HIP_FASTPATH")) c->fastpath = atoi(fp) != 0;
-  if (const char* sf = getenv("PYAPES_HIP_SF")) c->sf = atoi(sf) != 0;
-  if (const char* rs = getenv("PYAPES_HIP_RESIDENT")) c->resident = atoi(rs) != 0;
-  if (const char* rc = getenv("PYAPES_HIP_RESIDENT_COOP")) c->resident_coop = atoi(rc) != 0;
-  if (const char* pt = getenv("PYAPES_HIP_PITCH")) c->pitch = atoi(pt) != 0;
+  // Defaults of the options from the environment (the complete list: README.md "Switches"): nine named variables for
+  // the switches people flip, PYAPES_HIP_OPTIONS="name=value,..." for everything pa_ctx_set_option knows.
+  static const struct { const char* env; const char* opt; } named[] = {
+      {"PYAPES_HIP_FASTPATH", "fastpath"}, {"PYAPES_HIP_SF", "sf"}, {"PYAPES_HIP_FOLD", "fold"}, {"PYAPES_HIP_RESIDENT", "resident"},
+      {"PYAPES_HIP_PITCH", "pitch"}, {"PYAPES_HIP_BCL", "bcl"}, {"PYAPES_HIP_COMM", "comm"}, {"PYAPES_HIP_SLAB_FOLD", "slab_fold"},
+      {"PYAPES_HIP_COMM_OVERLAP", "comm_overlap"}, {"PYAPES_HIP_COMM_TIMEOUT", "comm_timeout"}};
+  int orc = PA_OK;
+  for (const auto& nv : named)
+    if (const char* v = getenv(nv.env)) orc = orc ? orc : pa_ctx_set_option(c, nv.opt, atoi(v));
   if (const char* pl = getenv("PYAPES_HIP_PLACE")) {   // 0 off, 1 on (default), 2 stress: every CG solve of any size, no budget
     c->place = atoi(pl) != 0;
     if (atoi(pl) == 2) { c->ps.minbytes = 0; c->ps.budget = 1e9; }
   }
-  if (const char* bl = getenv("PYAPES_HIP_BCL")) c->bcl = atoi(bl) != 0;
-  if (const char* m2 = getenv("PYAPES_HIP_CG2D_MINCELLS")) c->cg2d_mincells = atoll(m2);
+  if (const char* all = getenv("PYAPES_HIP_OPTIONS")) {
+    char buf[1024];
+    strncpy(buf, all, sizeof(buf) - 1);
+    buf[sizeof(buf) - 1] = 0;
+    for (char* tok = strtok(buf, ","); tok && !orc; tok = strtok(nullptr, ",")) {
+      char* eq = strchr(tok, '=');
+      if (!eq) { pa_set_err(c, "PYAPES_HIP_OPTIONS: '%s' is not name=value", tok); orc = PA_E_ARG; break; }
+      *eq = 0;
+      orc = pa_ctx_set_option(c, tok, atoi(eq + 1));
+    }
+  }
+  if (orc) {
+    pa_set_err(nullptr, "pa_ctx_create: %s", c->err);
+    delete c;
+    return orc;
+  }
   if (hipMalloc((void**)&c->sc_base, 2 * sizeof(SolverScalars)) != hipSuccess ||
       hipMalloc((void**)&c->sums, PA_NSUM * sizeof(double)) != hipSuccess ||
       hipHostMalloc((void**)&c->h_sc, sizeof(SolverScalars)) != hipSuccess ||
@@ -280,7 +293,6 @@ int pa_ctx_create(int device, void* hip_stream, pa_ctx** out) {
   c->sc = c->sc_base;
   c->sc_alt = c->sc_base + 1;
   (void)hipMemsetAsync(c->sc_base, 0, 2 * sizeof(SolverScalars), c->stream);
-  if (const char* fo = getenv("PYAPES_HIP_FOLD")) c->fold = atoi(fo) != 0;
   (void)hipMemsetAsync(c->sums, 0, PA_NSUM * sizeof(double), c->stream);
   *out = c;
   return PA_OK;
@@ -325,8 +337,33 @@ int pa_ctx_set_option(pa_ctx* c, const char* name, int value) {
   else if (!strcmp(name, "place_blocks")) c->ps.blocks = value < 0 ? 0 : (value > PA_PLACE_MAXSPARE ? PA_PLACE_MAXSPARE : value);
   else if (!strcmp(name, "place_budget")) c->ps.budget = 0.01 * (value < 0 ? 0 : value);      // per cent of the time solved so far
   else if (!strcmp(name, "resident_coop")) c->resident_coop = value != 0;   // 0: plain launch of the same grid (profiling, below)
+  else if (!strcmp(name, "bc_path")) c->bc_path = value & 7;
+  else if (!strcmp(name, "bicg_pfold")) c->bicg_pfold = value != 0;
+  else if (!strcmp(name, "rhs_full")) c->rhs_full = value != 0;
+  else if (!strcmp(name, "res_cells")) c->res_cells = value;
+  else if (!strcmp(name, "res_nt")) c->res_nt = value;
+  else if (!strcmp(name, "res_nt_cells")) c->res_nt_cells = value;
+  else if (!strcmp(name, "res_spin")) c->res_spin = value;
+  else if (!strcmp(name, "res_rzlean")) c->res_rzlean = value != 0;
+  else if (!strcmp(name, "comm")) c->opt_comm = value != 0;
+  else if (!strcmp(name, "slab_fold")) c->opt_slab_fold = value != 0;
+  else if (!strcmp(name, "comm_overlap")) c->comm_overlap = value < 0 ? -1 : (value != 0);
+  else if (!strcmp(name, "comm_timeout")) c->comm_timeout = value > 0 ? value : 60;
+  else if (!strcmp(name, "roctx")) { g_roctx.want = value != 0; g_roctx.state = 0; }   // (process-wide, like the variable)
   else { pa_set_err(c, "pa_ctx_set_option: unknown option '%s'", name); return PA_E_ARG; }
   return PA_OK;
+}
+
+int pa_ctx_get_option(const pa_ctx* c, const char* name, int* value) {
+  if (!c || !name || !value) return PA_E_ARG;
+  const struct { const char* n; int v; } tab[] = {
+      {"fastpath", c->fastpath}, {"sf", c->sf}, {"fold", c->fold}, {"resident", c->resident}, {"bcl", c->bcl}, {"pitch", c->pitch},
+      {"place", c->place}, {"resident_coop", c->resident_coop}, {"bc_path", c->bc_path}, {"bicg_pfold", c->bicg_pfold},
+      {"rhs_full", c->rhs_full}, {"comm", c->opt_comm}, {"slab_fold", c->opt_slab_fold}, {"comm_overlap", c->comm_overlap},
+      {"comm_timeout", c->comm_timeout}, {"place_blocks", c->ps.blocks}};
+  for (const auto& t : tab)
+    if (!strcmp(name, t.n)) { *value = t.v; return PA_OK; }
+  return PA_E_ARG;
 }
 
 int pa_ctx_destroy(pa_ctx* c) {

@@ -136,6 +136,15 @@ struct pa_ctx {
   int place = 1;             // option "place": large CG solves search, while they run, which allocations r / d live in
   PlaceSearch ps;            // ... pa_place.hip
   int pitch = 1;             // option "pitch" / PYAPES_HIP_PITCH: allow that layout (0: odd rows stay on the NARROW kernels)
+  // test / A-B switches without an environment variable of their own (pa_ctx_set_option, or PYAPES_HIP_OPTIONS=name=value,...)
+  int bc_path = 0;           // "bc_path": bit 0 never the closed-form fill, bit 1 never the per-axis pair kernels, bit 2 closed form at any size
+  int bicg_pfold = 1;        // "bicg_pfold": BiCGSTAB's next direction formed by the x / r update (0: the full p / v phase every iteration)
+  int rhs_full = 0;          // "rhs_full": pa_rhs_adjust visits the whole mesh instead of the Neumann layers
+  int res_cells = 0, res_nt = 0, res_nt_cells = 0, res_spin = -1, res_rzlean = 1;   // "res_*": box plan / threads / spin bound / rz stencil of pa_resident.hip
+  int opt_comm = 1;          // "comm" / PYAPES_HIP_COMM: slab driver may use RCCL inside the library (read by pyapes_amd/slab.py)
+  int opt_slab_fold = 1;     // "slab_fold" / PYAPES_HIP_SLAB_FOLD: ... with the folded iteration sequence
+  int comm_overlap = -1;     // "comm_overlap" / PYAPES_HIP_COMM_OVERLAP: plane exchange on a second communicator + stream (-1: iff N > 1)
+  int comm_timeout = 60;     // "comm_timeout" / PYAPES_HIP_COMM_TIMEOUT: seconds a collective of the set-up may take
   int cg_pitch = 0;          // live CG solve keeps r and the direction buffers in the PITCH layout of k_cg3d
   int64_t cg_ps1 = 0;        // ... with this row pitch (cells)
   // Field.VARo (var.save_old() at the top of every solver iteration, linalg.py:110 / 210): when the caller
@@ -155,6 +164,10 @@ struct pa_ctx {
   const void* bc_far_lo0 = nullptr;  // periodic axis-0 fill: x[N-1] (for the lower end rank)
   const void* bc_far_lo1 = nullptr;  //                       x[N-2]
   const void* bc_far_hi0 = nullptr;  //                       x[1] of the lower end rank (for the upper end rank)
+  void* v_send_lo = nullptr;         // stepwise BiCGSTAB on a slab (pa_slab_set_v): first / last owned plane of v' out,
+  void* v_send_hi = nullptr;
+  const void* v_recv_lo = nullptr;   // ... ghost planes of v' in
+  const void* v_recv_hi = nullptr;
   void* x_pack_lo1 = nullptr;        // pack destinations of x[1] / x[n0-1] / x[n0-2] (periodic end ranks)
   void* x_pack_hi0 = nullptr;
   void* x_pack_hi1 = nullptr;

@@ -328,7 +328,7 @@ static int rhs_adjust_t(pa_ctx* c, T* rhs) {
     ++R.nlay;
   }
   if (R.nlay == 0) return PA_OK;             // no Neumann layer on this rank
-  if (getenv("PYAPES_HIP_RHS_FULL")) R.nlay = 0;
+  if (c->rhs_full) R.nlay = 0;   // option "rhs_full" (tests: same bits)
   const int64_t work = R.nlay ? R.lay_start[R.nlay] : G.ncell;
   hipLaunchKernelGGL(k_rhs_adjust<T>, dim3(pa_grid_blocks(work)), dim3(PA_BLOCK), 0, c->stream, c->G, E, R, rhs);
   PA_HIP(c, hipGetLastError());

@@ -33,7 +33,7 @@
 #include <mutex>
 
 #define RES_MAXG_LIMIT 256   // one workgroup per CU of the MI355X
-// Default 128: measured in round 3 with PYAPES_HIP_RES_MAXG=256 (boxes of <= 4096 cells up to 100^3), the grid-wide
+// Default 128: measured in round 3 with a limit of 256 (boxes of <= 4096 cells up to 100^3), the grid-wide
 // step of 150-256 workgroups eats what the saved launches give -- CG 80^3 22.4 us / iteration against 22.9
 // launch-per-phase, 96^3 30.7 against 27.4, 1024^2 26.3 against 23.0; BiCGSTAB 64^3 (150 boxes) 40.8 against 41.8,
 // Jacobi 96^3 23.8 against 24.4 -- so above 128 boxes the launch-per-phase loops stay.
@@ -118,7 +118,7 @@ __device__ __forceinline__ bool res_grid_wait(ResSync& S) {
     // still below the step's target.  Either every arrival is in before anybody gives up (all pass) or the poison
     // is in before the last arrival (nobody passes, now or in any later step).
     const unsigned long long RES_POISON = 1ull << 62;
-    // test hook (PYAPES_HIP_RES_SPIN=0, "every wait gives up"): workgroup 0 poisons the counter BEFORE it arrives, so
+    // test hook (option res_spin 0, "every wait gives up"): workgroup 0 poisons the counter BEFORE it arrives, so
     // no workgroup can ever find the step complete -- without this the outcome would hang on whether all arrivals
     // happen to be in before the first look at the counter (seen: 8 workgroups passing every step of a solve)
     if (S.spin_max == 0 && blockIdx.x == 0)
@@ -1043,21 +1043,19 @@ struct ResPlan {
   int cells;
 };
 
-// tuning knobs of the plan (measurement runs only; the defaults are what DESIGN.md quotes)
-static int res_tune(const char* name, int dflt) {
-  const char* e = getenv(name);
-  return e && atoi(e) > 0 ? atoi(e) : dflt;
-}
+// tuning knobs of the plan (options "res_cells", "res_nt", "res_nt_cells": tests force other layouts; the defaults are
+// what DESIGN.md quotes)
+static int res_tune(int opt, int dflt) { return opt > 0 ? opt : dflt; }
 
 static bool res_plan(const pa_ctx* c, size_t es, int solver, ResPlan& R) {
   const DevGeom& G = c->G;
   const int64_t N[3] = {G.n0, G.n1, G.n2};
-  const int maxbox = std::min(RES_MAXBOX, res_tune("PYAPES_HIP_RES_BOX", RES_MAXBOX));
-  const int per_wg = res_tune("PYAPES_HIP_RES_CELLS", 1024);   // cells per workgroup aimed at (<= 64 workgroups)
-  const int maxg = std::min(RES_MAXG_LIMIT, res_tune("PYAPES_HIP_RES_MAXG", RES_MAXG));
+  const int maxbox = RES_MAXBOX;
+  const int per_wg = res_tune(c->res_cells, 1024);   // cells per workgroup aimed at (<= 64 workgroups)
+  const int maxg = RES_MAXG;
   if (G.ncell > (int64_t)maxg * maxbox) return false;
   int P[3] = {1, 1, 1};
-  const int want = (int)std::max<int64_t>(1, std::min<int64_t>(res_tune("PYAPES_HIP_RES_MAXWANT", 64), (G.ncell + per_wg - 1) / per_wg));
+  const int want = (int)std::max<int64_t>(1, std::min<int64_t>(64, (G.ncell + per_wg - 1) / per_wg));
   for (;;) {
     int b[3];
     for (int a = 0; a < 3; ++a) b[a] = (int)((N[a] + P[a] - 1) / P[a]);
@@ -1128,14 +1126,14 @@ int pa_resident_launch(pa_ctx* c, int solver, T* x, const T* rhs, double tol, in
   if (!res_plan(c, sizeof(T), solver, R)) return 0;
   // LEAN: one Laplacian term with a scalar coefficient -- on an xyz mesh, or on an axisymmetric one (the r axis takes
   // its rows from the table of pa_coord_set, staged in LDS)
-  const char* rzl_env = getenv("PYAPES_HIP_RES_RZLEAN");   // 0: pa_apply_terms on the box, as before round 3 (tests)
-  const bool rz_lean = c->coord != PA_COORD_XYZ && c->rz_tab && !(rzl_env && atoi(rzl_env) == 0);
+  // (option "res_rzlean" 0: pa_apply_terms on the box, as before round 3 -- tests)
+  const bool rz_lean = c->coord != PA_COORD_XYZ && c->rz_tab && c->res_rzlean;
   const bool lean = c->nterms == 1 && c->terms[0].kind == PA_OP_LAPLACIAN && (c->coord == PA_COORD_XYZ || rz_lean);
   // threads per workgroup: more waves hide the LDS latency of the cell passes once a thread has several cells;
   // the general-equation build needs more registers than 512 / 1024 threads leave
   int nt = 256;
-  if (lean && R.cells > res_tune("PYAPES_HIP_RES_NT_CELLS", 256))
-    nt = res_tune("PYAPES_HIP_RES_NT", R.cells > 1024 ? 1024 : 512);
+  if (lean && R.cells > res_tune(c->res_nt_cells, 256))
+    nt = res_tune(c->res_nt, R.cells > 1024 ? 1024 : 512);
   const void* fn;
   auto pick = [&](const void* f0, const void* f1, const void* f2) { return solver == 0 ? f0 : (solver == 1 ? f1 : f2); };
   if (!lean) fn = pick((const void*)k_resident<T, 0, false, 256>, (const void*)k_resident<T, 1, false, 256>, (const void*)k_resident<T, 2, false, 256>);
@@ -1212,7 +1210,7 @@ int pa_resident_launch(pa_ctx* c, int solver, T* x, const T* rhs, double tol, in
   A.parts = (double*)(base + head);
   A.mail = (T*)(base + head + parts_b);
   A.spin_max = 1u << 21;   // x (one atomic load + s_sleep) ~ seconds: far beyond any legitimate wait
-  if (const char* e = getenv("PYAPES_HIP_RES_SPIN")) A.spin_max = (unsigned)atoi(e);   // tests: 0 = every wait gives up
+  if (c->res_spin >= 0) A.spin_max = (unsigned)c->res_spin;   // option "res_spin" (tests: 0 = every wait gives up)
   A.o_h = R.o_h; A.o_p1 = R.o_p1; A.o_p2 = R.o_p2; A.o_bcc = R.o_bcc; A.o_sh = R.o_sh; A.o_meta = R.o_meta; A.o_lists = R.o_lists;
   A.o_h2 = R.o_h2; A.o_h3 = R.o_h3; A.o_p3 = R.o_p3;
   A.o_rz = R.o_rz;

@@ -522,11 +522,8 @@ template <typename T, int RJ, int PHASE, int KIND, bool HASU, bool BCL = false>
 static int sf_blocks_per_cu() {
   static int cached = 0;
   if (!cached) {
-    const char* e = getenv("PYAPES_HIP_BPC_SF");
-    int n = e ? atoi(e) : 0;
-    if (n <= 0) {
-      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_sf<T, RJ, PHASE, KIND, HASU, BCL>, 256, 0) != hipSuccess || n <= 0) n = 4;
-    }
+    int n = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_sf<T, RJ, PHASE, KIND, HASU, BCL>, 256, 0) != hipSuccess || n <= 0) n = 4;
     cached = n;
   }
   return cached;
@@ -569,9 +566,7 @@ static int launch_sf_any(pa_ctx* c, Cg3dArgs<T>& A) {
   constexpr int VEC = VecOf<T>::N;
   const DevGeom& G = c->G;
   int rj;
-  if (const char* e = getenv("PYAPES_HIP_RJ_SF"); e && (atoi(e) == 1 || atoi(e) == 2 || atoi(e) == 4)) {
-    rj = atoi(e);
-  } else if (G.n1 <= 4) {
+  if (G.n1 <= 4) {
     rj = 1;
   } else if (G.n1 <= 8) {
     rj = 2;

@@ -1528,9 +1528,8 @@ static int bicg_run_t(pa_ctx* c, T* x, const T* rhs, double tol, int64_t max_it,
   const bool fold = c->fold && !c->slab;
   int pend3 = 0;
   // the next direction formed by k_bicg_x (one array pass less per iteration, one haloed input instead of three in the
-  // p / v phase); PYAPES_HIP_BICG_PFOLD=0: every iteration through the p / v phase, as before round 3
-  const char* pf_env = getenv("PYAPES_HIP_BICG_PFOLD");
-  const bool pfold = !(pf_env && atoi(pf_env) == 0);
+  // p / v phase); option "bicg_pfold" 0: every iteration through the p / v phase, as before round 3
+  const bool pfold = c->bicg_pfold != 0;
   bool pgiven = false;
   c->fold_a_n = c->fold_b_n = c->fold_b_nsh = 0;
   auto flush3 = [&]() {
@@ -1874,3 +1873,360 @@ int pa_cg_end(pa_ctx* c, pa_report* out) {
 
 }  // extern "C"
 
+
+// ============================================================================
+//  stepwise BiCGSTAB on a slab (linalg.py:162-279 split at its reductions and exchanges)
+// ============================================================================
+// Config 3 is periodic: CG never meets the reference's stop test there, BiCGSTAB is the solver that
+// converges -- so it has to exist on slabs too.  Per iteration, with the planes a rank needs from its axis-0
+// neighbours:
+//   pv      p' = r + beta (p - omega v) -- on the ghost planes too, from the ghost planes of r, p, v with the owner's
+//           recurrence bit for bit, so p is never exchanged -- ; v' = A p' on S ; local sum r0.v'   -> [all-reduce 1]
+//                                                                                 -> [exchange the boundary planes of v']
+//   st      alpha ; s = r - alpha v' (ghost planes from those of r and v') ; t = A s on S ;
+//           local sums |s|^2, t.s, t.t, r0.t                                       -> [all-reduce 4]
+//   x       stop test 1, omega, rho' ; x += alpha p' + omega s ; r = s - omega t   -> [exchange r planes (+ periodic x planes)]
+//   bc      BC fill of x ; local sum |r|^2                                         -> [all-reduce 1]
+//   finish  stop test 2, beta, rho <- rho'
+// Two plane exchanges and three small all-reduces per iteration.  The sums travel in the caller's PA_NSUM buffer:
+// [0] r0.v', [1] |s|^2 (and r0.r0 of the start), [2] t.s, [3] t.t, [4] r0.t, [5] |r|^2.  Kernels: the tiled phases 5 / 6
+// where they apply (they take ghost planes through Vec<T>), else the generic ones; the next direction is NOT folded into
+// the x / r update here (its ghost planes would need the new residual's, which is still on the wire).
+template <typename T>
+__global__ void __launch_bounds__(PA_BLOCK) k_rows_to_sums(const SolverScalars* __restrict__ sc, const double* __restrict__ partials,
+                                                            int nblk, int ncol, double* __restrict__ sums, int off, int guarded) {
+  __shared__ double sm[PA_BLOCK / 64];
+  if (guarded && sc->done) return;
+  for (int q = 0; q < ncol; ++q) {
+    const double v = pa_reduce_partials(partials, nblk, ncol, q, sm);
+    if (threadIdx.x == 0) sums[off + q] = v;
+  }
+}
+
+// the scalar steps of k_bicg_post, from all-reduced sums instead of partial rows.  stage 10: start (rho' = r0.r0,
+// first beta); 0: alpha; 12: stop test 1, omega, rho'; 3: stop test 2, next beta
+template <typename T>
+__global__ void k_bicg_logic(SolverScalars* sc, const double* __restrict__ sums, int stage) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  if (stage == 10) {
+    sc->rr = (double)(T)sums[1];
+    sc->rho_next = sc->rr;
+    sc->tol = (double)(T)sqrt((T)sc->rr);
+    T b = (T)sc->rho_next / (T)1.0;
+    b = b * (T)1.0;
+    b = b / (T)1.0;
+    sc->beta = (double)b;
+    sc->rho = sc->rho_next;
+    sc->done = 0;   // `while not finished`: at least one iteration
+    return;
+  }
+  if (sc->done) return;
+  if (stage == 0) {
+    sc->itr += 1;
+    T r0v = (T)sums[0];
+    T rho = (T)sc->rho;
+    sc->alpha = pa_nan_to_num<T>(rho / r0v);
+  } else if (stage == 12) {
+    T tol = (T)sqrt(sums[1]);
+    sc->tol = (double)tol;
+    if (isnan(tol) || isinf(tol)) { sc->err = 1; sc->done = 1; return; }
+    sc->finished_early = (sc->tol <= sc->tolerance) ? 1 : 0;
+    if (!sc->finished_early) {
+      T om = (T)pa_nan_to_num<T>((T)sums[2] / (T)sums[3]);
+      sc->omega = (double)om;
+      T rn = -om;
+      rn = rn * (T)sums[4];
+      sc->rho_next = (double)rn;
+    }
+  } else {
+    if (sc->finished_early) { sc->done = 1; return; }
+    T tol = (T)sqrt(sums[5]);
+    sc->tol = (double)tol;
+    if (isnan(tol) || isinf(tol)) { sc->err = 1; sc->done = 1; return; }
+    if (sc->tol <= sc->tolerance) sc->done = 1;
+    if (sc->itr >= sc->max_it) sc->done = 1;
+    T b = (T)sc->rho_next / (T)sc->rho;
+    b = b * (T)sc->alpha;
+    b = b / (T)sc->omega;
+    sc->beta = (double)b;
+    sc->rho = sc->rho_next;
+  }
+}
+
+// ghost planes of p' = r + beta (p - omega v): the owner's recurrence (BicgPAcc::at / the combine of phase 5)
+template <typename T>
+__global__ void __launch_bounds__(PA_BLOCK) k_ghost_p(const SolverScalars* __restrict__ sc, int64_t n,
+                                                       const T* __restrict__ r_lo, const T* __restrict__ r_hi,
+                                                       const T* __restrict__ p_lo, const T* __restrict__ p_hi,
+                                                       const T* __restrict__ v_lo, const T* __restrict__ v_hi,
+                                                       T* __restrict__ o_lo, T* __restrict__ o_hi) {
+  if (sc->done) return;
+  const T beta = (T)sc->beta, omega = (T)sc->omega;
+  for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < n; q += (int64_t)gridDim.x * blockDim.x) {
+    if (r_lo) { T t = omega * v_lo[q]; t = p_lo[q] - t; t = beta * t; o_lo[q] = r_lo[q] + t; }
+    if (r_hi) { T t = omega * v_hi[q]; t = p_hi[q] - t; t = beta * t; o_hi[q] = r_hi[q] + t; }
+  }
+}
+
+// ghost planes of s = r - alpha v' (generic kernels only: the tiled phase 6 forms them on load)
+template <typename T>
+__global__ void __launch_bounds__(PA_BLOCK) k_ghost_s(const SolverScalars* __restrict__ sc, int64_t n,
+                                                       const T* __restrict__ r_lo, const T* __restrict__ r_hi,
+                                                       const T* __restrict__ v_lo, const T* __restrict__ v_hi,
+                                                       T* __restrict__ o_lo, T* __restrict__ o_hi) {
+  if (sc->done) return;
+  const T alpha = (T)sc->alpha;
+  for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < n; q += (int64_t)gridDim.x * blockDim.x) {
+    if (r_lo) { T av = alpha * v_lo[q]; o_lo[q] = r_lo[q] - av; }
+    if (r_hi) { T av = alpha * v_hi[q]; o_hi[q] = r_hi[q] - av; }
+  }
+}
+
+namespace {
+
+// a field of the slab solver with its ghost planes; a physical (non-periodic) end has none: no result uses that plane
+// (the end plane is a boundary node), the field's own end plane stands in so that speculative loads stay in valid memory
+template <typename T>
+Vec<T> slab_vec(const pa_ctx* c, const T* p, const void* glo, const void* ghi) {
+  Vec<T> v;
+  v.p = p;
+  v.glo = glo ? (const T*)glo : p;
+  v.ghi = ghi ? (const T*)ghi : p + (c->G.n0 - 1) * c->G.s0;
+  return v;
+}
+
+template <typename T>
+int bicg_slab_begin_t(pa_ctx* c, T* x, const T* rhs, double tol, int64_t max_it) {
+  const DevGeom& G = c->G;
+  const size_t fb = (size_t)G.ncell * sizeof(T), pb = (size_t)G.s0 * sizeof(T);
+  const int nblk = pa_grid_blocks(G.ncell);
+  int rc;
+  c->cg_pitch = 0;
+  c->cg_ps1 = 0;
+  const int ids[] = {SCR_R, SCR_D0, SCR_D1, SCR_R0, SCR_V0, SCR_V1, SCR_S, SCR_TT};
+  for (int id : ids)
+    if ((rc = pa_scratch(c, &c->scr[id], &c->cap[id], fb))) return rc;
+  if ((rc = pa_scratch(c, &c->scr[SCR_PART], &c->cap[SCR_PART], (size_t)PA_MAX_PARTIALS * 6 * sizeof(double)))) return rc;
+  if ((rc = pa_scratch(c, &c->scr[SCR_GHOST], &c->cap[SCR_GHOST], 6 * pb))) return rc;   // p ghosts (lo / hi x ping / pong), s ghosts
+  if ((rc = init_scalars(c, tol, max_it))) return rc;
+  DevEq<T> E;
+  pa_build_eq<T>(c, c->nterms, c->terms, E);
+  T* r = (T*)c->scr[SCR_R];
+  T* r0 = (T*)c->scr[SCR_R0];
+  // (the driver has filled the BCs and exchanged the ghost planes of x: linalg.py:181)
+  Vec<T> xv = pa_vec_self<T>(c, x);
+  xv.glo = (const T*)c->x_glo;
+  xv.ghi = (const T*)c->x_ghi;
+  for (int id : {SCR_D0, SCR_D1, SCR_V0, SCR_V1, SCR_S, SCR_TT}) PA_HIP(c, hipMemsetAsync(c->scr[id], 0, fb, c->stream));
+  PA_HIP(c, hipMemsetAsync(c->scr[SCR_GHOST], 0, 6 * pb, c->stream));
+  // r0 = r = b - A x on S ; local sum r0.r0 ; first / last owned plane of r for the neighbours
+  if ((rc = cg_residual_init<T>(c, E, xv, rhs, r0, r, (T*)c->r_send_lo, (T*)c->r_send_hi, (double*)c->scr[SCR_PART]))) return rc;
+  hipLaunchKernelGGL(k_rows_to_sums<T>, dim3(1), dim3(PA_BLOCK), 0, c->stream, c->sc, (const double*)c->scr[SCR_PART], nblk, 1,
+                     pa_sums(c), 1, 0);
+  c->cg_x = x;
+  c->cur = 0;
+  c->solver_live = 2;   // (2: the stepwise BiCGSTAB)
+  PA_HIP(c, hipGetLastError());
+  return PA_OK;
+}
+
+template <typename T>
+int bicg_slab_pv_t(pa_ctx* c) {
+  const DevGeom& G = c->G;
+  const int nblk = pa_grid_blocks(G.ncell);
+  const size_t pl = (size_t)G.s0;
+  DevEq<T> E;
+  pa_build_eq<T>(c, c->nterms, c->terms, E);
+  T* r = (T*)c->scr[SCR_R];
+  T* r0 = (T*)c->scr[SCR_R0];
+  T* p[2] = {(T*)c->scr[SCR_D0], (T*)c->scr[SCR_D1]};
+  T* v[2] = {(T*)c->scr[SCR_V0], (T*)c->scr[SCR_V1]};
+  T* g = (T*)c->scr[SCR_GHOST];
+  T* pg_lo[2] = {g, g + 2 * pl};
+  T* pg_hi[2] = {g + pl, g + 3 * pl};
+  double* part = (double*)c->scr[SCR_PART];
+  const int cur = c->cur;
+  const bool lo = c->r_recv_lo != nullptr, hi = c->r_recv_hi != nullptr;
+  if ((lo && !c->v_recv_lo) || (hi && !c->v_recv_hi)) { pa_set_err(c, "pa_bicg_pv: a neighbour without a receive plane for v (pa_slab_set_v)"); return PA_E_STATE; }
+  Vec<T> rv = slab_vec<T>(c, r, c->r_recv_lo, c->r_recv_hi);
+  Vec<T> pv = slab_vec<T>(c, p[cur], lo ? pg_lo[cur] : nullptr, hi ? pg_hi[cur] : nullptr);
+  Vec<T> vv = slab_vec<T>(c, v[cur], c->v_recv_lo, c->v_recv_hi);
+  if (lo || hi)   // the ghost planes of p' for the NEXT iteration (this one forms them on load)
+    hipLaunchKernelGGL(k_ghost_p<T>, dim3(pa_grid_blocks(G.s0)), dim3(PA_BLOCK), 0, c->stream, c->sc, G.s0,
+                       lo ? (const T*)c->r_recv_lo : nullptr, hi ? (const T*)c->r_recv_hi : nullptr, (const T*)pg_lo[cur],
+                       (const T*)pg_hi[cur], (const T*)c->v_recv_lo, (const T*)c->v_recv_hi, pg_lo[cur ^ 1], pg_hi[cur ^ 1]);
+  c->fold_a_n = c->fold_b_n = 0;
+  int used = pa_tile3d_bicg_pv<T>(c, E, rv, pv, vv, (const T*)r0, p[cur ^ 1], v[cur ^ 1], part);
+  if (used < 0) return used;
+  if (used == 0) {
+    hipLaunchKernelGGL(k_bicg_pv<T>, dim3(nblk), dim3(PA_BLOCK), 0, c->stream, G, E, c->sc, rv, pv, vv, (const T*)r0,
+                       p[cur ^ 1], v[cur ^ 1], part);
+    used = nblk;
+  }
+  hipLaunchKernelGGL(k_rows_to_sums<T>, dim3(1), dim3(PA_BLOCK), 0, c->stream, c->sc, (const double*)part, used, 1, pa_sums(c), 0, 1);
+  if (c->v_send_lo || c->v_send_hi)
+    hipLaunchKernelGGL(k_pack_planes<T>, dim3(pa_grid_blocks(G.s0)), dim3(PA_BLOCK), 0, c->stream, c->sc, G.s0,
+                       (const T*)v[cur ^ 1], (T*)c->v_send_lo, (const T*)v[cur ^ 1] + (G.n0 - 1) * G.s0, (T*)c->v_send_hi,
+                       (const T*)nullptr, (T*)nullptr);
+  PA_HIP(c, hipGetLastError());
+  return PA_OK;
+}
+
+template <typename T>
+int bicg_slab_st_t(pa_ctx* c) {
+  const DevGeom& G = c->G;
+  const int nblk = pa_grid_blocks(G.ncell);
+  const size_t pl = (size_t)G.s0;
+  DevEq<T> E;
+  pa_build_eq<T>(c, c->nterms, c->terms, E);
+  T* r = (T*)c->scr[SCR_R];
+  T* r0 = (T*)c->scr[SCR_R0];
+  T* vn = (T*)c->scr[c->cur ? SCR_V0 : SCR_V1];   // v' of this iteration
+  T* s = (T*)c->scr[SCR_S];
+  T* t = (T*)c->scr[SCR_TT];
+  T* g = (T*)c->scr[SCR_GHOST];
+  T* sg_lo = g + 4 * pl;
+  T* sg_hi = g + 5 * pl;
+  double* part = (double*)c->scr[SCR_PART] + (size_t)PA_MAX_PARTIALS;
+  hipLaunchKernelGGL(k_bicg_logic<T>, dim3(1), dim3(1), 0, c->stream, c->sc, (const double*)pa_sums(c), 0);   // alpha, itr
+  Vec<T> rv = slab_vec<T>(c, r, c->r_recv_lo, c->r_recv_hi);
+  Vec<T> vv = slab_vec<T>(c, vn, c->v_recv_lo, c->v_recv_hi);
+  c->fold_a_n = 0;
+  int used = pa_tile3d_bicg_st<T>(c, E, rv, vv, (const T*)r0, s, t, part);
+  if (used < 0) return used;
+  if (used > 0) {
+    hipLaunchKernelGGL(k_rows_to_sums<T>, dim3(1), dim3(PA_BLOCK), 0, c->stream, c->sc, (const double*)part, used, 4, pa_sums(c), 1, 1);
+  } else {
+    // generic kernels: s everywhere, its ghost planes, t = A s on S.  (Unlike the one-GPU loop, t is formed even when
+    // the first stop test is about to end the solve: the test needs the all-reduced |s|^2, which comes after this call.)
+    hipLaunchKernelGGL(k_bicg_s<T>, dim3(nblk), dim3(PA_BLOCK), 0, c->stream, G, c->sc, (const T*)r, (const T*)vn, s, part);
+    hipLaunchKernelGGL(k_rows_to_sums<T>, dim3(1), dim3(PA_BLOCK), 0, c->stream, c->sc, (const double*)part, nblk, 1, pa_sums(c), 1, 1);
+    const bool lo = c->r_recv_lo != nullptr, hi = c->r_recv_hi != nullptr;
+    if (lo || hi)
+      hipLaunchKernelGGL(k_ghost_s<T>, dim3(pa_grid_blocks(G.s0)), dim3(PA_BLOCK), 0, c->stream, c->sc, G.s0,
+                         lo ? (const T*)c->r_recv_lo : nullptr, hi ? (const T*)c->r_recv_hi : nullptr, (const T*)c->v_recv_lo,
+                         (const T*)c->v_recv_hi, sg_lo, sg_hi);
+    Vec<T> sv = slab_vec<T>(c, s, lo ? sg_lo : nullptr, hi ? sg_hi : nullptr);
+    hipLaunchKernelGGL(k_bicg_t<T>, dim3(nblk), dim3(PA_BLOCK), 0, c->stream, G, E, c->sc, sv, (const T*)r0, t, part);
+    hipLaunchKernelGGL(k_rows_to_sums<T>, dim3(1), dim3(PA_BLOCK), 0, c->stream, c->sc, (const double*)part, nblk, 3, pa_sums(c), 2, 1);
+  }
+  PA_HIP(c, hipGetLastError());
+  return PA_OK;
+}
+
+template <typename T>
+int bicg_slab_x_t(pa_ctx* c) {
+  const DevGeom& G = c->G;
+  const int nblk = pa_grid_blocks(G.ncell);
+  T* x = (T*)c->cg_x;
+  T* r = (T*)c->scr[SCR_R];
+  T* pn = (T*)c->scr[c->cur ? SCR_D0 : SCR_D1];   // p' of this iteration
+  T* s = (T*)c->scr[SCR_S];
+  T* t = (T*)c->scr[SCR_TT];
+  double* part = (double*)c->scr[SCR_PART] + 5 * (size_t)PA_MAX_PARTIALS;
+  hipLaunchKernelGGL(k_bicg_logic<T>, dim3(1), dim3(1), 0, c->stream, c->sc, (const double*)pa_sums(c), 12);   // stop test 1, omega, rho'
+  constexpr int XV = 16 / (int)sizeof(T);
+  const bool vec = G.ncell % XV == 0 && ((((uintptr_t)x | (uintptr_t)pn | (uintptr_t)s | (uintptr_t)t | (uintptr_t)r) & 15) == 0);
+  if (vec)
+    hipLaunchKernelGGL((k_bicg_x<T, XV>), dim3(nblk), dim3(PA_BLOCK), 0, c->stream, G, c->sc, x, (const T*)pn, (const T*)s, (const T*)t,
+                       r, part, (const double*)nullptr, 0, c->sc, (const T*)nullptr, (T*)nullptr);
+  else
+    hipLaunchKernelGGL((k_bicg_x<T, 1>), dim3(nblk), dim3(PA_BLOCK), 0, c->stream, G, c->sc, x, (const T*)pn, (const T*)s, (const T*)t,
+                       r, part, (const double*)nullptr, 0, c->sc, (const T*)nullptr, (T*)nullptr);
+  // what the neighbours need next: the first / last owned plane of the new residual and, on the end ranks of a
+  // periodic ring, the x planes the other end's BC fill reads (packed behind them by the driver's buffer layout)
+  if (c->r_send_lo || c->r_send_hi)
+    hipLaunchKernelGGL(k_pack_planes<T>, dim3(pa_grid_blocks(G.s0)), dim3(PA_BLOCK), 0, c->stream, c->sc, G.s0,
+                       (const T*)r, (T*)c->r_send_lo, (const T*)r + (G.n0 - 1) * G.s0, (T*)c->r_send_hi, (const T*)nullptr, (T*)nullptr);
+  if (c->x_pack_lo1 || c->x_pack_hi0 || c->x_pack_hi1) {
+    const T* xr = (const T*)x;
+    hipLaunchKernelGGL(k_pack_planes<T>, dim3(pa_grid_blocks(G.s0)), dim3(PA_BLOCK), 0, c->stream, c->sc, G.s0,
+                       xr + 1 * G.s0, (T*)c->x_pack_lo1, xr + (G.n0 - 1) * G.s0, (T*)c->x_pack_hi0,
+                       xr + (G.n0 - 2) * G.s0, (T*)c->x_pack_hi1);
+  }
+  PA_HIP(c, hipGetLastError());
+  return PA_OK;
+}
+
+template <typename T>
+int bicg_slab_bc_t(pa_ctx* c) {
+  const int nblk = pa_grid_blocks(c->G.ncell);
+  int rc = pa_bc_apply_auto<T>(c, (T*)c->cg_x, true);
+  if (rc) return rc;
+  hipLaunchKernelGGL(k_rows_to_sums<T>, dim3(1), dim3(PA_BLOCK), 0, c->stream, c->sc,
+                     (const double*)c->scr[SCR_PART] + 5 * (size_t)PA_MAX_PARTIALS, nblk, 1, pa_sums(c), 5, 1);
+  PA_HIP(c, hipGetLastError());
+  return PA_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int pa_slab_set_v(pa_ctx* c, void* v_send_lo, void* v_send_hi, const void* v_recv_lo, const void* v_recv_hi) {
+  if (!c) return PA_E_ARG;
+  if (c->solver_live) { pa_set_err(c, "pa_slab_set_v during a solve"); return PA_E_STATE; }
+  c->v_send_lo = v_send_lo; c->v_send_hi = v_send_hi;
+  c->v_recv_lo = v_recv_lo; c->v_recv_hi = v_recv_hi;
+  return PA_OK;
+}
+
+#define PA_BICG_LIVE(c, what)                                                                                         \
+  if (!(c) || (c)->solver_live != 2) { if (c) pa_set_err((c), what " without pa_bicg_begin"); return PA_E_STATE; }     \
+  PA_HIP((c), hipSetDevice((c)->device));
+
+int pa_bicg_begin(pa_ctx* c, void* x, const void* rhs, double tol, int64_t max_it) {
+  if (!c || !c->grid_set || !c->eq_set) { if (c) pa_set_err(c, "pa_bicg_begin: grid/equation not set"); return PA_E_STATE; }
+  if (int rc0 = pa_check_eq_applicable(c)) return rc0;
+  if (!c->slab || !c->ext_sums) { pa_set_err(c, "pa_bicg_begin is the stepwise form for slabs (pa_slab_set); one GPU: pa_bicgstab"); return PA_E_STATE; }
+  PA_HIP(c, hipSetDevice(c->device));
+  return c->dtype == PA_F64 ? bicg_slab_begin_t<double>(c, (double*)x, (const double*)rhs, tol, max_it)
+                            : bicg_slab_begin_t<float>(c, (float*)x, (const float*)rhs, tol, max_it);
+}
+
+int pa_bicg_start(pa_ctx* c) {   // after the all-reduce of sums[1] = r0.r0
+  PA_BICG_LIVE(c, "pa_bicg_start")
+  if (c->dtype == PA_F64) hipLaunchKernelGGL(k_bicg_logic<double>, dim3(1), dim3(1), 0, c->stream, c->sc, (const double*)pa_sums(c), 10);
+  else hipLaunchKernelGGL(k_bicg_logic<float>, dim3(1), dim3(1), 0, c->stream, c->sc, (const double*)pa_sums(c), 10);
+  PA_HIP(c, hipGetLastError());
+  return PA_OK;
+}
+
+int pa_bicg_pv(pa_ctx* c) {
+  PA_BICG_LIVE(c, "pa_bicg_pv")
+  return c->dtype == PA_F64 ? bicg_slab_pv_t<double>(c) : bicg_slab_pv_t<float>(c);
+}
+
+int pa_bicg_st(pa_ctx* c) {
+  PA_BICG_LIVE(c, "pa_bicg_st")
+  return c->dtype == PA_F64 ? bicg_slab_st_t<double>(c) : bicg_slab_st_t<float>(c);
+}
+
+int pa_bicg_x(pa_ctx* c) {
+  PA_BICG_LIVE(c, "pa_bicg_x")
+  return c->dtype == PA_F64 ? bicg_slab_x_t<double>(c) : bicg_slab_x_t<float>(c);
+}
+
+int pa_bicg_bc(pa_ctx* c) {
+  PA_BICG_LIVE(c, "pa_bicg_bc")
+  return c->dtype == PA_F64 ? bicg_slab_bc_t<double>(c) : bicg_slab_bc_t<float>(c);
+}
+
+int pa_bicg_finish(pa_ctx* c) {
+  PA_BICG_LIVE(c, "pa_bicg_finish")
+  if (c->dtype == PA_F64) hipLaunchKernelGGL(k_bicg_logic<double>, dim3(1), dim3(1), 0, c->stream, c->sc, (const double*)pa_sums(c), 3);
+  else hipLaunchKernelGGL(k_bicg_logic<float>, dim3(1), dim3(1), 0, c->stream, c->sc, (const double*)pa_sums(c), 3);
+  c->cur ^= 1;
+  PA_HIP(c, hipGetLastError());
+  return PA_OK;
+}
+
+int pa_bicg_end(pa_ctx* c, pa_report* out) {
+  PA_BICG_LIVE(c, "pa_bicg_end")
+  int rc = out ? pa_report_read(c, out) : PA_OK;
+  c->solver_live = 0;
+  if (rc) return rc;
+  return (out && out->status) ? PA_E_NONFINITE : PA_OK;
+}
+
+}  // extern "C"

@@ -63,6 +63,11 @@ class HipContext:
         "resident": small-mesh solves in one cooperative launch, changes the grouping of the global sums only)."""
         self._rc(self.lib.pa_ctx_set_option(self.h, name.encode(), int(value)))
 
+    def get_option(self, name: str) -> int:
+        v = C.c_int(0)
+        self._rc(self.lib.pa_ctx_get_option(self.h, name.encode(), C.byref(v)))
+        return int(v.value)
+
     def _rc(self, rc: int) -> None:
         _check(self, self.lib, rc, self.h)
 
@@ -313,6 +318,45 @@ class HipContext:
 
     def cg_finish_iter(self) -> None:
         self._rc(self.lib.pa_cg_finish_iter(self.h))
+
+    # stepwise BiCGSTAB on a slab (pyapes_amd/slab.py SlabBiCGSTAB)
+    def slab_set_v(self, v_send_lo: Tensor | None, v_send_hi: Tensor | None, v_recv_lo: Tensor | None,
+                   v_recv_hi: Tensor | None) -> None:
+        self._keep["slab_v"] = (v_send_lo, v_send_hi, v_recv_lo, v_recv_hi)
+        self._rc(self.lib.pa_slab_set_v(self.h, self._ptr(v_send_lo), self._ptr(v_send_hi), self._ptr(v_recv_lo),
+                                        self._ptr(v_recv_hi)))
+
+    def bicg_begin(self, x: Tensor, rhs: Tensor, tol: float, max_it: int) -> None:
+        self._keep["cg"] = (x, rhs)
+        self._rc(self.lib.pa_bicg_begin(self.h, self._ptr(self._field(x, "bicgstab")),
+                                        self._ptr(self._field(rhs, "bicgstab rhs")), float(tol), int(max_it)))
+
+    def bicg_start(self) -> None:
+        self._rc(self.lib.pa_bicg_start(self.h))
+
+    def bicg_pv(self) -> None:
+        self._rc(self.lib.pa_bicg_pv(self.h))
+
+    def bicg_st(self) -> None:
+        self._rc(self.lib.pa_bicg_st(self.h))
+
+    def bicg_x(self) -> None:
+        self._rc(self.lib.pa_bicg_x(self.h))
+
+    def bicg_bc(self) -> None:
+        self._rc(self.lib.pa_bicg_bc(self.h))
+
+    def bicg_finish(self) -> None:
+        self._rc(self.lib.pa_bicg_finish(self.h))
+
+    def bicg_end(self) -> L.PaReport:
+        rep = L.PaReport()
+        rc = self.lib.pa_bicg_end(self.h, C.byref(rep))
+        self._keep.pop("cg", None)
+        if rc == L.PA_E_NONFINITE:
+            raise RuntimeError(f"Invalid tolerance detected! tol: {rep.tol}")
+        self._rc(rc)
+        return rep
 
     def resident_plan(self, method: str = "cg") -> tuple[int, tuple[int, int, int]]:
         """(workgroups, boxes per internal axis) a solve with `method` on the bound mesh, BCs and equation would

@@ -67,6 +67,7 @@ SIGNATURES: dict[str, tuple[Any, list[Any]]] = {
     "pa_ctx_create": (C.c_int, [C.c_int, _VP, C.POINTER(_VP)]),
     "pa_ctx_destroy": (C.c_int, [_VP]),
     "pa_ctx_set_option": (C.c_int, [_VP, C.c_char_p, C.c_int]),
+    "pa_ctx_get_option": (C.c_int, [_VP, C.c_char_p, C.POINTER(C.c_int)]),
     "pa_ctx_set_stream": (C.c_int, [_VP, _VP]),
     "pa_cg_abort": (C.c_int, [_VP]),
     "pa_resident_plan": (C.c_int, [_VP, C.c_int, C.POINTER(C.c_int)]),
@@ -106,6 +107,15 @@ SIGNATURES: dict[str, tuple[Any, list[Any]]] = {
     "pa_cg_fold_set": (C.c_int, [_VP, _I64P]),
     "pa_cg_end": (C.c_int, [_VP, C.POINTER(PaReport)]),
     "pa_slab_set": (C.c_int, [_VP, C.POINTER(PaSlab)]),
+    "pa_slab_set_v": (C.c_int, [_VP, _VP, _VP, _VP, _VP]),
+    "pa_bicg_begin": (C.c_int, [_VP, _VP, _VP, C.c_double, C.c_int64]),
+    "pa_bicg_start": (C.c_int, [_VP]),
+    "pa_bicg_pv": (C.c_int, [_VP]),
+    "pa_bicg_st": (C.c_int, [_VP]),
+    "pa_bicg_x": (C.c_int, [_VP]),
+    "pa_bicg_bc": (C.c_int, [_VP]),
+    "pa_bicg_finish": (C.c_int, [_VP]),
+    "pa_bicg_end": (C.c_int, [_VP, C.POINTER(PaReport)]),
     "pa_comm_available": (C.c_int, []),
     "pa_comm_unique_id": (C.c_int, [_VP]),
     "pa_comm_count": (C.c_int, [_VP, C.POINTER(C.c_int)]),
@@ -117,6 +127,7 @@ SIGNATURES: dict[str, tuple[Any, list[Any]]] = {
     "pa_comm_abort": (C.c_int, [_VP]),
     "pa_stream_wait": (C.c_int, [_VP, C.c_double]),
     "pa_comm_impl": (C.c_char_p, []),
+    "pa_comm_use_impl": (C.c_int, [C.c_char_p]),
     "pa_comm_overlap": (C.c_int, [_VP]),
     "pa_report_read": (C.c_int, [_VP, C.POINTER(PaReport)]),
     "pa_scalars_read": (C.c_int, [_VP, _F64P]),

@@ -1,4 +1,4 @@
-"""Slab decomposition along axis 0 and the multi-GPU CG driver (new).
+"""Slab decomposition along axis 0 and the multi-GPU CG / BiCGSTAB drivers (new).
 
 The reference is single-device.  Here the 3-D grid is cut into P slabs of whole
 (n1 x n2) planes, one per rank / GPU.  Per CG iteration the ranks exchange
@@ -34,14 +34,15 @@ def slab_extent(n0: int, rank: int, world: int) -> tuple[int, int]:
     return off, base + (1 if rank < rem else 0)
 
 
-class SlabCG:
-    """Stepwise CG over P slabs.  ``begin`` / ``iterate(n)`` / ``end`` mirror pa_cg_begin /
-    pa_cg_iterate / pa_cg_end of the single-GPU path; nothing in ``iterate`` synchronises
-    the host with the device."""
+class _SlabDriver:
+    """What the slab solvers share: the neighbour relation, the packed exchange buffers and the plane exchange /
+    all-reduce primitives over ``torch.distributed``."""
+
+    uses_lib_comm = False     # (SlabCG: RCCL inside the library where the process group allows it)
 
     def __init__(self, mesh: Any, var: Any, rhs: Tensor, terms: Sequence[dict], dist: Any,
                  backend: Any = None, group: Any = None):
-        assert mesh.slab is not None, "SlabCG needs a Mesh(..., slab=(rank, world))"
+        assert mesh.slab is not None, f"{type(self).__name__} needs a Mesh(..., slab=(rank, world))"
         self.mesh, self.var, self.dist, self.group = mesh, var, dist, group
         self.rank, self.world = mesh.slab
         if backend is None:
@@ -51,10 +52,10 @@ class SlabCG:
         types = {bc.bc_face: bc.bc_type for bc in var.bcs}
         self.periodic0 = types.get("xl") == "periodic" or types.get("xu") == "periodic"
         if self.periodic0 and not (types.get("xl") == "periodic" and types.get("xu") == "periodic"):
-            raise ValueError("SlabCG: axis 0 must be periodic on both faces or on none")
+            raise ValueError("slab solvers: axis 0 must be periodic on both faces or on none")
         order = [bc.bc_face for bc in var.bcs]
         if order[:2] != ["xl", "xu"]:
-            raise ValueError("SlabCG: the BC list must start with xl, xu (factory order)")
+            raise ValueError("slab solvers: the BC list must start with xl, xu (factory order)")
         P, r = self.world, self.rank
         self.nb_lo = r - 1 if r > 0 else (P - 1 if self.periodic0 else None)
         self.nb_hi = r + 1 if r < P - 1 else (0 if self.periodic0 else None)
@@ -97,7 +98,7 @@ class SlabCG:
         self._iter_ops = None
         self.terms = list(terms)
         self._stage = None  # pinned CPU staging when the process group cannot move GPU tensors
-        self.lib_comm = self._setup_lib_comm()
+        self.lib_comm = self._setup_lib_comm() if self.uses_lib_comm else False
         self.folded = False
 
     # -- RCCL inside the library ---------------------------------------------------
@@ -106,13 +107,12 @@ class SlabCG:
         all-reduces and the plane exchange on one stream, no Python between the phases).  Used when the
         process group is RCCL and every rank passes the library's collective self-test; otherwise the
         stepwise torch.distributed path below stays (PYAPES_HIP_COMM=0 forces that)."""
-        import os
         be, d = self.be, self.dist
-        if os.environ.get("PYAPES_HIP_COMM", "1") == "0" or not hasattr(be, "comm_init"):
+        if not hasattr(be, "comm_init") or not be.get_option("comm"):     # option "comm" / PYAPES_HIP_COMM=0
             return False
-        # the test stand-in of csrc/pa_comm_hostring.hip (explicit hook PYAPES_HIP_COMM_IMPL=hostring): ranks are
-        # processes that may share one GPU, so the process group is gloo and the small agreement tensors live on the host
-        standin = os.environ.get("PYAPES_HIP_COMM_IMPL") == "hostring"
+        # a stand-in for librccl handed to the library by an explicit pa_comm_use_impl() call (tests: ranks as processes
+        # that may share one GPU, tests/lib): the process group is gloo then and the small agreement tensors live on the host
+        standin = be.comm_impl().startswith("custom")
         if not self.x.is_cuda or (d.get_backend(self.group) != "nccl" and not standin):
             return False
         if getattr(be, "comm_ready", None) == (self.rank, self.world):   # an earlier solve on this mesh made it
@@ -139,7 +139,7 @@ class SlabCG:
         self.lib_comm_error = None
         try:
             be.comm_init(self.rank, self.world, bytes(uid.cpu().numpy().tobytes()))
-            be.comm_selftest(float(os.environ.get("PYAPES_HIP_COMM_TIMEOUT", "30")))
+            be.comm_selftest(float(min(be.get_option("comm_timeout"), 30)))
         except Exception as e:   # this rank is out; the agreement below takes every rank to the stepwise driver
             ok = 0
             self.lib_comm_error = str(e)
@@ -221,6 +221,14 @@ class SlabCG:
     def _allreduce(self, lo: int, hi: int) -> None:
         self.dist.all_reduce(self.sums[lo:hi], op=self.dist.ReduceOp.SUM, group=self.group)
 
+
+class SlabCG(_SlabDriver):
+    """Stepwise CG over P slabs.  ``begin`` / ``iterate(n)`` / ``end`` mirror pa_cg_begin /
+    pa_cg_iterate / pa_cg_end of the single-GPU path; nothing in ``iterate`` synchronises
+    the host with the device."""
+
+    uses_lib_comm = True
+
     # -- solve ------------------------------------------------------------------------
     def begin(self, tol: float, max_it: int, adjust_rhs: bool = True) -> None:
         be = self.be
@@ -241,9 +249,8 @@ class SlabCG:
     def _agree_fold(self) -> bool:
         """Folded iterations of the library-side loop (include/pyapes_hip.h): every rank plans its partial-row
         counts, the ranks take the MAX -- or stay stepwise, all of them, if a single rank cannot fold."""
-        import os
         be, d = self.be, self.dist
-        if not self.lib_comm or not hasattr(be, "cg_fold_plan") or os.environ.get("PYAPES_HIP_SLAB_FOLD", "1") == "0":
+        if not self.lib_comm or not hasattr(be, "cg_fold_plan") or not be.get_option("slab_fold"):   # PYAPES_HIP_SLAB_FOLD=0
             return False
         rows = be.cg_fold_plan()
         t = torch.tensor([*rows, -min(rows[0], rows[1])], dtype=torch.int64, device=getattr(self, "_agree_dev", self.x.device))
@@ -268,10 +275,10 @@ class SlabCG:
             self._allreduce(1, 3)
             be.cg_finish_iter()                          # beta, stop test, itr (device side)
 
-    def solve(self, tol: float, max_it: int, poll: int = 8) -> Any:
+    def solve(self, tol: float, max_it: int, poll: int = 8, adjust_rhs: bool = True) -> Any:
         """Run to the reference's stop rule (tol / max_it + 1 iterations); polls the device-side
         done flag every ``poll`` iterations -- iterations enqueued after it is set are no-ops."""
-        self.begin(tol, max_it)
+        self.begin(tol, max_it, adjust_rhs=adjust_rhs)
         done = 0
         while done <= max_it:
             n = min(poll, max_it + 1 - done)
@@ -292,3 +299,89 @@ class SlabCG:
         rep = self.be.cg_end()
         self.be.slab_set(None)
         return rep
+
+
+class SlabBiCGSTAB(_SlabDriver):
+    """Stepwise BiCGSTAB over P slabs (linalg.py:162-279; include/pyapes_hip.h "stepwise BiCGSTAB on a slab").  Per
+    iteration: the boundary planes of v' = A p' and of the new residual (with the periodic x planes behind them) go to
+    the axis-0 neighbours, three small all-reduces carry r0.v', then (|s|^2, t.s, t.t, r0.t), then |r|^2; the direction
+    p is never sent -- its ghost planes follow the owner's recurrence on every rank.  Communication through
+    ``torch.distributed`` (RCCL on the GPUs of a node, gloo in the rehearsals)."""
+
+    def __init__(self, mesh: Any, var: Any, rhs: Tensor, terms: Sequence[dict], dist: Any,
+                 backend: Any = None, group: Any = None):
+        super().__init__(mesh, var, rhs, terms, dist, backend, group)
+        dev, f, plane = self.x.device, self.x.dtype, tuple(self.x.shape[1:])
+
+        def buf(cond):
+            return torch.zeros(plane, dtype=f, device=dev) if cond else None
+
+        self.v_send_lo, self.v_send_hi = buf(self.nb_lo is not None), buf(self.nb_hi is not None)
+        self.v_recv_lo, self.v_recv_hi = buf(self.nb_lo is not None), buf(self.nb_hi is not None)
+
+    def begin(self, tol: float, max_it: int, adjust_rhs: bool = True) -> None:
+        be = self.be
+        be.slab_set(self.bufs)
+        be.slab_set_v(self.v_send_lo, self.v_send_hi, self.v_recv_lo, self.v_recv_hi)
+        be.bind_bcs(self.var(), self.var.bcs, 0)
+        be.set_terms(self.terms)
+        if adjust_rhs:
+            be.rhs_adjust(self.rhs)
+        for t in (self.v_recv_lo, self.v_recv_hi):      # v = 0 at the start (linalg.py:191), on the ghost planes too
+            if t is not None:
+                t.zero_()
+        self._exchange_bc_far()
+        be.apply_bc_bound(self.x)                      # linalg.py:181, before the ghosts of x move
+        self._exchange_planes(self.x[0], self.x[-1], self.bufs["x_ghost_lo"], self.bufs["x_ghost_hi"])
+        be.bicg_begin(self.x, self.rhs, tol, max_it)    # r0 = r, local r0.r0 -> sums[1], r planes
+        self._exchange_planes(self.bufs["r_send_lo"], self.bufs["r_send_hi"],
+                              self.bufs["r_recv_lo"], self.bufs["r_recv_hi"])
+        self._allreduce(1, 2)
+        be.bicg_start()                                 # rho' = r0.r0, the first beta (device side)
+
+    def iterate(self, n: int) -> None:
+        be = self.be
+        for _ in range(n):
+            be.bicg_pv()                                 # p', v' = A p' ; local r0.v' ; v' planes out
+            self._allreduce(0, 1)
+            self._exchange_planes(self.v_send_lo, self.v_send_hi, self.v_recv_lo, self.v_recv_hi)
+            be.bicg_st()                                 # alpha ; s, t = A s ; local |s|^2, t.s, t.t, r0.t
+            self._allreduce(1, 5)
+            be.bicg_x()                                  # stop test 1, omega, rho' ; x, r update ; planes out
+            self._exchange_iter()
+            be.bicg_bc()                                 # BC fill of x ; local |r|^2
+            self._allreduce(5, 6)
+            be.bicg_finish()                             # stop test 2, beta, rho (device side)
+
+    def solve(self, tol: float, max_it: int, poll: int = 8, adjust_rhs: bool = True) -> Any:
+        """Run to the reference's stop rule (either stop test, or max_it iterations: linalg.py:262-271)."""
+        self.begin(tol, max_it, adjust_rhs=adjust_rhs)
+        done, limit = 0, max(int(max_it), 1)
+        while done < limit:
+            n = min(poll, limit - done)
+            self.iterate(n)
+            done += n
+            if self.be.report().itr < done:
+                break
+        return self.end()
+
+    def end(self) -> Any:
+        rep = self.be.bicg_end()
+        self.be.slab_set(None)
+        return rep
+
+
+def slab_solver(method: str, mesh: Any, var: Any, rhs: Tensor, terms: Sequence[dict], dist: Any = None,
+                backend: Any = None, group: Any = None) -> Any:
+    """The slab driver ``linalg.solve`` hands a solve on ``Mesh(..., slab=(rank, world))`` to."""
+    if dist is None:
+        import torch.distributed as dist_mod
+        dist = dist_mod
+        if not dist.is_initialized():
+            raise RuntimeError("pyapes_amd: a solve on a slab mesh needs torch.distributed to be initialised "
+                               "(one process per GPU, backend 'nccl' = RCCL)")
+    if method == "cg":
+        return SlabCG(mesh, var, rhs, terms, dist, backend, group)
+    if method == "bicgstab":
+        return SlabBiCGSTAB(mesh, var, rhs, terms, dist, backend, group)
+    raise NotImplementedError(f"pyapes_amd: method '{method}' is single-GPU only; slab meshes take cg and bicgstab")

@@ -156,8 +156,9 @@ class Discretizer:
 
 def _rhs_adjust(var: Field, term: dict, bcs: list) -> Tensor:
     """rhs_adj tensor of one operator: the kernel adds into zeros."""
-    require_gpu(var(), "adjust_rhs")
     ctx = context_for(var.mesh)
+    if not getattr(ctx, "is_standin", False):   # (tests hang a torch stand-in for the C calls on a CPU slab mesh)
+        require_gpu(var(), "adjust_rhs")
     out = torch.zeros_like(var())
     for d in range(var.dim):
         ctx.bind_bcs(var(), bcs, d, for_rhs=True)

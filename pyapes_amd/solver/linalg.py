@@ -82,8 +82,49 @@ def jacobi(var, rhs, Aop, eqs, config, mesh) -> ReportType:
     return _run("jacobi", var, rhs, eqs, config, mesh)
 
 
+def _run_slab(method: str, var: Field, rhs: Tensor, eqs: dict[int, OPStype], config: FDMSolverConfig,
+              mesh: Any) -> ReportType:
+    """``Solver.solve()`` on ``Mesh(..., slab=(rank, world))``: the same call on every rank of the process group, the grid
+    cut into slabs along axis 0 (pyapes_amd/slab.py: plane exchange with the two neighbours, scalar all-reduces).
+    ``set_eq`` has adjusted the rhs already -- rank-locally, each rank for the Neumann layers it owns."""
+    from ..slab import slab_solver
+    if mesh.obstacle is not None and len(var.bcs) > 0:
+        raise NotImplementedError  # linalg.py:287-292
+    if var.dim != 1:
+        raise NotImplementedError("pyapes_amd: solver equations are scalar (SURVEY Q7)")
+    backend = context_for(mesh)
+    if not getattr(backend, "is_standin", False):
+        require_gpu(var(), f"linalg.{method}")
+    if not var().is_contiguous():
+        var.set_var_tensor(var().contiguous())
+    tol, max_it = config["tol"], config["max_it"]
+    boundary_slicer(mesh.dim, var.bcs)
+    if any(bc.depends_on_var(var()) for bc in var.bcs):
+        raise NotImplementedError("pyapes_amd: BC callables that read the iterate are single-GPU only (solver/host_stepped.py)")
+    if config.get("save_old", False):
+        raise NotImplementedError('pyapes_amd: {"save_old": True} is single-GPU only')
+    terms, _ = terms_of(eqs)
+    drv = slab_solver(method, mesh, var, rhs, terms, backend=backend)
+    rep = drv.solve(tol, max_it, adjust_rhs=False)
+    var.mark_old_stale("solved on a slab mesh")
+    itr, rtol = int(rep.itr), float(rep.tol)
+    if getattr(rep, "status", 0) != 0:
+        raise RuntimeError(f"Invalid tolerance detected! tol: {rtol}")   # linalg.py:334-336
+    hit_max = (itr > max_it) if method != "bicgstab" else (itr >= max_it and rtol > tol)
+    if hit_max:
+        warnings.warn(f"Maximum iteration reached! max_it: {max_it}", RuntimeWarning)
+    elif config.get("report", False) and method != "bicgstab" and getattr(mesh, "slab", (0, 1))[0] == 0:
+        _solution_report(itr, rtol, method.upper())
+    if config.get("report", False) and method == "bicgstab" and getattr(mesh, "slab", (0, 1))[0] == 0:
+        _solution_report(itr, rtol, "BICGSTAB")
+    var.last_gpu_ms = None
+    return {"itr": itr, "tol": rtol, "converge": bool(itr < max_it)}
+
+
 def _run(method: str, var: Field, rhs: Tensor, eqs: dict[int, OPStype], config: FDMSolverConfig,
          mesh: Any) -> ReportType:
+    if getattr(mesh, "slab", None) is not None:
+        return _run_slab(method, var, rhs, eqs, config, mesh)
     require_gpu(var(), f"linalg.{method}")
     if mesh.obstacle is not None and len(var.bcs) > 0:
         raise NotImplementedError  # linalg.py:287-292

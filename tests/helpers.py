@@ -3,6 +3,7 @@
 from __future__ import annotations
 
 import contextlib
+import os
 
 import numpy as np
 import torch
@@ -16,6 +17,32 @@ from pyapes_amd.testing.poisson import poisson_bcs
 from pyapes_amd.variables import Field
 
 FACES = O.FACES
+
+HOSTRING_LIB = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libpa_hostring.so")
+
+
+def hip_options(monkeypatch, **kw):
+    """Options of every pa_ctx created from now on, in this process and in the processes it starts:
+    PYAPES_HIP_OPTIONS="name=value,..." (pa_ctx_set_option names; None takes a name out again)."""
+    cur = dict(item.split("=") for item in os.environ.get("PYAPES_HIP_OPTIONS", "").split(",") if item)
+    for k, v in kw.items():
+        if v is None:
+            cur.pop(k, None)
+        else:
+            cur[k] = str(int(v))
+    if cur:
+        monkeypatch.setenv("PYAPES_HIP_OPTIONS", ",".join(f"{k}={v}" for k, v in cur.items()))
+    else:
+        monkeypatch.delenv("PYAPES_HIP_OPTIONS", raising=False)
+
+
+def use_hostring():
+    """Hand the test stand-in for librccl (tests/lib/pa_hostring.hip: ranks as processes that may share one GPU, host
+    shared memory as the wire) to libpyapes_hip -- an explicit call in every rank process, before its first communicator."""
+    from pyapes_amd.hip.lib import load_library
+    assert os.path.exists(HOSTRING_LIB), f"{HOSTRING_LIB} missing: pyapes_amd/csrc/build.sh builds it"
+    rc = load_library().pa_comm_use_impl(HOSTRING_LIB.encode())
+    assert rc == 0, f"pa_comm_use_impl({HOSTRING_LIB}) -> {rc}"
 
 
 def case_faces(case):

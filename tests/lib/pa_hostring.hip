@@ -1,10 +1,12 @@
-// pa_comm_hostring.hip -- TEST-ONLY stand-in for the RCCL entry points of pa_comm_table.h.
+// pa_hostring.hip -- TEST-ONLY stand-in for the RCCL entry points libpyapes_hip uses (csrc/pa_comm_table.h), built into
+// tests/lib/libpa_hostring.so.  It is NOT part of the product library: a test hands its path to pa_comm_use_impl(), which
+// resolves the twelve nccl* symbols from it exactly as it resolves them from librccl.
 //
 // Why it exists: RCCL refuses two ranks on one device, and the builder's box has one GPU, so the N > 1 form of
 // the library-side slab loop (pa_cg_iterate_comm: grouped send / recv between distinct peers, the same-peer P = 2
 // ring, out-of-place row all-reduces with uneven slabs, the cross-stream event pair of the second communicator)
-// could not execute anywhere before the driver's multi-GPU run.  With PYAPES_HIP_COMM_IMPL=hostring (an explicit
-// hook, never chosen implicitly; pa_comm.hip) the SAME C code of pa_comm.hip runs with 2 / 4 rank PROCESSES that
+// could not execute anywhere before the driver's multi-GPU run.  With this library selected (pa_comm_use_impl: an explicit
+// call, never implicit) the SAME C code of pa_comm.hip runs with 2 / 4 rank PROCESSES that
 // share the one GPU: real kernels, real k_slab_mid, real streams and events; only the wire is replaced.
 //
 // Semantics kept from RCCL: every call ENQUEUES on the caller's stream and returns; data is read / written in
@@ -37,7 +39,7 @@
 #include <thread>
 #include <vector>
 
-#include "pa_comm_table.h"
+#include <rccl/rccl.h>
 
 namespace {
 
@@ -469,19 +471,21 @@ const char* hr_GetErrorString(ncclResult_t e) {
 
 }  // namespace
 
-void pa_hostring_table(Rccl* R) {
-  R->impl = "hostring (test stand-in: host shared memory, ranks may share a GPU)";
-  R->GetUniqueId = hr_GetUniqueId;
-  R->CommInitRank = hr_CommInitRank;
-  R->CommDestroy = hr_CommDestroy;
-  R->CommAbort = hr_CommAbort;
-  R->CommCount = hr_CommCount;
-  R->AllReduce = hr_AllReduce;
-  R->Broadcast = hr_Broadcast;
-  R->Send = hr_Send;
-  R->Recv = hr_Recv;
-  R->GroupStart = hr_GroupStart;
-  R->GroupEnd = hr_GroupEnd;
-  R->GetErrorString = hr_GetErrorString;
-  R->h = reinterpret_cast<void*>(R);
+// the entry points under RCCL's own names (C linkage, as rccl.h declares them): pa_comm_use_impl() dlopens this library
+// RTLD_LOCAL and takes them with dlsym from ITS handle, so a librccl that is also mapped into the process is not touched
+extern "C" {
+__attribute__((visibility("default"))) ncclResult_t ncclGetUniqueId(ncclUniqueId* id) { return hr_GetUniqueId(id); }
+__attribute__((visibility("default"))) ncclResult_t ncclCommInitRank(ncclComm_t* comm, int n, ncclUniqueId id, int rank) { return hr_CommInitRank(comm, n, id, rank); }
+__attribute__((visibility("default"))) ncclResult_t ncclCommDestroy(ncclComm_t comm) { return hr_CommDestroy(comm); }
+__attribute__((visibility("default"))) ncclResult_t ncclCommAbort(ncclComm_t comm) { return hr_CommAbort(comm); }
+__attribute__((visibility("default"))) ncclResult_t ncclCommCount(const ncclComm_t comm, int* n) { return hr_CommCount(comm, n); }
+__attribute__((visibility("default"))) ncclResult_t ncclAllReduce(const void* s, void* r, size_t n, ncclDataType_t t, ncclRedOp_t op, ncclComm_t comm, hipStream_t st) { return hr_AllReduce(s, r, n, t, op, comm, st); }
+__attribute__((visibility("default"))) ncclResult_t ncclBroadcast(const void* s, void* r, size_t n, ncclDataType_t t, int root, ncclComm_t comm, hipStream_t st) { return hr_Broadcast(s, r, n, t, root, comm, st); }
+__attribute__((visibility("default"))) ncclResult_t ncclSend(const void* s, size_t n, ncclDataType_t t, int peer, ncclComm_t comm, hipStream_t st) { return hr_Send(s, n, t, peer, comm, st); }
+__attribute__((visibility("default"))) ncclResult_t ncclRecv(void* r, size_t n, ncclDataType_t t, int peer, ncclComm_t comm, hipStream_t st) { return hr_Recv(r, n, t, peer, comm, st); }
+__attribute__((visibility("default"))) ncclResult_t ncclGroupStart() { return hr_GroupStart(); }
+__attribute__((visibility("default"))) ncclResult_t ncclGroupEnd() { return hr_GroupEnd(); }
+__attribute__((visibility("default"))) const char* ncclGetErrorString(ncclResult_t e) { return hr_GetErrorString(e); }
+// what pa_comm_impl() reports for a library that exports it
+__attribute__((visibility("default"))) const char* pa_comm_impl_name() { return "hostring (test stand-in: host shared memory, ranks may share a GPU)"; }
 }

@@ -1,5 +1,5 @@
 """TEST INFRASTRUCTURE: a torch-CPU stand-in for the stepwise C-ABI calls that
-``pyapes_amd.slab.SlabCG`` drives, so that the driver's communication pattern (ghost planes,
+``pyapes_amd.slab.SlabCG`` / ``SlabBiCGSTAB`` drive, so that the driver's communication pattern (ghost planes,
 ring wrap, periodic far planes, all-reduce slices, call order) can be exercised with gloo and
 world_size 2 on a machine without a GPU.  It follows SURVEY Appendix A on the LOCAL slab with
 ghost planes; results are checked against the single-domain oracle.  Never imported by the
@@ -13,6 +13,8 @@ import torch
 
 
 class TorchSlabBackend:
+    is_standin = True      # (pyapes_amd skips its "needs the GPU" guard for a backend object that says so)
+
     def __init__(self, mesh):
         self.mesh = mesh
         self.off = mesh.i_off
@@ -226,4 +228,111 @@ class TorchSlabBackend:
         return SimpleNamespace(itr=self.itr, tol=self.tol, converge=self.itr < self.max_it, status=0)
 
     def cg_end(self):
+        return self.report()
+
+    # -- stepwise BiCGSTAB (linalg.py:162-279 split at its reductions and exchanges; include/pyapes_hip.h) -------
+    def slab_set_v(self, v_send_lo, v_send_hi, v_recv_lo, v_recv_hi):
+        self.vb = {"send_lo": v_send_lo, "send_hi": v_send_hi, "recv_lo": v_recv_lo, "recv_hi": v_recv_hi}
+
+    def _t(self, v):
+        return torch.tensor(float(v), dtype=self.f)
+
+    def bicg_begin(self, x, rhs, tol, max_it):
+        b = self.bufs
+        self.x, self.tolerance, self.max_it = x, tol, max_it
+        self.S = self._S()
+        ax = self._A(x, b["x_ghost_lo"], b["x_ghost_hi"])
+        z = torch.zeros_like(x)
+        self.r0 = torch.where(self.S, rhs - ax, z)
+        self.r = self.r0.clone()
+        self.p, self.v, self.s, self.t = z.clone(), z.clone(), z.clone(), z.clone()
+        self.pg = [torch.zeros_like(x[0]), torch.zeros_like(x[0])]
+        self.itr, self.done, self.fe, self.tol = 0, False, False, 1.0
+        self._send_r()
+        b["sums"][1] = float(torch.sum(self.r0 * self.r0))
+
+    def bicg_start(self):
+        one = self._t(1.0)
+        self.rho_next = self._t(self.bufs["sums"][1])
+        self.tol = float(torch.sqrt(self.rho_next))
+        self.rho, self.alpha, self.omega = one, one, one
+        self.beta = self.rho_next / self.rho * self.alpha / self.omega
+        self.rho = self.rho_next
+
+    def bicg_pv(self):
+        if self.done:
+            return
+        b, vb = self.bufs, self.vb
+        rl, rh = b["r_recv_lo"], b["r_recv_hi"]
+        glo = None if rl is None else rl + self.beta * (self.pg[0] - self.omega * vb["recv_lo"])
+        ghi = None if rh is None else rh + self.beta * (self.pg[1] - self.omega * vb["recv_hi"])
+        self.p = self.r + self.beta * (self.p - self.omega * self.v)
+        if glo is not None:
+            self.pg[0] = glo
+        if ghi is not None:
+            self.pg[1] = ghi
+        self.v = torch.where(self.S, self._A(self.p, glo, ghi), torch.zeros_like(self.p))
+        b["sums"][0] = float(torch.sum(self.r0 * self.v))
+        if vb["send_lo"] is not None:
+            vb["send_lo"].copy_(self.v[0])
+        if vb["send_hi"] is not None:
+            vb["send_hi"].copy_(self.v[-1])
+
+    def bicg_st(self):
+        if self.done:
+            return
+        b, vb = self.bufs, self.vb
+        self.itr += 1
+        self.alpha = torch.nan_to_num(self.rho / self._t(b["sums"][0]), nan=0.0, posinf=0.0, neginf=0.0)
+        self.s = self.r - self.alpha * self.v
+        rl, rh = b["r_recv_lo"], b["r_recv_hi"]
+        sglo = None if rl is None else rl - self.alpha * vb["recv_lo"]
+        sghi = None if rh is None else rh - self.alpha * vb["recv_hi"]
+        b["sums"][1] = float(torch.sum(self.s * self.s))
+        self.t = torch.where(self.S, self._A(self.s, sglo, sghi), torch.zeros_like(self.s))
+        b["sums"][2] = float(torch.sum(self.t * self.s))
+        b["sums"][3] = float(torch.sum(self.t * self.t))
+        b["sums"][4] = float(torch.sum(self.r0 * self.t))
+
+    def bicg_x(self):
+        if self.done:
+            return
+        b = self.bufs
+        self.tol = float(torch.sqrt(self._t(b["sums"][1])))
+        if math.isnan(self.tol) or math.isinf(self.tol):
+            raise RuntimeError("Invalid tolerance detected!")
+        self.fe = self.tol <= self.tolerance
+        if self.fe:
+            self.x.copy_(self.x + self.alpha * self.p)
+        else:
+            self.omega = torch.nan_to_num(self._t(b["sums"][2]) / self._t(b["sums"][3]), nan=0.0, posinf=0.0, neginf=0.0)
+            self.rho_next = -self.omega * self._t(b["sums"][4])
+            self.x.copy_(self.x + self.alpha * self.p + self.s * self.omega)
+            self.r = self.s - self.omega * self.t
+        self._send_r()
+        for key, plane in (("x_pack_lo1", 1), ("x_pack_hi0", -1), ("x_pack_hi1", -2)):
+            if b.get(key) is not None:
+                b[key].copy_(self.x[plane])
+
+    def bicg_bc(self):
+        if self.done:
+            return
+        self.apply_bc_bound(self.x)
+        self.bufs["sums"][5] = float(torch.sum(self.r * self.r))
+
+    def bicg_finish(self):
+        if self.done:
+            return
+        if self.fe:
+            self.done = True
+            return
+        self.tol = float(torch.sqrt(self._t(self.bufs["sums"][5])))
+        if math.isnan(self.tol) or math.isinf(self.tol):
+            raise RuntimeError("Invalid tolerance detected!")
+        if self.tol <= self.tolerance or self.itr >= self.max_it:
+            self.done = True
+        self.beta = self.rho_next / self.rho * self.alpha / self.omega
+        self.rho = self.rho_next
+
+    def bicg_end(self):
         return self.report()

@@ -117,17 +117,19 @@ def test_launcher_budget_and_first_attempt_record(monkeypatch, capsys):
     assert bench.launch_ranks(8, ["--gpus", "8"]) == 1 and len(calls) == 1
 
 
-HOSTRING = {"BENCH_SINGLE_DEVICE": "1", "BENCH_BACKEND": "gloo", "PYAPES_HIP_COMM_IMPL": "hostring"}
+HOSTRING = {"BENCH_SINGLE_DEVICE": "1", "BENCH_BACKEND": "gloo",
+            "BENCH_COMM_LIB": os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libpa_hostring.so")}
 
 
 @pytest.mark.gpu
 def test_two_ranks_library_side_loop_through_the_entry_path():
     """python bench.py --gpus 2 with the library-side loop REALLY running between two ranks (they share cuda:0, so
-    the wire is the test stand-in of csrc/pa_comm_hostring.hip; everything else is what runs over RCCL)"""
+    the wire is the test stand-in of tests/lib/pa_hostring.hip, handed over by bench.py's rehearsal switch BENCH_COMM_LIB; everything else is what runs over RCCL)"""
     p = _run(["--gpus", "2", "--size", "48,40,136", "--steps", "4", "--warmup", "2", "--no-cpu-baseline"], HOSTRING)
     assert p.returncode == 0, p.stderr[-3000:]
     rec = json.loads([ln for ln in p.stdout.splitlines() if ln.strip()][0])
-    assert rec["n_gpus"] == 2 and rec["config"]["parallelism"] == "slab2 (rccl-in-library)"
+    # (the record names the implementation behind the library-side loop: here the stand-in, never "rccl")
+    assert rec["n_gpus"] == 2 and rec["config"]["parallelism"].startswith("slab2 (library loop over [custom: hostring")
     assert "first_attempt" not in rec
 
 

@@ -26,11 +26,8 @@ AXIS_CHOICES = [
 
 
 def _fill(bcs, slab, dtype, fused, monkeypatch):
-    if fused:
-        monkeypatch.delenv("PYAPES_HIP_BC_UNFUSED", raising=False)
-        monkeypatch.setenv("PYAPES_HIP_BC_FUSED", "1")
-    else:
-        monkeypatch.setenv("PYAPES_HIP_BC_UNFUSED", "1")
+    from helpers import hip_options
+    hip_options(monkeypatch, bc_path=4 if fused else 1)     # closed form at any size / never the closed form
     cfg = [{"bc_face": FACES[i], "bc_type": t, "bc_val": v, "bc_val_opt": None} for i, (t, v) in enumerate(bcs)]
     mesh = Mesh(Box[0:1, 0:1, 0:0.5], None, [12, 9, 11], "cuda", dtype, slab=slab)
     var = Field("p", 1, mesh, {"domain": cfg, "obstacle": None})

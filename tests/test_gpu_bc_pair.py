@@ -1,6 +1,6 @@
 """-m gpu: the per-axis BC pair kernels of the CG loop (k_bc_pair: lower + upper face of one axis and
 their share of the stop-test sum in one launch) against the face-by-face fill + k_shell path
-(PYAPES_HIP_BC_UNPAIRED=1, the literal reference order): the iterates must agree bit for bit for
+(option bc_path bit 1, the literal reference order): the iterates must agree bit for bit for
 every combination of face types, the stop-test value to summation order."""
 import itertools
 import warnings
@@ -27,11 +27,8 @@ AXIS_CHOICES = [
 
 
 def _solve(bcs, n, dtype, K, paired, monkeypatch, ndim=3):
-    if paired:
-        monkeypatch.delenv("PYAPES_HIP_BC_UNPAIRED", raising=False)
-    else:
-        monkeypatch.setenv("PYAPES_HIP_BC_UNPAIRED", "1")
-    monkeypatch.setenv("PYAPES_HIP_BC_UNFUSED", "1")   # the pair path is what runs where the fused one does not
+    from helpers import hip_options
+    hip_options(monkeypatch, bc_path=1 if paired else 3)   # never the closed form: the pair path is what runs where it does not
     cfg = [{"bc_face": FACES[i], "bc_type": t, "bc_val": v, "bc_val_opt": None} for i, (t, v) in enumerate(bcs)]
     box = Box[0:1, 0:1, 0:0.5] if ndim == 3 else Box[0:1, 0:0.7]
     mesh = Mesh(box, None, list(n), "cuda", dtype)
@@ -86,12 +83,9 @@ def test_stop_iteration_count_unchanged(monkeypatch):
     bcs = [("dirichlet", 0.0), ("dirichlet", 0.5), ("neumann", 0.0), ("dirichlet", 0.0), ("symmetry", None),
            ("dirichlet", 1.0)]
     out = []
-    monkeypatch.setenv("PYAPES_HIP_BC_UNFUSED", "1")
+    from helpers import hip_options
     for paired in (True, False):
-        if paired:
-            monkeypatch.delenv("PYAPES_HIP_BC_UNPAIRED", raising=False)
-        else:
-            monkeypatch.setenv("PYAPES_HIP_BC_UNPAIRED", "1")
+        hip_options(monkeypatch, bc_path=1 if paired else 3)
         cfg = [{"bc_face": FACES[i], "bc_type": t, "bc_val": v, "bc_val_opt": None} for i, (t, v) in enumerate(bcs)]
         mesh = Mesh(Box[0:1, 0:1, 0:1], None, [21, 23, 25], "cuda", "double")
         var = Field("p", 1, mesh, {"domain": cfg, "obstacle": None})

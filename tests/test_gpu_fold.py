@@ -94,7 +94,7 @@ def test_folded_sequence_is_bit_identical(monkeypatch, method):
 
 def test_rhs_adjust_on_the_neumann_layers_only(monkeypatch):
     """The rhs adjustment touches the nodes one step inside a Neumann face; the kernel visits those layers
-    (a node on two layers once) instead of the whole mesh (PYAPES_HIP_RHS_FULL=1): same bits."""
+    (a node on two layers once) instead of the whole mesh (option rhs_full): same bits."""
     from pyapes_amd.hip import lib as L
     from pyapes_amd.hip.context import context_for
     rng = random.Random(99)
@@ -123,11 +123,11 @@ def test_rhs_adjust_on_the_neumann_layers_only(monkeypatch):
         g = torch.Generator().manual_seed(case)
         rhs = torch.randn((1, *n), generator=g, dtype=torch.float64).to(tdt).cuda()
         a, b = rhs.clone(), rhs.clone()
-        monkeypatch.delenv("PYAPES_HIP_RHS_FULL", raising=False)
+        ctx.set_option("rhs_full", 0)
         ctx.rhs_adjust(a[0])
-        monkeypatch.setenv("PYAPES_HIP_RHS_FULL", "1")
+        ctx.set_option("rhs_full", 1)
         ctx.rhs_adjust(b[0])
-        monkeypatch.delenv("PYAPES_HIP_RHS_FULL", raising=False)
+        ctx.set_option("rhs_full", 0)
         assert torch.equal(a, b), (case, n, bcs, dtype)
         assert not torch.equal(a, rhs) or all(v == 0 for t, v in bcs if t == "neumann")
         seen += 1

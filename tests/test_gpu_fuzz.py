@@ -167,7 +167,8 @@ def test_seeded_fuzz_bicgstab(monkeypatch):
 
         def run(fast, pfold):
             monkeypatch.setenv("PYAPES_HIP_FASTPATH", "1" if fast else "0")
-            monkeypatch.setenv("PYAPES_HIP_BICG_PFOLD", "1" if pfold else "0")
+            from helpers import hip_options
+            hip_options(monkeypatch, bicg_pfold=pfold)
             nd = len(n)
             mesh = Mesh(Box([0.0] * nd, [1.0 + 0.1 * a for a in range(nd)]), None, list(n), "cuda", dtype)
             cfg = [{"bc_face": O.FACES[i], "bc_type": t, "bc_val": v, "bc_val_opt": None} for i, (t, v) in enumerate(bcs)]

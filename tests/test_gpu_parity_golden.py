@@ -21,7 +21,8 @@ from pyapes_amd.solver.ops import Solver
 def test_bc_fill_face_by_face_path(case, monkeypatch):
     """The unfused BC fill (one launch per face in list order) must give the same bits as the fused
     closed form that the factory order normally takes."""
-    monkeypatch.setenv("PYAPES_HIP_BC_UNFUSED", "1")
+    from helpers import hip_options
+    hip_options(monkeypatch, bc_path=1)
     g = golden_load(case["name"])
     mesh = product_mesh(case)
     var = product_field(case, mesh, g["x0"])

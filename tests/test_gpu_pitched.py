@@ -106,7 +106,8 @@ BICG_CASES = [
 
 def _solve_bicg(n, dtype, faces, K, pitch, rhs0, tol=1e-30, pfold=True, monkeypatch=None):
     if monkeypatch is not None:
-        monkeypatch.setenv("PYAPES_HIP_BICG_PFOLD", "1" if pfold else "0")
+        from helpers import hip_options
+        hip_options(monkeypatch, bicg_pfold=pfold)
     nd = len(n)
     mesh = Mesh(Box([0.0] * nd, [1.0] * nd), None, n, "cuda", dtype)
     ctx = context_for(mesh)

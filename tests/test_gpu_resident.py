@@ -29,8 +29,9 @@ FACES = ["xl", "xu", "yl", "yu", "zl", "zu"]
 def _solve(monkeypatch, resident, n, bcs, dtype, method, rhs, x0, tol, max_it, order=None, save_old=False, coeff=0.8,
            env=None, adv=False):
     monkeypatch.setenv("PYAPES_HIP_RESIDENT", "1" if resident else "0")
-    for k, v in (env or {}).items():
-        monkeypatch.setenv(k, v)
+    from helpers import hip_options
+    hip_options(monkeypatch, **{k: (None if (env or {}).get(k) is None else int(env[k])) for k in
+                                ("res_cells", "res_nt", "res_nt_cells", "res_spin")})
     nd = len(n)
     mesh = Mesh(Box([0.0] * nd, [1.0 + 0.1 * a for a in range(nd)]), None, list(n), "cuda", dtype)
     cfg = [{"bc_face": FACES[i], "bc_type": t, "bc_val": v, "bc_val_opt": None} for i, (t, v) in enumerate(bcs)]
@@ -149,11 +150,8 @@ def test_resident_plan_and_layouts(monkeypatch):
     rhs, x0 = _fields(n, "double", 8)
     xa, ra, _, _, _ = _solve(monkeypatch, False, n, bc3, "double", "cg", rhs, x0, -1.0, 9)
     seen = set()
-    for env in ({"PYAPES_HIP_RES_CELLS": "128"}, {"PYAPES_HIP_RES_CELLS": "4096"}, {"PYAPES_HIP_RES_NT": "256"},
-                {"PYAPES_HIP_RES_NT": "1024", "PYAPES_HIP_RES_NT_CELLS": "1"}):
+    for env in ({"res_cells": 128}, {"res_cells": 4096}, {"res_nt": 256}, {"res_nt": 1024, "res_nt_cells": 1}):
         xb, rb, ub, plan, _ = _solve(monkeypatch, True, n, bc3, "double", "cg", rhs, x0, -1.0, 9, env=env)
-        for k in env:
-            monkeypatch.delenv(k)
         assert ub > 0
         seen.add(ub)
         assert float((xa - xb).abs().max()) <= 1e-11 * float(xa.abs().max()), (env, plan)
@@ -245,8 +243,7 @@ def test_resident_wait_timeout_falls_back(monkeypatch, method):
     bcs = [("dirichlet", 0.0), ("neumann", 0.3), ("symmetry", None), ("dirichlet", 1.0), ("neumann", -0.2), ("dirichlet", 0.5)]
     rhs, x0 = _fields(n, "double", 31)
     xa, ra, ua, _, _ = _solve(monkeypatch, False, n, bcs, "double", method, rhs, x0, -1.0, 6)
-    xb, rb, ub, plan, _ = _solve(monkeypatch, True, n, bcs, "double", method, rhs, x0, -1.0, 6, env={"PYAPES_HIP_RES_SPIN": "0"})
-    monkeypatch.delenv("PYAPES_HIP_RES_SPIN")
+    xb, rb, ub, plan, _ = _solve(monkeypatch, True, n, bcs, "double", method, rhs, x0, -1.0, 6, env={"res_spin": 0})
     assert plan[0] > 1 and ub == 0
     assert ra["itr"] == rb["itr"] and ra["tol"] == rb["tol"]
     assert torch.equal(xa, xb)

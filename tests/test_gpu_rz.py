@@ -112,7 +112,7 @@ def test_rz_mesh_rules():
 @pytest.mark.parametrize("dtype", ["double", "single"])
 def test_rz_resident_lean_path_matches_the_generic_term_evaluation(method, dtype, monkeypatch):
     """Round 3: the resident solver's LEAN stencil on axisymmetric meshes (the r rows of pa_coord_set's table staged in
-    LDS) against pa_apply_terms on the box (PYAPES_HIP_RES_RZLEAN=0) and the launch-per-phase kernels: the same
+    LDS) against pa_apply_terms on the box (option res_rzlean 0) and the launch-per-phase kernels: the same
     arithmetic per node, so Jacobi is bit-identical and CG / BiCGSTAB agree to rounding with identical counts."""
     from pyapes_amd.hip.context import context_for
     n = (37, 45)
@@ -124,11 +124,12 @@ def test_rz_resident_lean_path_matches_the_generic_term_evaluation(method, dtype
     # magnitude every few iterations: a short run for it
     K = 6 if method == "bicgstab" else 24
     out = {}
-    for name, env in (("lean", {"PYAPES_HIP_RESIDENT": "1", "PYAPES_HIP_RES_RZLEAN": "1"}),
-                      ("terms", {"PYAPES_HIP_RESIDENT": "1", "PYAPES_HIP_RES_RZLEAN": "0"}),
-                      ("launch", {"PYAPES_HIP_RESIDENT": "0"})):
+    from helpers import hip_options
+    for name, env, lean in (("lean", {"PYAPES_HIP_RESIDENT": "1"}, 1), ("terms", {"PYAPES_HIP_RESIDENT": "1"}, 0),
+                            ("launch", {"PYAPES_HIP_RESIDENT": "0"}, 1)):
         for k, v in env.items():
             monkeypatch.setenv(k, v)
+        hip_options(monkeypatch, res_rzlean=lean)
         mesh = Mesh(Cylinder([0.0, 0.0], [1.0, 1.5]), None, list(n), "cuda", dtype)
         var = Field("p", 1, mesh, {"domain": pcfg, "obstacle": None})
         s = Solver({"fdm": {"method": method, "tol": -1.0, "max_it": K, "report": False}})

@@ -76,10 +76,11 @@ def test_two_slabs_on_one_gpu(name, shape, tmp_path, world=2):
 @pytest.mark.parametrize("name", list(CASES), ids=list(CASES))
 def test_two_slabs_pair_bc_kernels(name, tmp_path, monkeypatch):
     """same, with the per-axis BC pair kernels (what a large slab uses) instead of the fused fill"""
-    monkeypatch.setenv("PYAPES_HIP_BC_UNFUSED", "1")
+    from helpers import hip_options
+    hip_options(monkeypatch, bc_path=1)      # (PYAPES_HIP_OPTIONS: the rank processes inherit it)
     test_two_slabs_on_one_gpu(name, ((24, 20, 132), "double"), tmp_path)
     paired = torch.load(str(tmp_path / "x.pt"))
-    monkeypatch.setenv("PYAPES_HIP_BC_UNPAIRED", "1")
+    hip_options(monkeypatch, bc_path=3)
     test_two_slabs_on_one_gpu(name, ((24, 20, 132), "double"), tmp_path)
     plain = torch.load(str(tmp_path / "x.pt"))
     assert torch.equal(paired["x"], plain["x"])
@@ -174,5 +175,6 @@ def test_four_slabs_on_one_gpu(name, bc_path, tmp_path, monkeypatch):
     """P = 4: two interior ranks that own no global x face (no x BC fill, both neighbours real), the
     uneven split 26 = 7 + 7 + 6 + 6, a periodic ring longer than its two end ranks"""
     if bc_path == "pair":
-        monkeypatch.setenv("PYAPES_HIP_BC_UNFUSED", "1")
+        from helpers import hip_options
+        hip_options(monkeypatch, bc_path=1)
     test_two_slabs_on_one_gpu(name, ((26, 20, 132), "double"), tmp_path, world=4)

@@ -6,7 +6,7 @@ import pytest
 import torch
 
 import pyapes_oracle as O
-from helpers import rel_err
+from helpers import hip_options, rel_err
 
 pytestmark = pytest.mark.gpu
 
@@ -90,9 +90,9 @@ def test_next_direction_formed_by_the_x_update_changes_no_bit(case, monkeypatch)
     g = torch.Generator().manual_seed(17)
     rhs0 = torch.randn((1, *n), generator=g, dtype=torch.float64).to(tdt)
     for K, tol in ((1, 1e-30), (2, 1e-30), (3, 1e-30), (12, 1e-30), (400, 1e-7 if dtype == "double" else 1e-3)):
-        monkeypatch.setenv("PYAPES_HIP_BICG_PFOLD", "1")
+        hip_options(monkeypatch, bicg_pfold=1)
         xa, ra = _run(n, dtype, bcs, rhs0, K, tol, True, monkeypatch)
-        monkeypatch.setenv("PYAPES_HIP_BICG_PFOLD", "0")
+        hip_options(monkeypatch, bicg_pfold=0)
         xb, rb = _run(n, dtype, bcs, rhs0, K, tol, True, monkeypatch)
         assert ra["itr"] == rb["itr"] and ra["tol"] == rb["tol"], (K, ra, rb)
         assert torch.equal(xa, xb), (K, float((xa - xb).abs().max()))
