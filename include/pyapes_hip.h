@@ -357,6 +357,9 @@ int pa_comm_init(pa_ctx* ctx, int rank, int nranks, const void* id128);
 int pa_comm_selftest(pa_ctx* ctx, double timeout_s);
 int pa_comm_plan(pa_ctx* ctx, const pa_exchange* plan);
 int pa_cg_iterate_comm(pa_ctx* ctx, int64_t n);
+/* the same for the stepwise BiCGSTAB (pa_bicg_begin ... pa_bicg_end): n iterations = 5 step calls + 3 all-reduces + the
+ * exchanges of the v' planes (pa_slab_set_v) and of the packed r / x planes (pa_comm_plan) each, one C call */
+int pa_bicg_iterate_comm(pa_ctx* ctx, int64_t n);
 int pa_comm_destroy(pa_ctx* ctx);
 /* Give up on the library's communicators while work that uses them may still be queued (a collective some rank
  * never joined): ncclCommAbort on both, then the ctx streams are drained.  The stepwise calls remain usable. */

@@ -86,6 +86,21 @@ int exchange(pa_ctx* c, Rccl* R, ncclComm_t comm, hipStream_t st) {
   return PA_OK;
 }
 
+// the boundary planes of v' (stepwise BiCGSTAB, pa_slab_set_v): same neighbours, same order as exchange()
+int exchange_v(pa_ctx* c, Rccl* R, ncclComm_t comm, hipStream_t st) {
+  const pa_exchange& P = c->plan;
+  const ncclDataType_t dt = c->dtype == PA_F64 ? ncclDouble : ncclFloat;
+  const size_t n = (size_t)c->G.s0;
+  if (P.nb_lo < 0 && P.nb_hi < 0) return PA_OK;
+  PA_NCCL(c, R, R->GroupStart());
+  if (P.nb_lo >= 0 && c->v_send_lo) PA_NCCL(c, R, R->Send(c->v_send_lo, n, dt, P.nb_lo, comm, st));
+  if (P.nb_hi >= 0 && c->v_send_hi) PA_NCCL(c, R, R->Send(c->v_send_hi, n, dt, P.nb_hi, comm, st));
+  if (P.nb_hi >= 0 && c->v_recv_hi) PA_NCCL(c, R, R->Recv((void*)c->v_recv_hi, n, dt, P.nb_hi, comm, st));
+  if (P.nb_lo >= 0 && c->v_recv_lo) PA_NCCL(c, R, R->Recv((void*)c->v_recv_lo, n, dt, P.nb_lo, comm, st));
+  PA_NCCL(c, R, R->GroupEnd());
+  return PA_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -408,6 +423,33 @@ int pa_cg_iterate_comm(pa_ctx* c, int64_t n) {
   c->slab_fold_live = 0;
   if (rc == PA_E_HIP && !c->err[0]) pa_set_err(c, "pa_cg_iterate_comm: HIP / RCCL call failed in the folded sequence");
   return rc;
+}
+
+// n BiCGSTAB iterations on a slab with everything on the ctx stream: the five step calls of the stepwise form
+// (include/pyapes_hip.h), the three small all-reduces and the two plane exchanges between them.  Iterations enqueued
+// after the device-side stop are no-ops (the collectives still run: every rank enqueues the same sequence).
+int pa_bicg_iterate_comm(pa_ctx* c, int64_t n) {
+  if (!c || c->solver_live != 2) { if (c) pa_set_err(c, "pa_bicg_iterate_comm without pa_bicg_begin"); return PA_E_STATE; }
+  if (!c->slab || !c->ext_sums) { pa_set_err(c, "pa_bicg_iterate_comm needs slab mode (pa_slab_set)"); return PA_E_STATE; }
+  if (!c->comm || !c->plan_set) { pa_set_err(c, "pa_bicg_iterate_comm needs pa_comm_init + pa_comm_plan"); return PA_E_STATE; }
+  PA_HIP(c, hipSetDevice(c->device));
+  Rccl* R = rccl();
+  ncclComm_t comm = (ncclComm_t)c->comm;
+  double* sums = c->ext_sums;
+  int rc;
+  for (int64_t q = 0; q < n; ++q) {
+    if ((rc = pa_bicg_pv(c))) return rc;
+    PA_NCCL(c, R, R->AllReduce(sums + 0, sums + 0, 1, ncclDouble, ncclSum, comm, c->stream));
+    if ((rc = exchange_v(c, R, comm, c->stream))) return rc;
+    if ((rc = pa_bicg_st(c))) return rc;
+    PA_NCCL(c, R, R->AllReduce(sums + 1, sums + 1, 4, ncclDouble, ncclSum, comm, c->stream));
+    if ((rc = pa_bicg_x(c))) return rc;
+    if ((rc = exchange(c, R, comm, c->stream))) return rc;
+    if ((rc = pa_bicg_bc(c))) return rc;
+    PA_NCCL(c, R, R->AllReduce(sums + 5, sums + 5, 1, ncclDouble, ncclSum, comm, c->stream));
+    if ((rc = pa_bicg_finish(c))) return rc;
+  }
+  return PA_OK;
 }
 
 }  // extern "C"

@@ -465,6 +465,9 @@ class HipContext:
     def cg_iterate_comm(self, n: int) -> None:
         self._rc(self.lib.pa_cg_iterate_comm(self.h, int(n)))
 
+    def bicg_iterate_comm(self, n: int) -> None:
+        self._rc(self.lib.pa_bicg_iterate_comm(self.h, int(n)))
+
     def comm_destroy(self) -> None:
         self._rc(self.lib.pa_comm_destroy(self.h))
         self._keep.pop("plan", None)

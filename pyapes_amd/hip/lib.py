@@ -123,6 +123,7 @@ SIGNATURES: dict[str, tuple[Any, list[Any]]] = {
     "pa_comm_selftest": (C.c_int, [_VP, C.c_double]),
     "pa_comm_plan": (C.c_int, [_VP, C.POINTER(PaExchange)]),
     "pa_cg_iterate_comm": (C.c_int, [_VP, C.c_int64]),
+    "pa_bicg_iterate_comm": (C.c_int, [_VP, C.c_int64]),
     "pa_comm_destroy": (C.c_int, [_VP]),
     "pa_comm_abort": (C.c_int, [_VP]),
     "pa_stream_wait": (C.c_int, [_VP, C.c_double]),

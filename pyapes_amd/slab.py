@@ -306,7 +306,10 @@ class SlabBiCGSTAB(_SlabDriver):
     iteration: the boundary planes of v' = A p' and of the new residual (with the periodic x planes behind them) go to
     the axis-0 neighbours, three small all-reduces carry r0.v', then (|s|^2, t.s, t.t, r0.t), then |r|^2; the direction
     p is never sent -- its ghost planes follow the owner's recurrence on every rank.  Communication through
-    ``torch.distributed`` (RCCL on the GPUs of a node, gloo in the rehearsals)."""
+    RCCL inside the library where the process group allows it (``pa_bicg_iterate_comm``: n iterations, one C call),
+    else ``torch.distributed`` between the step calls (gloo in the rehearsals)."""
+
+    uses_lib_comm = True
 
     def __init__(self, mesh: Any, var: Any, rhs: Tensor, terms: Sequence[dict], dist: Any,
                  backend: Any = None, group: Any = None):
@@ -341,6 +344,9 @@ class SlabBiCGSTAB(_SlabDriver):
 
     def iterate(self, n: int) -> None:
         be = self.be
+        if self.lib_comm:
+            be.bicg_iterate_comm(n)
+            return
         for _ in range(n):
             be.bicg_pv()                                 # p', v' = A p' ; local r0.v' ; v' planes out
             self._allreduce(0, 1)

@@ -219,7 +219,8 @@ def test_a_rank_failing_set_up_takes_every_rank_to_the_same_fallback(fail, expec
 
 # ---- Solver.set_eq() / solve() on slab meshes: the reference's own surface on 2 and 4 ranks ---------------------------
 def _worker_solver(rank, world, port, name, n, jobs, dtype, out):
-    """jobs: list of (label, method, tol, K) solved one after the other through ``Solver`` on ``Mesh(..., slab=...)``."""
+    """jobs: list of (label, method, tol, K[, env]) solved one after the other through ``Solver`` on ``Mesh(..., slab=...)``;
+    env: variables set while that job's mesh / context is created (PYAPES_HIP_COMM=0: stepwise torch.distributed driver)."""
     import sys
     here = os.path.dirname(os.path.abspath(__file__))
     sys.path.insert(0, here)
@@ -245,7 +246,11 @@ def _worker_solver(rank, world, port, name, n, jobs, dtype, out):
         if name == "per":
             rhs_g -= rhs_g.mean()
         res = {}
-        for label, method, tol, K in jobs:
+        for job in jobs:
+            label, method, tol, K = job[:4]
+            for k in ENV_KEYS:
+                os.environ.pop(k, None)
+            os.environ.update(job[4] if len(job) > 4 else {})
             mesh = Mesh(Box[0:1, 0:1, 0:0.5], None, list(n), "cuda", dtype, slab=(rank, world))
             var = Field("p", 1, mesh, {"domain": bcs, "obstacle": None})
             rhs = rhs_g.to(mesh.dtype.float)[:, mesh.i_off:mesh.i_off + mesh.nx[0]].contiguous().cuda()
@@ -253,6 +258,7 @@ def _worker_solver(rank, world, port, name, n, jobs, dtype, out):
             solver.set_eq(-FDM().laplacian(0.7, var) == rhs)
             rep = solver.solve()
             ctx = context_for(mesh)
+            in_lib = bool(getattr(ctx, "comm_ready", None))
             if getattr(ctx, "comm_ready", None):      # release the communicators while every rank is alive
                 torch.cuda.synchronize()
                 ctx.comm_destroy()
@@ -260,7 +266,7 @@ def _worker_solver(rank, world, port, name, n, jobs, dtype, out):
             parts = [None] * world
             dist.all_gather_object(parts, var().cpu())
             res[label] = {"x": torch.cat(parts, dim=1), "itr": int(rep["itr"]), "tol": float(rep["tol"]),
-                          "converge": bool(rep["converge"])}
+                          "converge": bool(rep["converge"]), "in_lib": in_lib}
         if rank == 0:
             torch.save(res, out)
     finally:
@@ -283,14 +289,22 @@ def _oracle_any(name, n, method, tol, K, dtype="double"):
 @pytest.mark.parametrize("name", ["per", "xper", "mix"])
 def test_solver_solve_on_slab_meshes(name, world, n, tmp_path):
     """``Solver.solve()`` with ``Mesh(..., slab=(rank, world))`` on every rank: linalg.solve hands CG to SlabCG (the
-    library-side loop over the stand-in wire) and BiCGSTAB to SlabBiCGSTAB (stepwise, planes of v' and r, three small
-    all-reduces per iteration).  Identical iteration counts and <= 1e-10 against the single-domain oracle; fully
-    periodic, x-periodic (the ring across the ranks) and mixed faces; even and uneven slabs."""
-    jobs = [("cg", "cg", 1e-30, 6), ("bicgstab", "bicgstab", 1e-30, 6)]
+    library-side loop over the stand-in wire) and BiCGSTAB to SlabBiCGSTAB (planes of v' and r, three small all-reduces
+    per iteration: inside the library, pa_bicg_iterate_comm, and with torch.distributed between the step calls).
+    Identical iteration counts and <= 1e-10 against the single-domain oracle; fully periodic, x-periodic (the ring
+    across the ranks) and mixed faces; even and uneven slabs."""
+    jobs = [("cg", "cg", 1e-30, 6), ("bicgstab", "bicgstab", 1e-30, 6),
+            ("bicgstab_stepwise", "bicgstab", 1e-30, 6, {"PYAPES_HIP_COMM": "0"})]
     out = str(tmp_path / "res.pt")
     spawn_ranks(_worker_solver, lambda port: (world, port, name, n, jobs, "double", out), world)
     res = torch.load(out)
-    for label, method, tol, K in jobs:
+    assert res["cg"]["in_lib"] and res["bicgstab"]["in_lib"] and not res["bicgstab_stepwise"]["in_lib"]
+    # the same step calls, the sums added by the stand-in in rank order / by gloo: two ranks -> the same bits
+    if world == 2:
+        assert torch.equal(res["bicgstab"]["x"], res["bicgstab_stepwise"]["x"])
+    else:
+        assert _rel(res["bicgstab"]["x"], res["bicgstab_stepwise"]["x"]) < 1e-12
+    for label, method, tol, K in [j[:4] for j in jobs]:
         xo, ro = _oracle_any(name, n, method, tol, K)
         r = res[label]
         assert r["itr"] == ro["itr"] == (K + 1 if method == "cg" else K), (label, r["itr"], ro["itr"])
