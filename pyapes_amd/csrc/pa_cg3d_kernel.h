@@ -1131,7 +1131,11 @@ static int launch_any_w(pa_ctx* c, Cg3dArgs<T>& A) {
 #undef PA_DIV_CASE
     }
   }
-  switch (pick_rj<T>(c, NARROW == 1, PHASE == 0 || PHASE == 1 || PHASE == 5 || PHASE == 6 || PHASE == 8)) {
+  const int rj = pick_rj<T>(c, NARROW == 1, PHASE == 0 || PHASE == 1 || PHASE == 5 || PHASE == 6 || PHASE == 8);
+  // (Round 4 tried 32-row tiles, RJ = 8, for the fp64 CG phases at 512^3 -- half the halo rows per cell, against phase
+  // A's +5.7 % of re-read halo rows: 370 / 411 VGPRs instead of 223 / 237, i.e. ONE wave per SIMD, and phase A went from
+  // 0.59 to 0.69 ms while phase B stayed at 0.92-0.94 (three interleaved pairs on one box).  The instantiation is gone.)
+  switch (rj) {
     case 1: return launch_cg3d<T, 1, PHASE, false, 0, NARROW>(c, A);
     case 2: return launch_cg3d<T, 2, PHASE, false, 0, NARROW>(c, A);
     default: return launch_cg3d<T, 4, PHASE, false, 0, NARROW>(c, A);

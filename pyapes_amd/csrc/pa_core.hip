@@ -311,12 +311,17 @@ int pa_ctx_set_stream(pa_ctx* c, void* hip_stream) {
     // state the kernels on the new stream read: order the new stream after it
     PA_HIP(c, hipSetDevice(c->device));
     if (!c->ev_switch) PA_HIP(c, hipEventCreateWithFlags(&c->ev_switch, hipEventDisableTiming));
-    PA_HIP(c, hipEventRecord(c->ev_switch, c->stream));
-    PA_HIP(c, hipStreamWaitEvent(next, c->ev_switch, 0));
-    if (c->xstream) {
-      PA_HIP(c, hipEventRecord(c->ev_switch, c->xstream));
-      PA_HIP(c, hipStreamWaitEvent(next, c->ev_switch, 0));
-    }
+    // (the OLD stream may be gone by now -- an external, short-lived stream the caller handed in and destroyed: the
+    // record fails then.  The switch must still complete: what that stream held has either run or died with it, and a
+    // device-wide wait is the conservative order.)
+    auto order_after = [&](hipStream_t from) {
+      if (hipEventRecord(c->ev_switch, from) == hipSuccess && hipStreamWaitEvent(next, c->ev_switch, 0) == hipSuccess) return;
+      (void)hipGetLastError();
+      (void)hipDeviceSynchronize();
+      (void)hipGetLastError();
+    };
+    order_after(c->stream);
+    if (c->xstream) order_after(c->xstream);
   }
   c->stream = next;
   return PA_OK;
@@ -336,7 +341,10 @@ int pa_ctx_set_option(pa_ctx* c, const char* name, int value) {
   else if (!strcmp(name, "place_minbytes")) c->ps.minbytes = value < 0 ? 0 : (size_t)value;   // ... for arrays of at least this size (tests: 0)
   else if (!strcmp(name, "place_blocks")) c->ps.blocks = value < 0 ? 0 : (value > PA_PLACE_MAXSPARE ? PA_PLACE_MAXSPARE : value);
   else if (!strcmp(name, "place_budget")) c->ps.budget = 0.01 * (value < 0 ? 0 : value);      // per cent of the time solved so far
-  else if (!strcmp(name, "resident_coop")) c->resident_coop = value != 0;   // 0: plain launch of the same grid (profiling, below)
+  // 0: plain launch of the same grid.  PROFILING ONLY (rocprofv3 7.2 kills any process that made a cooperative launch,
+  // profiles/README.md): co-residency is then only what an occupancy query on an idle device promised; on a device
+  // shared with other work the bounded waits give up and the launch-per-phase loop runs (slow, never wrong)
+  else if (!strcmp(name, "resident_coop")) c->resident_coop = value != 0;
   else if (!strcmp(name, "bc_path")) c->bc_path = value & 7;
   else if (!strcmp(name, "bicg_pfold")) c->bicg_pfold = value != 0;
   else if (!strcmp(name, "rhs_full")) c->rhs_full = value != 0;

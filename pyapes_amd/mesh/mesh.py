@@ -239,6 +239,17 @@ class Mesh:
     def d_mask_dim(self, d_face: str) -> int:
         return d2n_coord(self.coord_sys)[d_face[0]]
 
+    def d_mask_dir(self, d_face: str) -> int:
+        """_mesh.py:144-147, literal: ``1 if d_face[1] == "r" else -1`` -- the faces are named ``l`` / ``u``, so this is
+        -1 for every face the package ever names (the reference's docstring example speaks of "xr")."""
+        return 1 if d_face[1] == "r" else -1
+
+    def d_mask_shift(self, d_face: str, shift: int):
+        """_mesh.py:149-175: the face mask rolled by ``-shift * d_mask_dir`` along the face's axis.  With the literal
+        direction above that is ``+shift`` for BOTH sides: a lower face's mask moves inwards, an upper face's mask wraps
+        round to the low end (kept as is; the BC classes of the reference do their own, correct rolls, bcs.py:84-95)."""
+        return torch.roll(self.d_mask[d_face], -shift * self.d_mask_dir(d_face), self.d_mask_dim(d_face))
+
     def face_index(self, face: str) -> int:
         """0..5 = lower / upper face of mesh axis 0, 1, 2 (the C ABI's face id)"""
         return 2 * self.d_mask_dim(face) + (0 if face[1] == "l" else 1)

@@ -20,13 +20,15 @@ from pyapes_amd.variables import Field
 from pyapes_amd.variables.bcs import homogeneous_bcs, mixed_bcs
 
 
-def _fixed_cg(mesh, bcs, rhs, K, fast=True):
+def _fixed_cg(mesh, bcs, rhs, K, fast=True, method="cg"):
     from pyapes_amd.hip.context import context_for
     ctx = context_for(mesh)
     ctx.set_option("fastpath", fast)                   # tiled kernels, or the generic ones
     try:
         var = Field("p", 1, mesh, {"domain": bcs, "obstacle": None})
-        solver = Solver({"fdm": {"method": "cg", "tol": -1.0, "max_it": K - 1, "report": False}})
+        # K iterations: CG and Jacobi run max_it + 1 (linalg.py:144-157), BiCGSTAB max_it
+        solver = Solver({"fdm": {"method": method, "tol": -1.0, "max_it": K if method == "bicgstab" else K - 1,
+                                 "report": False}})
         solver.set_eq(FDM().laplacian(1.0, var) == rhs.clone())
         with warnings.catch_warnings():
             warnings.simplefilter("ignore")
@@ -108,6 +110,50 @@ def test_full_size_fast_equals_generic_and_is_deterministic(workload):
     rel = float(torch.linalg.norm((xf - xg).double()) / torch.linalg.norm(xg.double()))
     assert rel <= (1e-12 if dtype == "double" else 1e-5), rel
     assert abs(rf["tol"] - rg["tol"]) <= (1e-10 if dtype == "double" else 1e-4) * abs(rg["tol"])
+
+
+SIZE_SWITCHED = {
+    # what switches on BY SIZE, at the default thresholds (round 3 only ever forced these paths onto small meshes, and the
+    # one data-corruption bug of that round surfaced in bench_ops.py, not in a test -- VERDICT r03 weak #5):
+    "2d_4096_f64": ([4096, 4096], "double", "dirichlet"),    # k_cg2d (>= 1.5 M cells), 128 MiB arrays: the placement search is on
+    "2d_4097_f64": ([4097, 4097], "double", "dirichlet"),    # ... with odd rows: PITCH layout of k_cg2d
+    "3d_257_f64": ([257, 257, 257], "double", "mixed"),      # odd rows in 3-D: PITCH layout of k_cg3d (CG and BiCGSTAB)
+    "3d_513_f32": ([513, 513, 513], "single", "mixed"),      # fp32 odd rows: PITCH for CG, one cell per lane (NARROW) for BiCGSTAB / Jacobi
+}
+
+
+@pytest.mark.parametrize("method", ["cg", "bicgstab", "jacobi"])
+@pytest.mark.parametrize("case", list(SIZE_SWITCHED), ids=list(SIZE_SWITCHED))
+def test_size_switched_paths_at_their_default_thresholds(case, method):
+    """K = 8 iterations on the meshes where k_cg2d, the PITCH layout, the one-cell-per-lane kernels and the online
+    placement search switch on by themselves: the tiled path twice (every bit equal, run to run) and the generic
+    kernels once (equal to rounding, identical counts)."""
+    n, dtype, kind = SIZE_SWITCHED[case]
+    nd = len(n)
+    if kind == "dirichlet":
+        bcs = homogeneous_bcs(nd, 0.0, "dirichlet")
+    else:
+        bcs = mixed_bcs([0, 0, 0, 0, 1, 0], ["dirichlet", "neumann", "dirichlet", "neumann", "dirichlet", "neumann"])
+    mesh = Mesh(Box([0.0] * nd, [1.0] * nd), None, n, "cuda", dtype)
+    g = torch.Generator(device="cuda").manual_seed(4)
+    rhs = torch.randn((1, *n), generator=g, dtype=mesh.dtype.float, device="cuda")
+    K = 8
+    xf, rf = _fixed_cg(mesh, bcs, rhs, K, True, method)
+    xf2, rf2 = _fixed_cg(mesh, bcs, rhs, K, True, method)
+    assert torch.equal(xf, xf2) and rf["tol"] == rf2["tol"], "not run-to-run deterministic"
+    del xf2
+    xg, rg = _fixed_cg(mesh, bcs, rhs, K, False, method)
+    assert rf["itr"] == rg["itr"] == K
+    assert bool(torch.isfinite(xf).all())
+    rel = float(torch.linalg.norm((xf - xg).double()) / torch.linalg.norm(xg.double()))
+    if method == "jacobi":
+        assert torch.equal(xf, xg)       # no global sum feeds back into a Jacobi iterate: the same bits on every path
+    else:
+        assert rel <= (1e-11 if dtype == "double" else 1e-5), rel
+    assert abs(rf["tol"] - rg["tol"]) <= (1e-9 if dtype == "double" else 1e-4) * abs(rg["tol"])
+    if method == "cg" and case == "2d_4096_f64":
+        from pyapes_amd.hip.context import context_for
+        assert context_for(mesh).place_stats()["state"] in ("searching", "done")     # on by default from 128 MiB arrays
 
 
 @pytest.mark.parametrize("speed", ["scalar", "tensor"])

@@ -206,6 +206,19 @@ def test_mesh_masks_and_geometry():
         assert box.lower == [0] * (i + 1) and box.upper == [2] * (i + 1)
 
 
+def test_mesh_d_mask_shift_is_the_references_literal_roll():
+    """_mesh.py:138-175: ``d_mask_dir`` compares the side letter with "r" (faces are named l / u), so the roll is +shift on
+    both sides -- a lower face's mask moves one node inwards, an upper face's mask wraps to the low end."""
+    mesh = Mesh(Box[0:1, 0:2], None, [5, 7], "cpu", "double")
+    assert mesh.d_mask_dir("xl") == -1 and mesh.d_mask_dir("xu") == -1 and mesh.d_mask_dim("yl") == 1
+    m = mesh.d_mask_shift("xl", 1)
+    assert bool(m[1].all()) and int(m.sum()) == 7
+    m = mesh.d_mask_shift("xu", 1)
+    assert bool(m[0].all()) and int(m.sum()) == 7           # wrapped: the reference's literal behaviour
+    m = mesh.d_mask_shift("yl", 2)
+    assert bool(m[:, 2].all()) and int(m.sum()) == 5
+
+
 def test_install_as_pyapes_aliases_are_the_same_modules():
     """unmodified pyapes imports (current layout and the notebooks' pyapes.core.* layout) resolve to
     this package's own module objects"""
