@@ -783,6 +783,27 @@ def main():
         cur = ctx.euler_march(a, b, kindc, u, nu, dts, W)
         oth = b if cur is a else a
         torch.cuda.synchronize()
+        try:
+            # The yardstick of THIS box for a step's arrays: a plain device copy of one of them into the other (1 read + 1
+            # write, the same two allocations, warm).  At 256^3 fp32 both arrays (64 MiB each) sit in the 256 MiB Infinity
+            # Cache, so this -- not 8 TB/s of HBM -- is the ceiling a 2-pass kernel can be held against.
+            for _ in range(3):
+                oth.copy_(cur)
+            torch.cuda.synchronize()
+            c0 = torch.cuda.Event(enable_timing=True)
+            c1 = torch.cuda.Event(enable_timing=True)
+            c0.record()
+            for _ in range(20):
+                oth.copy_(cur)
+            c1.record()
+            torch.cuda.synchronize()
+            cms = c0.elapsed_time(c1) / 20
+            box = {"copy_ms": cms, "copy_GBs": 2 * cur.numel() * cur.element_size() / (cms * 1e-3) / 1e9,
+                   "what": f"torch copy_ between the step's two {cur.numel() * cur.element_size() / 2**20:.0f} MiB arrays, warm "
+                           "(Infinity-Cache resident when they fit 256 MiB)"}
+            log(f"this box: copy between the step's arrays {cms * 1e3:.1f} us = {box['copy_GBs']:.0f} GB/s")
+        except Exception:
+            pass
         e0 = torch.cuda.Event(enable_timing=True)
         e1 = torch.cuda.Event(enable_timing=True)
         t0 = time.perf_counter()
@@ -811,6 +832,11 @@ def main():
                                    "carries ~32 VALU instructions per cell that may not be fused (13.8 us of pure issue at 256^3): "
                                    "bound by instruction issue plus one dependent launch per step, not by HBM -- the fraction "
                                    "of the HBM roofline is reported for comparison only (DESIGN.md section 4)")
+            if box.get("copy_GBs"):
+                # against the copy of the same arrays on this box (cache-resident or not): the honest ceiling of the step
+                extra["ceiling_GBs"] = box["copy_GBs"]
+                extra["ceiling_source"] = "torch copy_ between the step's own two arrays on this box, same run (box.copy_GBs)"
+                extra["frac_of_ceiling"] = (passes * esize * mesh.N / (k_ms * 1e-3) / 1e9) / box["copy_GBs"]
             roof = roofline("euler_step", k_ms, passes * esize * mesh.N, args.workload, bool(args.n), extra)
         wl_text = (f"3-D advection-diffusion {'x'.join(map(str, gn))} {dtype}, Div(upwind)+Laplacian explicit Euler march, "
                    f"{'scalar u' if solver == 'euler' else 'speed tensor u(x)'}, Neumann/Symmetry BCs (BASELINE config 4)")
@@ -884,7 +910,7 @@ def main():
             out["first_attempt"] = first_attempt
         if clocks:
             out["clocks"] = clocks
-        if solver == "cg" and box:
+        if box:
             out["box"] = box
         if solver == "cg" and not slab:
             out["setup_ms"] = setup["wall_ms"]

@@ -22,7 +22,11 @@
 
 #include <algorithm>
 
-template <typename T, int PHASE, bool PITCH>
+// RZ (round 4): axisymmetric meshes.  What differs from xyz is three coefficients of the r axis per r index -- Ap, Am
+// and the neumann / symmetry row value (tools.py:86-107, fdc.py:395-417: rows 0 - 2 of pa_coord_set's table) -- and r is
+// the MARCH axis here (internal axis 1): a triple per row, wave-uniform, loaded two rows ahead like the row itself.
+// Everything else is the xyz kernel, so the arithmetic per node is pa_apply_terms' rz branch operation for operation.
+template <typename T, int PHASE, bool PITCH, bool RZ = false>
 __global__ void __launch_bounds__(256) k_cg2d(Cg3dArgs<T> A) {
   static_assert(PHASE == 0 || PHASE == 1 || PHASE == 4 || PHASE == 6 || PHASE == 8, "CG phases, Jacobi sweep, BiCGSTAB s / t and v phases");
   static_assert(!PITCH || PHASE != 4, "the Jacobi sweep works on the caller's arrays");
@@ -270,6 +274,14 @@ __global__ void __launch_bounds__(256) k_cg2d(Cg3dArgs<T> A) {
   };
   V ea, ec, eb;      // behind / current / ahead in march order
   T xa, xe, xb;      // their edge cells (only the current row's is used)
+  // RZ: (Ap, Am, row value) of the r axis for the current row, the next one, and the one being loaded
+  struct RzRow { T p, m, b; };
+  auto rz_row = [&](int jrow) -> RzRow {
+    const int64_t jw = wrapj(jrow);
+    return RzRow{A.rz[jw], A.rz[A.rz_n + jw], A.rz[2 * A.rz_n + jw]};
+  };
+  RzRow zc{(T)0, (T)0, (T)0}, zn = zc;
+  if constexpr (RZ) { zc = rz_row(row_of(0)); zn = rz_row(row_of(1)); }
   Raw w0, w1, w2;
   issue(row_of(-1), w0);
   issue(row_of(0), w1);
@@ -300,15 +312,19 @@ __global__ void __launch_bounds__(256) k_cg2d(Cg3dArgs<T> A) {
     // a branch between the issue of a load and its use makes the compiler wait for everything outstanding
     Raw w;
     issue(row_of(m + 2), w);
+    RzRow zl = zc;
+    if constexpr (RZ) zl = rz_row(row_of(m + 2));
 
     // stencil on row jj (k_cg3d's per-component path; internal axis 0 is inactive on a 2-D mesh)
     const bool jS = jj >= G.slo[1] && jj <= G.shi[1];
     const bool jShell = jj == 0 || jj == n1 - 1;
     T cPj = A.lap.inv[1], cCj = A.lap.m2inv[1], cMj = A.lap.inv[1];
     {
+      T cBj = A.lap.c23[1];
+      if constexpr (RZ) { cPj = zc.p; cMj = zc.m; cBj = zc.b; }
       const int rc = pa_row_case(G, 1, jj, G.n1, G.treat);
-      if (rc == 1) { cPj = A.lap.c23[1]; cCj = -A.lap.c23[1]; cMj = (T)0; }
-      if (rc == 2) { cPj = (T)0; cCj = -A.lap.c23[1]; cMj = A.lap.c23[1]; }
+      if (rc == 1) { cPj = cBj; cCj = -cBj; cMj = (T)0; }
+      if (rc == 2) { cPj = (T)0; cCj = -cBj; cMj = cBj; }
     }
     const V dn = rev ? ea : eb;   // row jj + 1
     const V up = rev ? eb : ea;   // row jj - 1
@@ -418,6 +434,7 @@ __global__ void __launch_bounds__(256) k_cg2d(Cg3dArgs<T> A) {
     ec = eb;
     xe = xb;
     finish(w, eb, xb);
+    if constexpr (RZ) { zc = zn; zn = zl; }
   }
 
   if (PHASE == 0 || PHASE == 8) {
@@ -433,12 +450,12 @@ __global__ void __launch_bounds__(256) k_cg2d(Cg3dArgs<T> A) {
 }
 
 // ---- host side ------------------------------------------------------------------------------------------------
-template <typename T, int PHASE, bool PITCH>
+template <typename T, int PHASE, bool PITCH, bool RZ = false>
 static int cg2d_blocks_per_cu() {
   static int cached = 0;
   if (!cached) {
     int n = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_cg2d<T, PHASE, PITCH>, 256, 0) != hipSuccess || n <= 0) n = 4;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_cg2d<T, PHASE, PITCH, RZ>, 256, 0) != hipSuccess || n <= 0) n = 4;
     cached = n;
   }
   return cached;
@@ -450,9 +467,15 @@ static int launch_cg2d(pa_ctx* c, Cg3dArgs<T>& A, bool pitched) {
   constexpr int VEC = VecOf<T>::N;
   const DevGeom& G = c->G;
   const int minrows_env = 0;   // (round 3's measurement knob: chunks of >= this many rows; the rule below is what it found)
-  const int64_t mincells = c->cg2d_mincells;   // option "cg2d_mincells"; < 0: never
+  // axisymmetric mesh: this kernel is the ONLY tiled one (k_cg3d's one-plane tiling has no r rows), so it runs from
+  // the size on where the resident solver ends instead of from 1.5 M cells: the alternative is the generic kernels
+  const bool rz = c->coord == PA_COORD_RZ;
+  const int64_t mincells = rz ? (c->cg2d_mincells < 0 ? -1 : 0) : c->cg2d_mincells;   // option "cg2d_mincells"; < 0: never
   if (mincells < 0 || c->ndim != 2 || G.act[0] || A.coeff_f || A.kind != 0 || c->slab) return 0;
   if (G.n1 < 8 || G.n2 < 2 * VEC) return 0;
+  if (rz && !c->rz_tab) return 0;
+  A.rz = (const T*)c->rz_tab;
+  A.rz_n = G.n1;
   // Below ~1.5 M cells the one-plane tiling of k_cg3d stays: a wave here walks its rows one after the other (about
   // a microsecond each), and a small mesh has too few strips x chunks to hide that (measured, fp64 Dirichlet, us per
   // iteration old -> new: 1024^2 23 -> 31, 1536^2 56 -> 49, 2048^2 83 -> 57, 4096^2 265 -> 191, 8192^2 1021 -> 800)
@@ -461,7 +484,9 @@ static int launch_cg2d(pa_ctx* c, Cg3dArgs<T>& A, bool pitched) {
   int bpc;
   if constexpr (PHASE == 4) {   // (the Jacobi sweep is never pitched: the caller's arrays)
     if (pitched) return 0;
-    bpc = cg2d_blocks_per_cu<T, PHASE, false>();
+    bpc = rz ? cg2d_blocks_per_cu<T, PHASE, false, true>() : cg2d_blocks_per_cu<T, PHASE, false>();
+  } else if (rz) {
+    bpc = pitched ? cg2d_blocks_per_cu<T, PHASE, true, true>() : cg2d_blocks_per_cu<T, PHASE, false, true>();
   } else {
     bpc = pitched ? cg2d_blocks_per_cu<T, PHASE, true>() : cg2d_blocks_per_cu<T, PHASE, false>();
   }
@@ -488,10 +513,12 @@ static int launch_cg2d(pa_ctx* c, Cg3dArgs<T>& A, bool pitched) {
   if (c->plan_only) return nblk;
   if constexpr (PHASE != 4) {
     if (pitched) {
-      hipLaunchKernelGGL((k_cg2d<T, PHASE, true>), dim3(nblk), dim3(256), 0, c->stream, A);
+      if (rz) hipLaunchKernelGGL((k_cg2d<T, PHASE, true, true>), dim3(nblk), dim3(256), 0, c->stream, A);
+      else hipLaunchKernelGGL((k_cg2d<T, PHASE, true>), dim3(nblk), dim3(256), 0, c->stream, A);
       return nblk;
     }
   }
-  hipLaunchKernelGGL((k_cg2d<T, PHASE, false>), dim3(nblk), dim3(256), 0, c->stream, A);
+  if (rz) hipLaunchKernelGGL((k_cg2d<T, PHASE, false, true>), dim3(nblk), dim3(256), 0, c->stream, A);
+  else hipLaunchKernelGGL((k_cg2d<T, PHASE, false>), dim3(nblk), dim3(256), 0, c->stream, A);
   return nblk;
 }

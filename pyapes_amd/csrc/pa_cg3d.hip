@@ -5,8 +5,9 @@
 
 template <typename T>
 int pa_cg3d_phase_a(pa_ctx* c, const DevEq<T>& E, Vec<T> r, Vec<T> d, T* dnew, double* partials) {
-  const int mode = c->cg_pitch ? 3 : cg3d_mode<T>(c, E, {r.p, d.p, dnew, r.glo, r.ghi, d.glo, d.ghi});
+  const int mode = c->cg_pitch ? 3 : cg3d_mode<T>(c, E, {r.p, d.p, dnew, r.glo, r.ghi, d.glo, d.ghi}, false, false, true);
   if (!mode) return 0;
+  const bool rz = c->coord == PA_COORD_RZ;   // axisymmetric: k_cg2d<..., RZ> or nothing (no other tiled kernel has r rows)
   Cg3dArgs<T> A;
   memset(&A, 0, sizeof(A));
   fill_common<T>(c, E, A);
@@ -21,7 +22,8 @@ int pa_cg3d_phase_a(pa_ctx* c, const DevEq<T>& E, Vec<T> r, Vec<T> d, T* dnew, d
     A.sc_w = c->sc_alt;
     A.pre_sums = pa_sums(c);
   }
-  int n = (mode == 1 || mode == 3) ? launch_cg2d<T, 0>(c, A, mode == 3) : 0;   // 2-D meshes: marching along the slow axis
+  int n = (mode == 1 || mode == 3 || mode == 4) ? launch_cg2d<T, 0>(c, A, mode == 3) : 0;   // 2-D meshes: marching along the slow axis
+  if (n == 0 && rz) return 0;
   if (n == 0) n = launch_any<T, 0>(c, A, mode);
   if (n > 0 && hipGetLastError() != hipSuccess) { pa_set_err(c, "k_cg3d phase A launch failed"); return PA_E_HIP; }
   if (n > 0 && c->fold_b_n > 0) {
@@ -37,8 +39,9 @@ int pa_cg3d_phase_b(pa_ctx* c, const DevEq<T>& E, Vec<T> d, T* x, T* r, double* 
   // the new residual goes where the old one came from -- or, when the placement search moves r (pa_place.hip), straight
   // into its new block: the caller re-points SCR_R after this launch
   T* const r_out = c->cg_r_out ? (T*)c->cg_r_out : r;
-  const int mode = c->cg_pitch ? 3 : cg3d_mode<T>(c, E, {d.p, x, r, r_out, d.glo, d.ghi, c->r_send_lo, c->r_send_hi});
+  const int mode = c->cg_pitch ? 3 : cg3d_mode<T>(c, E, {d.p, x, r, r_out, d.glo, d.ghi, c->r_send_lo, c->r_send_hi}, false, false, true);
   if (!mode) return 0;
+  const bool rz = c->coord == PA_COORD_RZ;
   Cg3dArgs<T> A;
   memset(&A, 0, sizeof(A));
   fill_common<T>(c, E, A);
@@ -54,7 +57,8 @@ int pa_cg3d_phase_b(pa_ctx* c, const DevEq<T>& E, Vec<T> d, T* x, T* r, double* 
     A.sc_w = c->sc;
     A.pre_sums = pa_sums(c);
   }
-  int n = (mode == 1 || mode == 3) ? launch_cg2d<T, 1>(c, A, mode == 3) : 0;
+  int n = (mode == 1 || mode == 3 || mode == 4) ? launch_cg2d<T, 1>(c, A, mode == 3) : 0;
+  if (n == 0 && rz) return 0;
   if (n == 0) n = launch_any<T, 1>(c, A, mode);
   if (n > 0 && hipGetLastError() != hipSuccess) { pa_set_err(c, "k_cg3d phase B launch failed"); return PA_E_HIP; }
   if (n > 0) c->fold_a_n = 0;
@@ -64,8 +68,9 @@ int pa_cg3d_phase_b(pa_ctx* c, const DevEq<T>& E, Vec<T> d, T* x, T* r, double* 
 // ---- Jacobi sweep ---------------------------------------------------------------------------------
 template <typename T>
 int pa_tile3d_jacobi(pa_ctx* c, const DevEq<T>& E, Vec<T> x, const T* rhs, T* xnew, double omega, double* partials) {
-  const int mode = cg3d_mode<T>(c, E, {x.p, rhs, xnew, x.glo, x.ghi});
+  const int mode = cg3d_mode<T>(c, E, {x.p, rhs, xnew, x.glo, x.ghi}, false, false, true);
   if (!mode) return 0;
+  const bool rz = c->coord == PA_COORD_RZ;
   Cg3dArgs<T> A;
   memset(&A, 0, sizeof(A));
   fill_common<T>(c, E, A);
@@ -78,7 +83,8 @@ int pa_tile3d_jacobi(pa_ctx* c, const DevEq<T>& E, Vec<T> x, const T* rhs, T* xn
     A.sc_w = c->sc_alt;
     A.pre_sums = pa_sums(c);
   }
-  int n = mode == 1 ? launch_cg2d<T, 4>(c, A, false) : 0;   // large 2-D meshes: marching along the slow axis
+  int n = (mode == 1 || mode == 4) ? launch_cg2d<T, 4>(c, A, false) : 0;   // large 2-D meshes: marching along the slow axis
+  if (n == 0 && rz) return 0;
   if (n == 0) n = launch_any<T, 4>(c, A, mode);
   if (n > 0 && hipGetLastError() != hipSuccess) { pa_set_err(c, "k_cg3d Jacobi launch failed"); return PA_E_HIP; }
   if (n > 0 && c->fold_b_n > 0) {

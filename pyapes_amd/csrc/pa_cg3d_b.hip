@@ -7,6 +7,7 @@ template <typename T>
 int pa_tile3d_bicg_pv(pa_ctx* c, const DevEq<T>& E, Vec<T> r, Vec<T> p, Vec<T> v, const T* r0, T* pnew, T* vnew,
                       double* partials) {
   // (a pitched solve, bicg_run_t: every array of these phases is the ctx's, rows padded to 128 bytes)
+  if (c->coord != PA_COORD_XYZ) return 0;   // (the full p / v phase has no 2-D marching form: generic kernel, once per solve)
   const int mode = c->cg_pitch ? 3 : cg3d_mode<T>(c, E, {r.p, p.p, v.p, r0, pnew, vnew, r.glo, r.ghi, p.glo, p.ghi, v.glo, v.ghi}, true);
   if (!mode) return 0;
   Cg3dArgs<T> A;
@@ -31,8 +32,9 @@ int pa_tile3d_bicg_pv(pa_ctx* c, const DevEq<T>& E, Vec<T> r, Vec<T> p, Vec<T> v
 // the same phase when p' already exists (k_bicg_x formed it, pa_solver.hip): v' = A p' on the interior set, r0 . v'
 template <typename T>
 int pa_tile3d_bicg_v(pa_ctx* c, const DevEq<T>& E, Vec<T> p, const T* r0, T* vnew, double* partials) {
-  const int mode = c->cg_pitch ? 3 : cg3d_mode<T>(c, E, {p.p, r0, vnew, p.glo, p.ghi}, true);
+  const int mode = c->cg_pitch ? 3 : cg3d_mode<T>(c, E, {p.p, r0, vnew, p.glo, p.ghi}, true, false, true);
   if (!mode) return 0;
+  const bool rz = c->coord == PA_COORD_RZ;
   Cg3dArgs<T> A;
   memset(&A, 0, sizeof(A));
   fill_common<T>(c, E, A);
@@ -43,7 +45,8 @@ int pa_tile3d_bicg_v(pa_ctx* c, const DevEq<T>& E, Vec<T> p, const T* r0, T* vne
     A.pre_n = c->fold_b_n;
     A.sc_w = c->sc_alt;
   }
-  int n = (mode == 1 || mode == 3) ? launch_cg2d<T, 8>(c, A, mode == 3) : 0;   // large 2-D meshes: marching kernel
+  int n = (mode == 1 || mode == 3 || mode == 4) ? launch_cg2d<T, 8>(c, A, mode == 3) : 0;   // large 2-D meshes: marching kernel
+  if (n == 0 && rz) return 0;
   if (n == 0) n = launch_any<T, 8>(c, A, mode);
   if (n > 0 && hipGetLastError() != hipSuccess) { pa_set_err(c, "k_cg3d BiCGSTAB v launch failed"); return PA_E_HIP; }
   if (n > 0 && c->fold_b_n > 0) {
@@ -56,8 +59,9 @@ int pa_tile3d_bicg_v(pa_ctx* c, const DevEq<T>& E, Vec<T> p, const T* r0, T* vne
 template <typename T>
 int pa_tile3d_bicg_st(pa_ctx* c, const DevEq<T>& E, Vec<T> r, Vec<T> v, const T* r0, T* s_out, T* t_out,
                       double* partials) {
-  const int mode = c->cg_pitch ? 3 : cg3d_mode<T>(c, E, {r.p, v.p, r0, s_out, t_out, r.glo, r.ghi, v.glo, v.ghi}, true);
+  const int mode = c->cg_pitch ? 3 : cg3d_mode<T>(c, E, {r.p, v.p, r0, s_out, t_out, r.glo, r.ghi, v.glo, v.ghi}, true, false, true);
   if (!mode) return 0;
+  const bool rz = c->coord == PA_COORD_RZ;
   Cg3dArgs<T> A;
   memset(&A, 0, sizeof(A));
   fill_common<T>(c, E, A);
@@ -68,7 +72,8 @@ int pa_tile3d_bicg_st(pa_ctx* c, const DevEq<T>& E, Vec<T> r, Vec<T> v, const T*
     A.pre_n = c->fold_a_n;
     A.sc_w = c->sc;
   }
-  int n = (mode == 1 || mode == 3) ? launch_cg2d<T, 6>(c, A, mode == 3) : 0;
+  int n = (mode == 1 || mode == 3 || mode == 4) ? launch_cg2d<T, 6>(c, A, mode == 3) : 0;
+  if (n == 0 && rz) return 0;
   if (n == 0) n = launch_any<T, 6>(c, A, mode);
   if (n > 0 && hipGetLastError() != hipSuccess) { pa_set_err(c, "k_cg3d BiCGSTAB s/t launch failed"); return PA_E_HIP; }
   return n;

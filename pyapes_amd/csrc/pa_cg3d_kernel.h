@@ -71,6 +71,9 @@ struct Cg3dArgs {
   int gnd;              // phase 7: mesh dimension (components written: gnd, one field of ncell each)
   // PITCH layout (odd row lengths, below): row / plane strides of the ctx-owned arrays r, d, d'; x keeps G.s0 / G.s1
   int64_t ps0, ps1;
+  // axisymmetric mesh (k_cg2d<..., RZ>): the r rows of pa_coord_set's table, n_r entries each
+  const T* rz;
+  int64_t rz_n;
   int interior_only;    // A x: zero outside the interior set
   int out_all;          // Euler step (k_sf): the caller overwrites every node outside the interior set (its BC
                         // fill covers all 2 * ndim faces), so the step need not preserve phi there
@@ -973,12 +976,20 @@ static bool eq_lap_div(const DevEq<T>& E, int& il, int& id, bool field_speed = f
   return il >= 0 && id >= 0 && !E.t[il].coeff_f;
 }
 
-// 0: not for the tiled kernels; 1: 16-byte vector lanes; 2: one cell per lane (NARROW)
+// 0: not for the tiled kernels; 1: 16-byte vector lanes; 2: one cell per lane (NARROW); 4: axisymmetric mesh -- the 2-D
+// marching kernel k_cg2d<..., RZ> or nothing (only the callers that have a k_cg2d phase ask with rz_ok)
 template <typename T>
 static int cg3d_mode(const pa_ctx* c, const DevEq<T>& E, std::initializer_list<const void*> ptrs,
-                     bool allow_div = false, bool field_speed = false) {
+                     bool allow_div = false, bool field_speed = false, bool rz_ok = false) {
   if (!c->fastpath) return 0;
-  if (c->coord != PA_COORD_XYZ) return 0;  // r-dependent rows: generic kernels
+  if (c->coord != PA_COORD_XYZ) {   // r-dependent rows: k_cg2d where the phase has one, else the generic kernels
+    if (!rz_ok || c->coord != PA_COORD_RZ || c->ndim != 2 || E.nterms != 1 || E.t[0].kind != PA_OP_LAPLACIAN || E.t[0].coeff_f)
+      return 0;
+    uintptr_t bits = 0;
+    for (const void* q : ptrs) bits |= (uintptr_t)q;
+    if ((bits & 15) || c->G.n2 % VecOf<T>::N != 0) return 0;   // (odd rows: only in the PITCH layout, mode 3 of the callers)
+    return 4;
+  }
   if (c->ndim != 3 && c->ndim != 2) return 0;
   int il, id;
   if (!eq_lap_div<T>(E, il, id, field_speed) || (id >= 0 && !allow_div)) return 0;

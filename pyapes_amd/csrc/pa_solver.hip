@@ -94,6 +94,37 @@ __global__ void __launch_bounds__(PA_BLOCK) k_cg_init_ax_pitch(DevGeom G, const 
   pa_block_reduce_store<1>(s, partials);
 }
 
+// ... and with A x from the GENERIC term evaluation (axisymmetric meshes: no tiled A x), r / d (or r0 / r) pitched
+template <typename T>
+__global__ void __launch_bounds__(PA_BLOCK) k_cg_init_pitch(DevGeom G, DevEq<T> E, Vec<T> xv, const T* __restrict__ rhs,
+                                                             T* __restrict__ r, T* __restrict__ d, int64_t ps1,
+                                                             double* __restrict__ partials) {
+  FieldAcc<T> acc{xv};
+  double s[1] = {0.0};
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x, t0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  for (int64_t idx = t0; idx < G.ncell; idx += stride) {
+    int64_t i, j, k;
+    pa_decode(G, idx, i, j, k);
+    T rv = (T)0;
+    if (pa_in_S(G, i, j, k)) {
+      T ax = pa_apply_terms<T>(G, E, acc, i, j, k, xv.p[idx]);
+      rv = rhs[idx] - ax;
+      T p = rv * rv;
+      s[0] += (double)p;
+    }
+    const int64_t o = (i * G.n1 + j) * ps1 + k;
+    r[o] = rv;
+    d[o] = rv;
+  }
+  const int64_t rows = G.n0 * G.n1, pw = ps1 - G.n2;
+  for (int64_t q = t0; q < rows * pw; q += stride) {
+    const int64_t o = (q / pw) * ps1 + G.n2 + q % pw;
+    r[o] = (T)0;
+    d[o] = (T)0;
+  }
+  pa_block_reduce_store<1>(s, partials);
+}
+
 // ---- CG phase A: d' = r + beta d ; partial sum d'.(A d')  (linalg.py:115-120, 141) ----
 template <typename T>
 __global__ void __launch_bounds__(PA_BLOCK) k_cg_a(DevGeom G, DevEq<T> E, const SolverScalars* __restrict__ sc,
@@ -906,7 +937,10 @@ static int64_t solver_pitch(const pa_ctx* c, const T* x) {
   const DevGeom& G = c->G;
   constexpr int VECW = 16 / (int)sizeof(T);
   const bool shape = (c->ndim == 3 && G.n0 >= 3 && G.n1 >= 3) || (c->ndim == 2 && G.n1 >= 3);
-  if (!(c->pitch && c->fastpath && !c->slab && c->coord == PA_COORD_XYZ && shape && G.n2 % VECW != 0 && G.n2 >= 2 * VECW &&
+  // (axisymmetric meshes: their one tiled kernel is the 2-D marching k_cg2d<..., RZ>, pa_cg2d_kernel.h)
+  const bool coord_ok = c->coord == PA_COORD_XYZ ||
+                        (c->coord == PA_COORD_RZ && c->ndim == 2 && c->rz_tab && G.n1 >= 8 && c->cg2d_mincells >= 0);
+  if (!(c->pitch && c->fastpath && !c->slab && coord_ok && shape && G.n2 % VECW != 0 && G.n2 >= 2 * VECW &&
         c->nterms == 1 && c->terms[0].kind == PA_OP_LAPLACIAN && !c->terms[0].coeff_field &&
         G.bct[4] != PA_BC_PERIODIC && G.bct[5] != PA_BC_PERIODIC && ((uintptr_t)x & (sizeof(T) - 1)) == 0 &&
         ((G.n1 + 3) / 4) * ((G.n2 + 64 * VECW - 1) / (64 * VECW)) <= PA_MAX_PARTIALS))
@@ -983,6 +1017,8 @@ static int cg_begin_t(pa_ctx* c, T* x, const T* rhs, double tol, int64_t max_it)
     if (fr > 0) {
       hipLaunchKernelGGL(k_cg_init_ax_pitch<T>, dim3(nblk), dim3(PA_BLOCK), 0, c->stream, c->G, rhs, (const T*)ax, r, d,
                          c->cg_ps1, part);
+    } else if (c->coord == PA_COORD_RZ) {   // no tiled A x with r rows: the generic term evaluation, once per solve
+      hipLaunchKernelGGL(k_cg_init_pitch<T>, dim3(nblk), dim3(PA_BLOCK), 0, c->stream, c->G, E, xv, rhs, r, d, c->cg_ps1, part);
     } else {
       c->cg_pitch = 0;   // the tiled A x declined: contiguous layout, as before (the buffers are merely larger)
       c->cg_ps1 = 0;
@@ -1486,6 +1522,8 @@ static int bicg_run_t(pa_ctx* c, T* x, const T* rhs, double tol, int64_t max_it,
     if (fr > 0) {
       hipLaunchKernelGGL(k_cg_init_ax_pitch<T>, dim3(nblk), dim3(PA_BLOCK), 0, c->stream, c->G, rhs, (const T*)t, r0, r,
                          c->cg_ps1, part);
+    } else if (c->coord == PA_COORD_RZ) {
+      hipLaunchKernelGGL(k_cg_init_pitch<T>, dim3(nblk), dim3(PA_BLOCK), 0, c->stream, c->G, E, xv, rhs, r0, r, c->cg_ps1, part);
     } else {   // the tiled A x declined: contiguous layout (the buffers are merely larger)
       c->cg_pitch = 0;
       c->cg_ps1 = 0;
@@ -1532,6 +1570,20 @@ static int bicg_run_t(pa_ctx* c, T* x, const T* rhs, double tol, int64_t max_it,
   const bool pfold = c->bicg_pfold != 0;
   bool pgiven = false;
   c->fold_a_n = c->fold_b_n = c->fold_b_nsh = 0;
+  if (c->coord == PA_COORD_RZ && pfold && c->fastpath) {
+    // Axisymmetric mesh: the only tiled form of the p / v phase is the one that takes p' as given (k_cg2d<..., RZ>, phase
+    // 8).  The first iteration has p = v = 0, so its p' = r + beta (0 - omega 0) IS r, bit for bit (linalg.py:189-217):
+    // hand phase 8 a copy of r and every iteration -- the first included -- runs on the marching kernel.
+    c->plan_only = 1;
+    const int v_ok = pa_tile3d_bicg_v<T>(c, E, vec_of(p[0]), (const T*)r0, v[1], reg0);
+    c->plan_only = 0;
+    (void)hipGetLastError();
+    if (v_ok > 0) {
+      PA_HIP(c, hipMemcpyAsync(p[0], r, fb, hipMemcpyDeviceToDevice, c->stream));
+      pgiven = true;
+    }
+  }
+  if (c->cg_pitch && c->coord == PA_COORD_RZ && !pgiven) { pa_set_err(c, "pitched BiCGSTAB on an axisymmetric mesh needs the marching v phase"); return PA_E_STATE; }
   auto flush3 = [&]() {
     if (pend3 > 0) hipLaunchKernelGGL(k_bicg_post<T>, dim3(1), dim3(PA_BLOCK), 0, c->stream, c->sc, reg2, pend3, 3);
     pend3 = 0;

@@ -145,3 +145,79 @@ def test_rz_resident_lean_path_matches_the_generic_term_evaluation(method, dtype
     for other in ("terms", "launch"):
         err = rel_err(out["lean"][0], out[other][0])
         assert err <= tol, (other, err)
+
+
+RZ_LARGE = {
+    # beyond what the resident solver holds (128 boxes): the launch-per-phase loops, where round 4 put the axisymmetric
+    # rows on the 2-D marching kernel (k_cg2d<..., RZ>: r is its march axis, a coefficient triple per row)
+    "even_rows_f64": ((520, 1024), "double"),
+    "odd_rows_pitched_f64": ((513, 1025), "double"),     # PITCH layout: r / d (BiCGSTAB: every solver array) with padded rows
+    "even_rows_f32": ((384, 1536), "single"),
+}
+
+
+@pytest.mark.parametrize("method", ["cg", "bicgstab", "jacobi"])
+@pytest.mark.parametrize("case", list(RZ_LARGE), ids=list(RZ_LARGE))
+def test_rz_marching_kernel_matches_generic_kernels_and_oracle(case, method):
+    """Axisymmetric meshes on k_cg2d<..., RZ> against the generic kernels (pa_apply_terms' rz branch: the same arithmetic
+    per node, so the Jacobi sweep is bit-identical and CG / BiCGSTAB agree to rounding with identical counts) and against
+    the oracle."""
+    from pyapes_amd.hip.context import context_for
+    n, dtype = RZ_LARGE[case]
+    cfg = O.mixed_cfg([0.0, 1.0, 0.3, 0.5], ["neumann", "dirichlet", "dirichlet", "neumann"], O.FACES_RZ)
+    pcfg = [dict(c, bc_val_opt=None) for c in cfg]
+    g = torch.Generator().manual_seed(9)
+    rhs = torch.randn((1, *n), generator=g, dtype=torch.float64)
+    K = 6
+    out = {}
+    for fast in (True, False):
+        mesh = Mesh(Cylinder([0.0, 0.0], [1.0, 1.5]), None, list(n), "cuda", dtype)
+        ctx = context_for(mesh)
+        ctx.set_option("fastpath", fast)
+        var = Field("p", 1, mesh, {"domain": pcfg, "obstacle": None})
+        s = Solver({"fdm": {"method": method, "tol": -1.0, "max_it": K if method == "bicgstab" else K - 1, "report": False}})
+        s.set_eq(FDM().laplacian(0.9, var) == rhs.to(mesh.dtype.float).cuda().clone())
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            rep = s.solve()
+        assert ctx.resident_used() == 0
+        out[fast] = (var().cpu(), rep)
+    (xf, rf), (xg, rg) = out[True], out[False]
+    assert rf["itr"] == rg["itr"] == K
+    assert bool(torch.isfinite(xf).all())
+    if method == "jacobi" and n[1] % (2 if dtype == "double" else 4) == 0:
+        assert torch.equal(xf, xg)
+    rtol = 1e-11 if dtype == "double" else 1e-5
+    assert rel_err(xf, xg) <= rtol, rel_err(xf, xg)
+    mo = O.OMesh([0.0, 0.0], [1.0, 1.5], list(n), dtype, "rz")
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        xo, ro = O.solve_poisson(mo, cfg, rhs.to(mo.dtype), method=method, tol=-1.0,
+                                 max_it=K if method == "bicgstab" else K - 1, coeff=0.9)
+    assert ro["itr"] == K
+    assert rel_err(xf, xo) <= (1e-10 if dtype == "double" else 1e-5), rel_err(xf, xo)
+
+
+@pytest.mark.parametrize("n,pitched", [((520, 1024), False), ((513, 1025), True)], ids=["even_rows", "odd_rows_pitched"])
+def test_rz_marching_kernel_is_what_runs(n, pitched):
+    """the launch geometry log names the kernel (PYAPES_HIP_DEBUG): CG phases of a large axisymmetric mesh on k_cg2d"""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+            "import torch, warnings\nwarnings.simplefilter('ignore')\n"
+            "from pyapes_amd.geometry import Cylinder\nfrom pyapes_amd.mesh import Mesh\nfrom pyapes_amd.variables import Field\n"
+            "from pyapes_amd.solver.fdm import FDM\nfrom pyapes_amd.solver.ops import Solver\nimport pyapes_oracle as O\n"
+            "cfg = [dict(c, bc_val_opt=None) for c in O.mixed_cfg([0.0, 1.0, 0.3, 0.5], ['neumann', 'dirichlet', 'dirichlet', 'neumann'], O.FACES_RZ)]\n"
+            "mesh = Mesh(Cylinder([0.0, 0.0], [1.0, 1.5]), None, %r, 'cuda', 'double')\n"
+            "var = Field('p', 1, mesh, {'domain': cfg, 'obstacle': None})\n"
+            "s = Solver({'fdm': {'method': 'cg', 'tol': -1.0, 'max_it': 3, 'report': False}})\n"
+            "s.set_eq(FDM().laplacian(1.0, var) == torch.ones_like(var()))\n"
+            "s.solve()\n" % (root, os.path.join(root, "oracle"), list(n)))
+    env = dict(os.environ, PYAPES_HIP_DEBUG="1")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stderr.splitlines() if "k_cg2d phase" in ln]
+    tag = " (pitched)" if pitched else ":"
+    assert any(("phase A" + tag) in ln for ln in lines) and any(("phase B" + tag) in ln for ln in lines), r.stderr[-1500:]
