@@ -229,6 +229,7 @@ int pa_place_begin(pa_ctx* c, const void* x, size_t array_bytes);   // pa_cg_beg
 int pa_place_tick(pa_ctx* c);                                        // top of every iteration, before phase A
 int pa_place_batch_end(pa_ctx* c);                                   // after the last iteration a call enqueues
 void pa_place_r_written(pa_ctx* c);                                  // phase B has written r into c->cg_r_out
+int pa_place_prepare_block(pa_ctx* c, void* block);                  // pa_solver.hip: zero what the tiled phases never write
 void pa_place_end(pa_ctx* c, int may_free);                          // the solve is over (or dropped); may_free: the stream has been waited for
 void pa_place_reset(pa_ctx* c);                                      // the arrays changed: free the pool, forget the pass
 void pa_place_destroy(pa_ctx* c);

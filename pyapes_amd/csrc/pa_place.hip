@@ -12,16 +12,17 @@
 // iteration on the ctx stream; the host stays at most one iteration ahead of the GPU while a search is on, which costs
 // the GPU nothing: it always has a whole iteration queued).  After one clean iteration PAIR (both parities of the
 // direction ping-pong) a trial moves ONE role into another block:
-//   * a direction buffer exactly when phase A is about to overwrite it -- no copy, the old content is dead; a block
-//     fresh from hipMalloc gets one memset (the phases never write the boundary rows / pad cells they skip: 0.1
-//     iteration of traffic), a block that already carried r / d in this solve nothing at all;
+//   * a direction buffer exactly when phase A is about to overwrite it -- no copy, the old content is dead; in a block
+//     fresh from hipMalloc the few cells the tiled phases never write (the last boundary row / column of a non-periodic
+//     axis, pad cells of pitched rows) are zeroed first, O(n^2) of them; a block that already carried r / d in this
+//     solve needs nothing at all;
 //   * r by having ONE phase B write the new residual into the other block instead of in place (k_cg3d / k_cg2d / k_cg_b
 //     take the output pointer separately: no copy either, and moving back costs the same nothing).
 // The next iteration pair IS the measurement: accepted if it beats the best pair by 1.5 % (3 % at once, else a second
 // pair decides), otherwise undone.  hipMalloc costs ~10 us and does not wait for the stream (profiles/tools/
 // mallocbench.hip: 1 GiB 12 us, 2 GiB 0.2 ms; hipFree drains the device, so blocks are only freed where the solve
-// synchronises anyway, at its end).  What the trials cost -- the memsets, the lost time of trial iterations that ran
-// slower -- is accounted in microseconds against the time the solves of this context have taken so far, and a new
+// synchronises anyway, at its end).  What the trials cost -- the lost time of trial iterations that ran slower, the
+// allocations -- is accounted in microseconds against the time the solves of this context have taken so far, and a new
 // trial only starts while that share is below `budget` (3 %): a 30-iteration solve pays for at most one or two
 // trials, a 1000-iteration solve for the whole pass (3 roles x `blocks` candidates), and nobody pays up front.
 // The pass is remembered per context; up to four different x pointers get a pass of their own (the pairing that
@@ -206,7 +207,7 @@ int pa_place_tick(pa_ctx* c) {
   const size_t off_r = (size_t)((char*)c->scr[SCR_R] - (char*)c->scr_base[SCR_R]);
   // a device-side stop (converged, max_it) turns the remaining iterations into no-ops: their durations say nothing
   auto plausible = [&](int64_t j) { return dur(P, j) >= 0.3 * P.base; };
-  // what a switch (copy / memset, bracketed by its own event pair) took; both events are long complete when asked
+  // what a switch (zeroing the cells the phases skip, bracketed by its own event pair) took; both events are long complete when asked
   auto switch_us = [&]() -> double {
     float ms = 0.f;
     if (!P.sw_timed || hipEventElapsedTime(&ms, P.evs[0], P.evs[1]) != hipSuccess) { (void)hipGetLastError(); return 0.0; }
@@ -309,13 +310,15 @@ int pa_place_tick(pa_ctx* c) {
         const size_t off = (size_t)((char*)c->scr[SLOT[q]] - (char*)c->scr_base[SLOT[q]]);
         P.sw_timed = 0;
         if (P.spare_epoch[P.cand] != P.epoch) {
-          // the phases never write the boundary rows / pad cells they skip: those must read 0 (pa_cg_begin) -- one
-          // memset for a block that has not carried r / d in this solve
+          // the tiled phases never write the boundary rows / pad cells they skip: those must read 0 (pa_cg_begin) -- for
+          // a block that has not carried r / d in this solve, ONLY those are zeroed (O(n^2) cells; nothing at all on a
+          // fully periodic mesh), not the whole array
           PA_HIP(c, hipEventRecord(P.evs[0], c->stream));
-          PA_HIP(c, hipMemsetAsync(P.spare[P.cand] + off, 0, P.bytes, c->stream));
+          const int launched = pa_place_prepare_block(c, P.spare[P.cand] + off);
           PA_HIP(c, hipEventRecord(P.evs[1], c->stream));
+          PA_HIP(c, hipGetLastError());
           P.spare_epoch[P.cand] = P.epoch;
-          P.sw_timed = 1;
+          P.sw_timed = launched;
         }
         if (q == 0) {   // r: this iteration's phase B writes the new residual into the block; from i + 1 on r lives there
           c->cg_r_out = P.spare[P.cand] + off;

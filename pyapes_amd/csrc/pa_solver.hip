@@ -174,7 +174,6 @@ __global__ void __launch_bounds__(PA_BLOCK) k_cg_b(DevGeom G, DevEq<T> E, const 
       x[idx] = xn;
       T aAd = alpha * Ad;
       rn = r[idx] - aAd;
-      r_out[idx] = rn;   // (r itself, or r's new block when the placement search moves it; zero outside S there already)
       T p = rn * rn;
       s[0] += (double)p;
       if (!pa_on_shell(G, i, j, k)) {
@@ -183,6 +182,8 @@ __global__ void __launch_bounds__(PA_BLOCK) k_cg_b(DevGeom G, DevEq<T> E, const 
         s[1] += (double)p2;
       }
     }
+    // (every node: r itself, or r's new block when the placement search moves it -- 0 outside S, as r is everywhere)
+    r_out[idx] = rn;
     if (send_lo && i == 0) send_lo[j * G.s1 + k] = rn;
     if (send_hi && i == G.n0 - 1) send_hi[j * G.s1 + k] = rn;
   }
@@ -808,6 +809,43 @@ __global__ void __launch_bounds__(PA_BLOCK) k_bicg_post(SolverScalars* sc, const
       sc->rho = sc->rho_next;
     }
   }
+}
+
+// The cells of r / d the tiled CG phases never write -- the last boundary row / column of a non-periodic axis
+// (launch_cg3d does not tile them) and the pad cells of pitched rows -- must read 0 (pa_cg_begin zeroes them once).  A
+// block the placement search brings in fresh from hipMalloc (pa_place.hip) needs exactly these zeroed, not a memset of
+// the whole array: O(n^2) cells instead of a write pass (0.16 ms at 512^3, and nothing at all on a fully periodic mesh).
+template <typename T>
+__global__ void __launch_bounds__(PA_BLOCK) k_zero_skipped(DevGeom G, T* __restrict__ a, int64_t ps1, int zrow, int zcol) {
+  const int64_t s1 = ps1 ? ps1 : G.s1, rows = G.n0 * G.n1, pw = ps1 ? ps1 - G.n2 : 0;
+  const int64_t n_pad = rows * pw, n_row = zrow ? G.n0 * G.n2 : 0, n_col = zcol ? rows : 0;
+  for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < n_pad + n_row + n_col; q += (int64_t)gridDim.x * blockDim.x) {
+    int64_t o;
+    if (q < n_pad) {
+      o = (q / pw) * s1 + G.n2 + q % pw;
+    } else if (q < n_pad + n_row) {
+      const int64_t t = q - n_pad, i = t / G.n2, k = t - i * G.n2;
+      o = (i * G.n1 + G.n1 - 1) * s1 + k;
+    } else {
+      o = (q - n_pad - n_row) * s1 + G.n2 - 1;
+    }
+    a[o] = (T)0;
+  }
+}
+
+// pa_place.hip: make `block` (the place of r or of a direction buffer in a block that has not carried one in this solve)
+// fit for the phases; returns 1 if a kernel was enqueued
+int pa_place_prepare_block(pa_ctx* c, void* block) {
+  const DevGeom& G = c->G;
+  const int zrow = G.act[1] && G.bct[3] != PA_BC_PERIODIC && G.n1 > 2, zcol = G.bct[5] != PA_BC_PERIODIC && G.n2 > 2;
+  const int64_t ps1 = c->cg_pitch ? c->cg_ps1 : 0;
+  const int64_t work = (ps1 ? G.n0 * G.n1 * (ps1 - G.n2) : 0) + (zrow ? G.n0 * G.n2 : 0) + (zcol ? G.n0 * G.n1 : 0);
+  if (work <= 0) return 0;
+  if (c->dtype == PA_F64)
+    hipLaunchKernelGGL(k_zero_skipped<double>, dim3(pa_grid_blocks(work)), dim3(PA_BLOCK), 0, c->stream, G, (double*)block, ps1, zrow, zcol);
+  else
+    hipLaunchKernelGGL(k_zero_skipped<float>, dim3(pa_grid_blocks(work)), dim3(PA_BLOCK), 0, c->stream, G, (float*)block, ps1, zrow, zcol);
+  return 1;
 }
 
 // ---- host side ----------------------------------------------------------------------------------
