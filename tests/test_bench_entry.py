@@ -142,7 +142,7 @@ def test_hung_collective_in_the_warm_up_falls_back_inside_the_run():
     import time
     t0 = time.time()
     p = _run(["--gpus", "2", "--size", "48,40,136", "--steps", "4", "--warmup", "2", "--no-cpu-baseline"],
-             dict(HOSTRING, PYAPES_HIP_HOSTRING_FAIL="1:hang:1", BENCH_WARMUP_TIMEOUT="6", PYAPES_HIP_HOSTRING_TIMEOUT="40"))
+             dict(HOSTRING, PYAPES_HIP_HOSTRING_FAIL="1:hang:1", BENCH_WARMUP_TIMEOUT="6", PYAPES_HIP_HOSTRING_TIMEOUT="16"))
     assert p.returncode == 0, p.stderr[-3000:]
     assert time.time() - t0 < 300
     rec = json.loads([ln for ln in p.stdout.splitlines() if ln.strip()][0])

@@ -87,7 +87,9 @@ def test_two_slabs_pair_bc_kernels(name, tmp_path, monkeypatch):
     assert abs(paired["tol"] - plain["tol"]) <= 1e-12 * abs(plain["tol"])
 
 
-def _worker_rccl(rank, world, port, name, n, K, out, lib_comm, env=None):
+def _worker_rccl(rank, world, port, name, n, K, out, runs):
+    """runs: list of (label, env) solved one after the other in ONE process (one RCCL process group; a fresh mesh /
+    context / library-side communicator per run)."""
     import sys
     here = os.path.dirname(os.path.abspath(__file__))
     sys.path.insert(0, here)
@@ -95,36 +97,45 @@ def _worker_rccl(rank, world, port, name, n, K, out, lib_comm, env=None):
     warnings.filterwarnings("ignore")
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
-    os.environ["PYAPES_HIP_COMM"] = "1" if lib_comm else "0"
-    os.environ.update(env or {})
     torch.cuda.set_device(0)
     dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", 0))
     try:
         from pyapes_amd.geometry import Box
+        from pyapes_amd.hip.context import context_for
         from pyapes_amd.mesh import Mesh
         from pyapes_amd.slab import SlabCG
         from pyapes_amd.variables import Field
         bcs = [{"bc_face": O.FACES[i], "bc_type": t, "bc_val": v, "bc_val_opt": None}
                for i, (t, v) in enumerate(CASES[name])]
-        mesh = Mesh(Box[0:1, 0:1, 0:0.5], None, list(n), "cuda", "double", slab=(rank, world))
-        var = Field("p", 1, mesh, {"domain": bcs, "obstacle": None})
         g = torch.Generator().manual_seed(7)
         rhs_g = torch.randn((1, *n), generator=g, dtype=torch.float64)
         if name == "per":
             rhs_g -= rhs_g.mean()
-        drv = SlabCG(mesh, var, rhs_g.cuda(), [{"kind": 0, "sign": -1.0, "coeff": 0.7}], dist)
-        assert drv.lib_comm == lib_comm, "library-side RCCL communicator not in use"
-        rep = drv.solve(1e-30, K, poll=3)
-        want_fold = lib_comm and os.environ.get("PYAPES_HIP_SLAB_FOLD", "1") != "0"
-        assert drv.folded == want_fold, f"folded={drv.folded}, expected {want_fold}"
-        if lib_comm:   # a second solve on the same mesh reuses the communicator (no silent fallback)
-            first = var().clone()
-            var2 = Field("p", 1, mesh, {"domain": bcs, "obstacle": None})
-            drv2 = SlabCG(mesh, var2, rhs_g.cuda(), [{"kind": 0, "sign": -1.0, "coeff": 0.7}], dist)
-            assert drv2.lib_comm, "second solve fell back to the stepwise driver"
-            rep2 = drv2.solve(1e-30, K, poll=3)
-            assert torch.equal(var2(), first) and rep2.itr == rep.itr
-        torch.save({"x": var().cpu(), "itr": int(rep.itr), "tol": float(rep.tol)}, out)
+        res = {}
+        for label, env in runs:
+            for k in ("PYAPES_HIP_COMM", "PYAPES_HIP_COMM_OVERLAP", "PYAPES_HIP_SLAB_FOLD"):
+                os.environ.pop(k, None)
+            os.environ.update(env)
+            lib_comm = env.get("PYAPES_HIP_COMM", "1") != "0"
+            mesh = Mesh(Box[0:1, 0:1, 0:0.5], None, list(n), "cuda", "double", slab=(rank, world))
+            var = Field("p", 1, mesh, {"domain": bcs, "obstacle": None})
+            drv = SlabCG(mesh, var, rhs_g.cuda(), [{"kind": 0, "sign": -1.0, "coeff": 0.7}], dist)
+            assert drv.lib_comm == lib_comm, "library-side RCCL communicator not in use"
+            rep = drv.solve(1e-30, K, poll=3)
+            want_fold = lib_comm and env.get("PYAPES_HIP_SLAB_FOLD", "1") != "0"
+            assert drv.folded == want_fold, f"folded={drv.folded}, expected {want_fold}"
+            if lib_comm:   # a second solve on the same mesh reuses the communicator (no silent fallback)
+                first = var().clone()
+                var2 = Field("p", 1, mesh, {"domain": bcs, "obstacle": None})
+                drv2 = SlabCG(mesh, var2, rhs_g.cuda(), [{"kind": 0, "sign": -1.0, "coeff": 0.7}], dist)
+                assert drv2.lib_comm, "second solve fell back to the stepwise driver"
+                rep2 = drv2.solve(1e-30, K, poll=3)
+                assert torch.equal(var2(), first) and rep2.itr == rep.itr
+                torch.cuda.synchronize()          # release the communicators before the next run makes its own
+                context_for(mesh).comm_destroy()
+                context_for(mesh).comm_ready = None
+            res[label] = {"x": var().cpu(), "itr": int(rep.itr), "tol": float(rep.tol)}
+        torch.save(res, out)
     finally:
         dist.destroy_process_group()
 
@@ -137,25 +148,26 @@ LIB_MODES = {
 }
 
 
-@pytest.mark.parametrize("mode", list(LIB_MODES))
 @pytest.mark.parametrize("name", ["per", "xper", "mix"])
-def test_library_side_rccl_one_rank(name, mode, tmp_path):
+def test_library_side_rccl_one_rank(name, tmp_path):
     """The C-side iteration loop (pa_cg_iterate_comm) with a 1-rank RCCL communicator -- on a periodic
     axis 0 the rank is its own ring neighbour, so the packed plane exchange really runs -- against the
     stepwise torch.distributed driver (bit for bit: with one rank the folded sequence adds the same
     partial rows in the same order) and the single-domain oracle.  Modes: the folded sequence (row
     all-reduces, mid kernel), the same with the exchange on the second communicator / stream (the default
-    for N > 1 ranks), and the stepwise sequence inside the library."""
+    for N > 1 ranks), and the stepwise sequence inside the library.  (One rank process per BC mix runs all four.)"""
     if name not in CASES:
         pytest.skip(name)
     n, K = (24, 20, 132), 6
-    res = {}
-    for lib_comm in (True, False):
-        out = str(tmp_path / f"x{int(lib_comm)}.pt")
-        spawn_ranks(_worker_rccl, lambda port: (1, port, name, n, K, out, lib_comm, LIB_MODES[mode] if lib_comm else None), 1)
-        res[lib_comm] = torch.load(out)
-    assert torch.equal(res[True]["x"], res[False]["x"]) and res[True]["itr"] == res[False]["itr"] == K + 1
-    assert res[True]["tol"] == res[False]["tol"]
+    out = str(tmp_path / "x.pt")
+    runs = [("stepwise_driver", {"PYAPES_HIP_COMM": "0"})] + [(m, LIB_MODES[m]) for m in LIB_MODES]
+    spawn_ranks(_worker_rccl, lambda port: (1, port, name, n, K, out, runs), 1)
+    allres = torch.load(out)
+    ref = allres["stepwise_driver"]
+    for m in LIB_MODES:
+        assert torch.equal(allres[m]["x"], ref["x"]) and allres[m]["itr"] == ref["itr"] == K + 1, m
+        assert allres[m]["tol"] == ref["tol"], m
+    res = {True: allres["folded"], False: ref}
     mesh = O.OMesh([0, 0, 0], [1, 1, 0.5], list(n), "double")
     cfg = [{"bc_face": O.FACES[i], "bc_type": t, "bc_val": v} for i, (t, v) in enumerate(CASES[name])]
     g = torch.Generator().manual_seed(7)
