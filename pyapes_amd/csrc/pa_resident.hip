@@ -18,7 +18,8 @@
 // every workgroup return without storing anything, and the host runs the launch-per-phase loop instead.
 // Jacobi: one step per sweep (the outer layers of x travel with the stop-test partial).  BiCGSTAB: three.
 //
-// Scope: one GPU, scalar operator coefficients (any term list pa_apply_terms knows, xyz or rz), mesh <= 128
+// Scope: one GPU, any term list pa_apply_terms knows (xyz or rz; tensor coefficients / speed fields since round 4: read
+// from device memory by the general-equation build), mesh <= 128
 // boxes of <= 4096 cells (and what fits the LDS: BiCGSTAB keeps six arrays); a periodic axis is never cut (the
 // fill of its faces reads the far end of the axis), the box is its own neighbour there.  Everything else runs
 // the launch-per-phase loops.
@@ -971,7 +972,15 @@ __global__ void __launch_bounds__(NT) k_resident(DevGeom G, DevEq<T> E, ResArgs<
               T cC = (rc == 1 || rc == 2) ? -cB : E.lap.m2inv[a];
               dg = dg + cC;
             }
-            if (t.has_coeff) dg = dg * t.coeff;
+            if (t.has_coeff) {
+              T cfv = t.coeff;
+              if (!LEAN && t.coeff_f) {   // tensor coefficient Gamma(x) (fdm.py:166-169): read where it lives, device memory
+                int bi, bj, bk;
+                decode(c, bi, bj, bk);
+                cfv = t.coeff_f[(int64_t)(LO(0) + bi) * G.s0 + (int64_t)(LO(1) + bj) * G.s1 + (LO(2) + bk)];
+              }
+              dg = dg * cfv;
+            }
             dg = dg * t.sign;
             diag = diag + dg;
           }
@@ -1111,8 +1120,9 @@ static bool res_applicable(const pa_ctx* c) {
     if (lo == PA_BC_NONE || hi == PA_BC_NONE) return false;
     if ((lo == PA_BC_PERIODIC) != (hi == PA_BC_PERIODIC)) return false;
   }
-  for (int q = 0; q < c->nterms; ++q)
-    if (c->terms[q].coeff_field || c->terms[q].u_field) return false;
+  // (tensor coefficients / speed fields, round 4: the general-equation build evaluates pa_apply_terms with the mesh's
+  // node indices, so Gamma(x) and u(x) are read where they live -- device memory, L2 hits on meshes of this size -- while
+  // the solver's own fields stay in LDS; central Div with a speed field reads u's wrap-around neighbours the same way)
   for (int a = 0; a < 3; ++a)
     if (G.act[a] && (a == 0 ? G.g0 : (a == 1 ? G.n1 : G.n2)) < 5) return false;
   return true;
@@ -1128,7 +1138,8 @@ int pa_resident_launch(pa_ctx* c, int solver, T* x, const T* rhs, double tol, in
   // its rows from the table of pa_coord_set, staged in LDS)
   // (option "res_rzlean" 0: pa_apply_terms on the box, as before round 3 -- tests)
   const bool rz_lean = c->coord != PA_COORD_XYZ && c->rz_tab && c->res_rzlean;
-  const bool lean = c->nterms == 1 && c->terms[0].kind == PA_OP_LAPLACIAN && (c->coord == PA_COORD_XYZ || rz_lean);
+  const bool lean = c->nterms == 1 && c->terms[0].kind == PA_OP_LAPLACIAN && !c->terms[0].coeff_field &&
+                    (c->coord == PA_COORD_XYZ || rz_lean);
   // threads per workgroup: more waves hide the LDS latency of the cell passes once a thread has several cells;
   // the general-equation build needs more registers than 512 / 1024 threads leave
   int nt = 256;

@@ -266,3 +266,48 @@ def test_resident_nonfinite_stop_test_raises(monkeypatch, method):
             warnings.simplefilter("ignore")
             s.solve()
     assert context_for(mesh).resident_used() > 0
+
+
+@pytest.mark.parametrize("method", ["cg", "jacobi", "bicgstab"])
+@pytest.mark.parametrize("n", [[40, 36], [12, 16, 18]], ids=["2d", "3d"])
+def test_resident_tensor_coefficient(monkeypatch, method, n):
+    """Round 4: ``laplacian(Gamma(x), phi)`` with a tensor coefficient runs resident too -- the general-equation build reads
+    Gamma from device memory through pa_apply_terms (and, for the Jacobi sweep, in diag(A)) while the solver's own fields
+    stay in LDS.  Against the launch-per-phase loops (Jacobi bit for bit, CG / BiCGSTAB to rounding with identical counts)
+    and the oracle."""
+    import pyapes_oracle as O
+    nd = len(n)
+    bcs = [("dirichlet", 0.0), ("neumann", 0.3), ("symmetry", None), ("dirichlet", 1.0), ("neumann", -0.2), ("dirichlet", 0.5)][:2 * nd]
+    g = torch.Generator().manual_seed(13)
+    rhs = torch.randn((1, *n), generator=g, dtype=torch.float64)
+    x0 = torch.randn((1, *n), generator=g, dtype=torch.float64)
+    gamma = 1.0 + 0.2 * torch.rand((1, *n), generator=g, dtype=torch.float64)
+    K = 6
+    out = {}
+    for resident in (True, False):
+        monkeypatch.setenv("PYAPES_HIP_RESIDENT", "1" if resident else "0")
+        mesh = Mesh(Box([0.0] * nd, [1.0 + 0.1 * a for a in range(nd)]), None, list(n), "cuda", "double")
+        cfg = [{"bc_face": FACES[i], "bc_type": t, "bc_val": v, "bc_val_opt": None} for i, (t, v) in enumerate(bcs)]
+        var = Field("p", 1, mesh, {"domain": cfg, "obstacle": None})
+        var.set_var_tensor(x0.cuda().clone())
+        s = Solver({"fdm": {"method": method, "tol": -1.0, "max_it": K if method == "bicgstab" else K - 1, "report": False}})
+        s.set_eq(-FDM().laplacian(gamma.cuda(), var) == rhs.cuda().clone())
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            rep = s.solve()
+        used = context_for(mesh).resident_used()
+        assert (used > 0) == resident, (resident, used)
+        out[resident] = (var().cpu(), rep)
+    (xa, ra), (xb, rb) = out[True], out[False]
+    assert ra["itr"] == rb["itr"] == K
+    if method == "jacobi":
+        assert torch.equal(xa, xb)
+    assert float((xa - xb).abs().max()) <= 1e-11 * float(xb.abs().max())
+    om = O.OMesh([0.0] * nd, [1.0 + 0.1 * a for a in range(nd)], list(n), "double")
+    ocfg = [{"bc_face": FACES[i], "bc_type": t, "bc_val": v} for i, (t, v) in enumerate(bcs)]
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        xo, ro = O.solve_poisson(om, ocfg, rhs.clone(), x0=x0.clone(), method=method, tol=-1.0,
+                                 max_it=K if method == "bicgstab" else K - 1, coeff=gamma, sign=-1.0)
+    assert ro["itr"] == K
+    assert float(torch.linalg.norm(xa - xo) / torch.linalg.norm(xo)) <= 1e-10
