@@ -54,6 +54,13 @@ template <> struct SfBits<double> {
   static __device__ __forceinline__ double next(double x, double edge) { return mv(x, edge, false); }
 };
 
+// (Round 4, tried and removed: packed fp32 subtraction.  There is no v_pk_sub_f32, and the compiler issues four v_sub_f32
+// for a row of four cells -- 28 of the 104 VALU instructions of an Euler row.  a + (-b) through v_pk_add_f32 with the
+// negation as an operand modifier (inline asm) took the body from ~120 to ~98 VALU instructions, and the kernel from 158 /
+// 159 to 172 / 174 VGPRs, i.e. from three waves per SIMD to two: 256^3 fp32 31.4 against 31.6 us per step, c4t 35.9 / 35.9,
+// 512^3 210.0 / 210.4 -- nothing.  Forcing three waves (amdgpu_waves_per_eu) spills to scratch memory.  At 512^3 the step
+// runs at the speed of a plain copy of its arrays (210 us against 205); at 256^3, where both arrays sit in the Infinity
+// Cache and a copy takes 19.5 us, it is bound by issue AND by the waves it can keep in flight.)
 // PHASE 2: A x (KIND 0: Laplacian; else Laplacian + Div, or the Div term alone when lap_off)
 // PHASE 3: explicit Euler step (KIND = PA_OP_DIV_* of the advection term)
 // PHASE 7: explicit gradient
