@@ -468,9 +468,11 @@ static int launch_cg2d(pa_ctx* c, Cg3dArgs<T>& A, bool pitched) {
   const DevGeom& G = c->G;
   const int minrows_env = 0;   // (round 3's measurement knob: chunks of >= this many rows; the rule below is what it found)
   // axisymmetric mesh: this kernel is the ONLY tiled one (k_cg3d's one-plane tiling has no r rows), so it runs from
-  // the size on where the resident solver ends instead of from 1.5 M cells: the alternative is the generic kernels
+  // about the size on where the resident solver ends instead of from 1.5 M cells: the alternative is the generic kernels
   const bool rz = c->coord == PA_COORD_RZ;
-  const int64_t mincells = rz ? (c->cg2d_mincells < 0 ? -1 : 0) : c->cg2d_mincells;   // option "cg2d_mincells"; < 0: never
+  // (from 150 k cells on: below that a wave's row walk is latency, and the generic kernels win -- rz 101^2 launch per
+  // phase CG 25 us generic against 32 on this kernel; the resident solver takes such meshes anyway)
+  const int64_t mincells = rz ? (c->cg2d_mincells < 0 ? -1 : std::min<int64_t>(c->cg2d_mincells, 150000)) : c->cg2d_mincells;   // option "cg2d_mincells"; < 0: never
   if (mincells < 0 || c->ndim != 2 || G.act[0] || A.coeff_f || A.kind != 0 || c->slab) return 0;
   if (G.n1 < 8 || G.n2 < 2 * VEC) return 0;
   if (rz && !c->rz_tab) return 0;

@@ -977,7 +977,8 @@ static int64_t solver_pitch(const pa_ctx* c, const T* x) {
   const bool shape = (c->ndim == 3 && G.n0 >= 3 && G.n1 >= 3) || (c->ndim == 2 && G.n1 >= 3);
   // (axisymmetric meshes: their one tiled kernel is the 2-D marching k_cg2d<..., RZ>, pa_cg2d_kernel.h)
   const bool coord_ok = c->coord == PA_COORD_XYZ ||
-                        (c->coord == PA_COORD_RZ && c->ndim == 2 && c->rz_tab && G.n1 >= 8 && c->cg2d_mincells >= 0);
+                        (c->coord == PA_COORD_RZ && c->ndim == 2 && c->rz_tab && G.n1 >= 8 && c->cg2d_mincells >= 0 &&
+                         G.n1 * G.n2 >= std::min<int64_t>(c->cg2d_mincells, 150000));
   if (!(c->pitch && c->fastpath && !c->slab && coord_ok && shape && G.n2 % VECW != 0 && G.n2 >= 2 * VECW &&
         c->nterms == 1 && c->terms[0].kind == PA_OP_LAPLACIAN && !c->terms[0].coeff_field &&
         G.bct[4] != PA_BC_PERIODIC && G.bct[5] != PA_BC_PERIODIC && ((uintptr_t)x & (sizeof(T) - 1)) == 0 &&

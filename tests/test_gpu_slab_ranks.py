@@ -37,7 +37,7 @@ MODES = {
     "stepwise_in_library": {"PYAPES_HIP_SLAB_FOLD": "0"},             # round 1's sequence inside the C loop
 }
 ENV_KEYS = ("PYAPES_HIP_COMM", "PYAPES_HIP_COMM_OVERLAP", "PYAPES_HIP_SLAB_FOLD", "PYAPES_HIP_HOSTRING_FAIL",
-            "PYAPES_HIP_COMM_TIMEOUT", "PYAPES_HIP_HOSTRING_TIMEOUT")
+            "PYAPES_HIP_COMM_TIMEOUT", "PYAPES_HIP_HOSTRING_TIMEOUT", "PYAPES_HIP_PLACE")
 
 
 def _worker(rank, world, port, name, n, K, dtype, runs, out):
@@ -345,3 +345,20 @@ def test_solver_solve_on_a_slab_fp32(tmp_path):
         xo, ro = _oracle_any("mix", n, method, tol, K, "single")
         assert res[label]["itr"] == ro["itr"]
         assert _rel(res[label]["x"], xo) < 1e-5, (label, _rel(res[label]["x"], xo))
+
+
+def test_placement_search_inside_the_library_side_slab_loop(tmp_path):
+    """The online placement search (csrc/pa_place.hip) ticks inside pa_cg_iterate_comm too -- every rank searches for
+    itself while the row all-reduces and the plane exchange go on.  Forced onto these small slabs without a budget
+    (PYAPES_HIP_PLACE=2), where its timings are noise and roles move at random, it must change no bit of the folded
+    solve on two ranks -- r moves by having phase B write the new residual elsewhere AFTER the mid kernel has formed the
+    send planes from the old one -- and the stepwise-in-library sequence likewise."""
+    n, K = (24, 20, 132), 40
+    runs = [("folded", {"PYAPES_HIP_PLACE": "0"}, None), ("folded_search", {"PYAPES_HIP_PLACE": "2"}, None),
+            ("stepwise", {"PYAPES_HIP_SLAB_FOLD": "0", "PYAPES_HIP_PLACE": "0"}, None),
+            ("stepwise_search", {"PYAPES_HIP_SLAB_FOLD": "0", "PYAPES_HIP_PLACE": "2"}, None)]
+    res = _spawn(2, "xper", n, K, "double", runs, tmp_path)
+    assert all(k["lib_comm"] and k["folded"] for k in res["folded_search"]["ranks"])
+    assert torch.equal(res["folded"]["x"], res["folded_search"]["x"]) and res["folded"]["tol"] == res["folded_search"]["tol"]
+    assert torch.equal(res["stepwise"]["x"], res["stepwise_search"]["x"]) and res["stepwise"]["tol"] == res["stepwise_search"]["tol"]
+    assert res["folded"]["itr"] == res["folded_search"]["itr"] == K + 1
