@@ -300,6 +300,25 @@ int pa_bicg_x(pa_ctx* ctx);
 int pa_bicg_bc(pa_ctx* ctx);
 int pa_bicg_finish(pa_ctx* ctx);
 int pa_bicg_end(pa_ctx* ctx, pa_report* out);
+/* ---- stepwise Jacobi on a slab (the sweep of pa_jacobi, SURVEY a15, split at its exchanges and its reduction) ----
+ * The iterate ping-pongs between the caller's x and a field of the context, so the planes the neighbours need leave
+ * through the buffers of pa_slab_set: the periodic far planes of the new iterate through x_pack_*, its first / last
+ * owned plane (BCs filled) through r_send_lo / hi -- the driver (pyapes_amd/slab.py SlabJacobi) delivers the latter
+ * INTO the neighbours' x_ghost_lo / hi, which every sweep reads.
+ *   [pa_apply_bc, exchange ghost planes of x]
+ *   begin   records the start's boundary shell (x_old of the first stop test)
+ *   per sweep:
+ *     sweep   x' = x + omega (b - A x) / diag(A) on S; periodic far planes of x' out     -> [exchange far planes]
+ *     bc      BC fill of x'; local |x' - x|^2 -> sums[2]; first / last plane of x' out    -> [all-reduce sums[2]]
+ *                                                                                          [planes -> neighbours' x_ghost]
+ *     finish  stop test, sweep count (device side); the buffers change roles
+ *   end     report (synchronises); the final iterate is copied into x if it lives in the context's field
+ * Laplacian terms only, like pa_jacobi (a zero diagonal otherwise). */
+int pa_jacobi_begin(pa_ctx* ctx, void* x, const void* rhs, double tol, int64_t max_it, double omega);
+int pa_jacobi_sweep(pa_ctx* ctx);
+int pa_jacobi_bc(pa_ctx* ctx);
+int pa_jacobi_finish(pa_ctx* ctx);
+int pa_jacobi_end(pa_ctx* ctx, pa_report* out);
 /* While a stepwise solve is live (pa_cg_begin ... pa_cg_end / pa_cg_abort) pa_bc_clear, pa_bc_set and
  * pa_eq_set return PA_E_STATE: every phase re-reads that state. */
 int pa_report_read(pa_ctx* ctx, pa_report* out);  /* synchronises */
@@ -360,6 +379,9 @@ int pa_cg_iterate_comm(pa_ctx* ctx, int64_t n);
 /* the same for the stepwise BiCGSTAB (pa_bicg_begin ... pa_bicg_end): n iterations = 5 step calls + 3 all-reduces + the
  * exchanges of the v' planes (pa_slab_set_v) and of the packed r / x planes (pa_comm_plan) each, one C call */
 int pa_bicg_iterate_comm(pa_ctx* ctx, int64_t n);
+/* and for the stepwise Jacobi (pa_jacobi_begin ... pa_jacobi_end): n sweeps = 3 step calls + 1 all-reduce + the plane
+ * exchange(s) each, one C call */
+int pa_jacobi_iterate_comm(pa_ctx* ctx, int64_t n);
 int pa_comm_destroy(pa_ctx* ctx);
 /* Give up on the library's communicators while work that uses them may still be queued (a collective some rank
  * never joined): ncclCommAbort on both, then the ctx streams are drained.  The stepwise calls remain usable. */

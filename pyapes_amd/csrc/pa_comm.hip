@@ -101,6 +101,31 @@ int exchange_v(pa_ctx* c, Rccl* R, ncclComm_t comm, hipStream_t st) {
   return PA_OK;
 }
 
+// stepwise Jacobi: (which = 0) the periodic far planes of the new iterate, i.e. the packed buffers WITHOUT their first
+// plane, between the end ranks of the ring; (which = 1) the first / last owned plane of the new iterate into the
+// neighbours' ghost planes of x (pa_slab_set's x_ghost_lo / hi).  Same neighbours and same order as exchange().
+int exchange_jacobi(pa_ctx* c, Rccl* R, ncclComm_t comm, hipStream_t st, int which) {
+  const pa_exchange& P = c->plan;
+  const ncclDataType_t dt = c->dtype == PA_F64 ? ncclDouble : ncclFloat;
+  const int64_t n = c->G.s0;
+  if (P.nb_lo < 0 && P.nb_hi < 0) return PA_OK;
+  const size_t off = (size_t)n * (size_t)c->esize;
+  const void* s_lo = which ? c->r_send_lo : (const void*)((const char*)P.send_lo + off);
+  const void* s_hi = which ? c->r_send_hi : (const void*)((const char*)P.send_hi + off);
+  void* r_lo = which ? (void*)c->x_glo : (void*)((char*)P.recv_lo + off);
+  void* r_hi = which ? (void*)c->x_ghi : (void*)((char*)P.recv_hi + off);
+  const int64_t ns_lo = which ? (c->r_send_lo ? n : 0) : P.n_send_lo - n, ns_hi = which ? (c->r_send_hi ? n : 0) : P.n_send_hi - n;
+  const int64_t nr_lo = which ? (c->x_glo ? n : 0) : P.n_recv_lo - n, nr_hi = which ? (c->x_ghi ? n : 0) : P.n_recv_hi - n;
+  if (ns_lo <= 0 && ns_hi <= 0 && nr_lo <= 0 && nr_hi <= 0) return PA_OK;
+  PA_NCCL(c, R, R->GroupStart());
+  if (P.nb_lo >= 0 && ns_lo > 0) PA_NCCL(c, R, R->Send(s_lo, (size_t)ns_lo, dt, P.nb_lo, comm, st));
+  if (P.nb_hi >= 0 && ns_hi > 0) PA_NCCL(c, R, R->Send(s_hi, (size_t)ns_hi, dt, P.nb_hi, comm, st));
+  if (P.nb_hi >= 0 && nr_hi > 0) PA_NCCL(c, R, R->Recv(r_hi, (size_t)nr_hi, dt, P.nb_hi, comm, st));
+  if (P.nb_lo >= 0 && nr_lo > 0) PA_NCCL(c, R, R->Recv(r_lo, (size_t)nr_lo, dt, P.nb_lo, comm, st));
+  PA_NCCL(c, R, R->GroupEnd());
+  return PA_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -448,6 +473,29 @@ int pa_bicg_iterate_comm(pa_ctx* c, int64_t n) {
     if ((rc = pa_bicg_bc(c))) return rc;
     PA_NCCL(c, R, R->AllReduce(sums + 5, sums + 5, 1, ncclDouble, ncclSum, comm, c->stream));
     if ((rc = pa_bicg_finish(c))) return rc;
+  }
+  return PA_OK;
+}
+
+// n Jacobi sweeps on a slab, everything on the ctx stream: sweep -> [far planes of a periodic ring] -> BC fill + local
+// |dx|^2 -> all-reduce -> first / last plane into the neighbours' ghost planes -> stop test.  Sweeps enqueued after the
+// device-side stop are no-ops (the collectives still run).
+int pa_jacobi_iterate_comm(pa_ctx* c, int64_t n) {
+  if (!c || c->solver_live != 3) { if (c) pa_set_err(c, "pa_jacobi_iterate_comm without pa_jacobi_begin"); return PA_E_STATE; }
+  if (!c->slab || !c->ext_sums) { pa_set_err(c, "pa_jacobi_iterate_comm needs slab mode (pa_slab_set)"); return PA_E_STATE; }
+  if (!c->comm || !c->plan_set) { pa_set_err(c, "pa_jacobi_iterate_comm needs pa_comm_init + pa_comm_plan"); return PA_E_STATE; }
+  PA_HIP(c, hipSetDevice(c->device));
+  Rccl* R = rccl();
+  ncclComm_t comm = (ncclComm_t)c->comm;
+  double* sums = c->ext_sums;
+  int rc;
+  for (int64_t q = 0; q < n; ++q) {
+    if ((rc = pa_jacobi_sweep(c))) return rc;
+    if ((rc = exchange_jacobi(c, R, comm, c->stream, 0))) return rc;
+    if ((rc = pa_jacobi_bc(c))) return rc;
+    PA_NCCL(c, R, R->AllReduce(sums + PA_SUM_DX2, sums + PA_SUM_DX2, 1, ncclDouble, ncclSum, comm, c->stream));
+    if ((rc = exchange_jacobi(c, R, comm, c->stream, 1))) return rc;
+    if ((rc = pa_jacobi_finish(c))) return rc;
   }
   return PA_OK;
 }

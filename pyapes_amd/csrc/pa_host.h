@@ -130,6 +130,8 @@ struct pa_ctx {
   int bc_pair = 0;  // per-axis pair kernels (lower + upper face + shell stop-test term in one launch)
   int bc_fused = 0, shell_cur = 0;  // fused BC fill: which half of SCR_SHELL holds x_old on the shell
   void* cg_x = nullptr;
+  const void* jac_rhs = nullptr;   // stepwise Jacobi on a slab (pa_jacobi_begin): the right-hand side and omega of the live solve
+  double jac_omega = 1.0;
   void* cg_r_out = nullptr;  // placement search: the NEXT phase B writes the new residual here instead of in place
   int64_t cg2d_mincells = 1500000;   // 2-D meshes of at least this many cells run the CG phases on k_cg2d (< 0: never)
   int bcl = 1;               // option "bcl" / PYAPES_HIP_BCL: explicit Euler march without a BC-fill launch per step (pa_sf_kernel.h)

@@ -2321,3 +2321,180 @@ int pa_bicg_end(pa_ctx* c, pa_report* out) {
 }
 
 }  // extern "C"
+
+// ============================================================================
+//  stepwise Jacobi on a slab (SURVEY a15 + 8e): x <- B(x + omega (b - A x) / diag(A)), the CG's stop test
+// ============================================================================
+// Per sweep: the sweep kernel on the local planes (ghost planes of x through Vec<T>: pa_slab_set's x_ghost_lo / hi) ->
+// [exchange of the periodic far planes of the NEW iterate] -> BC fill + shell term, local sum |dx|^2 -> sums[2]
+// -> [all-reduce 1] -> stop test (device side) -> [exchange of the new iterate's first / last plane -> x_ghost].
+// The iterate ping-pongs between the caller's x and a scratch field; the planes the neighbours need leave through the
+// packed send buffers of pa_slab_set (r_send_lo / hi: first / last owned plane; x_pack_*: the periodic far planes).
+template <typename T>
+__global__ void __launch_bounds__(PA_BLOCK) k_jacobi_rows_to_sum(const SolverScalars* __restrict__ sc, const double* __restrict__ partials,
+                                                                  int nblk, const double* __restrict__ partials_shell, int nblk_shell,
+                                                                  double* __restrict__ sums) {
+  __shared__ double sm[PA_BLOCK / 64];
+  if (sc->done) return;
+  const double dx2 = pa_reduce_partials(partials, nblk, 2, 1, sm);
+  const double sh = nblk_shell > 0 ? pa_reduce_partials(partials_shell, nblk_shell, 1, 0, sm) : 0.0;
+  if (threadIdx.x == 0) sums[PA_SUM_DX2] = dx2 + sh;
+}
+
+template <typename T>
+__global__ void k_jacobi_logic(SolverScalars* sc, const double* __restrict__ sums) {
+  if (threadIdx.x != 0 || blockIdx.x != 0 || sc->done) return;
+  pa_logic_jacobi<T>(sc, sums[PA_SUM_DX2]);
+}
+
+namespace {
+
+template <typename T>
+int jacobi_slab_begin_t(pa_ctx* c, T* x, const T* rhs, double tol, int64_t max_it, double omega) {
+  const DevGeom& G = c->G;
+  for (int q = 0; q < c->nterms; ++q)
+    if (c->terms[q].kind != PA_OP_LAPLACIAN) { pa_set_err(c, "pa_jacobi_begin: laplacian terms only"); return PA_E_ARG; }
+  const size_t fb = (size_t)G.ncell * sizeof(T);
+  int rc;
+  if ((rc = pa_scratch(c, &c->scr[SCR_D0], &c->cap[SCR_D0], fb))) return rc;
+  if ((rc = pa_scratch(c, &c->scr[SCR_PART], &c->cap[SCR_PART], (size_t)PA_MAX_PARTIALS * 4 * sizeof(double)))) return rc;
+  if ((rc = pa_scratch(c, &c->scr[SCR_PART2], &c->cap[SCR_PART2], (size_t)3 * PA_MAX_GRID * sizeof(double)))) return rc;
+  if ((rc = pa_scratch(c, &c->scr[SCR_SHELL], &c->cap[SCR_SHELL], 2 * (size_t)pa_shell_elems(c) * sizeof(T)))) return rc;
+  if ((rc = init_scalars(c, tol, max_it))) return rc;
+  c->bc_static = pa_bc_is_static(c);
+  c->bc_fused = pa_bc_fusable(c);
+  c->bc_pair = (!c->bc_fused && pa_bc_pairable(c)) ? 1 : 0;
+  c->shell_cur = 0;
+  c->fold_a_n = c->fold_b_n = c->fold_b_nsh = 0;
+  c->cg_pitch = 0;
+  c->cg_ps1 = 0;
+  // the driver has filled the BCs (it needs the far planes for that) and exchanged the ghost planes of x: only the
+  // shell of the start is recorded here (x_old of the first stop test)
+  if (c->bc_pair) {
+    if ((rc = pa_bc_pair_apply<T>(c, x, nullptr, 3, false, nullptr))) return rc;
+  } else {
+    pa_shell_launch<T>(c, (const T*)x, (T*)c->scr[SCR_SHELL] + (c->shell_cur ? pa_shell_elems(c) : 0), (double*)c->scr[SCR_PART2], 0);
+  }
+  c->cg_x = x;
+  c->jac_rhs = rhs;
+  c->jac_omega = omega;
+  c->cur = 0;            // the iterate lives in x (0) or in the scratch field (1)
+  c->solver_live = 3;    // (3: the stepwise Jacobi)
+  PA_HIP(c, hipGetLastError());
+  return PA_OK;
+}
+
+template <typename T>
+int jacobi_slab_sweep_t(pa_ctx* c) {
+  const DevGeom& G = c->G;
+  const int nblk = pa_grid_blocks(G.ncell);
+  DevEq<T> E;
+  pa_build_eq<T>(c, c->nterms, c->terms, E);
+  T* buf[2] = {(T*)c->cg_x, (T*)c->scr[SCR_D0]};
+  const int cur = c->cur;
+  Vec<T> xv = slab_vec<T>(c, buf[cur], c->x_glo, c->x_ghi);
+  double* part = (double*)c->scr[SCR_PART];
+  c->fold_b_n = 0;
+  int used = pa_tile3d_jacobi<T>(c, E, xv, (const T*)c->jac_rhs, buf[cur ^ 1], c->jac_omega, part);
+  if (used < 0) return used;
+  if (used == 0) {
+    hipLaunchKernelGGL(k_jacobi<T>, dim3(nblk), dim3(PA_BLOCK), 0, c->stream, G, E, c->sc, xv, (const T*)c->jac_rhs, buf[cur ^ 1],
+                       (T)c->jac_omega, part);
+    used = nblk;
+  }
+  c->b_blocks = used;
+  // the planes of the NEW iterate the other end of a periodic ring needs for its BC fill
+  if (c->x_pack_lo1 || c->x_pack_hi0 || c->x_pack_hi1) {
+    const T* xr = (const T*)buf[cur ^ 1];
+    hipLaunchKernelGGL(k_pack_planes<T>, dim3(pa_grid_blocks(G.s0)), dim3(PA_BLOCK), 0, c->stream, c->sc, G.s0,
+                       xr + 1 * G.s0, (T*)c->x_pack_lo1, xr + (G.n0 - 1) * G.s0, (T*)c->x_pack_hi0,
+                       xr + (G.n0 - 2) * G.s0, (T*)c->x_pack_hi1);
+  }
+  PA_HIP(c, hipGetLastError());
+  return PA_OK;
+}
+
+template <typename T>
+int jacobi_slab_bc_t(pa_ctx* c) {
+  const DevGeom& G = c->G;
+  T* buf[2] = {(T*)c->cg_x, (T*)c->scr[SCR_D0]};
+  T* xn = buf[c->cur ^ 1];
+  double* part = (double*)c->scr[SCR_PART];
+  double* part2 = (double*)c->scr[SCR_PART2];
+  int nsh = 0, rc;
+  if (!c->bc_static) {
+    if (c->bc_fused) {
+      if ((rc = pa_bc_shell_fused<T>(c, xn, part2, 1, true, &nsh, false))) return rc;
+    } else if (c->bc_pair) {
+      if ((rc = pa_bc_pair_apply<T>(c, xn, part2, 1, true, &nsh))) return rc;
+    } else {
+      if ((rc = pa_bc_apply_faces<T>(c, xn, true))) return rc;
+      nsh = pa_shell_blocks(c);
+      pa_shell_launch<T>(c, (const T*)xn, (T*)c->scr[SCR_SHELL], part2, 1);
+    }
+  }
+  hipLaunchKernelGGL(k_jacobi_rows_to_sum<T>, dim3(1), dim3(PA_BLOCK), 0, c->stream, c->sc, (const double*)part, c->b_blocks,
+                     (const double*)part2, nsh, pa_sums(c));
+  // the first / last owned plane of the new iterate, BCs filled: the neighbours' ghost planes of the next sweep
+  if (c->r_send_lo || c->r_send_hi)
+    hipLaunchKernelGGL(k_pack_planes<T>, dim3(pa_grid_blocks(G.s0)), dim3(PA_BLOCK), 0, c->stream, c->sc, G.s0,
+                       (const T*)xn, (T*)c->r_send_lo, (const T*)xn + (G.n0 - 1) * G.s0, (T*)c->r_send_hi, (const T*)nullptr, (T*)nullptr);
+  PA_HIP(c, hipGetLastError());
+  return PA_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+#define PA_JAC_LIVE(c, what)                                                                                          \
+  if (!(c) || (c)->solver_live != 3) { if (c) pa_set_err((c), what " without pa_jacobi_begin"); return PA_E_STATE; }   \
+  PA_HIP((c), hipSetDevice((c)->device));
+
+int pa_jacobi_begin(pa_ctx* c, void* x, const void* rhs, double tol, int64_t max_it, double omega) {
+  if (!c || !c->grid_set || !c->eq_set) { if (c) pa_set_err(c, "pa_jacobi_begin: grid/equation not set"); return PA_E_STATE; }
+  if (int rc0 = pa_check_eq_applicable(c)) return rc0;
+  if (!c->slab || !c->ext_sums) { pa_set_err(c, "pa_jacobi_begin is the stepwise form for slabs (pa_slab_set); one GPU: pa_jacobi"); return PA_E_STATE; }
+  PA_HIP(c, hipSetDevice(c->device));
+  return c->dtype == PA_F64 ? jacobi_slab_begin_t<double>(c, (double*)x, (const double*)rhs, tol, max_it, omega)
+                            : jacobi_slab_begin_t<float>(c, (float*)x, (const float*)rhs, tol, max_it, omega);
+}
+
+int pa_jacobi_sweep(pa_ctx* c) {
+  PA_JAC_LIVE(c, "pa_jacobi_sweep")
+  return c->dtype == PA_F64 ? jacobi_slab_sweep_t<double>(c) : jacobi_slab_sweep_t<float>(c);
+}
+
+int pa_jacobi_bc(pa_ctx* c) {
+  PA_JAC_LIVE(c, "pa_jacobi_bc")
+  return c->dtype == PA_F64 ? jacobi_slab_bc_t<double>(c) : jacobi_slab_bc_t<float>(c);
+}
+
+int pa_jacobi_finish(pa_ctx* c) {   // after the all-reduce of sums[PA_SUM_DX2]
+  PA_JAC_LIVE(c, "pa_jacobi_finish")
+  if (c->dtype == PA_F64) hipLaunchKernelGGL(k_jacobi_logic<double>, dim3(1), dim3(1), 0, c->stream, c->sc, (const double*)pa_sums(c));
+  else hipLaunchKernelGGL(k_jacobi_logic<float>, dim3(1), dim3(1), 0, c->stream, c->sc, (const double*)pa_sums(c));
+  c->cur ^= 1;
+  PA_HIP(c, hipGetLastError());
+  return PA_OK;
+}
+
+int pa_jacobi_end(pa_ctx* c, pa_report* out) {
+  PA_JAC_LIVE(c, "pa_jacobi_end")
+  pa_report tmp;
+  int rc = pa_report_read(c, out ? out : &tmp);   // synchronises: itr sweeps were executed
+  c->solver_live = 0;
+  if (rc) return rc;
+  // the final iterate lives in the buffer the last EXECUTED sweep wrote (x after an even number of sweeps), the one
+  // before it (Field.VARo on request) in the other buffer
+  const size_t fb = (size_t)c->G.ncell * (size_t)c->esize;
+  void* buf[2] = {c->cg_x, c->scr[SCR_D0]};
+  const int fin = (int)(c->h_sc->itr & 1);
+  if (c->x_old_out && c->h_sc->itr >= 1)
+    PA_HIP(c, hipMemcpyAsync(c->x_old_out, buf[fin ^ 1], fb, hipMemcpyDeviceToDevice, c->stream));
+  if (fin) PA_HIP(c, hipMemcpyAsync(c->cg_x, buf[1], fb, hipMemcpyDeviceToDevice, c->stream));
+  PA_HIP(c, hipStreamSynchronize(c->stream));
+  return (out && out->status) ? PA_E_NONFINITE : PA_OK;
+}
+
+}  // extern "C"

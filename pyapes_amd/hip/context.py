@@ -458,6 +458,33 @@ class HipContext:
         self._rc(self.lib.pa_cg_fold_plan(self.h, rows))
         return [int(v) for v in rows]
 
+    # stepwise Jacobi on a slab (pyapes_amd/slab.py SlabJacobi)
+    def jacobi_begin(self, x: Tensor, rhs: Tensor, tol: float, max_it: int, omega: float = 1.0) -> None:
+        self._keep["cg"] = (x, rhs)
+        self._rc(self.lib.pa_jacobi_begin(self.h, self._ptr(self._field(x, "jacobi")),
+                                          self._ptr(self._field(rhs, "jacobi rhs")), float(tol), int(max_it), float(omega)))
+
+    def jacobi_sweep(self) -> None:
+        self._rc(self.lib.pa_jacobi_sweep(self.h))
+
+    def jacobi_bc(self) -> None:
+        self._rc(self.lib.pa_jacobi_bc(self.h))
+
+    def jacobi_finish(self) -> None:
+        self._rc(self.lib.pa_jacobi_finish(self.h))
+
+    def jacobi_end(self) -> L.PaReport:
+        rep = L.PaReport()
+        rc = self.lib.pa_jacobi_end(self.h, C.byref(rep))
+        self._keep.pop("cg", None)
+        if rc == L.PA_E_NONFINITE:
+            raise RuntimeError(f"Invalid tolerance detected! tol: {rep.tol}")
+        self._rc(rc)
+        return rep
+
+    def jacobi_iterate_comm(self, n: int) -> None:
+        self._rc(self.lib.pa_jacobi_iterate_comm(self.h, int(n)))
+
     def cg_fold_set(self, rows: Sequence[int]) -> None:
         arr = (C.c_int64 * 3)(*[int(v) for v in rows])
         self._rc(self.lib.pa_cg_fold_set(self.h, arr))

@@ -124,6 +124,12 @@ SIGNATURES: dict[str, tuple[Any, list[Any]]] = {
     "pa_comm_plan": (C.c_int, [_VP, C.POINTER(PaExchange)]),
     "pa_cg_iterate_comm": (C.c_int, [_VP, C.c_int64]),
     "pa_bicg_iterate_comm": (C.c_int, [_VP, C.c_int64]),
+    "pa_jacobi_begin": (C.c_int, [_VP, _VP, _VP, C.c_double, C.c_int64, C.c_double]),
+    "pa_jacobi_sweep": (C.c_int, [_VP]),
+    "pa_jacobi_bc": (C.c_int, [_VP]),
+    "pa_jacobi_finish": (C.c_int, [_VP]),
+    "pa_jacobi_end": (C.c_int, [_VP, C.POINTER(PaReport)]),
+    "pa_jacobi_iterate_comm": (C.c_int, [_VP, C.c_int64]),
     "pa_comm_destroy": (C.c_int, [_VP]),
     "pa_comm_abort": (C.c_int, [_VP]),
     "pa_stream_wait": (C.c_int, [_VP, C.c_double]),

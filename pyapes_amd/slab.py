@@ -1,4 +1,4 @@
-"""Slab decomposition along axis 0 and the multi-GPU CG / BiCGSTAB drivers (new).
+"""Slab decomposition along axis 0 and the multi-GPU CG / BiCGSTAB / Jacobi drivers (new).
 
 The reference is single-device.  Here the 3-D grid is cut into P slabs of whole
 (n1 x n2) planes, one per rank / GPU.  Per CG iteration the ranks exchange
@@ -377,8 +377,73 @@ class SlabBiCGSTAB(_SlabDriver):
         return rep
 
 
+class SlabJacobi(_SlabDriver):
+    """Stepwise Jacobi over P slabs (the sweep of ``pa_jacobi`` -- [new, SURVEY a15] -- split at its exchanges; include/
+    pyapes_hip.h "stepwise Jacobi on a slab").  Per sweep: on a periodic ring the far planes of the new iterate travel
+    between the end ranks for the BC fill, one all-reduce carries |dx|^2, and the first / last owned plane of the new
+    iterate lands in the neighbours' ghost planes of x.  RCCL inside the library where the process group allows it
+    (``pa_jacobi_iterate_comm``), else ``torch.distributed`` between the step calls."""
+
+    uses_lib_comm = True
+
+    def __init__(self, mesh: Any, var: Any, rhs: Tensor, terms: Sequence[dict], dist: Any,
+                 backend: Any = None, group: Any = None, omega: float = 1.0):
+        super().__init__(mesh, var, rhs, terms, dist, backend, group)
+        self.omega = float(omega)
+
+    def _far_ops(self):
+        """The periodic x planes packed behind the first plane of the send buffers (``x_pack_*``), without that plane."""
+        def tail(t):
+            return t[1:] if (t is not None and t.shape[0] > 1) else None
+        return self._plane_ops(tail(self.send_lo), tail(self.send_hi), tail(self.recv_lo), tail(self.recv_hi))
+
+    def begin(self, tol: float, max_it: int, adjust_rhs: bool = True) -> None:
+        be = self.be
+        be.slab_set(self.bufs)
+        be.bind_bcs(self.var(), self.var.bcs, 0)
+        be.set_terms(self.terms)
+        if adjust_rhs:
+            be.rhs_adjust(self.rhs)
+        self._exchange_bc_far()
+        be.apply_bc_bound(self.x)
+        self._exchange_planes(self.x[0], self.x[-1], self.bufs["x_ghost_lo"], self.bufs["x_ghost_hi"])
+        be.jacobi_begin(self.x, self.rhs, tol, max_it, self.omega)
+
+    def iterate(self, n: int) -> None:
+        be = self.be
+        if self.lib_comm:
+            be.jacobi_iterate_comm(n)
+            return
+        for _ in range(n):
+            be.jacobi_sweep()                            # x' on S ; periodic far planes of x' out
+            if self.periodic0:
+                self._p2p(*self._far_ops())
+            be.jacobi_bc()                               # BC fill of x' ; local |dx|^2 ; first / last plane out
+            self._allreduce(2, 3)
+            self._exchange_planes(self.bufs["r_send_lo"], self.bufs["r_send_hi"],
+                                  self.bufs["x_ghost_lo"], self.bufs["x_ghost_hi"])
+            be.jacobi_finish()                           # stop test, sweep count (device side)
+
+    def solve(self, tol: float, max_it: int, poll: int = 8, adjust_rhs: bool = True) -> Any:
+        """Run to the reference's stop rule as the CG has it (tol / max_it + 1 sweeps)."""
+        self.begin(tol, max_it, adjust_rhs=adjust_rhs)
+        done = 0
+        while done <= max_it:
+            n = min(poll, max_it + 1 - done)
+            self.iterate(n)
+            done += n
+            if self.be.report().itr < done:
+                break
+        return self.end()
+
+    def end(self) -> Any:
+        rep = self.be.jacobi_end()
+        self.be.slab_set(None)
+        return rep
+
+
 def slab_solver(method: str, mesh: Any, var: Any, rhs: Tensor, terms: Sequence[dict], dist: Any = None,
-                backend: Any = None, group: Any = None) -> Any:
+                backend: Any = None, group: Any = None, omega: float = 1.0) -> Any:
     """The slab driver ``linalg.solve`` hands a solve on ``Mesh(..., slab=(rank, world))`` to."""
     if dist is None:
         import torch.distributed as dist_mod
@@ -390,4 +455,6 @@ def slab_solver(method: str, mesh: Any, var: Any, rhs: Tensor, terms: Sequence[d
         return SlabCG(mesh, var, rhs, terms, dist, backend, group)
     if method == "bicgstab":
         return SlabBiCGSTAB(mesh, var, rhs, terms, dist, backend, group)
-    raise NotImplementedError(f"pyapes_amd: method '{method}' is single-GPU only; slab meshes take cg and bicgstab")
+    if method == "jacobi":
+        return SlabJacobi(mesh, var, rhs, terms, dist, backend, group, omega=omega)
+    raise NotImplementedError(f"pyapes_amd: no slab driver for method '{method}' (cg, bicgstab, jacobi)")

@@ -104,7 +104,7 @@ def _run_slab(method: str, var: Field, rhs: Tensor, eqs: dict[int, OPStype], con
     if config.get("save_old", False):
         raise NotImplementedError('pyapes_amd: {"save_old": True} is single-GPU only')
     terms, _ = terms_of(eqs)
-    drv = slab_solver(method, mesh, var, rhs, terms, backend=backend)
+    drv = slab_solver(method, mesh, var, rhs, terms, backend=backend, omega=float(config.get("omega", 1.0)))
     rep = drv.solve(tol, max_it, adjust_rhs=False)
     var.mark_old_stale("solved on a slab mesh")
     itr, rtol = int(rep.itr), float(rep.tol)

@@ -336,3 +336,59 @@ class TorchSlabBackend:
 
     def bicg_end(self):
         return self.report()
+
+    # -- stepwise Jacobi (the sweep of pa_jacobi [new, SURVEY a15] split at its exchanges; include/pyapes_hip.h) -------
+    def _diag(self):
+        gi = list(range(self.off, self.off + self.n[0]))
+        c0 = self._coef_vec(0, gi, self.gn[0], "xl", "xu")[1]
+        c1 = self._coef_vec(1, list(range(self.n[1])), self.gn[1], "yl", "yu")[1]
+        c2 = self._coef_vec(2, list(range(self.n[2])), self.gn[2], "zl", "zu")[1]
+        dg = c0[:, None, None] + c1[None, :, None]
+        dg = dg + c2[None, None, :]
+        if self.coeff is not None:
+            dg = dg * self.coeff
+        return dg * self.sign
+
+    def jacobi_begin(self, x, rhs, tol, max_it, omega=1.0):
+        self.x, self.rhs_j, self.tolerance, self.max_it = x, rhs, tol, max_it
+        self.om = self._t(omega)
+        self.S = self._S()
+        self.dg = self._diag()
+        self.itr, self.done, self.tol = 0, False, 1.0
+
+    def jacobi_sweep(self):
+        if self.done:
+            return
+        b = self.bufs
+        ax = self._A(self.x, b["x_ghost_lo"], b["x_ghost_hi"])
+        self.x_old = self.x.clone()
+        w = self.om * ((self.rhs_j - ax) / self.dg)
+        self.x.copy_(torch.where(self.S, self.x + w, self.x))
+        for key, plane in (("x_pack_lo1", 1), ("x_pack_hi0", -1), ("x_pack_hi1", -2)):
+            if b.get(key) is not None:
+                b[key].copy_(self.x[plane])
+
+    def jacobi_bc(self):
+        if self.done:
+            return
+        b = self.bufs
+        self.apply_bc_bound(self.x)
+        df = self.x - self.x_old
+        b["sums"][2] = float(torch.sum(df * df))
+        if b["r_send_lo"] is not None:
+            b["r_send_lo"].copy_(self.x[0])
+        if b["r_send_hi"] is not None:
+            b["r_send_hi"].copy_(self.x[-1])
+
+    def jacobi_finish(self):
+        if self.done:
+            return
+        self.tol = float(torch.sqrt(self._t(self.bufs["sums"][2])))
+        if math.isnan(self.tol) or math.isinf(self.tol):
+            raise RuntimeError("Invalid tolerance detected!")
+        self.itr += 1
+        if self.itr > self.max_it or not (self.tol > self.tolerance):
+            self.done = True
+
+    def jacobi_end(self):
+        return self.report()

@@ -254,7 +254,10 @@ def _worker_solver(rank, world, port, name, n, jobs, dtype, out):
             mesh = Mesh(Box[0:1, 0:1, 0:0.5], None, list(n), "cuda", dtype, slab=(rank, world))
             var = Field("p", 1, mesh, {"domain": bcs, "obstacle": None})
             rhs = rhs_g.to(mesh.dtype.float)[:, mesh.i_off:mesh.i_off + mesh.nx[0]].contiguous().cuda()
-            solver = Solver({"fdm": {"method": method, "tol": tol, "max_it": K, "report": False}})
+            cfg = {"method": method, "tol": tol, "max_it": K, "report": False}
+            if method == "jacobi":
+                cfg["omega"] = 0.9
+            solver = Solver({"fdm": cfg})
             solver.set_eq(-FDM().laplacian(0.7, var) == rhs)
             rep = solver.solve()
             ctx = context_for(mesh)
@@ -282,32 +285,38 @@ def _oracle_any(name, n, method, tol, K, dtype="double"):
         rhs -= rhs.mean()
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
-        return O.solve_poisson(mesh, cfg, rhs.to(mesh.dtype), method=method, tol=tol, max_it=K, coeff=0.7, sign=-1.0)
+        kw = {"omega": 0.9} if method == "jacobi" else {}
+        return O.solve_poisson(mesh, cfg, rhs.to(mesh.dtype), method=method, tol=tol, max_it=K, coeff=0.7, sign=-1.0, **kw)
 
 
 @pytest.mark.parametrize("world,n", [(2, (24, 20, 132)), (4, (26, 20, 132))], ids=["2ranks", "4ranks_uneven"])
 @pytest.mark.parametrize("name", ["per", "xper", "mix"])
 def test_solver_solve_on_slab_meshes(name, world, n, tmp_path):
     """``Solver.solve()`` with ``Mesh(..., slab=(rank, world))`` on every rank: linalg.solve hands CG to SlabCG (the
-    library-side loop over the stand-in wire) and BiCGSTAB to SlabBiCGSTAB (planes of v' and r, three small all-reduces
+    library-side loop over the stand-in wire), Jacobi to SlabJacobi and BiCGSTAB to SlabBiCGSTAB (planes of v' and r, three small all-reduces
     per iteration: inside the library, pa_bicg_iterate_comm, and with torch.distributed between the step calls).
     Identical iteration counts and <= 1e-10 against the single-domain oracle; fully periodic, x-periodic (the ring
     across the ranks) and mixed faces; even and uneven slabs."""
     jobs = [("cg", "cg", 1e-30, 6), ("bicgstab", "bicgstab", 1e-30, 6),
-            ("bicgstab_stepwise", "bicgstab", 1e-30, 6, {"PYAPES_HIP_COMM": "0"})]
+            ("bicgstab_stepwise", "bicgstab", 1e-30, 6, {"PYAPES_HIP_COMM": "0"}),
+            # Jacobi (SlabJacobi): 7 sweeps end in the context's field (copied back), 8 in the caller's
+            ("jacobi", "jacobi", 1e-30, 6), ("jacobi_even", "jacobi", 1e-30, 7),
+            ("jacobi_stepwise", "jacobi", 1e-30, 6, {"PYAPES_HIP_COMM": "0"})]
     out = str(tmp_path / "res.pt")
     spawn_ranks(_worker_solver, lambda port: (world, port, name, n, jobs, "double", out), world)
     res = torch.load(out)
     assert res["cg"]["in_lib"] and res["bicgstab"]["in_lib"] and not res["bicgstab_stepwise"]["in_lib"]
+    assert res["jacobi"]["in_lib"] and not res["jacobi_stepwise"]["in_lib"]
     # the same step calls, the sums added by the stand-in in rank order / by gloo: two ranks -> the same bits
-    if world == 2:
-        assert torch.equal(res["bicgstab"]["x"], res["bicgstab_stepwise"]["x"])
-    else:
-        assert _rel(res["bicgstab"]["x"], res["bicgstab_stepwise"]["x"]) < 1e-12
+    for m in ("bicgstab", "jacobi"):
+        if world == 2:
+            assert torch.equal(res[m]["x"], res[m + "_stepwise"]["x"])
+        else:
+            assert _rel(res[m]["x"], res[m + "_stepwise"]["x"]) < 1e-12
     for label, method, tol, K in [j[:4] for j in jobs]:
         xo, ro = _oracle_any(name, n, method, tol, K)
         r = res[label]
-        assert r["itr"] == ro["itr"] == (K + 1 if method == "cg" else K), (label, r["itr"], ro["itr"])
+        assert r["itr"] == ro["itr"] == (K if method == "bicgstab" else K + 1), (label, r["itr"], ro["itr"])
         assert r["converge"] == ro["converge"]
         assert _rel(r["x"], xo) < 1e-10, (label, _rel(r["x"], xo))
         assert abs(r["tol"] - ro["tol"]) <= 1e-7 * abs(ro["tol"]), (label, r["tol"], ro["tol"])
@@ -336,7 +345,7 @@ def test_slab_bicgstab_converges_on_the_periodic_problem_cg_cannot_finish(tmp_pa
 
 
 def test_solver_solve_on_a_slab_fp32(tmp_path):
-    jobs = [("cg", "cg", 1e-30, 6), ("bicgstab", "bicgstab", 1e-30, 6)]
+    jobs = [("cg", "cg", 1e-30, 6), ("bicgstab", "bicgstab", 1e-30, 6), ("jacobi", "jacobi", 1e-30, 6)]
     n = (16, 12, 136)
     out = str(tmp_path / "res.pt")
     spawn_ranks(_worker_solver, lambda port: (2, port, "mix", n, jobs, "single", out), 2)
