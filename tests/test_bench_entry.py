@@ -142,19 +142,19 @@ def test_hung_collective_in_the_warm_up_falls_back_inside_the_run():
     import time
     t0 = time.time()
     p = _run(["--gpus", "2", "--size", "48,40,136", "--steps", "4", "--warmup", "2", "--no-cpu-baseline"],
-             dict(HOSTRING, PYAPES_HIP_HOSTRING_FAIL="1:hang:1", BENCH_WARMUP_TIMEOUT="6", PYAPES_HIP_HOSTRING_TIMEOUT="16"))
+             dict(HOSTRING, PYAPES_HIP_HOSTRING_FAIL="1:hang:1", BENCH_WARMUP_TIMEOUT="4", PYAPES_HIP_HOSTRING_TIMEOUT="9"))
     assert p.returncode == 0, p.stderr[-3000:]
     assert time.time() - t0 < 300
     rec = json.loads([ln for ln in p.stdout.splitlines() if ln.strip()][0])
     assert rec["config"]["parallelism"].startswith("slab2 (torch.distributed-stepwise")
-    assert "timeout after 6 s in the warm-up" in rec["first_attempt"]["outcome"]
+    assert "timeout after 4 s in the warm-up" in rec["first_attempt"]["outcome"]
     assert rec["value"] > 0 and rec["steps"] == 4
 
 
 @pytest.mark.gpu
 def test_failed_first_attempt_is_retried_once_by_the_launcher():
     """The second line of defence: the ranks' own watchdog is out of the way (BENCH_WARMUP_TIMEOUT far away) and a
-    collective of the first attempt fails for good (the stand-in gives up on it after 10 s and refuses further
+    collective of the first attempt fails for good (the stand-in gives up on it after 5 s and refuses further
     work, as RCCL does after an asynchronous error): the ranks die with an error, the launching parent runs ONE
     attempt on the stepwise driver and the record carries how the first attempt ended.  (That a HUNG attempt is
     stopped after BENCH_RANKS_TIMEOUT and both attempts fit 600 s is pinned on the host by
@@ -163,7 +163,7 @@ def test_failed_first_attempt_is_retried_once_by_the_launcher():
     import time
     t0 = time.time()
     p = _run(["--gpus", "2", "--size", "48,40,136", "--steps", "4", "--warmup", "2", "--no-cpu-baseline"],
-             dict(HOSTRING, PYAPES_HIP_HOSTRING_FAIL="1:hang:1", BENCH_WARMUP_TIMEOUT="900", PYAPES_HIP_HOSTRING_TIMEOUT="10",
+             dict(HOSTRING, PYAPES_HIP_HOSTRING_FAIL="1:hang:1", BENCH_WARMUP_TIMEOUT="900", PYAPES_HIP_HOSTRING_TIMEOUT="5",
                   BENCH_RANKS_TIMEOUT="200", BENCH_RANKS_BUDGET="400"))
     assert p.returncode == 0, p.stderr[-3000:]
     assert time.time() - t0 < 400

@@ -40,9 +40,10 @@ ENV_KEYS = ("PYAPES_HIP_COMM", "PYAPES_HIP_COMM_OVERLAP", "PYAPES_HIP_SLAB_FOLD"
             "PYAPES_HIP_COMM_TIMEOUT", "PYAPES_HIP_HOSTRING_TIMEOUT", "PYAPES_HIP_PLACE")
 
 
-def _worker(rank, world, port, name, n, K, dtype, runs, out):
-    """runs: list of (label, env dict, generic_rank or None) executed one after the other in ONE process group,
-    each on a fresh mesh / ctx / communicator."""
+def _worker(rank, world, port, cases, out):
+    """cases: list of (key, BC mix, n, K, dtype, runs); runs: list of (label, env dict, generic_rank or None).  Everything is
+    executed one after the other by the SAME rank processes in ONE process group (a process start costs more than a
+    solve), each run on a fresh mesh / ctx / communicator."""
     import sys
     here = os.path.dirname(os.path.abspath(__file__))
     sys.path.insert(0, here)
@@ -60,45 +61,78 @@ def _worker(rank, world, port, name, n, K, dtype, runs, out):
         from pyapes_amd.slab import SlabCG
         from pyapes_amd.variables import Field
         torch.cuda.set_device(0)
-        bcs = [{"bc_face": O.FACES[i], "bc_type": t, "bc_val": v, "bc_val_opt": None}
-               for i, (t, v) in enumerate(CASES[name])]
-        g = torch.Generator().manual_seed(7)
-        rhs_g = torch.randn((1, *n), generator=g, dtype=torch.float64)
-        if name == "per":
-            rhs_g -= rhs_g.mean()
-        res = {}
-        for label, env, generic_rank in runs:
-            for k in ENV_KEYS:
-                os.environ.pop(k, None)
-            os.environ.update(env)
-            mesh = Mesh(Box[0:1, 0:1, 0:0.5], None, list(n), "cuda", dtype, slab=(rank, world))
-            ctx = context_for(mesh)
-            if generic_rank == rank:
-                ctx.set_option("fastpath", False)     # this rank runs the generic kernels: it cannot fold
-            var = Field("p", 1, mesh, {"domain": bcs, "obstacle": None})
-            rhs = rhs_g.to(mesh.dtype.float)[:, mesh.i_off:mesh.i_off + mesh.nx[0]].contiguous().cuda()
-            drv = SlabCG(mesh, var, rhs, TERMS, dist)
-            info = {"lib_comm": bool(drv.lib_comm), "impl": ctx.comm_impl(),
-                    "overlap": bool(drv.lib_comm and ctx.comm_overlap()), "err": getattr(drv, "lib_comm_error", None)}
-            rep = drv.solve(1e-30, K, poll=3)
-            info["folded"] = bool(drv.folded)
-            if drv.lib_comm:      # release the communicators while every rank is alive
-                torch.cuda.synchronize()
-                ctx.comm_destroy()
-                ctx.comm_ready = None
-            parts, infos = [None] * world, [None] * world
-            dist.all_gather_object(parts, var().cpu())
-            dist.all_gather_object(infos, info)
-            res[label] = {"x": torch.cat(parts, dim=1), "itr": int(rep.itr), "tol": float(rep.tol), "ranks": infos}
+        allres = {}
+        for key, name, n, K, dtype, runs in cases:
+            bcs = [{"bc_face": O.FACES[i], "bc_type": t, "bc_val": v, "bc_val_opt": None}
+                   for i, (t, v) in enumerate(CASES[name])]
+            g = torch.Generator().manual_seed(7)
+            rhs_g = torch.randn((1, *n), generator=g, dtype=torch.float64)
+            if name == "per":
+                rhs_g -= rhs_g.mean()
+            res = {}
+            for label, env, generic_rank in runs:
+                for k in ENV_KEYS:
+                    os.environ.pop(k, None)
+                os.environ.update(env)
+                mesh = Mesh(Box[0:1, 0:1, 0:0.5], None, list(n), "cuda", dtype, slab=(rank, world))
+                ctx = context_for(mesh)
+                if generic_rank == rank:
+                    ctx.set_option("fastpath", False)     # this rank runs the generic kernels: it cannot fold
+                var = Field("p", 1, mesh, {"domain": bcs, "obstacle": None})
+                rhs = rhs_g.to(mesh.dtype.float)[:, mesh.i_off:mesh.i_off + mesh.nx[0]].contiguous().cuda()
+                drv = SlabCG(mesh, var, rhs, TERMS, dist)
+                info = {"lib_comm": bool(drv.lib_comm), "impl": ctx.comm_impl(),
+                        "overlap": bool(drv.lib_comm and ctx.comm_overlap()), "err": getattr(drv, "lib_comm_error", None)}
+                rep = drv.solve(1e-30, K, poll=3)
+                info["folded"] = bool(drv.folded)
+                if drv.lib_comm:      # release the communicators while every rank is alive
+                    torch.cuda.synchronize()
+                    ctx.comm_destroy()
+                    ctx.comm_ready = None
+                parts, infos = [None] * world, [None] * world
+                dist.all_gather_object(parts, var().cpu())
+                dist.all_gather_object(infos, info)
+                res[label] = {"x": torch.cat(parts, dim=1), "itr": int(rep.itr), "tol": float(rep.tol), "ranks": infos}
+            allres[key] = res
         if rank == 0:
-            torch.save(res, out)
+            torch.save(allres, out)
     finally:
         dist.destroy_process_group()
 
 
 def _spawn(world, name, n, K, dtype, runs, tmp_path):
     out = str(tmp_path / "res.pt")
-    spawn_ranks(_worker, lambda port: (world, port, name, n, K, dtype, runs, out), world)
+    spawn_ranks(_worker, lambda port: (world, port, [("only", name, n, K, dtype, runs)], out), world)
+    return torch.load(out)["only"]
+
+
+N2, N4, K_IT = (24, 20, 132), (26, 20, 132), 6
+CANNOT_FOLD = [("stepwise_driver", MODES["stepwise_driver"], 1), ("library", {}, 1)]
+THREE = [(m, MODES[m], None) for m in ("stepwise_driver", "folded", "stepwise_in_library")]
+PLACE_RUNS = [("folded", {"PYAPES_HIP_PLACE": "0"}, None), ("folded_search", {"PYAPES_HIP_PLACE": "2"}, None),
+              ("stepwise", {"PYAPES_HIP_SLAB_FOLD": "0", "PYAPES_HIP_PLACE": "0"}, None),
+              ("stepwise_search", {"PYAPES_HIP_SLAB_FOLD": "0", "PYAPES_HIP_PLACE": "2"}, None)]
+
+
+@pytest.fixture(scope="module")
+def two_ranks(tmp_path_factory):
+    """ONE pair of rank processes runs every fault-free two-rank case of the SlabCG tests below."""
+    cases = [(f"modes-{name}", name, N2, K_IT, "double", [(m, MODES[m], None) for m in MODES])
+             for name in ("per", "xper", "mix", "dir")]
+    cases += [("fp32", "xper", (16, 12, 136), K_IT, "single", THREE),
+              ("cannot_fold", "xper", N2, K_IT, "double", CANNOT_FOLD),
+              ("place", "xper", N2, 40, "double", PLACE_RUNS)]
+    out = str(tmp_path_factory.mktemp("two_ranks") / "res.pt")
+    spawn_ranks(_worker, lambda port: (2, port, cases, out), 2)
+    return torch.load(out)
+
+
+@pytest.fixture(scope="module")
+def four_ranks(tmp_path_factory):
+    cases = [(f"uneven-{name}", name, N4, K_IT, "double", THREE) for name in ("per", "xper", "mix")]
+    cases += [("cannot_fold", "xper", N4, K_IT, "double", CANNOT_FOLD)]
+    out = str(tmp_path_factory.mktemp("four_ranks") / "res.pt")
+    spawn_ranks(_worker, lambda port: (4, port, cases, out), 4)
     return torch.load(out)
 
 
@@ -128,13 +162,13 @@ def _check_against_oracle(res, name, n, K, dtype):
 
 
 @pytest.mark.parametrize("name", ["per", "xper", "mix", "dir"])
-def test_two_ranks_every_library_mode(name, tmp_path):
+def test_two_ranks_every_library_mode(name, two_ranks):
     """P = 2.  On the periodic ring ("per", "xper") both neighbours of a rank are the SAME peer: two sends and two
     receives per group to one rank, paired in program order (pa_comm.hip exchange())."""
     if name not in CASES:
         pytest.skip(name)
-    n, K = (24, 20, 132), 6
-    res = _spawn(2, name, n, K, "double", [(m, MODES[m], None) for m in MODES], tmp_path)
+    n, K = N2, K_IT
+    res = two_ranks[f"modes-{name}"]
     ref = res["stepwise_driver"]
     assert all(not r["lib_comm"] for r in ref["ranks"])
     for m in ("folded", "folded_one_stream", "stepwise_in_library"):
@@ -152,13 +186,12 @@ def test_two_ranks_every_library_mode(name, tmp_path):
 
 
 @pytest.mark.parametrize("name", ["per", "xper", "mix"])
-def test_four_ranks_uneven_slabs(name, tmp_path):
+def test_four_ranks_uneven_slabs(name, four_ranks):
     """P = 4, 26 planes = 7 + 7 + 6 + 6: interior ranks with two DISTINCT neighbours and no global x face, a ring
     longer than its end ranks, and per-rank grids of different size -- ranks 2 and 3 write fewer partial rows than
     the agreed counts, so their row all-reduces run out of place (rows they never write stay zero)."""
-    n, K = (26, 20, 132), 6
-    runs = [(m, MODES[m], None) for m in ("stepwise_driver", "folded", "stepwise_in_library")]
-    res = _spawn(4, name, n, K, "double", runs, tmp_path)
+    n, K = N4, K_IT
+    res = four_ranks[f"uneven-{name}"]
     ref = res["stepwise_driver"]
     for m in ("folded", "stepwise_in_library"):
         r = res[m]
@@ -169,10 +202,9 @@ def test_four_ranks_uneven_slabs(name, tmp_path):
     _check_against_oracle(res, name, n, K, "double")
 
 
-def test_fp32_two_ranks(tmp_path):
-    n, K = (16, 12, 136), 6
-    res = _spawn(2, "xper", n, K, "single", [(m, MODES[m], None) for m in ("stepwise_driver", "folded", "stepwise_in_library")],
-                 tmp_path)
+def test_fp32_two_ranks(two_ranks):
+    n, K = (16, 12, 136), K_IT
+    res = two_ranks["fp32"]
     assert torch.equal(res["stepwise_in_library"]["x"], res["stepwise_driver"]["x"])
     assert all(k["lib_comm"] and k["folded"] for k in res["folded"]["ranks"])
     assert _rel(res["folded"]["x"], res["stepwise_driver"]["x"]) < 1e-5
@@ -180,12 +212,11 @@ def test_fp32_two_ranks(tmp_path):
 
 
 @pytest.mark.parametrize("world,n", [(2, (24, 20, 132)), (4, (26, 20, 132))])
-def test_one_rank_cannot_fold_all_stay_stepwise(world, n, tmp_path):
+def test_one_rank_cannot_fold_all_stay_stepwise(world, n, request):
     """Rank 1 runs the generic kernels (no partial rows to fold): the ranks must agree to stay on the stepwise
     sequence INSIDE the library -- a rank folding alone would all-reduce rows against its peers' sums."""
-    K = 6
-    runs = [("stepwise_driver", MODES["stepwise_driver"], 1), ("library", {}, 1)]
-    res = _spawn(world, "xper", n, K, "double", runs, tmp_path)
+    K = K_IT
+    res = request.getfixturevalue("two_ranks" if world == 2 else "four_ranks")["cannot_fold"]
     assert all(k["lib_comm"] and not k["folded"] for k in res["library"]["ranks"]), res["library"]["ranks"]
     if world == 2:
         assert torch.equal(res["library"]["x"], res["stepwise_driver"]["x"])
@@ -218,9 +249,10 @@ def test_a_rank_failing_set_up_takes_every_rank_to_the_same_fallback(fail, expec
 
 
 # ---- Solver.set_eq() / solve() on slab meshes: the reference's own surface on 2 and 4 ranks ---------------------------
-def _worker_solver(rank, world, port, name, n, jobs, dtype, out):
-    """jobs: list of (label, method, tol, K[, env]) solved one after the other through ``Solver`` on ``Mesh(..., slab=...)``;
-    env: variables set while that job's mesh / context is created (PYAPES_HIP_COMM=0: stepwise torch.distributed driver)."""
+def _worker_solver(rank, world, port, cases, out):
+    """cases: list of (key, BC mix, n, jobs, dtype); jobs: list of (label, method, tol, K[, env]) solved one after the other
+    through ``Solver`` on ``Mesh(..., slab=...)`` by the same rank processes; env: variables set while that job's mesh /
+    context is created (PYAPES_HIP_COMM=0: stepwise torch.distributed driver)."""
     import sys
     here = os.path.dirname(os.path.abspath(__file__))
     sys.path.insert(0, here)
@@ -239,41 +271,70 @@ def _worker_solver(rank, world, port, name, n, jobs, dtype, out):
         from pyapes_amd.solver.ops import Solver
         from pyapes_amd.variables import Field
         torch.cuda.set_device(0)
-        bcs = [{"bc_face": O.FACES[i], "bc_type": t, "bc_val": v, "bc_val_opt": None}
-               for i, (t, v) in enumerate(CASES[name])]
-        g = torch.Generator().manual_seed(7)
-        rhs_g = torch.randn((1, *n), generator=g, dtype=torch.float64)
-        if name == "per":
-            rhs_g -= rhs_g.mean()
-        res = {}
-        for job in jobs:
-            label, method, tol, K = job[:4]
-            for k in ENV_KEYS:
-                os.environ.pop(k, None)
-            os.environ.update(job[4] if len(job) > 4 else {})
-            mesh = Mesh(Box[0:1, 0:1, 0:0.5], None, list(n), "cuda", dtype, slab=(rank, world))
-            var = Field("p", 1, mesh, {"domain": bcs, "obstacle": None})
-            rhs = rhs_g.to(mesh.dtype.float)[:, mesh.i_off:mesh.i_off + mesh.nx[0]].contiguous().cuda()
-            cfg = {"method": method, "tol": tol, "max_it": K, "report": False}
-            if method == "jacobi":
-                cfg["omega"] = 0.9
-            solver = Solver({"fdm": cfg})
-            solver.set_eq(-FDM().laplacian(0.7, var) == rhs)
-            rep = solver.solve()
-            ctx = context_for(mesh)
-            in_lib = bool(getattr(ctx, "comm_ready", None))
-            if getattr(ctx, "comm_ready", None):      # release the communicators while every rank is alive
-                torch.cuda.synchronize()
-                ctx.comm_destroy()
-                ctx.comm_ready = None
-            parts = [None] * world
-            dist.all_gather_object(parts, var().cpu())
-            res[label] = {"x": torch.cat(parts, dim=1), "itr": int(rep["itr"]), "tol": float(rep["tol"]),
-                          "converge": bool(rep["converge"]), "in_lib": in_lib}
+        allres = {}
+        for key, name, n, jobs, dtype in cases:
+            bcs = [{"bc_face": O.FACES[i], "bc_type": t, "bc_val": v, "bc_val_opt": None}
+                   for i, (t, v) in enumerate(CASES[name])]
+            g = torch.Generator().manual_seed(7)
+            rhs_g = torch.randn((1, *n), generator=g, dtype=torch.float64)
+            if name == "per":
+                rhs_g -= rhs_g.mean()
+            res = {}
+            for job in jobs:
+                label, method, tol, K = job[:4]
+                for k in ENV_KEYS:
+                    os.environ.pop(k, None)
+                os.environ.update(job[4] if len(job) > 4 else {})
+                mesh = Mesh(Box[0:1, 0:1, 0:0.5], None, list(n), "cuda", dtype, slab=(rank, world))
+                var = Field("p", 1, mesh, {"domain": bcs, "obstacle": None})
+                rhs = rhs_g.to(mesh.dtype.float)[:, mesh.i_off:mesh.i_off + mesh.nx[0]].contiguous().cuda()
+                cfg = {"method": method, "tol": tol, "max_it": K, "report": False}
+                if method == "jacobi":
+                    cfg["omega"] = 0.9
+                solver = Solver({"fdm": cfg})
+                solver.set_eq(-FDM().laplacian(0.7, var) == rhs)
+                rep = solver.solve()
+                ctx = context_for(mesh)
+                in_lib = bool(getattr(ctx, "comm_ready", None))
+                if getattr(ctx, "comm_ready", None):      # release the communicators while every rank is alive
+                    torch.cuda.synchronize()
+                    ctx.comm_destroy()
+                    ctx.comm_ready = None
+                parts = [None] * world
+                dist.all_gather_object(parts, var().cpu())
+                res[label] = {"x": torch.cat(parts, dim=1), "itr": int(rep["itr"]), "tol": float(rep["tol"]),
+                              "converge": bool(rep["converge"]), "in_lib": in_lib}
+            allres[key] = res
         if rank == 0:
-            torch.save(res, out)
+            torch.save(allres, out)
     finally:
         dist.destroy_process_group()
+
+
+SOLVER_JOBS = [("cg", "cg", 1e-30, 6), ("bicgstab", "bicgstab", 1e-30, 6),
+               ("bicgstab_stepwise", "bicgstab", 1e-30, 6, {"PYAPES_HIP_COMM": "0"}),
+               # Jacobi (SlabJacobi): 7 sweeps end in the context's field (copied back), 8 in the caller's
+               ("jacobi", "jacobi", 1e-30, 6), ("jacobi_even", "jacobi", 1e-30, 7),
+               ("jacobi_stepwise", "jacobi", 1e-30, 6, {"PYAPES_HIP_COMM": "0"})]
+CONV_JOBS = [("bicgstab", "bicgstab", 1e-8, 1500), ("cg", "cg", 1e-8, 30)]
+FP32_JOBS = [("cg", "cg", 1e-30, 6), ("bicgstab", "bicgstab", 1e-30, 6), ("jacobi", "jacobi", 1e-30, 6)]
+
+
+@pytest.fixture(scope="module")
+def solver_two_ranks(tmp_path_factory):
+    cases = [(f"solve-{name}", name, N2, SOLVER_JOBS, "double") for name in ("per", "xper", "mix")]
+    cases += [("converge", "xper", (24, 20, 36), CONV_JOBS, "double"), ("fp32", "mix", (16, 12, 136), FP32_JOBS, "single")]
+    out = str(tmp_path_factory.mktemp("solver_two") / "res.pt")
+    spawn_ranks(_worker_solver, lambda port: (2, port, cases, out), 2)
+    return torch.load(out)
+
+
+@pytest.fixture(scope="module")
+def solver_four_ranks(tmp_path_factory):
+    cases = [(f"solve-{name}", name, N4, SOLVER_JOBS, "double") for name in ("per", "xper", "mix")]
+    out = str(tmp_path_factory.mktemp("solver_four") / "res.pt")
+    spawn_ranks(_worker_solver, lambda port: (4, port, cases, out), 4)
+    return torch.load(out)
 
 
 def _oracle_any(name, n, method, tol, K, dtype="double"):
@@ -291,20 +352,14 @@ def _oracle_any(name, n, method, tol, K, dtype="double"):
 
 @pytest.mark.parametrize("world,n", [(2, (24, 20, 132)), (4, (26, 20, 132))], ids=["2ranks", "4ranks_uneven"])
 @pytest.mark.parametrize("name", ["per", "xper", "mix"])
-def test_solver_solve_on_slab_meshes(name, world, n, tmp_path):
+def test_solver_solve_on_slab_meshes(name, world, n, request):
     """``Solver.solve()`` with ``Mesh(..., slab=(rank, world))`` on every rank: linalg.solve hands CG to SlabCG (the
     library-side loop over the stand-in wire), Jacobi to SlabJacobi and BiCGSTAB to SlabBiCGSTAB (planes of v' and r, three small all-reduces
     per iteration: inside the library, pa_bicg_iterate_comm, and with torch.distributed between the step calls).
     Identical iteration counts and <= 1e-10 against the single-domain oracle; fully periodic, x-periodic (the ring
     across the ranks) and mixed faces; even and uneven slabs."""
-    jobs = [("cg", "cg", 1e-30, 6), ("bicgstab", "bicgstab", 1e-30, 6),
-            ("bicgstab_stepwise", "bicgstab", 1e-30, 6, {"PYAPES_HIP_COMM": "0"}),
-            # Jacobi (SlabJacobi): 7 sweeps end in the context's field (copied back), 8 in the caller's
-            ("jacobi", "jacobi", 1e-30, 6), ("jacobi_even", "jacobi", 1e-30, 7),
-            ("jacobi_stepwise", "jacobi", 1e-30, 6, {"PYAPES_HIP_COMM": "0"})]
-    out = str(tmp_path / "res.pt")
-    spawn_ranks(_worker_solver, lambda port: (world, port, name, n, jobs, "double", out), world)
-    res = torch.load(out)
+    jobs = SOLVER_JOBS
+    res = request.getfixturevalue("solver_two_ranks" if world == 2 else "solver_four_ranks")[f"solve-{name}"]
     assert res["cg"]["in_lib"] and res["bicgstab"]["in_lib"] and not res["bicgstab_stepwise"]["in_lib"]
     assert res["jacobi"]["in_lib"] and not res["jacobi_stepwise"]["in_lib"]
     # the same step calls, the sums added by the stand-in in rank order / by gloo: two ranks -> the same bits
@@ -322,17 +377,14 @@ def test_solver_solve_on_slab_meshes(name, world, n, tmp_path):
         assert abs(r["tol"] - ro["tol"]) <= 1e-7 * abs(ro["tol"]), (label, r["tol"], ro["tol"])
 
 
-def test_slab_bicgstab_converges_on_the_periodic_problem_cg_cannot_finish(tmp_path):
+def test_slab_bicgstab_converges_on_the_periodic_problem_cg_cannot_finish(solver_two_ranks):
     """The 3-D form of the reference's tests/test_solver.py:164-207 (x periodic, the other faces Dirichlet, ``-laplacian ==
     rhs``, BiCGSTAB): on two ranks -- the periodic axis is the ring across them -- BiCGSTAB meets its stop test, where CG
     with a periodic face runs to max_it.  The count of such a run is summation-order sensitive; the
     bar is convergence, the stop-test value and the solution."""
     n = (24, 20, 36)
     bc_name = "xper"
-    jobs = [("bicgstab", "bicgstab", 1e-8, 1500), ("cg", "cg", 1e-8, 30)]
-    out = str(tmp_path / "res.pt")
-    spawn_ranks(_worker_solver, lambda port: (2, port, bc_name, n, jobs, "double", out), 2)
-    res = torch.load(out)
+    res = solver_two_ranks["converge"]
     xo, ro = _oracle_any(bc_name, n, "bicgstab", 1e-8, 1500)
     b = res["bicgstab"]
     assert b["converge"] and ro["converge"] and b["tol"] <= 1e-8
@@ -344,29 +396,24 @@ def test_slab_bicgstab_converges_on_the_periodic_problem_cg_cannot_finish(tmp_pa
     assert not res["cg"]["converge"] and res["cg"]["itr"] == 31        # K + 1 iterations, stop test never met
 
 
-def test_solver_solve_on_a_slab_fp32(tmp_path):
-    jobs = [("cg", "cg", 1e-30, 6), ("bicgstab", "bicgstab", 1e-30, 6), ("jacobi", "jacobi", 1e-30, 6)]
+def test_solver_solve_on_a_slab_fp32(solver_two_ranks):
+    jobs = FP32_JOBS
     n = (16, 12, 136)
-    out = str(tmp_path / "res.pt")
-    spawn_ranks(_worker_solver, lambda port: (2, port, "mix", n, jobs, "single", out), 2)
-    res = torch.load(out)
+    res = solver_two_ranks["fp32"]
     for label, method, tol, K in jobs:
         xo, ro = _oracle_any("mix", n, method, tol, K, "single")
         assert res[label]["itr"] == ro["itr"]
         assert _rel(res[label]["x"], xo) < 1e-5, (label, _rel(res[label]["x"], xo))
 
 
-def test_placement_search_inside_the_library_side_slab_loop(tmp_path):
+def test_placement_search_inside_the_library_side_slab_loop(two_ranks):
     """The online placement search (csrc/pa_place.hip) ticks inside pa_cg_iterate_comm too -- every rank searches for
     itself while the row all-reduces and the plane exchange go on.  Forced onto these small slabs without a budget
     (PYAPES_HIP_PLACE=2), where its timings are noise and roles move at random, it must change no bit of the folded
     solve on two ranks -- r moves by having phase B write the new residual elsewhere AFTER the mid kernel has formed the
     send planes from the old one -- and the stepwise-in-library sequence likewise."""
-    n, K = (24, 20, 132), 40
-    runs = [("folded", {"PYAPES_HIP_PLACE": "0"}, None), ("folded_search", {"PYAPES_HIP_PLACE": "2"}, None),
-            ("stepwise", {"PYAPES_HIP_SLAB_FOLD": "0", "PYAPES_HIP_PLACE": "0"}, None),
-            ("stepwise_search", {"PYAPES_HIP_SLAB_FOLD": "0", "PYAPES_HIP_PLACE": "2"}, None)]
-    res = _spawn(2, "xper", n, K, "double", runs, tmp_path)
+    K = 40
+    res = two_ranks["place"]
     assert all(k["lib_comm"] and k["folded"] for k in res["folded_search"]["ranks"])
     assert torch.equal(res["folded"]["x"], res["folded_search"]["x"]) and res["folded"]["tol"] == res["folded_search"]["tol"]
     assert torch.equal(res["stepwise"]["x"], res["stepwise_search"]["x"]) and res["stepwise"]["tol"] == res["stepwise_search"]["tol"]
