@@ -213,7 +213,10 @@ int pa_bicgstab(pa_ctx* ctx, void* x, const void* rhs, double tol, int64_t max_i
 /* new: weighted Jacobi with the CG's BC fill / interior set / stop test */
 int pa_jacobi(pa_ctx* ctx, void* x, const void* rhs, double tol, int64_t max_it, double omega,
               pa_report* out);
-/* new: phi_out = B(phi + dt (nu lap(phi) - div(u phi))) on the interior set */
+/* new: phi_out = B(phi + dt (nu lap(phi) - div(u phi))) on the interior set.
+ * In slab mode (pa_slab_set) the step reads the ghost planes x_ghost_lo / hi (NULL = physical end) and leaves the BC
+ * fill B to the driver (pyapes_amd/slab.py SlabEuler: exchange first / last plane of phi -> step -> on a periodic axis 0
+ * exchange the far planes of phi_out -> pa_apply_bc). */
 int pa_euler_step(pa_ctx* ctx, const void* phi_in, void* phi_out, int div_kind, double u,
                   const void* u_field, double nu, double dt);
 

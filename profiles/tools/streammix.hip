@@ -6,6 +6,7 @@
 // hipcc --offload-arch=gfx950 -O2 streammix.hip -o streammix
 #include <hip/hip_runtime.h>
 #include <stdio.h>
+#include <stdlib.h>
 typedef double V2 __attribute__((ext_vector_type(2)));
 
 template <int R, int W, bool INPLACE>
@@ -30,37 +31,50 @@ __global__ void __launch_bounds__(256) k_mix(V2* __restrict__ a0, V2* __restrict
 
 // the same mixes with the CG kernels' access pattern: a workgroup owns a tile of 16 rows x 128 doubles (4 waves x 4 rows,
 // a wave covers 1 KiB of a row) and marches over a chunk of planes; the grid is one resident wave of workgroups
-template <int R, int W, bool INPLACE>
+template <int R, int W, bool INPLACE, bool NT>
 __global__ void __launch_bounds__(256) k_march(double* __restrict__ a0, double* __restrict__ a1, double* __restrict__ a2,
-                                               double* __restrict__ a3, double* __restrict__ a4, int n, int chunks, double beta) {
+                                               double* __restrict__ a3, double* __restrict__ a4, int n, int chunks, double beta,
+                                               int rev = 0) {
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int tiles_k = n / 128, tiles_j = n / 16, tiles = tiles_j * tiles_k;
   // blocks b and b + 8 share an XCD: consecutive tiles of one chunk on one XCD (the CG kernels' map)
   const int nb = gridDim.x, per = nb / 8, vb = (blockIdx.x % 8) * per + blockIdx.x / 8;
   const int chunk = vb / tiles, tl = vb % tiles, tj = tl / tiles_k, tk = tl % tiles_k;
   const int i0 = (long)chunk * n / chunks, i1 = (long)(chunk + 1) * n / chunks;
-  for (int i = i0; i < i1; ++i) {
+  for (int q = i0; q < i1; ++q) {
+    const int i = rev ? i1 - 1 - (q - i0) : q;
     V2 v[4];
 #pragma unroll
     for (int jj = 0; jj < 4; ++jj) {
       const size_t o = ((size_t)i * n + tj * 16 + wv * 4 + jj) * n + tk * 128 + lane * 2;
-      v[jj] = *(const V2*)(a0 + o);
-      if (R >= 2) v[jj] = v[jj] + beta * *(const V2*)(a1 + o);
-      if (R >= 3) v[jj] = v[jj] + beta * *(const V2*)(a2 + o);
+      auto ld = [](const double* p) { return NT ? __builtin_nontemporal_load((const V2*)p) : *(const V2*)p; };
+      v[jj] = ld(a0 + o);
+      if (R >= 2) v[jj] = v[jj] + beta * ld(a1 + o);
+      if (R >= 3) v[jj] = v[jj] + beta * ld(a2 + o);
     }
 #pragma unroll
     for (int jj = 0; jj < 4; ++jj) {
       const size_t o = ((size_t)i * n + tj * 16 + wv * 4 + jj) * n + tk * 128 + lane * 2;
-      if (W >= 1) *(V2*)((INPLACE ? a1 : a3) + o) = v[jj];
-      if (W >= 2) *(V2*)((INPLACE ? a2 : a4) + o) = v[jj] * beta;
+      auto st = [](double* p, V2 val) { if (NT) __builtin_nontemporal_store(val, (V2*)p); else *(V2*)p = val; };
+      if (W >= 1) st((INPLACE ? a1 : a3) + o, v[jj]);
+      if (W >= 2) st((INPLACE ? a2 : a4) + o, v[jj] * beta);
     }
   }
 }
 
-int main() {
+int main(int argc, char** argv) {
   const size_t N = (size_t)512 * 512 * 512, n = N / 2;
+  // argv[1]: byte offset between the starts of consecutive arrays modulo their size (0: every array starts on the same
+  // channel / bank phase, what five hipMalloc blocks of 1 GiB give; the library staggers its blocks by 69888 B)
+  const size_t stagger = argc > 1 ? (size_t)atol(argv[1]) : 0;
+  printf("stagger %zu B\n", stagger);
   V2* a[5];
-  for (auto& p : a) { hipMalloc(&p, N * 8); hipMemset(p, 0, N * 8); }
+  for (int q = 0; q < 5; ++q) {
+    char* p;
+    hipMalloc((void**)&p, N * 8 + 5 * stagger);
+    hipMemset(p, 0, N * 8 + 5 * stagger);
+    a[q] = (V2*)(p + q * stagger);
+  }
   double* sink; hipMalloc(&sink, 8);
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
   auto run = [&](const char* name, int passes, auto f) {
@@ -83,16 +97,35 @@ int main() {
   MIX(2, 2, false, "2 reads : 2 writes")
   MIX(3, 2, false, "3 reads : 2 writes, five arrays")
   MIX(3, 2, true, "3 reads : 2 writes in place (phase B's mix)")
-#define MARCH(R, W, IP, label)                                                                                        \
+#define MARCH(R, W, IP, NT, label)                                                                                        \
   for (int cap : {1024, 2048}) {                                                                                       \
     const int tiles = (512 / 16) * (512 / 128), chunks = cap / tiles;                                                  \
     sprintf(nm, "march: %s (%d blocks)", label, tiles * chunks);                                                       \
-    run(nm, R + W, [&] { hipLaunchKernelGGL((k_march<R, W, IP>), dim3(tiles * chunks), dim3(256), 0, 0, (double*)a[0], (double*)a[1], \
+    run(nm, R + W, [&] { hipLaunchKernelGGL((k_march<R, W, IP, NT>), dim3(tiles * chunks), dim3(256), 0, 0, (double*)a[0], (double*)a[1], \
                                             (double*)a[2], (double*)a[3], (double*)a[4], 512, chunks, 0.5); });        \
   }
-  MARCH(1, 1, false, "1 : 1 (copy)")
-  MARCH(2, 1, false, "2 : 1 (phase A's mix)")
-  MARCH(3, 2, false, "3 : 2, five arrays")
-  MARCH(3, 2, true, "3 : 2 in place (phase B's mix)")
+  MARCH(1, 1, false, false, "1 : 1 (copy)")
+  MARCH(2, 1, false, false, "2 : 1 (phase A's mix)")
+  MARCH(3, 2, false, false, "3 : 2, five arrays")
+  MARCH(3, 2, true, false, "3 : 2 in place (phase B's mix)")
+  // with the non-temporal loads / stores the CG kernels use on their once-touched streams
+  MARCH(1, 1, false, true, "nt 1 : 1 (copy)")
+  MARCH(2, 1, false, true, "nt 2 : 1 (phase A's mix)")
+  MARCH(3, 2, false, true, "nt 3 : 2, five arrays")
+  MARCH(3, 2, true, true, "nt 3 : 2 in place (phase B's mix)")
+  // the CG iteration's traffic without its stencil: A' reads r (a0), d (a1), writes d' (a2); B' reads d' (a2), x (a3), r (a0)
+  // and writes x, r in place -- B' marching its chunks forward like A', or backward (what the library does: the planes
+  // A' touched last, still in the 256 MiB Infinity Cache, are the ones B' reads first, and vice versa)
+  for (int rev = 0; rev < 2; ++rev)
+    for (int cap : {1024, 2048}) {
+      const int tiles = (512 / 16) * (512 / 128), chunks = cap / tiles;
+      sprintf(nm, "march nt: pair A' (2 : 1) + B' (3 : 2 in place) %s (%d blocks)", rev ? "B' BACKWARD" : "both forward", tiles * chunks);
+      run(nm, 8, [&] {
+        hipLaunchKernelGGL((k_march<2, 1, false, true>), dim3(tiles * chunks), dim3(256), 0, 0, (double*)a[0], (double*)a[1],
+                           (double*)nullptr, (double*)a[2], (double*)nullptr, 512, chunks, 0.5, 0);
+        hipLaunchKernelGGL((k_march<3, 2, true, true>), dim3(tiles * chunks), dim3(256), 0, 0, (double*)a[2], (double*)a[3],
+                           (double*)a[0], (double*)nullptr, (double*)nullptr, 512, chunks, 0.5, rev);
+      });
+    }
   return 0;
 }

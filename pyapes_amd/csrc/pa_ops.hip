@@ -409,8 +409,11 @@ static int euler_t(pa_ctx* c, const T* in, T* out, int kind, double u, const voi
   pa_build_eq<T>(c, 1, &ta, Ea);
   Vec<T> pv = pa_vec_self<T>(c, in);
   if (c->G.n0 != c->G.g0 && c->ndim == 3) {
-    if (!c->x_glo || !c->x_ghi) { pa_set_err(c, "pa_euler_step on a slab needs ghost planes"); return PA_E_STATE; }
-    pv.glo = (const T*)c->x_glo; pv.ghi = (const T*)c->x_ghi;
+    // a slab (pyapes_amd/slab.py SlabEuler): ghost planes from pa_slab_set; a NULL one marks a physical end, whose
+    // boundary plane no interior node reads across -- the field's own end plane stands in for the speculative loads
+    if (!c->slab) { pa_set_err(c, "pa_euler_step on a slab needs pa_slab_set (ghost planes)"); return PA_E_STATE; }
+    pv.glo = c->x_glo ? (const T*)c->x_glo : in;
+    pv.ghi = c->x_ghi ? (const T*)c->x_ghi : in + (c->G.n0 - 1) * c->G.s0;
   }
   if (c->profile) (void)hipEventRecord(c->pev[0], c->stream);   // slot 0: the step kernel (without its BC fill)
   int fr = pa_tile3d_euler<T>(c, pv, out, kind, u, u_field, nu, dt);
@@ -420,6 +423,9 @@ static int euler_t(pa_ctx* c, const T* in, T* out, int kind, double u, const voi
                        out, (T)nu, (T)dt);
   if (c->profile) pa_profile_stop(c, 0);
   PA_HIP(c, hipGetLastError());
+  // slab mode: the step kernel alone.  The fill of a periodic axis 0 reads planes of the NEW field that live on the
+  // other end rank of the ring, so the driver exchanges those first and then calls pa_apply_bc itself.
+  if (c->slab) return PA_OK;
   return pa_bc_apply_auto<T>(c, out, false);
 }
 

@@ -1,4 +1,4 @@
-"""Slab decomposition along axis 0 and the multi-GPU CG / BiCGSTAB / Jacobi drivers (new).
+"""Slab decomposition along axis 0 and the multi-GPU CG / BiCGSTAB / Jacobi drivers and the explicit Euler march (new).
 
 The reference is single-device.  Here the 3-D grid is cut into P slabs of whole
 (n1 x n2) planes, one per rank / GPU.  Per CG iteration the ranks exchange
@@ -193,16 +193,17 @@ class _SlabDriver:
             recvs.append((lo_recv, self.nb_lo, 0))
         return sends, recvs
 
-    def _bc_far_ops(self):
+    def _bc_far_ops(self, x: Tensor | None = None):
         """Periodic axis 0: planes of x the end ranks' BC fill reads across the ring."""
+        x = self.x if x is None else x
         sends, recvs = [], []
         if self.periodic0:
             P, r = self.world, self.rank
             if r == P - 1:
-                sends += [(self.x[-1], 0, 2), (self.x[-2], 0, 3)]
+                sends += [(x[-1], 0, 2), (x[-2], 0, 3)]
                 recvs += [(self.bufs["bc_far_hi0"], 0, 4)]
             if r == 0:
-                sends += [(self.x[1], P - 1, 4)]
+                sends += [(x[1], P - 1, 4)]
                 recvs += [(self.bufs["bc_far_lo0"], P - 1, 2), (self.bufs["bc_far_lo1"], P - 1, 3)]
         return sends, recvs
 
@@ -440,6 +441,34 @@ class SlabJacobi(_SlabDriver):
         rep = self.be.jacobi_end()
         self.be.slab_set(None)
         return rep
+
+
+class SlabEuler(_SlabDriver):
+    """The explicit Euler march (``solver/march.py``, [new, SURVEY a15]) over P slabs: per step the first / last owned
+    plane of phi goes into the neighbours' ghost planes, every rank runs the step kernel on its planes
+    (``pa_euler_step`` in slab mode: no fill), on a periodic axis 0 the far planes of the NEW field travel between the
+    end ranks, and every rank fills its BCs.  No reduction: nothing but neighbour planes crosses the ranks."""
+
+    def __init__(self, mesh: Any, var: Any, dist: Any, backend: Any = None, group: Any = None):
+        super().__init__(mesh, var, var(), [], dist, backend, group)
+
+    def march(self, kind: int, u: Any, nu: float, dt: float, nsteps: int) -> Tensor:
+        """-> the tensor (one of the two ping-pong buffers) that holds the state after ``nsteps`` steps."""
+        be = self.be
+        be.slab_set(self.bufs)
+        be.bind_bcs(self.var(), self.var.bcs, 0)
+        cur, nxt = self.x, torch.empty_like(self.x)
+        try:
+            for _ in range(int(nsteps)):
+                self._exchange_planes(cur[0], cur[-1], self.bufs["x_ghost_lo"], self.bufs["x_ghost_hi"])
+                be.euler_step(cur, nxt, kind, u, nu, dt)
+                if self.periodic0:
+                    self._p2p(*self._bc_far_ops(nxt))
+                be.apply_bc_bound(nxt)
+                cur, nxt = nxt, cur
+        finally:
+            be.slab_set(None)
+        return cur
 
 
 def slab_solver(method: str, mesh: Any, var: Any, rhs: Tensor, terms: Sequence[dict], dist: Any = None,

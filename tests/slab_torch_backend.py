@@ -1,5 +1,5 @@
 """TEST INFRASTRUCTURE: a torch-CPU stand-in for the stepwise C-ABI calls that
-``pyapes_amd.slab.SlabCG`` / ``SlabBiCGSTAB`` drive, so that the driver's communication pattern (ghost planes,
+``pyapes_amd.slab.SlabCG`` / ``SlabBiCGSTAB`` / ``SlabJacobi`` / ``SlabEuler`` drive, so that the driver's communication pattern (ghost planes,
 ring wrap, periodic far planes, all-reduce slices, call order) can be exercised with gloo and
 world_size 2 on a machine without a GPU.  It follows SURVEY Appendix A on the LOCAL slab with
 ghost planes; results are checked against the single-domain oracle.  Never imported by the
@@ -71,6 +71,12 @@ class TorchSlabBackend:
 
     def _A(self, v, glo, ghi):
         """sign*coeff*laplacian on the local planes; ghost planes complete axis 0."""
+        ax = self._lap(v, glo, ghi)
+        if self.coeff is not None:
+            ax = ax * self.coeff
+        return ax * self.sign
+
+    def _lap(self, v, glo, ghi):
         z = torch.zeros_like(v[0])
         pad = torch.cat([(glo if glo is not None else z)[None], v, (ghi if ghi is not None else z)[None]], 0)
         gi = list(range(self.off, self.off + self.n[0]))
@@ -90,9 +96,7 @@ class TorchSlabBackend:
         t = t + c2[1][None, None, :] * v
         t = t + c2[2][None, None, :] * torch.roll(v, 1, 2)
         ax = ax + t
-        if self.coeff is not None:
-            ax = ax * self.coeff
-        return ax * self.sign
+        return ax
 
     def rhs_adjust(self, rhs):
         for face, typ, val in self.bcs:
@@ -392,3 +396,24 @@ class TorchSlabBackend:
 
     def jacobi_end(self):
         return self.report()
+
+    # -- explicit Euler step on a slab (solver/march.py; oracle euler_step / div_upwind_intended): kernel only, no fill ----
+    def euler_step(self, phi, out, kind, u, nu, dt):
+        assert not isinstance(u, torch.Tensor), "stand-in: scalar advection speed"
+        b = self.bufs
+        glo, ghi = b["x_ghost_lo"], b["x_ghost_hi"]
+        lap = self._lap(phi, glo, ghi)
+        z = torch.zeros_like(phi[0])
+        pad = torch.cat([(glo if glo is not None else z)[None], phi, (ghi if ghi is not None else z)[None]], 0)
+        uu = self._t(u)
+        up, um = torch.clamp(uu, min=0.0), torch.clamp(uu, max=0.0)
+        adv = torch.zeros_like(phi)
+        for a in range(3):
+            inv = torch.ones((), dtype=self.f) / self.h[a]
+            if a == 0:
+                bwd, fwd = phi - pad[:-2], pad[2:] - phi
+            else:
+                bwd, fwd = phi - torch.roll(phi, 1, a), torch.roll(phi, -1, a) - phi
+            adv = adv + (up * bwd + um * fwd) * inv
+        new = phi + self._t(dt) * (self._t(nu) * lap - adv)
+        out.copy_(torch.where(self._S(), new, phi))

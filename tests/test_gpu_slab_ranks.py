@@ -36,7 +36,7 @@ MODES = {
     "folded_one_stream": {"PYAPES_HIP_COMM_OVERLAP": "0"},            # exchange on the ctx stream
     "stepwise_in_library": {"PYAPES_HIP_SLAB_FOLD": "0"},             # round 1's sequence inside the C loop
 }
-ENV_KEYS = ("PYAPES_HIP_COMM", "PYAPES_HIP_COMM_OVERLAP", "PYAPES_HIP_SLAB_FOLD", "PYAPES_HIP_HOSTRING_FAIL",
+ENV_KEYS = ("PYAPES_HIP_FASTPATH", "PYAPES_HIP_COMM", "PYAPES_HIP_COMM_OVERLAP", "PYAPES_HIP_SLAB_FOLD", "PYAPES_HIP_HOSTRING_FAIL",
             "PYAPES_HIP_COMM_TIMEOUT", "PYAPES_HIP_HOSTRING_TIMEOUT", "PYAPES_HIP_PLACE")
 
 
@@ -287,6 +287,15 @@ def _worker_solver(rank, world, port, cases, out):
                 os.environ.update(job[4] if len(job) > 4 else {})
                 mesh = Mesh(Box[0:1, 0:1, 0:0.5], None, list(n), "cuda", dtype, slab=(rank, world))
                 var = Field("p", 1, mesh, {"domain": bcs, "obstacle": None})
+                if method == "euler":     # the explicit march (solver/march.py -> SlabEuler), K steps
+                    from pyapes_amd.solver.march import euler_march
+                    from test_slab_gloo import EULER_DT, EULER_NU, EULER_U, euler_start
+                    var.set_var_tensor(euler_start(name, n, dtype)[:, mesh.i_off:mesh.i_off + mesh.nx[0]].contiguous().cuda())
+                    euler_march(var, EULER_U, EULER_NU, EULER_DT, K)
+                    parts = [None] * world
+                    dist.all_gather_object(parts, var().cpu())
+                    res[label] = {"x": torch.cat(parts, dim=1)}
+                    continue
                 rhs = rhs_g.to(mesh.dtype.float)[:, mesh.i_off:mesh.i_off + mesh.nx[0]].contiguous().cuda()
                 cfg = {"method": method, "tol": tol, "max_it": K, "report": False}
                 if method == "jacobi":
@@ -316,6 +325,7 @@ SOLVER_JOBS = [("cg", "cg", 1e-30, 6), ("bicgstab", "bicgstab", 1e-30, 6),
                # Jacobi (SlabJacobi): 7 sweeps end in the context's field (copied back), 8 in the caller's
                ("jacobi", "jacobi", 1e-30, 6), ("jacobi_even", "jacobi", 1e-30, 7),
                ("jacobi_stepwise", "jacobi", 1e-30, 6, {"PYAPES_HIP_COMM": "0"})]
+EULER_JOBS = [("euler", "euler", 0.0, 5), ("euler_generic", "euler", 0.0, 5, {"PYAPES_HIP_FASTPATH": "0"})]
 CONV_JOBS = [("bicgstab", "bicgstab", 1e-8, 1500), ("cg", "cg", 1e-8, 30)]
 FP32_JOBS = [("cg", "cg", 1e-30, 6), ("bicgstab", "bicgstab", 1e-30, 6), ("jacobi", "jacobi", 1e-30, 6)]
 
@@ -324,6 +334,8 @@ FP32_JOBS = [("cg", "cg", 1e-30, 6), ("bicgstab", "bicgstab", 1e-30, 6), ("jacob
 def solver_two_ranks(tmp_path_factory):
     cases = [(f"solve-{name}", name, N2, SOLVER_JOBS, "double") for name in ("per", "xper", "mix")]
     cases += [("converge", "xper", (24, 20, 36), CONV_JOBS, "double"), ("fp32", "mix", (16, 12, 136), FP32_JOBS, "single")]
+    cases += [(f"euler-{name}", name, N2, EULER_JOBS, "double") for name in ("per", "xper", "mix", "neu_hi")]
+    cases += [("euler-fp32", "mix", (16, 12, 136), EULER_JOBS[:1], "single")]
     out = str(tmp_path_factory.mktemp("solver_two") / "res.pt")
     spawn_ranks(_worker_solver, lambda port: (2, port, cases, out), 2)
     return torch.load(out)
@@ -332,6 +344,7 @@ def solver_two_ranks(tmp_path_factory):
 @pytest.fixture(scope="module")
 def solver_four_ranks(tmp_path_factory):
     cases = [(f"solve-{name}", name, N4, SOLVER_JOBS, "double") for name in ("per", "xper", "mix")]
+    cases += [(f"euler-{name}", name, N4, EULER_JOBS, "double") for name in ("xper", "mix")]
     out = str(tmp_path_factory.mktemp("solver_four") / "res.pt")
     spawn_ranks(_worker_solver, lambda port: (4, port, cases, out), 4)
     return torch.load(out)
@@ -418,3 +431,19 @@ def test_placement_search_inside_the_library_side_slab_loop(two_ranks):
     assert torch.equal(res["folded"]["x"], res["folded_search"]["x"]) and res["folded"]["tol"] == res["folded_search"]["tol"]
     assert torch.equal(res["stepwise"]["x"], res["stepwise_search"]["x"]) and res["stepwise"]["tol"] == res["stepwise_search"]["tol"]
     assert res["folded"]["itr"] == res["folded_search"]["itr"] == K + 1
+
+
+@pytest.mark.parametrize("world,name,dtype", [(2, "per", "double"), (2, "xper", "double"), (2, "mix", "double"),
+                                              (2, "neu_hi", "double"), (2, "fp32", "single"), (4, "xper", "double"),
+                                              (4, "mix", "double")])
+def test_euler_march_on_slab_meshes(world, name, dtype, request):
+    """``euler_march`` on ``Mesh(..., slab=(rank, world))`` (SlabEuler): five steps (the result ends in the second
+    ping-pong buffer) on 2 and 4 ranks, with the marching step kernel and with the generic one (the same bits), against
+    the single-domain oracle; a periodic ring (the far planes of the NEW field cross it before the fill), uneven slabs."""
+    from test_slab_gloo import euler_oracle
+    res = request.getfixturevalue("solver_two_ranks" if world == 2 else "solver_four_ranks")[f"euler-{name}"]
+    bc, n = ("mix", (16, 12, 136)) if name == "fp32" else (name, N2 if world == 2 else N4)
+    xo = euler_oracle(bc, n, 5, dtype)
+    assert _rel(res["euler"]["x"], xo) < (1e-12 if dtype == "double" else 1e-5), _rel(res["euler"]["x"], xo)
+    if "euler_generic" in res:
+        assert torch.equal(res["euler"]["x"], res["euler_generic"]["x"])

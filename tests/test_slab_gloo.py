@@ -203,3 +203,69 @@ def test_slab_bicgstab_converges_where_periodic_cg_cannot(tmp_path):
     assert res["tol"] <= 1e-9 and ro["tol"] <= 1e-9
     err = float(torch.linalg.norm(res["x"] - xo) / torch.linalg.norm(xo))
     assert err < 1e-6, err
+
+
+# ---- the explicit Euler march on slab meshes (solver/march.py -> slab.SlabEuler) -------------------------------------------
+def _worker_euler(rank, world, port, name, n, nsteps, out):
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    sys.path.insert(0, here)
+    sys.path.insert(0, os.path.dirname(here))
+    warnings.filterwarnings("ignore")
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from pyapes_amd.geometry import Box
+        from pyapes_amd.mesh import Mesh
+        from pyapes_amd.solver.march import euler_march
+        from pyapes_amd.variables import Field
+        from slab_torch_backend import TorchSlabBackend
+        bcs = [{"bc_face": O.FACES[i], "bc_type": t, "bc_val": v, "bc_val_opt": None}
+               for i, (t, v) in enumerate(CASES[name])]
+        mesh = Mesh(Box[0:1, 0:1, 0:0.5], None, list(n), "cpu", "double", slab=(rank, world))
+        mesh._hip = TorchSlabBackend(mesh)
+        phi = Field("phi", 1, mesh, {"domain": bcs, "obstacle": None})
+        phi.set_var_tensor(euler_start(name, n)[:, mesh.i_off:mesh.i_off + mesh.nx[0]].clone())
+        euler_march(phi, EULER_U, EULER_NU, EULER_DT, nsteps)
+        parts = [None] * world
+        dist.all_gather_object(parts, phi().clone())
+        if rank == 0:
+            torch.save({"x": torch.cat(parts, dim=1)}, out)
+    finally:
+        dist.destroy_process_group()
+
+
+EULER_U, EULER_NU, EULER_DT = 0.8, 0.05, 2e-4
+
+
+def euler_start(name, n, dtype="double"):
+    """A BC-filled start field (the march assumes one, like the single-GPU march)."""
+    mesh = O.OMesh([0, 0, 0], [1, 1, 0.5], list(n), dtype)
+    cfg = [{"bc_face": O.FACES[i], "bc_type": t, "bc_val": v} for i, (t, v) in enumerate(CASES[name])]
+    g = torch.Generator().manual_seed(11)
+    phi = torch.randn((1, *n), generator=g, dtype=torch.float64).to(mesh.dtype)
+    return O.bc_fill(phi, O.make_bcs(mesh, cfg))
+
+
+def euler_oracle(name, n, nsteps, dtype="double"):
+    mesh = O.OMesh([0, 0, 0], [1, 1, 0.5], list(n), dtype)
+    cfg = [{"bc_face": O.FACES[i], "bc_type": t, "bc_val": v} for i, (t, v) in enumerate(CASES[name])]
+    bcs = O.make_bcs(mesh, cfg)
+    phi = euler_start(name, n, dtype)
+    for _ in range(nsteps):
+        phi = O.euler_step(phi, EULER_U, EULER_NU, EULER_DT, mesh, bcs)
+    return phi
+
+
+@pytest.mark.parametrize("name", list(CASES), ids=list(CASES))
+def test_euler_march_on_a_slab_mesh_two_ranks(name, tmp_path):
+    """``euler_march`` with ``Mesh(..., slab=(rank, 2))`` on both ranks (SlabEuler: ghost planes of phi in, step, the far
+    planes of the new field across a periodic ring, BC fill), odd number of steps, against the single-domain oracle."""
+    n, nsteps = (12, 9, 10), 5
+    out = str(tmp_path / "x.pt")
+    spawn_ranks(_worker_euler, lambda port: (2, port, name, n, nsteps, out), 2)
+    res = torch.load(out)
+    xo = euler_oracle(name, n, nsteps)
+    err = float(torch.linalg.norm(res["x"] - xo) / torch.linalg.norm(xo))
+    assert err < 1e-12, err
