@@ -225,6 +225,17 @@ int pa_euler_step(pa_ctx* ctx, const void* phi_in, void* phi_out, int div_kind, 
 int pa_euler_march(pa_ctx* ctx, void* phi, void* tmp, int div_kind, double u, const void* u_field,
                    double nu, double dt, int64_t nsteps);
 
+/* ---- vector steps for a host-stepped solver loop (pyapes_amd/solver/host_stepped.py: BC callables that read the iterate
+ * make the reference's loop come back to Python for every face of every fill, bcs.py:200-253; the loop's AXPYs and dot
+ * products between those fills are these).  Fields of the grid's shape and dtype.
+ *   pa_vec_axpy  out = y + a x, the product rounded before the sum (linalg.py:120, 127, 138; "-": pass -a); out may be y or x
+ *   pa_vec_dot   *result = sum a.b (diff 0) or sum (a - b)^2 (diff 1: the stop test's norm, linalg.py:321-338), products in
+ *                the grid dtype, summed in double; synchronises */
+int pa_vec_axpy(pa_ctx* ctx, void* out, const void* y, double a, const void* x);
+int pa_vec_dot(pa_ctx* ctx, const void* a, const void* b, int diff, double* result);
+/* x <- 0 off the interior set of the BC list bound last (r = b - A x lives on it, linalg.py:99-101) */
+int pa_vec_mask_interior(pa_ctx* ctx, void* x);
+
 /* ---- stepwise CG (slab-decomposed multi-GPU driver and bench.py) -------
  * pa_cg above is the single-GPU loop.  The stepwise form lets a host driver put
  * the halo exchange and the scalar all-reduces (RCCL through torch.distributed)

@@ -441,7 +441,100 @@ static int euler_bcl_t(pa_ctx* c, const T* in, T* out, int kind, double u, const
   return 1;
 }
 
+// ---- vector steps of the host-stepped solver loops (pyapes_amd/solver/host_stepped.py) ------------------------------
+// out = y + a x, the product rounded before the sum (torch: y + a * x; "y - a x" is the same bits with -a)
+template <typename T>
+__global__ void __launch_bounds__(PA_BLOCK) k_vec_axpy(T* __restrict__ out, const T* __restrict__ y, T a,
+                                                        const T* __restrict__ x, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    T t = a * x[i];
+    out[i] = y[i] + t;
+  }
+}
+
+// partial sums of a.b (diff = 0) or of (a - b)^2 (diff = 1), products rounded in T, summed in double
+template <typename T>
+__global__ void __launch_bounds__(PA_BLOCK) k_vec_dot(const T* __restrict__ a, const T* __restrict__ b, int diff, int64_t n,
+                                                       double* __restrict__ partials) {
+  double s[1] = {0.0};
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    T p;
+    if (diff) { T d = a[i] - b[i]; p = d * d; } else { p = a[i] * b[i]; }
+    s[0] += (double)p;
+  }
+  pa_block_reduce_store<1>(s, partials);
+}
+
+// x <- 0 off the interior set of the bound BC list (the residual lives on S, linalg.py:99-101)
+template <typename T>
+__global__ void __launch_bounds__(PA_BLOCK) k_vec_mask_interior(DevGeom G, T* __restrict__ x) {
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < G.ncell; idx += (int64_t)gridDim.x * blockDim.x) {
+    int64_t i, j, k;
+    pa_decode(G, idx, i, j, k);
+    if (!pa_in_S(G, i, j, k)) x[idx] = (T)0;
+  }
+}
+
+__global__ void __launch_bounds__(PA_BLOCK) k_vec_dot_final(const double* __restrict__ partials, int nblk, double* __restrict__ out) {
+  __shared__ double sm[PA_BLOCK / 64];
+  double v = 0.0;
+  for (int b = threadIdx.x; b < nblk; b += blockDim.x) v += partials[b];
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+  if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = v;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double t = sm[0];
+    for (int w = 1; w < (int)(blockDim.x >> 6); ++w) t += sm[w];
+    out[0] = t;
+  }
+}
+
 extern "C" {
+
+int pa_vec_axpy(pa_ctx* c, void* out, const void* y, double a, const void* x) {
+  if (!c || !c->grid_set || !out || !y || !x) return PA_E_STATE;
+  PA_HIP(c, hipSetDevice(c->device));
+  const int nb = pa_grid_blocks(c->G.ncell);
+  if (c->dtype == PA_F64)
+    hipLaunchKernelGGL(k_vec_axpy<double>, dim3(nb), dim3(PA_BLOCK), 0, c->stream, (double*)out, (const double*)y, a,
+                       (const double*)x, c->G.ncell);
+  else
+    hipLaunchKernelGGL(k_vec_axpy<float>, dim3(nb), dim3(PA_BLOCK), 0, c->stream, (float*)out, (const float*)y, (float)a,
+                       (const float*)x, c->G.ncell);
+  PA_HIP(c, hipGetLastError());
+  return PA_OK;
+}
+
+int pa_vec_mask_interior(pa_ctx* c, void* x) {
+  if (!c || !c->grid_set || !x) return PA_E_STATE;
+  PA_HIP(c, hipSetDevice(c->device));
+  const int nb = pa_grid_blocks(c->G.ncell);
+  if (c->dtype == PA_F64) hipLaunchKernelGGL(k_vec_mask_interior<double>, dim3(nb), dim3(PA_BLOCK), 0, c->stream, c->G, (double*)x);
+  else hipLaunchKernelGGL(k_vec_mask_interior<float>, dim3(nb), dim3(PA_BLOCK), 0, c->stream, c->G, (float*)x);
+  PA_HIP(c, hipGetLastError());
+  return PA_OK;
+}
+
+int pa_vec_dot(pa_ctx* c, const void* a, const void* b, int diff, double* result) {
+  if (!c || !c->grid_set || !a || !b || !result) return PA_E_STATE;
+  PA_HIP(c, hipSetDevice(c->device));
+  const int nb = pa_grid_blocks(c->G.ncell);
+  int rc;
+  if ((rc = pa_scratch(c, &c->scr[SCR_PART2], &c->cap[SCR_PART2], (size_t)3 * PA_MAX_GRID * sizeof(double)))) return rc;
+  double* part = (double*)c->scr[SCR_PART2];
+  if (nb + 1 > 3 * PA_MAX_GRID) { pa_set_err(c, "pa_vec_dot: grid too large for the partials buffer"); return PA_E_STATE; }
+  if (c->dtype == PA_F64)
+    hipLaunchKernelGGL(k_vec_dot<double>, dim3(nb), dim3(PA_BLOCK), 0, c->stream, (const double*)a, (const double*)b, diff,
+                       c->G.ncell, part);
+  else
+    hipLaunchKernelGGL(k_vec_dot<float>, dim3(nb), dim3(PA_BLOCK), 0, c->stream, (const float*)a, (const float*)b, diff,
+                       c->G.ncell, part);
+  hipLaunchKernelGGL(k_vec_dot_final, dim3(1), dim3(PA_BLOCK), 0, c->stream, (const double*)part, nb, part + nb);
+  PA_HIP(c, hipMemcpyAsync(result, part + nb, sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  PA_HIP(c, hipStreamSynchronize(c->stream));
+  return PA_OK;
+}
 
 int pa_aop(pa_ctx* c, const void* x, void* y, int interior_only) {
   if (!c || !c->grid_set || !c->eq_set) { if (c) pa_set_err(c, "pa_aop: grid/equation not set"); return PA_E_STATE; }

@@ -458,6 +458,25 @@ class HipContext:
         self._rc(self.lib.pa_cg_fold_plan(self.h, rows))
         return [int(v) for v in rows]
 
+    # vector steps of the host-stepped loops (solver/host_stepped.py)
+    def vec_axpy(self, out: Tensor, y: Tensor, a: float, x: Tensor) -> Tensor:
+        """out = y + a * x (the product rounded first); out may alias y or x"""
+        self._rc(self.lib.pa_vec_axpy(self.h, self._ptr(self._field(out, "vec_axpy")), self._ptr(self._field(y, "vec_axpy")),
+                                      float(a), self._ptr(self._field(x, "vec_axpy"))))
+        return out
+
+    def vec_dot(self, a: Tensor, b: Tensor, diff: bool = False) -> float:
+        """sum a.b, or sum (a - b)^2 with ``diff`` (synchronises)"""
+        res = C.c_double(0.0)
+        self._rc(self.lib.pa_vec_dot(self.h, self._ptr(self._field(a, "vec_dot")), self._ptr(self._field(b, "vec_dot")),
+                                     1 if diff else 0, C.byref(res)))
+        return float(res.value)
+
+    def vec_mask_interior(self, x: Tensor) -> Tensor:
+        """x <- 0 off the interior set of the BC list bound last"""
+        self._rc(self.lib.pa_vec_mask_interior(self.h, self._ptr(self._field(x, "vec_mask_interior"))))
+        return x
+
     # stepwise Jacobi on a slab (pyapes_amd/slab.py SlabJacobi)
     def jacobi_begin(self, x: Tensor, rhs: Tensor, tol: float, max_it: int, omega: float = 1.0) -> None:
         self._keep["cg"] = (x, rhs)

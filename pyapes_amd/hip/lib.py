@@ -124,6 +124,9 @@ SIGNATURES: dict[str, tuple[Any, list[Any]]] = {
     "pa_comm_plan": (C.c_int, [_VP, C.POINTER(PaExchange)]),
     "pa_cg_iterate_comm": (C.c_int, [_VP, C.c_int64]),
     "pa_bicg_iterate_comm": (C.c_int, [_VP, C.c_int64]),
+    "pa_vec_axpy": (C.c_int, [_VP, _VP, _VP, C.c_double, _VP]),
+    "pa_vec_dot": (C.c_int, [_VP, _VP, _VP, C.c_int, C.POINTER(C.c_double)]),
+    "pa_vec_mask_interior": (C.c_int, [_VP, _VP]),
     "pa_jacobi_begin": (C.c_int, [_VP, _VP, _VP, C.c_double, C.c_int64, C.c_double]),
     "pa_jacobi_sweep": (C.c_int, [_VP]),
     "pa_jacobi_bc": (C.c_int, [_VP]),
