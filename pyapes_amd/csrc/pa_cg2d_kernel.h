@@ -41,7 +41,7 @@ __global__ void __launch_bounds__(256) k_cg2d(Cg3dArgs<T> A) {
   const int n1 = (int)G.n1, n2 = (int)G.n2;
   const int j0 = (int)((int64_t)chunk * n1 / A.chunks), j1 = (int)((int64_t)(chunk + 1) * n1 / A.chunks);
   const int CJ = j1 - j0;
-  const int rev = A.reverse;
+  constexpr int rev = (PHASE == 1) ? 1 : 0;          // phase B marches backwards (pa_cg3d_kernel.h)
   const int64_t fs1 = PITCH ? A.ps1 : G.s1;           // row stride of r, d, d' (x: G.s1)
   const int64_t k0 = ((int64_t)sg * 4 + wv) * TK;
   const int64_t kg = k0 + (int64_t)lane * VEC;

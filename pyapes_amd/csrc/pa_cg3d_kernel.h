@@ -140,7 +140,9 @@ __global__ void __launch_bounds__(256) k_cg3d(Cg3dArgs<T> A) {
   const int64_t i0 = (int64_t)chunk * G.n0 / A.chunks, i1 = (int64_t)(chunk + 1) * G.n0 / A.chunks;
   const int CI = (int)(i1 - i0);
   const int64_t j0 = (int64_t)tjb * TJ, k0 = (int64_t)tkb * TK;
-  const int rev = A.reverse;
+  // phase B marches its chunks backwards (header comment); a compile-time fact, so that "ahead" / "behind" resolve to
+  // registers instead of 2 * RJ * VEC selects per plane (32 of the 459 VALU instructions of the fp64 phase-A loop)
+  constexpr int rev = (PHASE == 1) ? 1 : 0;
 
   // ---- per-thread geometry: RJ rows x VEC columns --------------------------------
   const int64_t kg = k0 + (int64_t)lane * VEC;            // global k of element 0 (may be >= n2)
@@ -188,6 +190,11 @@ __global__ void __launch_bounds__(256) k_cg3d(Cg3dArgs<T> A) {
     if (rc == 1) colLo |= 1u << v;
     if (rc == 2) colHi |= 1u << v;
   }
+#ifdef PA_PLAIN_EXPERIMENT   // measurement only: what the phases cost without their per-row / per-column case logic
+  rowLo = rowHi = colLo = colHi = 0;
+  rowS = rowValid = (1u << RJ) - 1;
+  colS = (1u << VEC) - 1;
+#endif
   // halo duty of this wave: wave 0 -> row above the tile, wave 3 -> row below (vector loads);
   // wave 1, lanes < 2*TJ -> the single cells left / right of each tile row (scalar loads)
   const int64_t hrow = (wv == 0) ? pa_wrapmod(j0 - 1, G.n1) : pa_wrapmod(j0 + TJ, G.n1);
@@ -214,10 +221,7 @@ __global__ void __launch_bounds__(256) k_cg3d(Cg3dArgs<T> A) {
   };
   constexpr bool HAS_R = (PHASE == 0 || PHASE == 5 || PHASE == 6);
   constexpr bool HAS_Q = (PHASE == 5);
-  auto issue = [&](int64_t ii, Raw& w, bool with_halo) {
-    const T* dp = pptr(A.d, ii);
-    const T* rp = HAS_R ? pptr(A.r, ii) : dp;
-    const T* qp = HAS_Q ? pptr(A.v, ii) : dp;
+  auto issue_at = [&](const T* dp, const T* rp, const T* qp, Raw& w, bool with_halo) {
 #pragma unroll
     for (int jj = 0; jj < RJ; ++jj) {
       const int64_t o = jrow[jj] * fs1 + kcf;
@@ -238,6 +242,10 @@ __global__ void __launch_bounds__(256) k_cg3d(Cg3dArgs<T> A) {
         if (HAS_Q) w.sq = qp[hs_off];
       }
     }
+  };
+  auto issue = [&](int64_t ii, Raw& w, bool with_halo) {
+    const T* dp = pptr(A.d, ii);
+    issue_at(dp, HAS_R ? pptr(A.r, ii) : dp, HAS_Q ? pptr(A.v, ii) : dp, w, with_halo);
   };
   // the staged field from the raw loads: phase A r + beta d ; phase 5 r + beta (p - omega v)
   // (linalg.py:217) ; phase 6 r - alpha v (linalg.py:230) ; else the field itself
@@ -501,6 +509,7 @@ __global__ void __launch_bounds__(256) k_cg3d(Cg3dArgs<T> A) {
   double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
   const T sgn = A.sign, cf = A.coeff;
   const int hasc = A.has_coeff;
+  const T cfe = hasc ? cf : (T)1;   // (x * 1 is x, bit for bit: one multiply instead of a select per cell in the solver phases)
   // the stencil works on whole V rows (packed fp32 multiplies / adds; the explicit Euler step moves only
   // 8 B / cell and is VALU-bound when written per component): per-component k-axis coefficients
   // CG / BiCGSTAB phases of a pure Laplacian: per component (A/B: -9 % on fp32 CG as V rows)
@@ -527,6 +536,19 @@ __global__ void __launch_bounds__(256) k_cg3d(Cg3dArgs<T> A) {
       gPkV[v] = p; gCkV[v] = c0; gMkV[v] = mq;
     }
   }
+
+  // Plane pointers of the loads issued inside the loop (plane m + 2 of the march).  Every plane but the one BEYOND the
+  // chunk's last lies inside the array: a running pointer, one scalar add per plane; the plane beyond -- the only one
+  // that can be a ghost / wrap-around plane -- is resolved once, here.  (Resolved per plane through pptr() the three
+  // Vec<T> of the kernel argument were re-read from spilled scalar registers in every iteration: 64 v_readlane of the
+  // 459 VALU instructions of the fp64 phase-A loop.)
+  const int64_t pstep = rev ? -fs0 : fs0;
+  const T* d_run = A.d.p + plane_of(1) * fs0;
+  const T* r_run = HAS_R ? A.r.p + plane_of(1) * fs0 : d_run;
+  const T* q_run = HAS_Q ? A.v.p + plane_of(1) * fs0 : d_run;
+  const T* const d_end = pptr(A.d, plane_of(CI));
+  const T* const r_end = HAS_R ? pptr(A.r, plane_of(CI)) : d_end;
+  const T* const q_end = HAS_Q ? pptr(A.v, plane_of(CI)) : d_end;
 
   for (int m = 0; m < CI; ++m) {
     const int buf = m & 1;
@@ -571,7 +593,13 @@ __global__ void __launch_bounds__(256) k_cg3d(Cg3dArgs<T> A) {
                        : *reinterpret_cast<const V*>(A.aux + ii * G.s0 + jrow[jj] * G.s1 + kc);
     }
     // loads of plane m+2 (own cells + halo): in flight during the stencil below
-    if (more) issue(plane_of(m + 2), w, m + 2 < CI);
+    d_run += pstep;
+    if (HAS_R) r_run += pstep;
+    if (HAS_Q) q_run += pstep;
+    if (more) {
+      const bool inside = m + 2 < CI;
+      issue_at(inside ? d_run : d_end, HAS_R ? (inside ? r_run : r_end) : d_run, HAS_Q ? (inside ? q_run : q_end) : d_run, w, inside);
+    }
 
     // ---- stencil on plane ii, every cell of the thread (masks are applied afterwards) --------
     const int64_t gi = ii + G.off0;
@@ -582,6 +610,9 @@ __global__ void __launch_bounds__(256) k_cg3d(Cg3dArgs<T> A) {
       const int rc = pa_row_case(G, 0, gi, G.g0, G.treat);
       if (rc == 1) { cPi = A.lap.c23[0]; cCi = -A.lap.c23[0]; cMi = (T)0; }
       if (rc == 2) { cPi = (T)0; cCi = -A.lap.c23[0]; cMi = A.lap.c23[0]; }
+      // a 2-D mesh has no i axis: its planes behind / ahead are +0 (prologue), and with zero coefficients the i term of
+      // the solver phases is +0 exactly -- (+0)(+0) + (+0) x + (+0)(+0) -- as the select it replaces gave
+      if (!act0) { cPi = (T)0; cCi = (T)0; cMi = (T)0; }
     }
     const bool iPLo = (PHASE == 3 || PHASE == 7 || KIND != 0) && G.bct[0] == 4 && gi == 1;
     const bool iPHi = (PHASE == 3 || PHASE == 7 || KIND != 0) && G.bct[1] == 4 && gi == G.g0 - 2;
@@ -781,7 +812,7 @@ __global__ void __launch_bounds__(256) k_cg3d(Cg3dArgs<T> A) {
           s = s + mm;
           mm = cMi * xmi;
           s = s + mm;
-          T ax = act0 ? s : (T)0;
+          T ax = s;
           s = cPj * dn[v];
           mm = cCj * xc;
           s = s + mm;
@@ -799,7 +830,7 @@ __global__ void __launch_bounds__(256) k_cg3d(Cg3dArgs<T> A) {
           mm = cMk * xmk;
           s = s + mm;
           ax = ax + s;
-          if (hasc) ax = ax * (CF ? cv[jj][v] : cf);
+          if (CF) ax = ax * cv[jj][v]; else ax = ax * cfe;
           ax = ax * sgn;
           if (PHASE == 4) {
             // Jacobi:  x + omega (b - A x) / diag(A)   (k_jacobi, pa_solver.hip)
@@ -870,7 +901,7 @@ __global__ void __launch_bounds__(256) k_cg3d(Cg3dArgs<T> A) {
           const T e = inS ? xc : (T)0;
           outd[v] = e;
           T p = e * res[jj][v];
-          s0 += inS ? (double)p : 0.0;
+          s0 += (double)p;    // (off the interior set e is 0 and the product a signed zero: no second select)
         } else {
           const T xo = xv[jj][v];
           T ad = alpha * xc;
@@ -880,7 +911,7 @@ __global__ void __launch_bounds__(256) k_cg3d(Cg3dArgs<T> A) {
           xn = inS ? xn : xo;
           rn = inS ? rn : (T)0;
           T p = rn * rn;
-          s0 += inS ? (double)p : 0.0;
+          s0 += (double)p;    // (rn is 0 off the interior set)
           const bool offshell = inS && !(iShell || (rowShell >> jj & 1) || (colShell >> v & 1));
           T df = xn - xo;
           T p2 = df * df;
