@@ -413,8 +413,8 @@ __global__ void __launch_bounds__(256) k_cg2d(Cg3dArgs<T> A) {
         __builtin_nontemporal_store(outd, reinterpret_cast<V*>(A.dnew + (int64_t)jj * fs1 + kcf));
       } else if (PHASE == 4) {
         *reinterpret_cast<V*>(A.out + (int64_t)jj * G.s1 + kcf) = outd;
-      } else if (PHASE == 6) {
-        *reinterpret_cast<V*>(A.out + (int64_t)jj * fs1 + kcf) = outd;
+      } else if (PHASE == 6) {   // (s leaves only when asked for: k_bicg_x<..., SRV> re-forms it from r and v)
+        if (A.out) *reinterpret_cast<V*>(A.out + (int64_t)jj * fs1 + kcf) = outd;
         *reinterpret_cast<V*>(A.out2 + (int64_t)jj * fs1 + kcf) = outx;
       } else if (PHASE == 8) {
         *reinterpret_cast<V*>(A.out2 + (int64_t)jj * fs1 + kcf) = outx;

@@ -926,7 +926,9 @@ __global__ void __launch_bounds__(256) k_cg3d(Cg3dArgs<T> A) {
         if (PHASE == 8) {   // p' is the input field itself (k_bicg_x formed it): only v' = A p' leaves
           *reinterpret_cast<V*>(A.out2 + ob) = outx;
         } else if (PHASE == 5 || PHASE == 6) {   // (non-temporal r0 loads / p, v, s, t stores: within the noise, A/B)
-          *reinterpret_cast<V*>(A.out + ob) = outd;
+          // phase 6 on one GPU stores t alone (out = null): s = r - alpha v is re-formed, operation for operation, by the
+          // x / r update that follows (k_bicg_x<..., SRV>), which reads r and v anyway -- 15 array passes for 16
+          if (PHASE == 5 || A.out) *reinterpret_cast<V*>(A.out + ob) = outd;
           *reinterpret_cast<V*>(A.out2 + ob) = outx;
         } else if (PHASE >= 2) {
           *reinterpret_cast<V*>(A.out + o) = outd;

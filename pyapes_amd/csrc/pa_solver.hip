@@ -589,7 +589,10 @@ __global__ void __launch_bounds__(PA_BLOCK) k_bicg_t(DevGeom G, DevEq<T> E, cons
 // DESIGN.md section 4; 1: any alignment / cell count)
 // PITCHED (odd row lengths, bicg_run_t): p, s, t, r, v, p_next with a row pitch of ps1 cells (a multiple of the
 // vector), x contiguous and touched cell by cell; pad cells are written as 0.
-template <typename T, int VEC, bool PITCHED = false>
+// SRV (round 4): s is not read but re-formed from r and v' -- s = r - alpha v', the combine of phase 6, operation for
+// operation, so the same bits -- and r is updated IN PLACE: the tiled s / t phase then stores t alone (15 array passes per
+// iteration for 16; s_in unused, v_in required).
+template <typename T, int VEC, bool PITCHED = false, bool SRV = false>
 __global__ void __launch_bounds__(PA_BLOCK) k_bicg_x(DevGeom G, const SolverScalars* __restrict__ sc,
                                                       T* __restrict__ x, const T* p,   // (p_next may be p: in place)
                                                       const T* __restrict__ s_in, const T* __restrict__ t_in,
@@ -700,10 +703,20 @@ __global__ void __launch_bounds__(PA_BLOCK) k_bicg_x(DevGeom G, const SolverScal
     }
     V xn, rn, sv, tv, vv, pq;
     if (!early) {
-      sv = reinterpret_cast<const V*>(s_in)[iv];
+      if (SRV) {
+        const V ro = reinterpret_cast<const V*>(r)[iv];
+        vv = reinterpret_cast<const V*>(v_in)[iv];
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) {
+          T av = alpha * vv[v];
+          sv[v] = ro[v] - av;
+        }
+      } else {
+        sv = reinterpret_cast<const V*>(s_in)[iv];
+      }
       tv = reinterpret_cast<const V*>(t_in)[iv];
     }
-    if (pn) vv = reinterpret_cast<const V*>(v_in)[iv];
+    if (pn && !SRV) vv = reinterpret_cast<const V*>(v_in)[iv];
 #pragma unroll
     for (int v = 0; v < VEC; ++v) {
       T ap = alpha * pv[v];
@@ -1667,7 +1680,9 @@ static int bicg_run_t(pa_ctx* c, T* x, const T* rhs, double tol, int64_t max_it,
     if (!pend0) hipLaunchKernelGGL(k_bicg_post<T>, dim3(1), dim3(PA_BLOCK), 0, c->stream, c->sc, reg0, used, 0);
     Vec<T> vnv = vec_of(v[cur ^ 1]);
     c->fold_a_n = pend0;          // phase 6 computes alpha itself
-    int used2 = pa_tile3d_bicg_st<T>(c, E, rv, vnv, (const T*)r0, s, t, reg1);
+    // (option "bicg_srv", default on: the tiled phase stores t alone and k_bicg_x re-forms s from r and v')
+    int used2 = pa_tile3d_bicg_st<T>(c, E, rv, vnv, (const T*)r0, c->bicg_srv ? (T*)nullptr : s, t, reg1);
+    const bool srv = c->bicg_srv && used2 > 0;
     c->fold_a_n = 0;
     if (used2 < 0) return used2;
     if (c->cg_pitch && used2 == 0) { pa_set_err(c, "pitched BiCGSTAB: the tiled s / t phase declined"); return PA_E_STATE; }
@@ -1687,18 +1702,18 @@ static int bicg_run_t(pa_ctx* c, T* x, const T* rhs, double tol, int64_t max_it,
     {
       constexpr int XV = 16 / (int)sizeof(T);
       const bool vec = G.ncell % XV == 0 && ((((uintptr_t)x | (uintptr_t)p[cur ^ 1] | (uintptr_t)s | (uintptr_t)t | (uintptr_t)r) & 15) == 0);
-      if (c->cg_pitch)
-        hipLaunchKernelGGL((k_bicg_x<T, XV, true>), dim3(nblk), dim3(PA_BLOCK), 0, c->stream, G, c->sc, x, (const T*)p_it,
-                           (const T*)s, (const T*)t, r, reg2, (const double*)reg1, pend12, c->sc, (const T*)v[cur ^ 1],
-                           pnext ? p[cur ^ 1] : (T*)nullptr, c->cg_ps1);
-      else if (vec)
-        hipLaunchKernelGGL((k_bicg_x<T, XV>), dim3(nblk), dim3(PA_BLOCK), 0, c->stream, G, c->sc, x, (const T*)p_it,
-                           (const T*)s, (const T*)t, r, reg2, (const double*)reg1, pend12, c->sc, (const T*)v[cur ^ 1],
-                           pnext ? p[cur ^ 1] : (T*)nullptr);
-      else
-        hipLaunchKernelGGL((k_bicg_x<T, 1>), dim3(nblk), dim3(PA_BLOCK), 0, c->stream, G, c->sc, x, (const T*)p_it,
-                           (const T*)s, (const T*)t, r, reg2, (const double*)reg1, pend12, c->sc, (const T*)v[cur ^ 1],
-                           pnext ? p[cur ^ 1] : (T*)nullptr);
+#define PA_BICG_X(VV, PP, SS, ...)                                                                                          \
+      hipLaunchKernelGGL((k_bicg_x<T, VV, PP, SS>), dim3(nblk), dim3(PA_BLOCK), 0, c->stream, G, c->sc, x, (const T*)p_it, \
+                         (const T*)s, (const T*)t, r, reg2, (const double*)reg1, pend12, c->sc, (const T*)v[cur ^ 1],      \
+                         pnext ? p[cur ^ 1] : (T*)nullptr, ##__VA_ARGS__)
+      if (c->cg_pitch) {
+        if (srv) PA_BICG_X(XV, true, true, c->cg_ps1); else PA_BICG_X(XV, true, false, c->cg_ps1);
+      } else if (vec) {
+        if (srv) PA_BICG_X(XV, false, true); else PA_BICG_X(XV, false, false);
+      } else {
+        if (srv) PA_BICG_X(1, false, true); else PA_BICG_X(1, false, false);
+      }
+#undef PA_BICG_X
       pgiven = pnext;   // (p[cur ^ 1] is p[cur] of the next iteration; in place when p' came from the p / v phase)
     }
     if ((rc = pa_bc_apply_auto<T>(c, x, true))) return rc;

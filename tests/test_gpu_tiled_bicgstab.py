@@ -96,3 +96,24 @@ def test_next_direction_formed_by_the_x_update_changes_no_bit(case, monkeypatch)
         xb, rb = _run(n, dtype, bcs, rhs0, K, tol, True, monkeypatch)
         assert ra["itr"] == rb["itr"] and ra["tol"] == rb["tol"], (K, ra, rb)
         assert torch.equal(xa, xb), (K, float((xa - xb).abs().max()))
+
+
+@pytest.mark.parametrize("case", CASES, ids=lambda c: "x".join(map(str, c[0])) + c[1][0])
+def test_s_reformed_by_the_x_update_changes_no_bit(case, monkeypatch):
+    """Round 4: the tiled s / t phase stores t alone; the x / r update re-forms s = r - alpha v' from r and v' (which it reads
+    anyway) with the combine of phase 6, operation for operation, and updates r in place -- 15 array passes per iteration for
+    16.  Every bit of the iterate, the iteration count and the stop-test value must equal the sequence that stores s
+    (option bicg_srv 0), with and without the folded next direction, early exit on |s| included (the long run)."""
+    n, dtype, bcs = case
+    tdt = torch.float64 if dtype == "double" else torch.float32
+    g = torch.Generator().manual_seed(23)
+    rhs0 = torch.randn((1, *n), generator=g, dtype=torch.float64).to(tdt)
+    for pfold in (1, 0):
+        for K, tol in ((1, 1e-30), (2, 1e-30), (7, 1e-30), (400, 1e-7 if dtype == "double" else 1e-3)):
+            hip_options(monkeypatch, bicg_pfold=pfold, bicg_srv=1)
+            xa, ra = _run(n, dtype, bcs, rhs0, K, tol, True, monkeypatch)
+            hip_options(monkeypatch, bicg_pfold=pfold, bicg_srv=0)
+            xb, rb = _run(n, dtype, bcs, rhs0, K, tol, True, monkeypatch)
+            assert ra["itr"] == rb["itr"] and ra["tol"] == rb["tol"], (pfold, K, ra, rb)
+            assert torch.equal(xa, xb), (pfold, K, float((xa - xb).abs().max()))
+    hip_options(monkeypatch, bicg_pfold=None, bicg_srv=None)
