@@ -96,7 +96,8 @@ int pa_ctx_set_option(pa_ctx* ctx, const char* name, int value);
  * any option of this list for every ctx of the process): "bc_path" (bit 0: never the closed-form BC fill, bit 1: never
  * the per-axis pair kernels, bit 2: closed form at any size; all paths bit-identical), "bicg_pfold" 0 = BiCGSTAB with the
  * full p / v phase in every iteration, "bicg_srv" 0 = BiCGSTAB's tiled s / t phase stores s as well (1: t alone, the x / r
- * update re-forms s = r - alpha v', the same bits), "rhs_full" 1 = pa_rhs_adjust over the whole mesh, "res_cells" / "res_nt" /
+ * update re-forms s = r - alpha v', the same bits), "jac_alt" 0 = every Jacobi sweep of a 3-D mesh marches forwards (1: consecutive
+ * sweeps in opposite directions; the iterates are the same bits, the stop-test sums are added in another order), "rhs_full" 1 = pa_rhs_adjust over the whole mesh, "res_cells" / "res_nt" /
  * "res_nt_cells" / "res_spin" / "res_rzlean" (box plan, threads per workgroup, spin bound, rz stencil of the resident
  * solver), "comm" / "slab_fold" (read back by the slab driver: library-side RCCL loop, folded sequence), "comm_overlap"
  * (-1 auto), "comm_timeout" (s), "roctx" (process-wide).  pa_ctx_get_option reads a value back. */

@@ -85,7 +85,11 @@ int pa_tile3d_jacobi(pa_ctx* c, const DevEq<T>& E, Vec<T> x, const T* rhs, T* xn
   }
   int n = (mode == 1 || mode == 4) ? launch_cg2d<T, 4>(c, A, false) : 0;   // large 2-D meshes: marching along the slow axis
   if (n == 0 && rz) return 0;
-  if (n == 0) n = launch_any<T, 4>(c, A, mode);
+  if (n == 0) {   // 3-D: consecutive sweeps march in opposite directions (k_cg3d PHASE 9; option "jac_alt" 0: all forwards)
+    const bool back = c->jac_alt && c->jac_dir && !c->plan_only;
+    n = back ? launch_any<T, 9>(c, A, mode) : launch_any<T, 4>(c, A, mode);
+    if (n > 0 && !c->plan_only) c->jac_dir ^= 1;
+  }
   if (n > 0 && hipGetLastError() != hipSuccess) { pa_set_err(c, "k_cg3d Jacobi launch failed"); return PA_E_HIP; }
   if (n > 0 && c->fold_b_n > 0) {
     SolverScalars* t = c->sc; c->sc = c->sc_alt; c->sc_alt = t;

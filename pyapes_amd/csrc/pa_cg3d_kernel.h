@@ -120,15 +120,19 @@ __device__ __forceinline__ int64_t pa_wrapmod(int64_t v, int64_t n) {
 // phases is the ctx's (r, p, v, r0, s, t) and pitched; only the x / r update (k_bicg_x, pa_solver.hip) touches x.
 template <typename T, int RJ, int PHASE, bool CF = false, int KIND = 0, int LAY = 0>
 __global__ void __launch_bounds__(256) k_cg3d(Cg3dArgs<T> A) {
+  // PHASE 9 = the Jacobi sweep (phase 4) marching its chunks BACKWARDS: consecutive sweeps alternate, so the planes a sweep
+  // wrote last -- still in the 256 MiB Infinity Cache -- are the ones the next sweep reads first (what phase B does for
+  // phase A).  Everything below tests PH.
+  constexpr int PH = PHASE == 9 ? 4 : PHASE;
   constexpr bool NARROW = LAY == 1, PITCH = LAY == 2;
-  static_assert(!PITCH || ((PHASE == 0 || PHASE == 1 || PHASE == 5 || PHASE == 6 || PHASE == 8) && !CF && KIND == 0),
+  static_assert(!PITCH || ((PH == 0 || PH == 1 || PH == 5 || PH == 6 || PH == 8) && !CF && KIND == 0),
                 "PITCH: the CG / BiCGSTAB phases of a plain Laplacian");
   constexpr int VEC = NARROW ? 1 : VecOf<T>::N;
   typedef T V __attribute__((ext_vector_type(VEC)));
   constexpr int TJ = 4 * RJ, TK = 64 * VEC, TKP = TK + 2 * VEC;
   __shared__ __attribute__((aligned(16))) T tile[2][TJ + 2][TKP];
 
-  (void)sizeof(int[PHASE >= 0 && PHASE <= 8 ? 1 : -1]);
+  (void)sizeof(int[PH >= 0 && PH <= 8 ? 1 : -1]);
   T beta = (T)0, alpha = (T)0;
   T omega = (T)0;
   const DevGeom& G = A.G;
@@ -142,7 +146,9 @@ __global__ void __launch_bounds__(256) k_cg3d(Cg3dArgs<T> A) {
   const int64_t j0 = (int64_t)tjb * TJ, k0 = (int64_t)tkb * TK;
   // phase B marches its chunks backwards (header comment); a compile-time fact, so that "ahead" / "behind" resolve to
   // registers instead of 2 * RJ * VEC selects per plane (32 of the 459 VALU instructions of the fp64 phase-A loop)
-  constexpr int rev = (PHASE == 1) ? 1 : 0;
+  // (BiCGSTAB's s / t phase marching backwards as well -- between the forward v phase and the x / r update -- measured in
+  // round 4, interleaved on one box: 256^3 0.3984 / 0.3984 ms, 512^3 3.069 / 3.059, 2.973 / 2.969: nothing, not kept)
+  constexpr int rev = (PHASE == 1 || PHASE == 9) ? 1 : 0;
 
   // ---- per-thread geometry: RJ rows x VEC columns --------------------------------
   const int64_t kg = k0 + (int64_t)lane * VEC;            // global k of element 0 (may be >= n2)
@@ -167,7 +173,7 @@ __global__ void __launch_bounds__(256) k_cg3d(Cg3dArgs<T> A) {
     if (rc == 2) rowHi |= 1u << jj;
   }
   unsigned rowPLo = 0, rowPHi = 0, colPLo = 0, colPHi = 0;  // periodic rows of the central Div (fdc.py:596-602)
-  if (PHASE == 3 || PHASE == 7 || KIND != 0) {
+  if (PH == 3 || PH == 7 || KIND != 0) {
 #pragma unroll
     for (int jj = 0; jj < RJ; ++jj) {
       const int64_t jg = j0 + wv * RJ + jj;
@@ -219,8 +225,8 @@ __global__ void __launch_bounds__(256) k_cg3d(Cg3dArgs<T> A) {
     V hd, hr, hq;  // halo row (waves 0 and 3)
     T sd, sr, sq;  // halo cell (wave 1)
   };
-  constexpr bool HAS_R = (PHASE == 0 || PHASE == 5 || PHASE == 6);
-  constexpr bool HAS_Q = (PHASE == 5);
+  constexpr bool HAS_R = (PH == 0 || PH == 5 || PH == 6);
+  constexpr bool HAS_Q = (PH == 5);
   auto issue_at = [&](const T* dp, const T* rp, const T* qp, Raw& w, bool with_halo) {
 #pragma unroll
     for (int jj = 0; jj < RJ; ++jj) {
@@ -250,15 +256,15 @@ __global__ void __launch_bounds__(256) k_cg3d(Cg3dArgs<T> A) {
   // the staged field from the raw loads: phase A r + beta d ; phase 5 r + beta (p - omega v)
   // (linalg.py:217) ; phase 6 r - alpha v (linalg.py:230) ; else the field itself
   auto combine = [&](T rr_, T dd_, T qq_) -> T {
-    if (PHASE == 0) {
+    if (PH == 0) {
       T bd = beta * dd_;
       return rr_ + bd;
-    } else if (PHASE == 5) {
+    } else if (PH == 5) {
       T t = omega * qq_;
       t = dd_ - t;
       t = beta * t;
       return rr_ + t;
-    } else if (PHASE == 6) {
+    } else if (PH == 6) {
       T av = alpha * dd_;
       return rr_ - av;
     }
@@ -305,7 +311,7 @@ __global__ void __launch_bounds__(256) k_cg3d(Cg3dArgs<T> A) {
   issue(plane_of(0), wc, true);
   if (act0) issue(plane_of(1), w, CI > 1);
 
-  if ((PHASE == 0 || PHASE == 4) && A.pre_n > 0) {
+  if ((PH == 0 || PH == 4) && A.pre_n > 0) {
     // the scalar step that closes the PREVIOUS iteration (CG: linalg.py:128-141, 321-338; the Jacobi
     // sweep has the stop test and the iteration count only).  Every load of
     // the prologue is issued before the first wait -- one memory round trip (~1-2 us right after a
@@ -317,7 +323,7 @@ __global__ void __launch_bounds__(256) k_cg3d(Cg3dArgs<T> A) {
     const long long itr_in = si->itr, max_it = si->max_it;
     double v0 = 0.0, v1 = 0.0, v2 = 0.0;
     for (int b = threadIdx.x; b < A.pre_n; b += 256) {
-      if (PHASE == 0) v0 += A.pre_part[2 * (int64_t)b];
+      if (PH == 0) v0 += A.pre_part[2 * (int64_t)b];
       v1 += A.pre_part[2 * (int64_t)b + 1];
     }
     for (int b = threadIdx.x; b < A.pre_nsh; b += 256) v2 += A.pre_shell[b];
@@ -359,21 +365,21 @@ __global__ void __launch_bounds__(256) k_cg3d(Cg3dArgs<T> A) {
         if (bad) {
           so->err = 1;
         } else {
-          if (PHASE == 0) {
+          if (PH == 0) {
             so->rr_old = (double)rr_old;
             so->beta = bq;
             so->rr = (double)rr_new;
           }
           so->itr = itr;
         }
-        if (PHASE == 0) A.pre_sums[1] = rr;
+        if (PH == 0) A.pre_sums[1] = rr;
         A.pre_sums[2] = dx2 + sh;
       }
     }
     __syncthreads();
     if (pre_sm[13] != 0.0) return;
     beta = (T)pre_sm[12];
-  } else if (PHASE == 1 && A.pre_n > 0) {
+  } else if (PH == 1 && A.pre_n > 0) {
     // alpha = r.r / d.Ad of THIS iteration (linalg.py:118-120); loads first, as above
     __shared__ double pre_sm[8];
     const int done_in = A.sc->done;
@@ -399,7 +405,7 @@ __global__ void __launch_bounds__(256) k_cg3d(Cg3dArgs<T> A) {
     }
     __syncthreads();
     alpha = (T)pre_sm[4];
-  } else if ((PHASE == 5 || PHASE == 8) && A.pre_n > 0) {
+  } else if ((PH == 5 || PH == 8) && A.pre_n > 0) {
     // BiCGSTAB: the step that closes the PREVIOUS iteration (k_bicg_post stage 3; linalg.py:212-214,
     // 236-262): early exit, stop test 2, next beta, rho <- rho_next.  Next state -> the other slot.
     __shared__ double pre_sm[8];
@@ -452,7 +458,7 @@ __global__ void __launch_bounds__(256) k_cg3d(Cg3dArgs<T> A) {
     if (pre_sm[5] != 0.0) return;
     beta = (T)pre_sm[4];
     omega = (T)omega_in;
-  } else if (PHASE == 6 && A.pre_n > 0) {
+  } else if (PH == 6 && A.pre_n > 0) {
     // BiCGSTAB: alpha = rho / (r0 . v) of THIS iteration, iteration count (k_bicg_post stage 0)
     __shared__ double pre_sm[8];
     const int done_in = A.sc->done;
@@ -477,11 +483,11 @@ __global__ void __launch_bounds__(256) k_cg3d(Cg3dArgs<T> A) {
     __syncthreads();
     alpha = (T)pre_sm[4];
   } else {
-    if (PHASE != 2 && PHASE != 3 && PHASE != 7 && A.sc->done) return;
-    if (PHASE == 0) beta = (T)A.sc->beta;
-    if (PHASE == 1) alpha = (T)A.sc->alpha;
-    if (PHASE == 5) { beta = (T)A.sc->beta; omega = (T)A.sc->omega; }
-    if (PHASE == 6) alpha = (T)A.sc->alpha;
+    if (PH != 2 && PH != 3 && PH != 7 && A.sc->done) return;
+    if (PH == 0) beta = (T)A.sc->beta;
+    if (PH == 1) alpha = (T)A.sc->alpha;
+    if (PH == 5) { beta = (T)A.sc->beta; omega = (T)A.sc->omega; }
+    if (PH == 6) alpha = (T)A.sc->alpha;
   }
 
   if (act0) {
@@ -513,7 +519,7 @@ __global__ void __launch_bounds__(256) k_cg3d(Cg3dArgs<T> A) {
   // the stencil works on whole V rows (packed fp32 multiplies / adds; the explicit Euler step moves only
   // 8 B / cell and is VALU-bound when written per component): per-component k-axis coefficients
   // CG / BiCGSTAB phases of a pure Laplacian: per component (A/B: -9 % on fp32 CG as V rows)
-  constexpr bool VROW = (PHASE == 2 || PHASE == 3 || PHASE == 4 || PHASE == 7 || KIND != 0);
+  constexpr bool VROW = (PH == 2 || PH == 3 || PH == 4 || PH == 7 || KIND != 0);
   V cPkV, cCkV, cMkV;
   if (VROW) {
 #pragma unroll
@@ -525,7 +531,7 @@ __global__ void __launch_bounds__(256) k_cg3d(Cg3dArgs<T> A) {
     }
   }
   V gPkV, gCkV, gMkV;   // phase 7: k-axis rows of the gradient (k_grad, pa_ops.hip)
-  if (PHASE == 7) {
+  if (PH == 7) {
 #pragma unroll
     for (int v = 0; v < VEC; ++v) {
       T p = A.grd.g[2], c0 = (T)0, mq = A.grd.mg[2];
@@ -559,7 +565,7 @@ __global__ void __launch_bounds__(256) k_cg3d(Cg3dArgs<T> A) {
     // phase B: the thread's x and r of THIS plane, issued first so that their wait (at the update,
     // below the stencil) does not have to cover the younger loads of plane m+2
     V xv[RJ], rv[RJ];
-    if (PHASE == 1) {
+    if (PH == 1) {
 #pragma unroll
       for (int jj = 0; jj < RJ; ++jj) {
         const int64_t o = ii * G.s0 + jrow[jj] * G.s1 + kc;
@@ -586,7 +592,7 @@ __global__ void __launch_bounds__(256) k_cg3d(Cg3dArgs<T> A) {
       for (int jj = 0; jj < RJ; ++jj)
         cv[jj] = *reinterpret_cast<const V*>(A.coeff_f + ii * G.s0 + jrow[jj] * G.s1 + kc);
     }
-    if (PHASE == 4 || PHASE == 5 || PHASE == 6 || PHASE == 8 || ((PHASE == 3 || (PHASE == 2 && KIND != 0)) && A.aux)) {  // rhs / u / r0 of this plane
+    if (PH == 4 || PH == 5 || PH == 6 || PH == 8 || ((PH == 3 || (PH == 2 && KIND != 0)) && A.aux)) {  // rhs / u / r0 of this plane
 #pragma unroll
       for (int jj = 0; jj < RJ; ++jj)
         xv[jj] = PITCH ? *reinterpret_cast<const V*>(A.aux + ii * fs0 + jrow[jj] * fs1 + kcf)   // (BiCGSTAB: r0, pitched)
@@ -614,10 +620,10 @@ __global__ void __launch_bounds__(256) k_cg3d(Cg3dArgs<T> A) {
       // the solver phases is +0 exactly -- (+0)(+0) + (+0) x + (+0)(+0) -- as the select it replaces gave
       if (!act0) { cPi = (T)0; cCi = (T)0; cMi = (T)0; }
     }
-    const bool iPLo = (PHASE == 3 || PHASE == 7 || KIND != 0) && G.bct[0] == 4 && gi == 1;
-    const bool iPHi = (PHASE == 3 || PHASE == 7 || KIND != 0) && G.bct[1] == 4 && gi == G.g0 - 2;
+    const bool iPLo = (PH == 3 || PH == 7 || KIND != 0) && G.bct[0] == 4 && gi == 1;
+    const bool iPHi = (PH == 3 || PH == 7 || KIND != 0) && G.bct[1] == 4 && gi == G.g0 - 2;
     T gP0 = A.grd.g[0], gC0 = (T)0, gM0 = A.grd.mg[0];
-    if (PHASE == 7) {
+    if (PH == 7) {
       const int rc = pa_row_case(G, 0, gi, G.g0, G.treat);
       if (rc == 1) { gP0 = A.grd.lo_p[0]; gC0 = A.grd.lo_c[0]; gM0 = (T)0; }
       if (rc == 2) { gP0 = (T)0; gC0 = A.grd.hi_c[0]; gM0 = A.grd.hi_m[0]; }
@@ -649,7 +655,7 @@ __global__ void __launch_bounds__(256) k_cg3d(Cg3dArgs<T> A) {
           xpk[v] = (v < VEC - 1) ? xc[v + 1 < VEC ? v + 1 : v] : right;
           xmk[v] = (v > 0) ? xc[v > 0 ? v - 1 : 0] : left;
         }
-        if constexpr (PHASE == 7) {
+        if constexpr (PH == 7) {
           // grad: y[a] = cP xp + cC xc + cM xm with the rows of k_grad (fdc.py:80-87, 543-609), same order
           T pj = A.grd.g[1], cj = (T)0, mj = A.grd.mg[1];
           if (rowLo >> jj & 1) { pj = A.grd.lo_p[1]; cj = A.grd.lo_c[1]; mj = (T)0; }
@@ -764,7 +770,7 @@ __global__ void __launch_bounds__(256) k_cg3d(Cg3dArgs<T> A) {
           }
           return adv;
         };
-        if constexpr (PHASE == 3) {
+        if constexpr (PH == 3) {
           const V ax = axv;
           V uc;
           if (A.aux) uc = xv[jj]; else uc = (V)A.u;
@@ -775,10 +781,10 @@ __global__ void __launch_bounds__(256) k_cg3d(Cg3dArgs<T> A) {
           res[jj] = xc + q;
           continue;
         }
-        if constexpr (KIND != 0 && PHASE != 3) {
+        if constexpr (KIND != 0 && PH != 3) {
           // sum_k sign_k Aop_k (ops.py:122-154) of {Laplacian, Div(scalar u)}: p0 = sign of the Div term,
           // p1 != 0: the Div term comes first in the equation
-          V dv = div_row((PHASE == 2 && A.aux) ? xv[jj] : (V)A.u);   // A x: the speed may be a field (upwind)
+          V dv = div_row((PH == 2 && A.aux) ? xv[jj] : (V)A.u);   // A x: the speed may be a field (upwind)
           dv = dv * A.p0;
           if (A.lap_off) axv = (V)(T)0;   // Div alone: 0 + sign * Div, as the generic kernel's running sum
           if (A.p1 != (T)0) axv = dv + axv; else axv = axv + dv;
@@ -787,7 +793,7 @@ __global__ void __launch_bounds__(256) k_cg3d(Cg3dArgs<T> A) {
         for (int v = 0; v < VEC; ++v) {
           T ax = axv[v];
           T cCk = cCkV[v];
-          if (PHASE == 4) {
+          if (PH == 4) {
             // Jacobi:  x + omega (b - A x) / diag(A)   (k_jacobi, pa_solver.hip)
             T dg = act0 ? cCi : (T)0;
             dg = dg + cCj;
@@ -832,7 +838,7 @@ __global__ void __launch_bounds__(256) k_cg3d(Cg3dArgs<T> A) {
           ax = ax + s;
           if (CF) ax = ax * cv[jj][v]; else ax = ax * cfe;
           ax = ax * sgn;
-          if (PHASE == 4) {
+          if (PH == 4) {
             // Jacobi:  x + omega (b - A x) / diag(A)   (k_jacobi, pa_solver.hip)
             T dg = act0 ? cCi : (T)0;
             dg = dg + cCj;
@@ -852,7 +858,7 @@ __global__ void __launch_bounds__(256) k_cg3d(Cg3dArgs<T> A) {
     // ---- outputs of plane ii --------------------------------------------------------------------
 #pragma unroll
     for (int jj = 0; jj < RJ; ++jj) {
-      if constexpr (PHASE == 7) {
+      if constexpr (PH == 7) {
         if (kvalid && (rowValid >> jj & 1)) {
           const int64_t o = ii * G.s0 + jrow[jj] * G.s1 + kc;
           const int c0 = A.gnd - 3;   // component of internal axis a is a - (3 - nd)
@@ -868,14 +874,14 @@ __global__ void __launch_bounds__(256) k_cg3d(Cg3dArgs<T> A) {
       for (int v = 0; v < VEC; ++v) {
         const bool inS = iS && (rowS >> jj & 1) && (colS >> v & 1);
         const T xc = ec[jj][v];
-        if (PHASE == 5 || PHASE == 6 || PHASE == 8) {
+        if (PH == 5 || PH == 6 || PH == 8) {
           // own cells: p' (or s) everywhere, v' = A p' (or t = A s) on the interior set
           const bool mine = kvalid && (rowValid >> jj & 1);
           const T an = inS ? res[jj][v] : (T)0;
           outd[v] = xc;
           outx[v] = an;
           const T r0c = xv[jj][v];
-          if (PHASE == 5 || PHASE == 8) {
+          if (PH == 5 || PH == 8) {
             T p = r0c * an;
             s0 += inS ? (double)p : 0.0;
           } else {
@@ -886,18 +892,18 @@ __global__ void __launch_bounds__(256) k_cg3d(Cg3dArgs<T> A) {
             s2 += inS ? (double)b : 0.0;
             s3 += inS ? (double)cc : 0.0;
           }
-        } else if (PHASE == 2) {
+        } else if (PH == 2) {
           outd[v] = (inS || !A.interior_only) ? res[jj][v] : (T)0;
-        } else if (PHASE == 3) {
+        } else if (PH == 3) {
           outd[v] = inS ? res[jj][v] : xc;
-        } else if (PHASE == 4) {
+        } else if (PH == 4) {
           const T xn = inS ? res[jj][v] : xc;
           const bool offshell = inS && !(iShell || (rowShell >> jj & 1) || (colShell >> v & 1));
           T df = xn - xc;
           T p2 = df * df;
           s1 += offshell ? (double)p2 : 0.0;
           outd[v] = xn;
-        } else if (PHASE == 0) {
+        } else if (PH == 0) {
           const T e = inS ? xc : (T)0;
           outd[v] = e;
           T p = e * res[jj][v];
@@ -923,16 +929,16 @@ __global__ void __launch_bounds__(256) k_cg3d(Cg3dArgs<T> A) {
       if (kvalid && (rowValid >> jj & 1)) {
         const int64_t o = ii * G.s0 + jrow[jj] * G.s1 + kc;
         const int64_t ob = PITCH ? ii * fs0 + jrow[jj] * fs1 + kcf : o;   // BiCGSTAB: pitched outputs
-        if (PHASE == 8) {   // p' is the input field itself (k_bicg_x formed it): only v' = A p' leaves
+        if (PH == 8) {   // p' is the input field itself (k_bicg_x formed it): only v' = A p' leaves
           *reinterpret_cast<V*>(A.out2 + ob) = outx;
-        } else if (PHASE == 5 || PHASE == 6) {   // (non-temporal r0 loads / p, v, s, t stores: within the noise, A/B)
+        } else if (PH == 5 || PH == 6) {   // (non-temporal r0 loads / p, v, s, t stores: within the noise, A/B)
           // phase 6 on one GPU stores t alone (out = null): s = r - alpha v is re-formed, operation for operation, by the
           // x / r update that follows (k_bicg_x<..., SRV>), which reads r and v anyway -- 15 array passes for 16
-          if (PHASE == 5 || A.out) *reinterpret_cast<V*>(A.out + ob) = outd;
+          if (PH == 5 || A.out) *reinterpret_cast<V*>(A.out + ob) = outd;
           *reinterpret_cast<V*>(A.out2 + ob) = outx;
-        } else if (PHASE >= 2) {
+        } else if (PH >= 2) {
           *reinterpret_cast<V*>(A.out + o) = outd;
-        } else if (PHASE == 0) {
+        } else if (PH == 0) {
           if (PITCH) __builtin_nontemporal_store(outd, reinterpret_cast<V*>(A.dnew + ii * fs0 + jrow[jj] * fs1 + kcf));
           else if (NARROW) *reinterpret_cast<V*>(A.dnew + o) = outd;
           else __builtin_nontemporal_store(outd, reinterpret_cast<V*>(A.dnew + o));  // -1.5 % (measured)
@@ -969,16 +975,16 @@ __global__ void __launch_bounds__(256) k_cg3d(Cg3dArgs<T> A) {
     __syncthreads();
   }
 
-  if (PHASE == 0) {
+  if (PH == 0) {
     double s[1] = {s0};
     pa_block_reduce_store<1>(s, A.partials);
-  } else if (PHASE == 1 || PHASE == 4) {
+  } else if (PH == 1 || PH == 4) {
     double s[2] = {s0, s1};
     pa_block_reduce_store<2>(s, A.partials);
-  } else if (PHASE == 5 || PHASE == 8) {
+  } else if (PH == 5 || PH == 8) {
     double s[1] = {s0};
     pa_block_reduce_store<1>(s, A.partials);
-  } else if (PHASE == 6) {
+  } else if (PH == 6) {
     double s[4] = {s0, s1, s2, s3};
     pa_block_reduce_store<4>(s, A.partials);
   }
@@ -1131,7 +1137,7 @@ static int pick_rj(pa_ctx* c, bool narrow = false, bool cg_phase = false) {
 
 template <typename T, int PHASE, int NARROW>   // NARROW = LAY of k_cg3d: 0 vector, 1 one cell per lane, 2 pitched
 static int launch_any_w(pa_ctx* c, Cg3dArgs<T>& A) {
-  constexpr bool CF_OK = (PHASE == 0 || PHASE == 1 || PHASE == 2 || PHASE == 4);
+  constexpr bool CF_OK = (PHASE == 0 || PHASE == 1 || PHASE == 2 || PHASE == 4 || PHASE == 9);
   if (A.coeff_f) {  // tensor coefficient: separate instantiation, so the scalar-coefficient kernels stay lean
     if (!CF_OK) return 0;
     if constexpr (CF_OK) {

@@ -348,6 +348,7 @@ int pa_ctx_set_option(pa_ctx* c, const char* name, int value) {
   else if (!strcmp(name, "bc_path")) c->bc_path = value & 7;
   else if (!strcmp(name, "bicg_pfold")) c->bicg_pfold = value != 0;
   else if (!strcmp(name, "bicg_srv")) c->bicg_srv = value != 0;
+  else if (!strcmp(name, "jac_alt")) c->jac_alt = value != 0;
   else if (!strcmp(name, "rhs_full")) c->rhs_full = value != 0;
   else if (!strcmp(name, "res_cells")) c->res_cells = value;
   else if (!strcmp(name, "res_nt")) c->res_nt = value;
@@ -367,7 +368,7 @@ int pa_ctx_get_option(const pa_ctx* c, const char* name, int* value) {
   if (!c || !name || !value) return PA_E_ARG;
   const struct { const char* n; int v; } tab[] = {
       {"fastpath", c->fastpath}, {"sf", c->sf}, {"fold", c->fold}, {"resident", c->resident}, {"bcl", c->bcl}, {"pitch", c->pitch},
-      {"place", c->place}, {"resident_coop", c->resident_coop}, {"bc_path", c->bc_path}, {"bicg_pfold", c->bicg_pfold}, {"bicg_srv", c->bicg_srv},
+      {"place", c->place}, {"resident_coop", c->resident_coop}, {"bc_path", c->bc_path}, {"bicg_pfold", c->bicg_pfold}, {"bicg_srv", c->bicg_srv}, {"jac_alt", c->jac_alt},
       {"rhs_full", c->rhs_full}, {"comm", c->opt_comm}, {"slab_fold", c->opt_slab_fold}, {"comm_overlap", c->comm_overlap},
       {"comm_timeout", c->comm_timeout}, {"place_blocks", c->ps.blocks}};
   for (const auto& t : tab)

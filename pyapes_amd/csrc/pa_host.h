@@ -142,6 +142,8 @@ struct pa_ctx {
   int bc_path = 0;           // "bc_path": bit 0 never the closed-form fill, bit 1 never the per-axis pair kernels, bit 2 closed form at any size
   int bicg_pfold = 1;        // "bicg_pfold": BiCGSTAB's next direction formed by the x / r update (0: the full p / v phase every iteration)
   int bicg_srv = 1;          // "bicg_srv": the tiled s / t phase stores t alone, the x / r update re-forms s = r - alpha v' (0: s stored, as before round 4)
+  int jac_alt = 1;           // "jac_alt": consecutive Jacobi sweeps of 3-D meshes march in opposite directions (0: all forwards)
+  int jac_dir = 0;           // ... direction of the next sweep
   int rhs_full = 0;          // "rhs_full": pa_rhs_adjust visits the whole mesh instead of the Neumann layers
   int res_cells = 0, res_nt = 0, res_nt_cells = 0, res_spin = -1, res_rzlean = 1;   // "res_*": box plan / threads / spin bound / rz stencil of pa_resident.hip
   int opt_comm = 1;          // "comm" / PYAPES_HIP_COMM: slab driver may use RCCL inside the library (read by pyapes_amd/slab.py)

@@ -178,3 +178,42 @@ def test_tensor_coefficient_laplacian_tiled(shape, monkeypatch):
         xs, ro = O.cg(xo, rhs, [O.OTerm("laplacian", tabs, gamma, 1.0)], om, bo, 1e-30, 5)
     assert ro["itr"] == 6
     assert rel_err(out[True]["cg"], xs) <= (1e-10 if dtype == "double" else 1e-5)
+
+
+@pytest.mark.parametrize("bc", ["mix", "per", "xper"], ids=["mix", "per", "xper"])
+@pytest.mark.parametrize("shape", [((20, 37, 50), "double"), ((17, 70, 260), "double"), ((12, 18, 133), "single")],
+                         ids=lambda s: "x".join(map(str, s[0])) + s[1][0])
+def test_jacobi_sweeps_marching_in_alternating_directions(shape, bc, monkeypatch):
+    """Round 4: consecutive Jacobi sweeps of a 3-D mesh march their chunks in opposite directions (k_cg3d PHASE 9: what a
+    sweep wrote last is what the next one reads first).  No global sum feeds back into a Jacobi iterate, so for a fixed
+    number of sweeps -- odd and even: the last sweep forwards / backwards -- every bit of the iterate must equal the
+    all-forwards sequence (option jac_alt 0) and the generic kernels; the stop-test value differs only by the order its
+    partial sums are added in."""
+    from helpers import hip_options
+    n, dtype = shape
+    tdt = torch.float64 if dtype == "double" else torch.float32
+    g = torch.Generator().manual_seed(31)
+    rhs0 = torch.randn((1, *n), generator=g, dtype=torch.float64).to(tdt)
+
+    def run(K, alt, fast=True):
+        hip_options(monkeypatch, jac_alt=alt)
+        monkeypatch.setenv("PYAPES_HIP_FASTPATH", "1" if fast else "0")
+        mesh = Mesh(Box[0:1, 0:1, 0:0.5], None, list(n), "cuda", dtype)
+        var = Field("p", 1, mesh, {"domain": _cfg(BCS[bc]), "obstacle": None})
+        solver = Solver({"fdm": {"method": "jacobi", "tol": 1e-30, "max_it": K - 1, "report": False, "omega": 0.9}})
+        solver.set_eq(FDM().laplacian(0.8, var) == rhs0.cuda().clone())
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            rep = solver.solve()
+        return var().cpu(), rep
+
+    for K in (1, 2, 7, 12):
+        xa, ra = run(K, 1)
+        xb, rb = run(K, 0)
+        assert ra["itr"] == rb["itr"] == K
+        assert torch.equal(xa, xb), (K, float((xa - xb).abs().max()))
+        assert abs(ra["tol"] - rb["tol"]) <= (1e-12 if dtype == "double" else 1e-5) * abs(rb["tol"])
+    xg, rg = run(7, 1, fast=False)
+    xa, ra = run(7, 1)
+    assert torch.equal(xa, xg)
+    hip_options(monkeypatch, jac_alt=None)
