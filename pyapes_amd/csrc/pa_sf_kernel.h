@@ -83,9 +83,22 @@ template <> struct SfBits<double> {
 // of pa_bc.hip), the boundary nodes of the intermediate states stay unfilled, and ONE ordered fill after the last
 // step makes the result's boundary what the step-by-step sequence leaves there.  Without periodic faces only
 // (their fill reads the far end of the axis and puts boundary nodes into the interior set).
-template <typename T, int RJ, int PHASE, int KIND, bool HASU, bool BCL = false>
+// US (round 4): sign of a SCALAR advection speed of the upwind scheme, known at launch -- 1: u >= 0, 2: u < 0, 0: not used
+// (speed field, other schemes).  One of u+ = max(u, 0) / u- = min(u, 0) is then zero and its half of every axis term
+//   t = u+ (x - x[-1]) + u- (x[+1] - x)
+// is a signed zero: t = u+ (x - x[-1]) + (+-0) has the value of its first product, and if that is itself +-0 only the sign
+// of a zero can differ -- which the accumulation adv = (+0) + t_0 + t_1 + t_2 absorbs (+0 + -0 = +0, and a sum that starts
+// at +0 never becomes -0).  So the dead half -- one subtraction, one product, one addition per axis, 9 of the ~42 row
+// operations of an Euler step -- is not computed, and every FINITE field gives the same bits (tests/test_gpu_tiled_ops.py
+// against the generic kernels, which form both halves).  Only a non-finite neighbour on the dead side differs: 0 x inf is
+// NaN in the literal form, nothing here.
+#ifndef PA_SF_USIGN
+#define PA_SF_USIGN 1
+#endif
+template <typename T, int RJ, int PHASE, int KIND, bool HASU, bool BCL = false, int US = 0>
 __global__ void __launch_bounds__(256) k_sf(Cg3dArgs<T> A) {
   static_assert(!BCL || PHASE == 3, "BC on load: the Euler step");
+  static_assert(US == 0 || (KIND == 4 && !HASU), "US: scalar speed of the upwind scheme");
   constexpr int VEC = VecOf<T>::N;
   typedef T V __attribute__((ext_vector_type(VEC)));
   constexpr int TJ = 4 * RJ, TK = 64 * VEC;
@@ -443,11 +456,20 @@ __global__ void __launch_bounds__(256) k_sf(Cg3dArgs<T> A) {
             }
 #pragma unroll
             for (int a = 0; a < 3; ++a) {
-              V bwd = xc - xm3[a];
-              V fwd = xp3[a] - xc;
-              V t = upl * bwd;
-              V m2 = umi * fwd;
-              t = t + m2;
+              V t;
+              if constexpr (US == 1) {          // u >= 0: u- = +0, its half is a signed zero
+                V bwd = xc - xm3[a];
+                t = upl * bwd;
+              } else if constexpr (US == 2) {   // u < 0: u+ = +0
+                V fwd = xp3[a] - xc;
+                t = umi * fwd;
+              } else {
+                V bwd = xc - xm3[a];
+                V fwd = xp3[a] - xc;
+                t = upl * bwd;
+                V m2 = umi * fwd;
+                t = t + m2;
+              }
               t = t * A.ih[a];
               adv = adv + t;
             }
@@ -525,18 +547,18 @@ __global__ void __launch_bounds__(256) k_sf(Cg3dArgs<T> A) {
 }
 
 // ---- host side ---------------------------------------------------------------------------------------
-template <typename T, int RJ, int PHASE, int KIND, bool HASU, bool BCL = false>
+template <typename T, int RJ, int PHASE, int KIND, bool HASU, bool BCL = false, int US = 0>
 static int sf_blocks_per_cu() {
   static int cached = 0;
   if (!cached) {
     int n = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_sf<T, RJ, PHASE, KIND, HASU, BCL>, 256, 0) != hipSuccess || n <= 0) n = 4;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_sf<T, RJ, PHASE, KIND, HASU, BCL, US>, 256, 0) != hipSuccess || n <= 0) n = 4;
     cached = n;
   }
   return cached;
 }
 
-template <typename T, int RJ, int PHASE, int KIND, bool HASU, bool BCL = false>
+template <typename T, int RJ, int PHASE, int KIND, bool HASU, bool BCL = false, int US = 0>
 static int launch_sf(pa_ctx* c, Cg3dArgs<T>& A) {
   constexpr int VEC = VecOf<T>::N;
   constexpr int TJ = 4 * RJ, TK = 64 * VEC;
@@ -544,7 +566,7 @@ static int launch_sf(pa_ctx* c, Cg3dArgs<T>& A) {
   A.tiles_j = (int)((G.n1 + TJ - 1) / TJ);
   A.tiles_k = (int)((G.n2 + TK - 1) / TK);
   const int tiles = A.tiles_j * A.tiles_k;
-  const int capacity = cus_of(c) * sf_blocks_per_cu<T, RJ, PHASE, KIND, HASU, BCL>();
+  const int capacity = cus_of(c) * sf_blocks_per_cu<T, RJ, PHASE, KIND, HASU, BCL, US>();
   int chunks = capacity / tiles;
   if (chunks < 1) chunks = 1;
   if (chunks > G.n0) chunks = (int)G.n0;
@@ -557,9 +579,9 @@ static int launch_sf(pa_ctx* c, Cg3dArgs<T>& A) {
     --dbg;
     fprintf(stderr, "[pyapes_hip] k_sf phase %d kind %d RJ %d%s: tiles %dx%d chunks %d (CI ~%lld) blocks %d, %d blocks/CU\n",
             PHASE, KIND, RJ, BCL ? " (BC on load)" : "", A.tiles_j, A.tiles_k, chunks, (long long)(G.n0 / chunks), nblk,
-            sf_blocks_per_cu<T, RJ, PHASE, KIND, HASU, BCL>());
+            sf_blocks_per_cu<T, RJ, PHASE, KIND, HASU, BCL, US>());
   }
-  hipLaunchKernelGGL((k_sf<T, RJ, PHASE, KIND, HASU, BCL>), dim3(nblk), dim3(256), 0, c->stream, A);
+  hipLaunchKernelGGL((k_sf<T, RJ, PHASE, KIND, HASU, BCL, US>), dim3(nblk), dim3(256), 0, c->stream, A);
   return nblk;
 }
 
@@ -586,7 +608,27 @@ static int launch_sf_any(pa_ctx* c, Cg3dArgs<T>& A) {
     if (A.bcl_type[0] | A.bcl_type[1] | A.bcl_type[2] | A.bcl_type[3] | A.bcl_type[4] | A.bcl_type[5]) {
       if (rj < 2 || (c->G.n1 - 1) % rj == 0) return 0;   // PATCH: rows n1 - 2, n1 - 1 in one wave's block
       if (A.aux) return rj == 2 ? launch_sf<T, 2, 3, KIND, true, true>(c, A) : launch_sf<T, 4, 3, KIND, true, true>(c, A);
+      if (PA_SF_USIGN) {   // scalar speed: its sign is a launch-time fact (US, above)
+        if (A.u < (T)0) return rj == 2 ? launch_sf<T, 2, 3, KIND, false, true, 2>(c, A) : launch_sf<T, 4, 3, KIND, false, true, 2>(c, A);
+        return rj == 2 ? launch_sf<T, 2, 3, KIND, false, true, 1>(c, A) : launch_sf<T, 4, 3, KIND, false, true, 1>(c, A);
+      }
       return rj == 2 ? launch_sf<T, 2, 3, KIND, false, true>(c, A) : launch_sf<T, 4, 3, KIND, false, true>(c, A);
+    }
+  }
+  if constexpr (KIND == PA_OP_DIV_UPWIND) {
+    if (PA_SF_USIGN && !A.aux) {
+      if (A.u < (T)0) {
+        switch (rj) {
+          case 1: return launch_sf<T, 1, PHASE, KIND, false, false, 2>(c, A);
+          case 2: return launch_sf<T, 2, PHASE, KIND, false, false, 2>(c, A);
+          default: return launch_sf<T, 4, PHASE, KIND, false, false, 2>(c, A);
+        }
+      }
+      switch (rj) {
+        case 1: return launch_sf<T, 1, PHASE, KIND, false, false, 1>(c, A);
+        case 2: return launch_sf<T, 2, PHASE, KIND, false, false, 1>(c, A);
+        default: return launch_sf<T, 4, PHASE, KIND, false, false, 1>(c, A);
+      }
     }
   }
   constexpr bool CAN_U = (PHASE == 3 || (PHASE == 2 && KIND != 0));
