@@ -60,7 +60,9 @@ template <> struct SfBits<double> {
 // 159 to 172 / 174 VGPRs, i.e. from three waves per SIMD to two: 256^3 fp32 31.4 against 31.6 us per step, c4t 35.9 / 35.9,
 // 512^3 210.0 / 210.4 -- nothing.  Forcing three waves (amdgpu_waves_per_eu) spills to scratch memory.  At 512^3 the step
 // runs at the speed of a plain copy of its arrays (210 us against 205); at 256^3, where both arrays sit in the Infinity
-// Cache and a copy takes 19.5 us, it is bound by issue AND by the waves it can keep in flight.)
+// Cache and a copy takes 19.5 us, it is bound by issue AND by the waves it can keep in flight.  Tried again on top of the US
+// kernels below (153 -> 164 VGPRs, still three waves per SIMD): 27.96 / 28.10, 28.08 / 28.19, 29.22 / 28.15 us -- with the
+// dead upwind half gone the step no longer responds to instruction counts.)
 // PHASE 2: A x (KIND 0: Laplacian; else Laplacian + Div, or the Div term alone when lap_off)
 // PHASE 3: explicit Euler step (KIND = PA_OP_DIV_* of the advection term)
 // PHASE 7: explicit gradient
