@@ -142,6 +142,7 @@ struct pa_ctx {
   int bc_path = 0;           // "bc_path": bit 0 never the closed-form fill, bit 1 never the per-axis pair kernels, bit 2 closed form at any size
   int bicg_pfold = 1;        // "bicg_pfold": BiCGSTAB's next direction formed by the x / r update (0: the full p / v phase every iteration)
   int bicg_srv = 1;          // "bicg_srv": the tiled s / t phase stores t alone, the x / r update re-forms s = r - alpha v' (0: s stored, as before round 4)
+  int bicg_s_stored = 1;     // slab BiCGSTAB: did the s / t step of this iteration store s (else the x / r step re-forms it)
   int jac_alt = 1;           // "jac_alt": consecutive Jacobi sweeps of 3-D meshes march in opposite directions (0: all forwards)
   int jac_dir = 0;           // ... direction of the next sweep
   int rhs_full = 0;          // "rhs_full": pa_rhs_adjust visits the whole mesh instead of the Neumann layers

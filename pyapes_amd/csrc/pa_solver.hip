@@ -2214,8 +2214,10 @@ int bicg_slab_st_t(pa_ctx* c) {
   Vec<T> rv = slab_vec<T>(c, r, c->r_recv_lo, c->r_recv_hi);
   Vec<T> vv = slab_vec<T>(c, vn, c->v_recv_lo, c->v_recv_hi);
   c->fold_a_n = 0;
-  int used = pa_tile3d_bicg_st<T>(c, E, rv, vv, (const T*)r0, s, t, part);
+  // (as on one GPU: the tiled phase stores t alone and the x / r step re-forms s from r and v', option "bicg_srv")
+  int used = pa_tile3d_bicg_st<T>(c, E, rv, vv, (const T*)r0, c->bicg_srv ? (T*)nullptr : s, t, part);
   if (used < 0) return used;
+  c->bicg_s_stored = (used > 0 && c->bicg_srv) ? 0 : 1;
   if (used > 0) {
     hipLaunchKernelGGL(k_rows_to_sums<T>, dim3(1), dim3(PA_BLOCK), 0, c->stream, c->sc, (const double*)part, used, 4, pa_sums(c), 1, 1);
   } else {
@@ -2249,12 +2251,16 @@ int bicg_slab_x_t(pa_ctx* c) {
   hipLaunchKernelGGL(k_bicg_logic<T>, dim3(1), dim3(1), 0, c->stream, c->sc, (const double*)pa_sums(c), 12);   // stop test 1, omega, rho'
   constexpr int XV = 16 / (int)sizeof(T);
   const bool vec = G.ncell % XV == 0 && ((((uintptr_t)x | (uintptr_t)pn | (uintptr_t)s | (uintptr_t)t | (uintptr_t)r) & 15) == 0);
-  if (vec)
-    hipLaunchKernelGGL((k_bicg_x<T, XV>), dim3(nblk), dim3(PA_BLOCK), 0, c->stream, G, c->sc, x, (const T*)pn, (const T*)s, (const T*)t,
-                       r, part, (const double*)nullptr, 0, c->sc, (const T*)nullptr, (T*)nullptr);
-  else
-    hipLaunchKernelGGL((k_bicg_x<T, 1>), dim3(nblk), dim3(PA_BLOCK), 0, c->stream, G, c->sc, x, (const T*)pn, (const T*)s, (const T*)t,
-                       r, part, (const double*)nullptr, 0, c->sc, (const T*)nullptr, (T*)nullptr);
+  const T* vn = (const T*)c->scr[c->cur ? SCR_V0 : SCR_V1];   // v' of this iteration (s = r - alpha v' when s was not stored)
+#define PA_BICG_XS(VV, SS)                                                                                                        \
+  hipLaunchKernelGGL((k_bicg_x<T, VV, false, SS>), dim3(nblk), dim3(PA_BLOCK), 0, c->stream, G, c->sc, x, (const T*)pn, (const T*)s, \
+                     (const T*)t, r, part, (const double*)nullptr, 0, c->sc, SS ? vn : (const T*)nullptr, (T*)nullptr)
+  if (vec) {
+    if (c->bicg_s_stored) PA_BICG_XS(XV, false); else PA_BICG_XS(XV, true);
+  } else {
+    if (c->bicg_s_stored) PA_BICG_XS(1, false); else PA_BICG_XS(1, true);
+  }
+#undef PA_BICG_XS
   // what the neighbours need next: the first / last owned plane of the new residual and, on the end ranks of a
   // periodic ring, the x planes the other end's BC fill reads (packed behind them by the driver's buffer layout)
   if (c->r_send_lo || c->r_send_hi)
