@@ -221,6 +221,15 @@ def solver_rows(q, emit, sections):
     ms, wall, itr, N = solver_ms(lambda: Mesh(Box[0:1, 0:1, 0:1], None, [n, n, n], "cuda", "double"),
                                  mixed_bcs([0, 0, 0, 0, 1, 0], ["dirichlet", "neumann"] * 3), "bicgstab", 100)
     emit(f"bicgstab 3-D {n}^3 f64 mixed", N, ms, 22, 8, {"wall_ms_per_iter": wall, "iters": itr})
+    if not q:
+        # round 4: the three solver loops at BASELINE config 3's size (512^3 fp64), Dirichlet and fully periodic -- BiCGSTAB is
+        # the method that converges on the periodic problem; passes = the algorithmic count
+        per3 = mixed_bcs([None] * 6, ["periodic"] * 6)
+        for bname, bcs3 in (("dirichlet", homogeneous_bcs(3, 0.0, "dirichlet")), ("periodic", per3)):
+            for meth, its, passes in (("jacobi", 60, 3), ("cg", 60, 10), ("bicgstab", 40, 22)):
+                ms, wall, itr, N = solver_ms(lambda: Mesh(Box[0:1, 0:1, 0:1], None, [512, 512, 512], "cuda", "double"), bcs3, meth, its)
+                emit(f"{meth} 3-D 512^3 f64 {bname}", N, ms, passes, 8, {"wall_ms_per_iter": wall, "iters": itr})
+                torch.cuda.empty_cache()
     def advdiff_ms(n):
         mesh = Mesh(Box[0:1, 0:1, 0:1], None, [n, n, n], "cuda", "double")
         var = Field("p", 1, mesh, {"domain": homogeneous_bcs(3, 0.0, "dirichlet"), "obstacle": None})
