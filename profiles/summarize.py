@@ -49,7 +49,8 @@ def counters(root):
     return out
 
 
-PHASES = {0: "phaseA", 1: "phaseB", 2: "Ax", 3: "euler", 4: "jacobi", 5: "bicg_pv", 6: "bicg_st", 7: "grad", 8: "bicg_v"}
+PHASES = {0: "phaseA", 1: "phaseB", 2: "Ax", 3: "euler", 4: "jacobi", 5: "bicg_pv", 6: "bicg_st", 7: "grad", 8: "bicg_v",
+          9: "jacobi_backwards"}
 
 
 def short(name):
@@ -64,11 +65,12 @@ def short(name):
         if m.group(6) == "true":
             s += "_narrow"
         return s
-    m = re.search(r"k_sf<(\w+), (\d+), (\d+), (\d+), (\w+)(?:, (\w+))?>", name)   # (..., HASU[, BCL])
+    m = re.search(r"k_sf<(\w+), (\d+), (\d+), (\d+), (\w+)(?:, (\w+))?(?:, (\d+))?>", name)   # (..., HASU[, BCL[, US]])
     if m:
         t = "f64" if m.group(1) == "double" else "f32"
         return (f"k_sf_{PHASES.get(int(m.group(3)), m.group(3))}_{t}_RJ{m.group(2)}_kind{m.group(4)}" +
-                ("_ufield" if m.group(5) == "true" else "") + ("_bcl" if m.group(6) == "true" else ""))
+                ("_ufield" if m.group(5) == "true" else "") + ("_bcl" if m.group(6) == "true" else "") +
+                ({"1": "_upos", "2": "_uneg"}.get(m.group(7) or "0", "")))
     m = re.search(r"k_resident<(\w+), (\d+), (\w+), (\d+)>", name)
     if m:
         t = "f64" if m.group(1) == "double" else "f32"
