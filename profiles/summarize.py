@@ -126,7 +126,7 @@ def main():
                         "bytes_per_launch": d["hbm_bytes_per_launch"], "avg_us": d.get("avg_us"), "kernel": k,
                         "source_hash": source_hash(),
                         "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), 2*FETCH+WRITE KiB "
-                                  f"(gfx950 correction); profiles/{os.path.basename(root.rstrip('/'))}"}
+                                  f"(gfx950 correction); profiles/{os.path.basename(root.rstrip('/')).replace('prof_', '', 1)}_summary.json"}
         with open(path, "w") as f:
             json.dump(t, f, indent=1)
 
