@@ -221,3 +221,36 @@ def test_jacobi_sweeps_marching_in_alternating_directions(shape, bc, monkeypatch
     xa, ra = run(7, 1)
     assert torch.equal(xa, xg)
     hip_options(monkeypatch, jac_alt=None)
+
+
+@pytest.mark.parametrize("shape", [((20, 37, 50), "double"), ((12, 18, 133), "single")],
+                         ids=lambda s: "x".join(map(str, s[0])) + s[1][0])
+def test_jacobi_with_a_tensor_coefficient_alternating_sweeps(shape, monkeypatch):
+    """The Jacobi sweep with laplacian(Gamma(x), phi) on the tiled kernels (k_cg3d<..., CF>, phases 4 and 9: sweeps in
+    alternating directions): every bit of the iterate equal to the generic kernels and to the all-forwards sequence."""
+    from helpers import hip_options
+    n, dtype = shape
+    tdt = torch.float64 if dtype == "double" else torch.float32
+    g = torch.Generator().manual_seed(41)
+    rhs0 = torch.randn((1, *n), generator=g, dtype=torch.float64).to(tdt)
+    gamma = (1.0 + 0.2 * torch.rand((1, *n), generator=g, dtype=torch.float64)).to(tdt)
+
+    def run(K, alt, fast):
+        hip_options(monkeypatch, jac_alt=alt)
+        monkeypatch.setenv("PYAPES_HIP_FASTPATH", "1" if fast else "0")
+        mesh = Mesh(Box[0:1, 0:1, 0:0.5], None, list(n), "cuda", dtype)
+        var = Field("p", 1, mesh, {"domain": _cfg(BCS["mix"]), "obstacle": None})
+        solver = Solver({"fdm": {"method": "jacobi", "tol": 1e-30, "max_it": K - 1, "report": False, "omega": 0.8}})
+        solver.set_eq(FDM().laplacian(gamma.cuda(), var) == rhs0.cuda().clone())
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            rep = solver.solve()
+        return var().cpu(), rep
+
+    for K in (2, 5):
+        xa, ra = run(K, 1, True)
+        xb, _ = run(K, 0, True)
+        xg, rg = run(K, 1, False)
+        assert ra["itr"] == rg["itr"] == K
+        assert torch.equal(xa, xb) and torch.equal(xa, xg), (K, float((xa - xg).abs().max()))
+    hip_options(monkeypatch, jac_alt=None)
