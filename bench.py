@@ -9,7 +9,7 @@ fill) for c4, a Jacobi sweep for c1.  Default workload at every N: BASELINE conf
 configuration the metric is quoted on -- 3-D Poisson 512^3 fp64, periodic BCs, CG -- slab-
 decomposed along axis 0 for N > 1 (strong scaling: the global grid is fixed).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c3|c2|c5|c4|c4t|c4_512|c1]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c3|c2|c5|c4|c4t|c4_512|c1|c3b|c3j]
                     [--size n0,n1,n2]
 
 ``--gpus N`` with N > 1 and no WORLD_SIZE in the environment starts the N ranks itself (a child
@@ -50,7 +50,12 @@ WORKLOADS = {
     "c4t": ("euler_t", (256, 256, 256), "single", "neusym", (1.0, 1.0, 1.0), 4),
     "c4_512": ("euler", (512, 512, 512), "single", "neusym", (1.0, 1.0, 1.0), 4),
     "c1": ("jacobi", (128, 128), "double", "poisson2d", (1.0, 1.0), 1),
+    # config 3's mesh under the other two solver loops (round 4): BiCGSTAB is the method that CONVERGES on the periodic
+    # problem (linalg.py:162-279), Jacobi the sweep of BASELINE config 1 at a size where bytes count
+    "c3b": ("bicgstab", (512, 512, 512), "double", "periodic", (1.0, 1.0, 1.0), 3),
+    "c3j": ("jacobi3", (512, 512, 512), "double", "periodic", (1.0, 1.0, 1.0), 3),
 }
+ALG_PASSES_ONESHOT = {"bicgstab": 22, "jacobi3": 3}   # array passes per iteration, algorithmic count
 
 
 def log(msg):
@@ -371,9 +376,9 @@ def cpu_baseline(solver, kind, dtype, gn):
     fd = torch.float64 if dtype == "double" else torch.float32
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
-        if solver == "cg":
+        if solver in ("cg", "bicgstab", "jacobi3"):
             n = [min(256, gn[0]), min(256, gn[1]), min(256, gn[2] if kind != "mixed" else 128)]
-            its = 24
+            its = 24 if solver != "bicgstab" else 12
             why = ""
             cells_full = gn[0] * gn[1] * gn[2]
             if list(n) != list(gn):
@@ -383,7 +388,7 @@ def cpu_baseline(solver, kind, dtype, gn):
                 need = 34 * cells_full * (8 if dtype == "double" else 4)
                 avail = host_mem_available()
                 per_it = cells_full / (1.4e7 * max(1, cores) / 16.0)
-                if os.environ.get("BENCH_CPU_FULL", "1") != "0" and avail >= 1.5 * need and 3 * per_it <= 45.0:
+                if solver == "cg" and os.environ.get("BENCH_CPU_FULL", "1") != "0" and avail >= 1.5 * need and 3 * per_it <= 45.0:
                     n, its = list(gn), 3
                 else:
                     why = (f" (full size {'x'.join(map(str, gn))} not run: needs ~{need / 2**30:.0f} GiB of host memory "
@@ -396,11 +401,16 @@ def cpu_baseline(solver, kind, dtype, gn):
             tabs = O.laplacian_tables(x, mesh, bcs)
             rhs += O.laplacian_rhs_adjust(x, mesh, bcs)
             terms = [O.OTerm("laplacian", tabs, 1.0, 1.0)]
-            log(f"cpu_baseline: oracle CG {n} on {cores} host threads ...")
+            log(f"cpu_baseline: oracle {solver} {n} on {cores} host threads ...")
             t0 = time.perf_counter()
-            _, rep = O.cg(x, rhs, terms, mesh, bcs, -1.0, its - 1)
+            if solver == "cg":
+                _, rep = O.cg(x, rhs, terms, mesh, bcs, -1.0, its - 1)
+            elif solver == "bicgstab":
+                _, rep = O.bicgstab(x, rhs, terms, mesh, bcs, -1.0, its)
+            else:
+                _, rep = O.jacobi(x, rhs, terms, mesh, bcs, -1.0, its - 1, 1.0)
             dt = time.perf_counter() - t0
-            steps, what = rep["itr"], "CG iterations" + why
+            steps, what = rep["itr"], {"cg": "CG iterations", "bicgstab": "BiCGSTAB iterations", "jacobi3": "Jacobi sweeps"}[solver] + why
         elif solver in ("euler", "euler_t"):
             n = [min(256, v) for v in gn]
             mesh = O.OMesh([0, 0, 0], [1, 1, 1], n, dtype)
@@ -840,6 +850,38 @@ def main():
             roof = roofline("euler_step", k_ms, passes * esize * mesh.N, args.workload, bool(args.n), extra)
         wl_text = (f"3-D advection-diffusion {'x'.join(map(str, gn))} {dtype}, Div(upwind)+Laplacian explicit Euler march, "
                    f"{'scalar u' if solver == 'euler' else 'speed tensor u(x)'}, Neumann/Symmetry BCs (BASELINE config 4)")
+    elif solver in ("bicgstab", "jacobi3"):
+        # one-shot library loops (pa_bicgstab / pa_jacobi) with a fixed iteration count: tolerance -1, the stop test is
+        # evaluated every iteration and can never end the solve; the timed region is ONE call of K iterations, set-up
+        # (scratch, BC fill, first residual) included -- it is part of what a user's solve() costs
+        method = "bicgstab" if solver == "bicgstab" else "jacobi"
+        rhs = synth_rhs(gn, 0, gn[0], kind, mesh.dtype.float, mesh.device)
+        terms = [{"kind": L.OP_LAPLACIAN, "sign": 1.0, "coeff": 1.0}]
+        ctx = context_for(mesh)
+        ctx.bind_bcs(var(), var.bcs, 0)
+        ctx.set_terms(terms)
+        ctx.rhs_adjust(rhs[0])
+        mi = (lambda n: n) if method == "bicgstab" else (lambda n: n - 1)   # CG / Jacobi run max_it + 1 (linalg.py:144-157)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            if W > 0:
+                ctx.solve(method, var()[0], rhs[0], -1.0, mi(W))
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            rep = ctx.solve(method, var()[0], rhs[0], -1.0, mi(K))
+            torch.cuda.synchronize()
+            secs = time.perf_counter() - t0
+        ev_ms = rep.gpu_ms
+        assert rep.itr == K and rep.status == 0, f"work was skipped: itr={rep.itr} status={rep.status}"
+        assert bool(torch.isfinite(var()).all()), "iterate became non-finite inside the timed region"
+        passes = ALG_PASSES_ONESHOT[solver]
+        moved = {"bicgstab": 15, "jacobi3": 3}[solver]
+        roof = roofline(f"{method} iteration (all kernels of the loop: stream time of the iterations / K)", ev_ms / K,
+                        passes * esize * mesh.N, args.workload, True,
+                        {"remark": f"{passes} array passes per iteration by the algorithmic count, {moved} really moved "
+                                   "(DESIGN.md section 4); per-kernel table: profiles/r04_bicgstab512_kernel_stats.csv"})
+        wl_text = (f"3-D Poisson {gn[0]}x{gn[1]}x{gn[2]} {dtype}, {kind} BCs, "
+                   f"{'BiCGSTAB' if method == 'bicgstab' else 'Jacobi'} (BASELINE config {cfg_no}'s mesh)")
     else:  # jacobi (config 1)
         from pyapes_amd.testing.poisson import poisson_rhs_nd
         rhs = poisson_rhs_nd(mesh, var)
@@ -887,7 +929,8 @@ def main():
         if wl_text is None:
             wl_text = f"3-D Poisson {gn[0]}x{gn[1]}x{gn[2]} {dtype}, {kind} BCs, CG (BASELINE config {cfg_no})"
         out = {
-            "metric": "cell-updates*iters/sec" + (", 3-D Poisson CG" if solver == "cg" else ""),
+            "metric": "cell-updates*iters/sec" + {"cg": ", 3-D Poisson CG", "bicgstab": ", 3-D Poisson BiCGSTAB",
+                                                    "jacobi3": ", 3-D Poisson Jacobi"}.get(solver, ""),
             "value": value,
             "unit": "cell-updates*iters/s",
             "n_gpus": world,
