@@ -1622,6 +1622,7 @@ static int bicg_run_t(pa_ctx* c, T* x, const T* rhs, double tol, int64_t max_it,
   }
   int cur = 0;
   const int poll = poll_interval(c);
+  const bool bicg_static = pa_bc_is_static(c);
   PA_HIP(c, hipEventRecord(c->ev0, c->stream));
   int64_t enq = 0;
   // The three single-block scalar kernels of an iteration are folded into the prologue of the kernel
@@ -1732,7 +1733,10 @@ static int bicg_run_t(pa_ctx* c, T* x, const T* rhs, double tol, int64_t max_it,
 #undef PA_BICG_X
       pgiven = pnext;   // (p[cur ^ 1] is p[cur] of the next iteration; in place when p' came from the p / v phase)
     }
-    if ((rc = pa_bc_apply_auto<T>(c, x, true))) return rc;
+    // Dirichlet faces only: the fill of pa_bicg's set-up stands -- p and s are +-0 on every boundary node, so the x / r
+    // update leaves x there as it is (alpha, omega are finite by pa_nan_to_num) and a fill would rewrite the same values
+    // (the CG loop skips it the same way): one launch less per iteration, 26 us of 2.9 ms at 512^3, 6 of 40 us at 64^3
+    if (!bicg_static && (rc = pa_bc_apply_auto<T>(c, x, true))) return rc;
     if (fold && nblk <= PA_MAX_GRID)
       pend3 = nblk;
     else
@@ -2279,7 +2283,7 @@ int bicg_slab_x_t(pa_ctx* c) {
 template <typename T>
 int bicg_slab_bc_t(pa_ctx* c) {
   const int nblk = pa_grid_blocks(c->G.ncell);
-  int rc = pa_bc_apply_auto<T>(c, (T*)c->cg_x, true);
+  int rc = pa_bc_is_static(c) ? PA_OK : pa_bc_apply_auto<T>(c, (T*)c->cg_x, true);   // (Dirichlet faces only: bicg_run_t)
   if (rc) return rc;
   hipLaunchKernelGGL(k_rows_to_sums<T>, dim3(1), dim3(PA_BLOCK), 0, c->stream, c->sc,
                      (const double*)c->scr[SCR_PART] + 5 * (size_t)PA_MAX_PARTIALS, nblk, 1, pa_sums(c), 5, 1);
