@@ -28,8 +28,10 @@
 // Everything else is the xyz kernel, so the arithmetic per node is pa_apply_terms' rz branch operation for operation.
 template <typename T, int PHASE, bool PITCH, bool RZ = false>
 __global__ void __launch_bounds__(256) k_cg2d(Cg3dArgs<T> A) {
-  static_assert(PHASE == 0 || PHASE == 1 || PHASE == 4 || PHASE == 6 || PHASE == 8, "CG phases, Jacobi sweep, BiCGSTAB s / t and v phases");
-  static_assert(!PITCH || PHASE != 4, "the Jacobi sweep works on the caller's arrays");
+  // PHASE 9 = the Jacobi sweep (4) marching backwards: consecutive sweeps alternate (pa_cg3d_kernel.h); the body tests PH
+  constexpr int PH = PHASE == 9 ? 4 : PHASE;
+  static_assert(PH == 0 || PH == 1 || PH == 4 || PH == 6 || PH == 8, "CG phases, Jacobi sweep, BiCGSTAB s / t and v phases");
+  static_assert(!PITCH || PH != 4, "the Jacobi sweep works on the caller's arrays");
   constexpr int VEC = VecOf<T>::N;
   typedef T V __attribute__((ext_vector_type(VEC)));
   constexpr int TK = 64 * VEC;
@@ -41,7 +43,7 @@ __global__ void __launch_bounds__(256) k_cg2d(Cg3dArgs<T> A) {
   const int n1 = (int)G.n1, n2 = (int)G.n2;
   const int j0 = (int)((int64_t)chunk * n1 / A.chunks), j1 = (int)((int64_t)(chunk + 1) * n1 / A.chunks);
   const int CJ = j1 - j0;
-  constexpr int rev = (PHASE == 1) ? 1 : 0;          // phase B marches backwards (pa_cg3d_kernel.h)
+  constexpr int rev = (PHASE == 1 || PHASE == 9) ? 1 : 0;          // phase B marches backwards (pa_cg3d_kernel.h)
   const int64_t fs1 = PITCH ? A.ps1 : G.s1;           // row stride of r, d, d' (x: G.s1)
   const int64_t k0 = ((int64_t)sg * 4 + wv) * TK;
   const int64_t kg = k0 + (int64_t)lane * VEC;
@@ -54,7 +56,7 @@ __global__ void __launch_bounds__(256) k_cg2d(Cg3dArgs<T> A) {
   // ---- the scalar step folded into this kernel's prologue (k_cg3d, same code: every block reduces the partial
   //      rows the previous kernel left, in the same fixed order -> the same bits in every block) -----------------
   T beta = (T)0, alpha = (T)0;
-  if ((PHASE == 0 || PHASE == 4) && A.pre_n > 0) {
+  if ((PH == 0 || PH == 4) && A.pre_n > 0) {
     __shared__ double pre_sm[16];
     const SolverScalars* si = A.sc;
     const int done_in = si->done;
@@ -62,7 +64,7 @@ __global__ void __launch_bounds__(256) k_cg2d(Cg3dArgs<T> A) {
     const long long itr_in = si->itr, max_it = si->max_it;
     double v0 = 0.0, v1 = 0.0, v2 = 0.0;
     for (int b = threadIdx.x; b < A.pre_n; b += 256) {
-      if (PHASE == 0) v0 += A.pre_part[2 * (int64_t)b];
+      if (PH == 0) v0 += A.pre_part[2 * (int64_t)b];
       v1 += A.pre_part[2 * (int64_t)b + 1];
     }
     for (int b = threadIdx.x; b < A.pre_nsh; b += 256) v2 += A.pre_shell[b];
@@ -102,21 +104,21 @@ __global__ void __launch_bounds__(256) k_cg2d(Cg3dArgs<T> A) {
         if (bad) {
           so->err = 1;
         } else {
-          if (PHASE == 0) {
+          if (PH == 0) {
             so->rr_old = (double)rr_old;
             so->beta = bq;
             so->rr = (double)rr_new;
           }
           so->itr = itr;
         }
-        if (PHASE == 0) A.pre_sums[1] = rr;
+        if (PH == 0) A.pre_sums[1] = rr;
         A.pre_sums[2] = dx2 + sh;
       }
     }
     __syncthreads();
     if (pre_sm[13] != 0.0) return;
     beta = (T)pre_sm[12];
-  } else if (PHASE == 1 && A.pre_n > 0) {
+  } else if (PH == 1 && A.pre_n > 0) {
     __shared__ double pre_sm[8];
     const int done_in = A.sc->done;
     const double rr_in = A.sc->rr;
@@ -141,7 +143,7 @@ __global__ void __launch_bounds__(256) k_cg2d(Cg3dArgs<T> A) {
     }
     __syncthreads();
     alpha = (T)pre_sm[4];
-  } else if (PHASE == 8 && A.pre_n > 0) {
+  } else if (PH == 8 && A.pre_n > 0) {
     // BiCGSTAB: the step that closes the PREVIOUS iteration (k_cg3d phase 5 / 8 prologue, k_bicg_post stage 3)
     __shared__ double pre_sm[8];
     const SolverScalars* si = A.sc;
@@ -190,7 +192,7 @@ __global__ void __launch_bounds__(256) k_cg2d(Cg3dArgs<T> A) {
     }
     __syncthreads();
     if (pre_sm[5] != 0.0) return;
-  } else if (PHASE == 6 && A.pre_n > 0) {
+  } else if (PH == 6 && A.pre_n > 0) {
     // BiCGSTAB: alpha = rho / (r0 . v) of THIS iteration, iteration count (k_bicg_post stage 0)
     __shared__ double pre_sm[8];
     const int done_in = A.sc->done;
@@ -216,8 +218,8 @@ __global__ void __launch_bounds__(256) k_cg2d(Cg3dArgs<T> A) {
     alpha = (T)pre_sm[4];
   } else {
     if (A.sc->done) return;
-    if (PHASE == 0) beta = (T)A.sc->beta;
-    if (PHASE == 1 || PHASE == 6) alpha = (T)A.sc->alpha;
+    if (PH == 0) beta = (T)A.sc->beta;
+    if (PH == 1 || PH == 6) alpha = (T)A.sc->alpha;
   }
 
   // ---- per-lane constants of the contiguous axis -------------------------------------------------------------
@@ -244,14 +246,14 @@ __global__ void __launch_bounds__(256) k_cg2d(Cg3dArgs<T> A) {
     const T* dp = A.d.p + jw * fs1;
     w.d = *reinterpret_cast<const V*>(dp + kcf);
     w.ed = dp[ecol];
-    if (PHASE == 0 || PHASE == 6) {
+    if (PH == 0 || PH == 6) {
       const T* rp = A.r.p + jw * fs1;
       w.r = *reinterpret_cast<const V*>(rp + kcf);
       w.er = rp[ecol];
     }
   };
   auto finish = [&](const Raw& w, V& e, T& ee) {
-    if (PHASE == 0) {
+    if (PH == 0) {
 #pragma unroll
       for (int v = 0; v < VEC; ++v) {
         T bd = beta * w.d[v];
@@ -259,7 +261,7 @@ __global__ void __launch_bounds__(256) k_cg2d(Cg3dArgs<T> A) {
       }
       T bd = beta * w.ed;
       ee = w.er + bd;
-    } else if (PHASE == 6) {   // s = r - alpha v (linalg.py:230), on the strip and on its edge cell
+    } else if (PH == 6) {   // s = r - alpha v (linalg.py:230), on the strip and on its edge cell
 #pragma unroll
       for (int v = 0; v < VEC; ++v) {
         T av = alpha * w.d[v];
@@ -295,7 +297,7 @@ __global__ void __launch_bounds__(256) k_cg2d(Cg3dArgs<T> A) {
   for (int m = 0; m < CJ; ++m) {
     const int jj = row_of(m);
     V xv, rv;
-    if (PHASE == 1) {
+    if (PH == 1) {
       if (PITCH) {
         rv = __builtin_nontemporal_load(reinterpret_cast<const V*>(A.rw + (int64_t)jj * fs1 + kcf));
         const T* xp = A.x + (int64_t)jj * G.s1;
@@ -306,7 +308,9 @@ __global__ void __launch_bounds__(256) k_cg2d(Cg3dArgs<T> A) {
         rv = __builtin_nontemporal_load(reinterpret_cast<const V*>(A.rw + (int64_t)jj * fs1 + kcf));
       }
     }
-    if (PHASE == 4 || PHASE == 6 || PHASE == 8)   // Jacobi: the right-hand side ; BiCGSTAB: r0 (pitched with the rest)
+    if (PH == 4)        // Jacobi: the right-hand side, touched once per sweep (non-temporal, as in k_cg3d)
+      xv = __builtin_nontemporal_load(reinterpret_cast<const V*>(A.aux + (int64_t)jj * fs1 + kcf));
+    else if (PH == 6 || PH == 8)   // BiCGSTAB: r0 (pitched with the rest)
       xv = *reinterpret_cast<const V*>(A.aux + (int64_t)jj * fs1 + kcf);
     // row m + 2 (wrapped: the rows past the chunk's end are valid memory and their values unused) -- unconditional,
     // a branch between the issue of a load and its use makes the compiler wait for everything outstanding
@@ -352,12 +356,12 @@ __global__ void __launch_bounds__(256) k_cg2d(Cg3dArgs<T> A) {
       if (hasc) ax = ax * cf;
       ax = ax * sgn;
       const bool inS = jS && (colS >> v & 1);
-      if (PHASE == 0) {
+      if (PH == 0) {
         const T e = inS ? xc : (T)0;
         outd[v] = e;
         T p = e * ax;
         s0 += inS ? (double)p : 0.0;
-      } else if (PHASE == 4) {
+      } else if (PH == 4) {
         // Jacobi:  x + omega (b - A x) / diag(A)   (k_cg3d phase 4 / k_jacobi, operation for operation)
         T dg = (T)0;
         dg = dg + cCj;
@@ -373,13 +377,13 @@ __global__ void __launch_bounds__(256) k_cg2d(Cg3dArgs<T> A) {
         T p2 = df * df;
         s1 += offshell ? (double)p2 : 0.0;
         outd[v] = xn;
-      } else if (PHASE == 6 || PHASE == 8) {
+      } else if (PH == 6 || PH == 8) {
         // own cells: s (phase 6) everywhere, t = A s / v' = A p' on the interior set (k_cg3d phases 6 / 8)
         const T an = inS ? ax : (T)0;
         outd[v] = xc;
         outx[v] = an;
         const T r0c = xv[v];
-        if (PHASE == 8) {
+        if (PH == 8) {
           T p = r0c * an;
           s0 += inS ? (double)p : 0.0;
         } else {
@@ -409,14 +413,14 @@ __global__ void __launch_bounds__(256) k_cg2d(Cg3dArgs<T> A) {
       }
     }
     if (kvalid) {
-      if (PHASE == 0) {
+      if (PH == 0) {
         __builtin_nontemporal_store(outd, reinterpret_cast<V*>(A.dnew + (int64_t)jj * fs1 + kcf));
-      } else if (PHASE == 4) {
+      } else if (PH == 4) {
         *reinterpret_cast<V*>(A.out + (int64_t)jj * G.s1 + kcf) = outd;
-      } else if (PHASE == 6) {   // (s leaves only when asked for: k_bicg_x<..., SRV> re-forms it from r and v)
+      } else if (PH == 6) {   // (s leaves only when asked for: k_bicg_x<..., SRV> re-forms it from r and v)
         if (A.out) *reinterpret_cast<V*>(A.out + (int64_t)jj * fs1 + kcf) = outd;
         *reinterpret_cast<V*>(A.out2 + (int64_t)jj * fs1 + kcf) = outx;
-      } else if (PHASE == 8) {
+      } else if (PH == 8) {
         *reinterpret_cast<V*>(A.out2 + (int64_t)jj * fs1 + kcf) = outx;
       } else {
         __builtin_nontemporal_store(outd, reinterpret_cast<V*>(A.rw_out + (int64_t)jj * fs1 + kcf));
@@ -437,10 +441,10 @@ __global__ void __launch_bounds__(256) k_cg2d(Cg3dArgs<T> A) {
     if constexpr (RZ) { zc = zn; zn = zl; }
   }
 
-  if (PHASE == 0 || PHASE == 8) {
+  if (PH == 0 || PH == 8) {
     double s[1] = {s0};
     pa_block_reduce_store<1>(s, A.partials);
-  } else if (PHASE == 6) {
+  } else if (PH == 6) {
     double s[4] = {s0, s1, s2, s3};
     pa_block_reduce_store<4>(s, A.partials);
   } else {
@@ -484,7 +488,7 @@ static int launch_cg2d(pa_ctx* c, Cg3dArgs<T>& A, bool pitched) {
   if (G.n1 * G.n2 < mincells) return 0;
   const int groups = (int)((G.n2 + 4 * 64 * VEC - 1) / (4 * 64 * VEC));
   int bpc;
-  if constexpr (PHASE == 4) {   // (the Jacobi sweep is never pitched: the caller's arrays)
+  if constexpr (PHASE == 4 || PHASE == 9) {   // (the Jacobi sweep is never pitched: the caller's arrays)
     if (pitched) return 0;
     bpc = rz ? cg2d_blocks_per_cu<T, PHASE, false, true>() : cg2d_blocks_per_cu<T, PHASE, false>();
   } else if (rz) {
@@ -513,7 +517,7 @@ static int launch_cg2d(pa_ctx* c, Cg3dArgs<T>& A, bool pitched) {
             (char)('A' + PHASE), pitched ? " (pitched)" : "", groups, chunks, (long long)(G.n1 / chunks), nblk, bpc);
   }
   if (c->plan_only) return nblk;
-  if constexpr (PHASE != 4) {
+  if constexpr (PHASE != 4 && PHASE != 9) {
     if (pitched) {
       if (rz) hipLaunchKernelGGL((k_cg2d<T, PHASE, true, true>), dim3(nblk), dim3(256), 0, c->stream, A);
       else hipLaunchKernelGGL((k_cg2d<T, PHASE, true>), dim3(nblk), dim3(256), 0, c->stream, A);

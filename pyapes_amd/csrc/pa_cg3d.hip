@@ -83,7 +83,12 @@ int pa_tile3d_jacobi(pa_ctx* c, const DevEq<T>& E, Vec<T> x, const T* rhs, T* xn
     A.sc_w = c->sc_alt;
     A.pre_sums = pa_sums(c);
   }
-  int n = (mode == 1 || mode == 4) ? launch_cg2d<T, 4>(c, A, false) : 0;   // large 2-D meshes: marching along the slow axis
+  int n = 0;
+  if (mode == 1 || mode == 4) {   // large 2-D meshes: marching along the slow axis, consecutive sweeps in opposite directions too
+    const bool back2 = c->jac_alt && c->jac_dir && !c->plan_only;
+    n = back2 ? launch_cg2d<T, 9>(c, A, false) : launch_cg2d<T, 4>(c, A, false);
+    if (n > 0 && !c->plan_only) c->jac_dir ^= 1;
+  }
   if (n == 0 && rz) return 0;
   if (n == 0) {   // 3-D: consecutive sweeps march in opposite directions (k_cg3d PHASE 9; option "jac_alt" 0: all forwards)
     const bool back = c->jac_alt && c->jac_dir && !c->plan_only;
