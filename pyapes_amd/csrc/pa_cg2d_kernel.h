@@ -311,7 +311,7 @@ __global__ void __launch_bounds__(256) k_cg2d(Cg3dArgs<T> A) {
     if (PH == 4)        // Jacobi: the right-hand side, touched once per sweep (non-temporal, as in k_cg3d)
       xv = __builtin_nontemporal_load(reinterpret_cast<const V*>(A.aux + (int64_t)jj * fs1 + kcf));
     else if (PH == 6 || PH == 8)   // BiCGSTAB: r0 (pitched with the rest)
-      xv = *reinterpret_cast<const V*>(A.aux + (int64_t)jj * fs1 + kcf);
+      xv = __builtin_nontemporal_load(reinterpret_cast<const V*>(A.aux + (int64_t)jj * fs1 + kcf));   // (read once per phase)
     // row m + 2 (wrapped: the rows past the chunk's end are valid memory and their values unused) -- unconditional,
     // a branch between the issue of a load and its use makes the compiler wait for everything outstanding
     Raw w;

@@ -594,12 +594,20 @@ __global__ void __launch_bounds__(256) k_cg3d(Cg3dArgs<T> A) {
     }
     if (PH == 4 || PH == 5 || PH == 6 || PH == 8 || ((PH == 3 || (PH == 2 && KIND != 0)) && A.aux)) {  // rhs / u / r0 of this plane
 #pragma unroll
-      for (int jj = 0; jj < RJ; ++jj)
+      for (int jj = 0; jj < RJ; ++jj) {
+        // BiCGSTAB's r0 is read once per phase and never written: non-temporal (round 4, three interleaved pairs: 256^3 fp64
+        // 0.3854 -> 0.3765 ms / iteration, 512^3 3.098 -> 3.055; 8-byte lanes of the NARROW kernels: not, as everywhere)
+        if ((PH == 5 || PH == 6 || PH == 8) && !NARROW) {
+          xv[jj] = PITCH ? __builtin_nontemporal_load(reinterpret_cast<const V*>(A.aux + ii * fs0 + jrow[jj] * fs1 + kcf))
+                         : __builtin_nontemporal_load(reinterpret_cast<const V*>(A.aux + ii * G.s0 + jrow[jj] * G.s1 + kc));
+          continue;
+        }
         xv[jj] = PITCH ? *reinterpret_cast<const V*>(A.aux + ii * fs0 + jrow[jj] * fs1 + kcf)   // (BiCGSTAB: r0, pitched)
                  // (the Jacobi right-hand side is touched once per sweep: non-temporal, so that it does not push the iterate
                  // the next sweep starts on out of the Infinity Cache -- 256^3 fp64 0.0845 -> 0.0810 ms / sweep, 512^3 -1 %)
                  : (PH == 4 && !NARROW) ? __builtin_nontemporal_load(reinterpret_cast<const V*>(A.aux + ii * G.s0 + jrow[jj] * G.s1 + kc))
                        : *reinterpret_cast<const V*>(A.aux + ii * G.s0 + jrow[jj] * G.s1 + kc);
+      }
     }
     // loads of plane m+2 (own cells + halo): in flight during the stencil below
     d_run += pstep;
