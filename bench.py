@@ -592,7 +592,7 @@ def main():
     if solver == "cg" and not slab:
         rhs = synth_rhs(gn, 0, gn[0], kind, mesh.dtype.float, mesh.device)
         if os.environ.get("BENCH_FRESH_X"):
-            # diagnostic (slow boxes): x and the right-hand side in blocks the driver hands out NOW,
+            # diagnostic (docs/HISTORY.md "Section 8", slow boxes): x and the right-hand side in blocks the driver hands out NOW,
             # not in blocks the caching allocator recycled from the mesh / input construction
             torch.cuda.synchronize()
             torch.cuda.empty_cache()

@@ -4,7 +4,7 @@
 // Why.  The arrays of a CG iteration are streamed in lockstep, and whether they collide in the memory system is decided
 // by where the driver put their pages: phase B of 512^3 fp64 measures 853 us or 931 us with the SAME kernel from one
 // process / box to the next; a plain copy between 1 GiB blocks of one process runs at 4.65 ... 5.51 TB/s by PAIR of
-// blocks while every block alone gives 5.5-5.6, and no offset inside a block changes that.
+// blocks while every block alone gives 5.5-5.6, and no offset inside a block changes that (docs/HISTORY.md, "Section 8").
 // Round 3 asked the hardware in the set-up, with ~86 dry-run iterations on an empty interior set before the first real
 // one: a solve shorter than ~1,700 iterations never earned that back.
 //
