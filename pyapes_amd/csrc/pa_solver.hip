@@ -584,6 +584,15 @@ __global__ void __launch_bounds__(PA_BLOCK) k_bicg_t(DevGeom G, DevEq<T> E, cons
   pa_block_reduce_store<3>(s, partials);
 }
 
+#ifndef PA_BX_NTP
+#define PA_BX_NTP 1   // k_bicg_x PITCHED: non-temporal accesses of the pitched (vector-aligned) arrays, as in the contiguous layout
+#endif
+#ifndef PA_BX_XU
+#define PA_BX_XU 1    // k_bicg_x PITCHED: x in whole vectors at cell-aligned addresses (one 16-byte access for VEC 8- / 4-byte ones)
+#endif
+#ifndef PA_BX_XNT
+#define PA_BX_XNT 1   // ... and those non-temporal
+#endif
 // early exit: x += alpha p ; otherwise x = x + alpha p + s omega ; r = s - omega t ; |r|^2
 // VEC cells per lane and step (16-byte lane accesses where the four arrays allow them: 166 -> 1xx us at 256^3 fp64,
 // DESIGN.md section 4; 1: any alignment / cell count)
@@ -689,7 +698,8 @@ __global__ void __launch_bounds__(PA_BLOCK) k_bicg_x(DevGeom G, const SolverScal
   // marched its chunks forwards, the v phase after will again, so what was touched last (still in the Infinity Cache) is
   // read first -- and the once-touched streams (x, r, t) move with non-temporal loads / stores.  The bare 5 : 3 mix at
   // 512^3 fp64 (profiles/tools/streammix2.hip): grid-stride 1.78-1.83 ms, contiguous ranges backwards + nt 1.64.
-  constexpr bool NT = VEC > 1 && !PITCHED;
+  constexpr bool NT = VEC > 1 && (!PITCHED || PA_BX_NTP);
+  typedef T VU __attribute__((ext_vector_type(VEC), aligned(sizeof(T))));   // PITCHED: a vector of x at a cell-aligned address
   const int64_t per = ((nvec + gridDim.x - 1) / gridDim.x + PA_BLOCK - 1) / PA_BLOCK * PA_BLOCK;
   const int64_t b0 = (int64_t)blockIdx.x * per, b1 = b0 + per < nvec ? b0 + per : nvec;
   auto ldnt = [](const T* q, int64_t i) -> V {
@@ -710,8 +720,12 @@ __global__ void __launch_bounds__(PA_BLOCK) k_bicg_x(DevGeom G, const SolverScal
       if (col >= G.n2) continue;   // a vector of pad cells: zero since the start of the solve, stays zero
       xrow = x + (int64_t)row * G.n2 + col;
       nval = (int)(G.n2 - col < VEC ? G.n2 - col : VEC);
+      if (PA_BX_XU && VEC > 1 && nval == VEC) {
+        xv = PA_BX_XNT ? __builtin_nontemporal_load(reinterpret_cast<const VU*>(xrow)) : *reinterpret_cast<const VU*>(xrow);
+      } else {
 #pragma unroll
-      for (int v = 0; v < VEC; ++v) xv[v] = v < nval ? xrow[v] : (T)0;
+        for (int v = 0; v < VEC; ++v) xv[v] = v < nval ? xrow[v] : (T)0;
+      }
     } else {
       xv = ldnt(x, iv);
     }
@@ -758,9 +772,14 @@ __global__ void __launch_bounds__(PA_BLOCK) k_bicg_x(DevGeom G, const SolverScal
       if (NT) __builtin_nontemporal_store(rn, reinterpret_cast<V*>(r) + iv); else reinterpret_cast<V*>(r)[iv] = rn;
     }
     if (PITCHED) {
+      if (PA_BX_XU && VEC > 1 && nval == VEC) {
+        if (PA_BX_XNT) __builtin_nontemporal_store((VU)xn, reinterpret_cast<VU*>(xrow));
+        else *reinterpret_cast<VU*>(xrow) = xn;
+      } else {
 #pragma unroll
-      for (int v = 0; v < VEC; ++v)
-        if (v < nval) xrow[v] = xn[v];
+        for (int v = 0; v < VEC; ++v)
+          if (v < nval) xrow[v] = xn[v];
+      }
     } else if (NT) {
       __builtin_nontemporal_store(xn, reinterpret_cast<V*>(x) + iv);
     } else {
