@@ -879,7 +879,11 @@ def main():
         roof = roofline(f"{method} iteration (all kernels of the loop: stream time of the iterations / K)", ev_ms / K,
                         passes * esize * mesh.N, args.workload, True,
                         {"remark": f"{passes} array passes per iteration by the algorithmic count, {moved} really moved "
-                                   "(DESIGN.md section 4); per-kernel table: profiles/r04_bicgstab512_kernel_stats.csv"})
+                                   "(DESIGN.md section 4); per-kernel table: profiles/r04_bicgstab512_kernel_stats.csv; "
+                                   "frac can exceed 1 on the algorithmic count because fused phases never store "
+                                   "what the count assumes stored -- frac_moved prices the passes the loop really makes",
+                         "passes_moved": moved,
+                         "frac_moved": moved * esize * mesh.N / (ev_ms / K * 1e-3) / 1e9 / HBM_PEAK_GBS})
         wl_text = (f"3-D Poisson {gn[0]}x{gn[1]}x{gn[2]} {dtype}, {kind} BCs, "
                    f"{'BiCGSTAB' if method == 'bicgstab' else 'Jacobi'} (BASELINE config {cfg_no}'s mesh)")
     else:  # jacobi (config 1)
