@@ -16,7 +16,9 @@ for w in "$@"; do
   cp "$d/kernel_stats.csv" "$HERE/${R}_${w}_kernel_stats.csv"
   cp "$d/bench_kt.json" "$HERE/${R}_${w}_bench_under_rocprof.json"
   cp "$d/exit_codes.txt" "$HERE/${R}_${w}_exit_codes.txt"
-  DIRS+=("$d")
+  # a custom-size run (slab64 = workload c3 at 64 x 512 x 512) writes its traffic entry under the WORKLOAD's key: its
+  # files are installed, its entry is never merged (bench.py reads no traffic for custom sizes)
+  case "$w" in c1|c2|c3|c4|c4t|c4_512|c5) DIRS+=("$d") ;; esac
   echo "installed $w"
 done
 [ ${#DIRS[@]} -gt 0 ] && python3 "$HERE/merge_traffic.py" "${DIRS[@]}"
