@@ -45,7 +45,7 @@ namespace {
 
 constexpr int HR_MAXR = 8;
 constexpr size_t HR_AR_CAP = 256u << 10;    // bytes of one all-reduce / broadcast contribution
-constexpr size_t HR_P2P_CAP = 1u << 20;     // bytes of one message
+constexpr size_t HR_P2P_CAP = 8u << 20;     // bytes of one message (a plane of BASELINE config 3 / 5 is 2 MiB, the periodic ring sends three at once)
 constexpr int HR_P2P_DEPTH = 2;
 constexpr int HR_NS = 8;                    // staging slots (operations in flight) per communicator
 constexpr size_t HR_STAGE_CAP = HR_P2P_CAP;

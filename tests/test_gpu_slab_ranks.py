@@ -447,3 +447,107 @@ def test_euler_march_on_slab_meshes(world, name, dtype, request):
     assert _rel(res["euler"]["x"], xo) < (1e-12 if dtype == "double" else 1e-5), _rel(res["euler"]["x"], xo)
     if "euler_generic" in res:
         assert torch.equal(res["euler"]["x"], res["euler_generic"]["x"])
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# BASELINE config 3 at its full size on slabs ("configs 3 and 5 only in their 1-GPU form")
+
+
+def _worker_config3(rank, world, port, n, K, method, outdir):
+    """Solver.set_eq() / solve() on Mesh(..., slab=(rank, world)) at 512^3 fp64, fully periodic: the default N > 1 sequence
+    (library-side loop, folded iterations, plane exchange on the second communicator) between rank PROCESSES sharing cuda:0."""
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    sys.path.insert(0, here)
+    sys.path.insert(0, os.path.dirname(here))
+    warnings.filterwarnings("ignore")
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    for k in ENV_KEYS:
+        os.environ.pop(k, None)
+    import json
+    os.environ.update(json.loads(os.environ.get("PA_TEST_SLAB_ENV", "{}")))     # (profiles/tools/slab_bicg_diag.py: other modes)
+    from helpers import use_hostring
+    use_hostring()
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import bench
+        from pyapes_amd.geometry import Box
+        from pyapes_amd.hip.context import context_for
+        from pyapes_amd.mesh import Mesh
+        from pyapes_amd.solver.fdm import FDM
+        from pyapes_amd.solver.ops import Solver
+        from pyapes_amd.variables import Field
+        torch.cuda.set_device(0)
+        mesh = Mesh(Box([0.0] * 3, [1.0] * 3), None, list(n), "cuda", "double", slab=(rank, world))
+        var = Field("p", 1, mesh, {"domain": bench.make_bcs("periodic"), "obstacle": None})
+        rhs = bench.synth_rhs(n, mesh.i_off, mesh.nx[0], os.environ.get("PA_TEST_SLAB_RHS_KIND", "periodic"), mesh.dtype.float,
+                              mesh.device)
+        solver = Solver({"fdm": {"method": method, "tol": 1e-30, "max_it": K, "report": False}})
+        solver.set_eq(FDM().laplacian(1.0, var) == rhs)
+        rep = solver.solve()
+        ctx = context_for(mesh)
+        in_lib = bool(getattr(ctx, "comm_ready", None))
+        impl = ctx.comm_impl() if in_lib else None
+        torch.cuda.synchronize()
+        if in_lib:      # release the communicators while every rank is alive
+            ctx.comm_destroy()
+            ctx.comm_ready = None
+        torch.save({"x": var().cpu(), "i_off": int(mesh.i_off), "itr": int(rep["itr"]), "tol": float(rep["tol"]),
+                    "in_lib": in_lib, "impl": impl}, os.path.join(outdir, f"rank{rank}.pt"))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("method,K,rhs_kind,bar", [("cg", 8, "periodic", 1e-10), ("bicgstab", 6, "mixed", 1e-12)])
+def test_config3_full_size_on_two_and_four_slabs(method, K, rhs_kind, bar, tmp_path, monkeypatch):
+    """512^3 fp64, fully periodic (the mesh BASELINE's metric is quoted on), 2 x 256 and 4 x 128 planes, through
+    Solver.set_eq() / solve(), against the SAME solve on the whole mesh on one GPU: identical iteration counts, iterate and
+    stop-test value within the bar (the slabs add the same products in another order).  The one-GPU solve at this size is
+    what test_gpu_properties.py pins (eigen-solution, null space, fast == generic); the CPU oracle needs ~10 s per iteration
+    here.  CG runs bench.py's own right-hand side.  BiCGSTAB runs the right-hand side with bench.synth_rhs's pseudo-random
+    term: on the periodic one (a sum of Fourier modes) |r| drops seven orders in two iterations, BiCGSTAB's scalars are then
+    quotients of nearly cancelled sums and the ORDER of the sums alone moves the iterate by 2e-11 ... 7e-11 and the residual
+    norm by a factor with four ranks, while on a generic right-hand side 2, 3 and 4 ranks sit within 6e-16 of the whole mesh
+    (profiles/r04_slab_bicg_diag.txt, made by profiles/tools/slab_bicg_diag.py)."""
+    import bench
+    from pyapes_amd.geometry import Box
+    from pyapes_amd.mesh import Mesh
+    from pyapes_amd.solver.fdm import FDM
+    from pyapes_amd.solver.ops import Solver
+    from pyapes_amd.variables import Field
+    n = (512, 512, 512)
+    monkeypatch.setenv("PA_TEST_SLAB_RHS_KIND", rhs_kind)      # (the rank processes inherit it)
+    free_b, _ = torch.cuda.mem_get_info()
+    if free_b < 40 * 2 ** 30:
+        pytest.skip("needs ~ 30 GiB of device memory")
+    results = {}
+    for world in (2, 4):
+        d = tmp_path / f"w{world}"
+        d.mkdir()
+        spawn_ranks(_worker_config3, lambda port: (world, port, n, K, method, str(d)), world)
+        results[world] = [torch.load(str(d / f"rank{r}.pt")) for r in range(world)]
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        mesh = Mesh(Box([0.0] * 3, [1.0] * 3), None, list(n), "cuda", "double")
+        var = Field("p", 1, mesh, {"domain": bench.make_bcs("periodic"), "obstacle": None})
+        rhs = bench.synth_rhs(n, 0, n[0], rhs_kind, mesh.dtype.float, mesh.device)
+        solver = Solver({"fdm": {"method": method, "tol": 1e-30, "max_it": K, "report": False}})
+        solver.set_eq(FDM().laplacian(1.0, var) == rhs)
+        rep = solver.solve()
+    x1 = var()
+    assert bool(torch.isfinite(x1).all()) and float(x1.abs().max()) > 0
+    for world, parts in results.items():
+        assert all(p["in_lib"] and "hostring" in p["impl"] for p in parts), [(p["in_lib"], p["impl"]) for p in parts]
+        assert sorted(p["i_off"] for p in parts) == [r * (n[0] // world) for r in range(world)]
+        num = den = 0.0
+        for p in parts:
+            xs = p["x"].cuda()
+            ref = x1[:, p["i_off"]:p["i_off"] + xs.shape[1]]
+            num += float(((xs - ref) ** 2).sum())
+            den += float((ref ** 2).sum())
+            assert p["itr"] == int(rep["itr"]), (world, p["itr"], rep["itr"])
+            assert abs(p["tol"] - float(rep["tol"])) <= 1e-9 * abs(float(rep["tol"])), (world, p["tol"], rep["tol"])
+            del xs
+        assert (num / den) ** 0.5 < bar, (world, (num / den) ** 0.5)
