@@ -21,7 +21,8 @@
 // The next iteration pair IS the measurement: accepted if it beats the best pair by 1.5 % (3 % at once, else a second
 // pair decides), otherwise undone.  hipMalloc costs ~10 us and does not wait for the stream (profiles/tools/
 // mallocbench.hip: 1 GiB 12 us, 2 GiB 0.2 ms; hipFree drains the device, so blocks are only freed where the solve
-// synchronises anyway, at its end).  What the trials cost -- the lost time of trial iterations that ran slower, the
+// synchronises anyway, at its end; on one box of round 4's last session the first 128 MiB block took 3.4 ms -- the budget
+// then holds every further trial back until the solves have earned it).  What the trials cost -- the lost time of trial iterations that ran slower, the
 // allocations -- is accounted in microseconds against the time the solves of this context have taken so far, and a new
 // trial only starts while that share is below `budget` (3 %): a 30-iteration solve pays for at most one or two
 // trials, a 1000-iteration solve for the whole pass (3 roles x `blocks` candidates), and nobody pays up front.
