@@ -137,11 +137,12 @@ def test_a_short_solve_does_not_pay_for_the_search():
         assert rep["itr"] == 30
     st = ctx.place_stats()
     assert st["state"] in ("searching", "done"), st
-    # the search only STARTS a trial while its spending is below its share (3 %) of the time solved: what it cannot know
-    # before it asks is the price of the one hipMalloc a first trial needs -- ~10 us on most boxes, 3.4 ms on one box of
-    # round 4's last session (spent 3866 us of 15471 us solved, allocations 1, no further trial until the share is back
-    # under the budget): one allocation of that kind is allowed for, a second one is what the budget exists to prevent
+    # the search only STARTS a trial while its spending is below its share (3 %) of the time solved.  What it cannot know
+    # before it asks is the price of the hipMalloc a first trial needs: ~10 us on most boxes, 3.4 ms on one box of round
+    # 4's last session (spent 3866 us of 15471 us solved), 30 ms on another.  Past its share the
+    # budget has to have stopped the search: one allocation, the trial it was made for, nothing after it
     assert st["allocations"] <= 2, st
-    assert st["spent_us"] <= 0.08 * st["timed_us"] + 500.0 + 4000.0 * min(st["allocations"], 1.0), st
+    if st["spent_us"] > 0.08 * st["timed_us"] + 500.0:
+        assert st["allocations"] == 1 and st["trials"] <= 2, st
     assert min(w / g_ for w, g_ in zip(walls, gpus)) < 1.3, (walls, gpus, st)
     assert min(gpus) / 30 < 0.30, gpus      # ms per iteration (0.18-0.19 on the marching kernel; a sanity bound, not a benchmark)
