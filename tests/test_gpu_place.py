@@ -141,7 +141,6 @@ def test_a_short_solve_does_not_pay_for_the_search():
     # before it asks is the price of the hipMalloc a first trial needs: ~10 us on most boxes, 3.4 ms on one box of round
     # 4's last session (spent 3866 us of 15471 us solved), 30 ms on another.  Past its share the
     # budget has to have stopped the search: one allocation, the trial it was made for, nothing after it
-    assert st["allocations"] <= 2, st
     if st["spent_us"] > 0.08 * st["timed_us"] + 500.0:
         assert st["allocations"] == 1 and st["trials"] <= 2, st
     assert min(w / g_ for w, g_ in zip(walls, gpus)) < 1.3, (walls, gpus, st)
